@@ -1,0 +1,267 @@
+/*
+ * mir_optim_amd.h -- C ABI of the MI355X-native Levenberg-Marquardt solver.
+ *
+ * Drop-in boundary for ONE path of libmir/mir-optim: `mir.optim.least_squares`.
+ * Part 1 declares exactly the `extern(C)` symbols the reference exports for that path,
+ * with ABI-identical structs; each declaration cites the reference interface it replaces
+ * (LS = source/mir/optim/least_squares.d, QP = source/mir/optim/boxcqp.d under
+ * /root/reference).  Part 2 is additive (device-pointer callbacks, batched residuals,
+ * multi-GPU communicator, reusable workspace, statistics); nothing in part 2 exists in the
+ * reference.
+ *
+ * All entry points are re-entrant; no global solver state. Errors never throw or abort:
+ * every failure is a negative `status` in the returned struct (LS:132).
+ * A process without a usable HIP device gets status = mir_ls_numericError from the solve
+ * entry points and a diagnostic on stderr -- there is NO CPU fallback in this library.
+ */
+#ifndef MIR_OPTIM_AMD_H
+#define MIR_OPTIM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ======================================================================================
+ * Part 1 -- the reference's extern(C) surface
+ * ====================================================================================== */
+
+/* LeastSquaresStatus, LS:20-46 (32-bit enum) */
+typedef enum mir_least_squares_status {
+    mir_ls_maxIterations = -1,
+    mir_ls_furtherImprovement = 0,
+    mir_ls_xConverged = 1,
+    mir_ls_gConverged = 2,
+    mir_ls_fConverged = 3,
+    mir_ls_badBounds = -32,
+    mir_ls_badGuess = -31,
+    mir_ls_badMinStepQuality = -30,
+    mir_ls_badGoodStepQuality = -29,
+    mir_ls_badStepQuality = -28,
+    mir_ls_badLambdaParams = -27,
+    mir_ls_numericError = -26
+} mir_least_squares_status;
+
+/* BoxQPStatus, QP:18-26 */
+typedef enum mir_box_qp_status {
+    mir_box_qp_solved = 0,
+    mir_box_qp_numericError = 1,
+    mir_box_qp_maxIterations = 2
+} mir_box_qp_status;
+
+/* BoxQPSettings!T, QP:56-71 */
+typedef struct mir_box_qp_settings_d { double relTolerance, absTolerance; uint32_t maxIterations; } mir_box_qp_settings_d;
+typedef struct mir_box_qp_settings_s { float relTolerance, absTolerance; uint32_t maxIterations; } mir_box_qp_settings_s;
+
+/* LeastSquaresSettings!double, LS:85-123: 128 bytes, align 8 */
+typedef struct mir_least_squares_settings_d {
+    uint32_t maxIterations;     /* @0   LS:94  */
+    uint32_t maxAge;            /* @4   LS:96  */
+    double jacobianEpsilon;     /* @8   LS:98  */
+    double absTolerance;        /* @16  LS:100 */
+    double relTolerance;        /* @24  LS:102 */
+    double gradTolerance;       /* @32  LS:104 */
+    double maxGoodResidual;     /* @40  LS:106 */
+    double maxStep;             /* @48  LS:108 */
+    double maxLambda;           /* @56  LS:110 */
+    double minLambda;           /* @64  LS:112 */
+    double minStepQuality;      /* @72  LS:114 */
+    double goodStepQuality;     /* @80  LS:116 */
+    double lambdaIncrease;      /* @88  LS:118 */
+    double lambdaDecrease;      /* @96  LS:120 */
+    mir_box_qp_settings_d qpSettings;  /* @104 LS:122 */
+} mir_least_squares_settings_d;
+
+/* LeastSquaresSettings!float: 68 bytes, align 4 */
+typedef struct mir_least_squares_settings_s {
+    uint32_t maxIterations, maxAge;
+    float jacobianEpsilon, absTolerance, relTolerance, gradTolerance, maxGoodResidual, maxStep,
+          maxLambda, minLambda, minStepQuality, goodStepQuality, lambdaIncrease, lambdaDecrease;
+    mir_box_qp_settings_s qpSettings;
+} mir_least_squares_settings_s;
+
+/* LeastSquaresResult!T, LS:128-143: 32 bytes (double) / 24 bytes (float), returned by hidden pointer */
+typedef struct mir_least_squares_result_d {
+    int32_t status;             /* LeastSquaresStatus; default numericError (LS:132) */
+    uint32_t iterations, fCalls, gCalls;
+    double residual;            /* sum of squares, no 1/2, no sqrt (LS:955, LS:1137) */
+    double lambda;
+} mir_least_squares_result_d;
+typedef struct mir_least_squares_result_s {
+    int32_t status;
+    uint32_t iterations, fCalls, gCalls;
+    float residual, lambda;
+} mir_least_squares_result_s;
+
+/* mir.ndslice Slice!(T*) 1-D contiguous = { size_t length; T* ptr } (mir-algorithm; LS:713-714) */
+typedef struct mir_slice_d { size_t length; double* ptr; } mir_slice_d;
+typedef struct mir_slice_s { size_t length; float* ptr; } mir_slice_s;
+typedef struct mir_slice_i { size_t length; int32_t* ptr; } mir_slice_i;   /* lapackint = int */
+
+/* LeastSquaresFunctionBetterC / LeastSquaresJacobianBetterC, LS:78-80. J is row-major m x n. */
+typedef void (*mir_least_squares_function_d)(void* context, size_t m, size_t n, const double* x, double* y);
+typedef void (*mir_least_squares_jacobian_d)(void* context, size_t m, size_t n, const double* x, double* J);
+typedef void (*mir_least_squares_function_s)(void* context, size_t m, size_t n, const float* x, float* y);
+typedef void (*mir_least_squares_jacobian_s)(void* context, size_t m, size_t n, const float* x, float* J);
+
+/* LeastSquaresTask (an opaque 16-byte D delegate, LS:560-564), LeastSquaresTaskBetterC (LS:567-572)
+ * and LeastSquaresThreadManagerBetterC (LS:672-678). The manager must call
+ * task(taskContext, totalThreads, threadId, i) once for every i in [0, count). */
+typedef struct mir_least_squares_task { void* context; void* function; } mir_least_squares_task;
+typedef void (*mir_least_squares_task_function)(mir_least_squares_task task, uint32_t totalThreads,
+                                                uint32_t threadId, uint32_t i);
+typedef void (*mir_least_squares_thread_manager)(void* context, uint32_t count,
+                                                 mir_least_squares_task taskContext,
+                                                 mir_least_squares_task_function task);
+
+/* LS:642-646 */
+size_t mir_least_squares_work_length(size_t m, size_t n);
+/* LS:651-656 */
+size_t mir_least_squares_iwork_length(size_t m, size_t n);
+/* QP:36-42 */
+size_t mir_box_qp_work_length(size_t n);
+/* QP:47-50 */
+size_t mir_box_qp_iwork_length(size_t n);
+/* LS:666-669 (strings LS:528-557) */
+const char* mir_least_squares_status_string(mir_least_squares_status st);
+/* LS:761-770 */
+void mir_least_squares_init_d(mir_least_squares_settings_d* settings);
+void mir_least_squares_init_s(mir_least_squares_settings_s* settings);
+/* LS:783-792 */
+void mir_least_squares_reset_d(mir_least_squares_settings_d* settings);
+void mir_least_squares_reset_s(mir_least_squares_settings_s* settings);
+
+/* LS:705-724. Host-pointer contract of the reference: x/l/u/work/iwork are host memory, f/g/tm
+ * are host functions on host memory. The LM arithmetic runs on the GPU; y (and J when g is
+ * given) are staged through pinned host buffers. `work`/`iwork` are accepted for ABI
+ * compatibility and are not used (device workspace is allocated internally). */
+mir_least_squares_result_d mir_optimize_least_squares_d(
+    const mir_least_squares_settings_d* settings, size_t m, size_t n,
+    double* x, const double* l, const double* u,
+    mir_slice_d work, mir_slice_i iwork,
+    void* fContext, mir_least_squares_function_d f,
+    void* gContext, mir_least_squares_jacobian_d g,
+    void* tmContext, mir_least_squares_thread_manager tm);
+
+/* LS:729-748. NOTE: the reference's float entry passes the literal 2 for m (LS:629, a bug);
+ * this implementation uses the caller's m. */
+mir_least_squares_result_s mir_optimize_least_squares_s(
+    const mir_least_squares_settings_s* settings, size_t m, size_t n,
+    float* x, const float* l, const float* u,
+    mir_slice_s work, mir_slice_i iwork,
+    void* fContext, mir_least_squares_function_s f,
+    void* gContext, mir_least_squares_jacobian_s g,
+    void* tmContext, mir_least_squares_thread_manager tm);
+
+/* ======================================================================================
+ * Part 2 -- additive MI355X-native surface (not in the reference)
+ * ====================================================================================== */
+
+typedef struct mir_lsq_comm mir_lsq_comm;            /* row-shard communicator */
+typedef struct mir_lsq_workspace mir_lsq_workspace;  /* reusable device workspace */
+
+/* Batched residual callback: evaluate p parameter vectors in one sweep over the user's data.
+ * X is p x n row-major, Y is p x m row-major (point k's residual vector at Y + k*m); both are
+ * DEVICE pointers; work must be enqueued on the options' stream. It is the GPU analogue of the
+ * reference's thread manager (LS:184-215): it lets the finite-difference Jacobian evaluate its
+ * 2n perturbed points together instead of one at a time. */
+typedef void (*mir_lsq_batched_function_d)(void* context, size_t m, size_t n, size_t p, const double* X, double* Y);
+typedef void (*mir_lsq_batched_function_s)(void* context, size_t m, size_t n, size_t p, const float* X, float* Y);
+
+enum {
+    MIR_LSQ_DEVICE_CALLBACKS = 1u,   /* f/g/fb receive DEVICE pointers and enqueue on `stream` (no host staging) */
+    MIR_LSQ_TIME_KERNELS = 2u        /* bracket the hot kernels with HIP events and fill `stats` */
+};
+
+typedef struct mir_lsq_stats {
+    uint64_t passes, accepted, rejected, step_guard_rejects;
+    uint64_t jacobian_full, jacobian_broyden;
+    uint64_t jtj_launches;           /* launches of the fused Broyden + J^T J + J^T y kernel */
+    uint64_t jtj_broyden_launches;   /* of those, with the Broyden update fused in */
+    double jtj_ms;                   /* sum of event-timed durations of those launches (ms) */
+    double jtj_broyden_ms;
+    double solve_ms;                 /* n x n damped solve kernel */
+    uint64_t solve_launches;
+    double fd_ms;                    /* finite-difference refresh incl. callbacks */
+    double total_ms;                 /* whole call, host wall clock */
+    uint64_t qp_active_set_passes;   /* passes in which BOXCQP's active-set loop ran */
+} mir_lsq_stats;
+
+typedef struct mir_lsq_gpu_options {
+    uint32_t struct_size;            /* = sizeof(mir_lsq_gpu_options) */
+    uint32_t flags;
+    void* stream;                    /* hipStream_t; NULL = a stream owned by the call */
+    mir_lsq_comm* comm;              /* NULL = single GPU; else m is this rank's row count */
+    mir_lsq_workspace* workspace;    /* NULL = allocate/free per call */
+    void* fbContext;
+    void* fb;                        /* mir_lsq_batched_function_{d,s} or NULL */
+    uint32_t fd_batch;               /* max points per fb call (0 = 2n) */
+    uint32_t reserved;
+    mir_lsq_stats* stats;            /* optional out */
+} mir_lsq_gpu_options;
+
+/* Same algorithm and result contract as mir_optimize_least_squares_{d,s}; x/l/u stay host
+ * pointers (n is small); callbacks follow `options->flags`. `options` may be NULL. */
+mir_least_squares_result_d mir_optimize_least_squares_gpu_d(
+    const mir_least_squares_settings_d* settings, size_t m, size_t n,
+    double* x, const double* l, const double* u, const mir_lsq_gpu_options* options,
+    void* fContext, mir_least_squares_function_d f,
+    void* gContext, mir_least_squares_jacobian_d g,
+    void* tmContext, mir_least_squares_thread_manager tm);
+mir_least_squares_result_s mir_optimize_least_squares_gpu_s(
+    const mir_least_squares_settings_s* settings, size_t m, size_t n,
+    float* x, const float* l, const float* u, const mir_lsq_gpu_options* options,
+    void* fContext, mir_least_squares_function_s f,
+    void* gContext, mir_least_squares_jacobian_s g,
+    void* tmContext, mir_least_squares_thread_manager tm);
+
+/* Standalone BOXCQP on the device (the reference's convenience overload QP:85-102 is D-only).
+ * P: host row-major n x n, lower triangle meaningful; q,l,u,x host n-vectors. Returns BoxQPStatus
+ * (mir_box_qp_numericError also when no device is usable). */
+int mir_solve_box_qp_gpu_d(const mir_box_qp_settings_d* settings, size_t n, const double* P,
+                           const double* q, const double* l, const double* u, double* x,
+                           int unconstrainedSolution, int* iterations);
+int mir_solve_box_qp_gpu_s(const mir_box_qp_settings_s* settings, size_t n, const float* P,
+                           const float* q, const float* l, const float* u, float* x,
+                           int unconstrainedSolution, int* iterations);
+
+/* Unit-level access to the hot kernels (parity tests and micro-benchmarks). All pointers are
+ * DEVICE pointers; stream may be NULL (default stream; the call synchronises before returning).
+ * JJ: n x n row-major, full symmetric on return. broyden != 0 first applies
+ *   J += ((y - y_old - J dx) / (dx.dx)) dx^T  (LS:1002-1006) in the same pass. Returns 0 on success. */
+int mir_lsq_jtj_d(size_t m, size_t n, double* J, const double* y, const double* y_old, const double* dx,
+                  int broyden, double* JJ, double* Jy, void* stream, float* kernel_ms);
+int mir_lsq_jtj_s(size_t m, size_t n, float* J, const float* y, const float* y_old, const float* dx,
+                  int broyden, float* JJ, float* Jy, void* stream, float* kernel_ms);
+
+/* Workspace: device buffers for one (m, n, element size) problem, reusable across calls. */
+mir_lsq_workspace* mir_lsq_workspace_create(size_t m, size_t n, size_t elem_size);
+void mir_lsq_workspace_destroy(mir_lsq_workspace* ws);
+
+/* Row-shard communicators: one fused sum-all-reduce of the packed
+ * [J^T J lower | J^T y] buffer per Jacobian-changing pass, one 1-scalar all-reduce per trial step. */
+int mir_lsq_rccl_unique_id(void* out_128_bytes);                       /* ncclGetUniqueId */
+mir_lsq_comm* mir_lsq_comm_create_rccl(int nranks, int rank, const void* unique_id_128_bytes);
+/* callback communicator: `allreduce(ctx, device_buf, count_of_doubles, stream)` must sum `buf` over
+ * ranks in place, ordered after prior work on `stream` (used with gloo in the tests). */
+typedef void (*mir_lsq_allreduce_fn)(void* ctx, double* device_buf, size_t count, void* stream);
+mir_lsq_comm* mir_lsq_comm_create_callback(int nranks, int rank, mir_lsq_allreduce_fn fn, void* ctx);
+void mir_lsq_comm_destroy(mir_lsq_comm* comm);
+
+/* Small device utilities for language bindings that have no HIP runtime of their own. */
+int mir_lsq_device_count(void);
+void* mir_lsq_device_malloc(size_t bytes);
+void mir_lsq_device_free(void* p);
+int mir_lsq_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes, void* stream);
+int mir_lsq_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes, void* stream);
+void* mir_lsq_stream_create(void);
+void mir_lsq_stream_destroy(void* stream);
+int mir_lsq_stream_synchronize(void* stream);
+const char* mir_lsq_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIR_OPTIM_AMD_H */

@@ -1,0 +1,88 @@
+// common.h -- shared device/host helpers for the MI355X LM solver (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+
+namespace mirlsq {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+#define MIRLSQ_HIP_CHECK(expr)                                                                  \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            std::fprintf(stderr, "[mir_optim_amd] HIP error %s at %s:%d: %s\n",                 \
+                         hipGetErrorName(_e), __FILE__, __LINE__, #expr);                       \
+            return _e;                                                                          \
+        }                                                                                       \
+    } while (0)
+
+template <typename T> struct Lim;
+template <> struct Lim<double> {
+    static constexpr double eps = DBL_EPSILON, max = DBL_MAX, min_normal = DBL_MIN;
+    __host__ __device__ static double inf() { return __builtin_huge_val(); }
+};
+template <> struct Lim<float> {
+    static constexpr float eps = FLT_EPSILON, max = FLT_MAX, min_normal = FLT_MIN;
+    __host__ __device__ static float inf() { return __builtin_huge_valf(); }
+};
+
+// ---- MFMA 16x16x4 for f64 / f32: identical A/B operand lane maps
+//      (lane l holds A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]);
+//      the C/D maps differ: f64 row = (l >> 4) + 4 r, f32 row = 4 (l >> 4) + r; col = l & 15.
+template <typename T> struct Mma;
+template <> struct Mma<double> {
+    using Acc = __attribute__((ext_vector_type(4))) double;
+    __device__ static inline Acc mma(double a, double b, Acc c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    __host__ __device__ static inline int row(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <> struct Mma<float> {
+    using Acc = __attribute__((ext_vector_type(4))) float;
+    __device__ static inline Acc mma(float a, float b, Acc c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    __host__ __device__ static inline int row(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+
+template <typename T> __device__ inline T wave_shfl_xor(T v, int mask) { return __shfl_xor(v, mask, kWave); }
+
+// sum over the 16 lanes that share lane >> 4
+template <typename T> __device__ inline T sum16(T v) {
+    v += wave_shfl_xor(v, 1);
+    v += wave_shfl_xor(v, 2);
+    v += wave_shfl_xor(v, 4);
+    v += wave_shfl_xor(v, 8);
+    return v;
+}
+template <typename T> __device__ inline T wave_sum(T v) {
+    v = sum16(v);
+    v += wave_shfl_xor(v, 16);
+    v += wave_shfl_xor(v, 32);
+    return v;
+}
+template <typename T> __device__ inline T wave_max(T v) {
+#pragma unroll
+    for (int k = 1; k < kWave; k <<= 1) {
+        T o = wave_shfl_xor(v, k);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+__device__ inline double dsqrt(double v) { return sqrt(v); }
+__device__ inline float dsqrt(float v) { return sqrtf(v); }
+__device__ inline double dabs(double v) { return fabs(v); }
+__device__ inline float dabs(float v) { return fabsf(v); }
+__device__ inline double dfmax(double a, double b) { return fmax(a, b); }
+__device__ inline float dfmax(float a, float b) { return fmaxf(a, b); }
+__device__ inline double dfmin(double a, double b) { return fmin(a, b); }
+__device__ inline float dfmin(float a, float b) { return fminf(a, b); }
+
+}  // namespace mirlsq

@@ -1,0 +1,1043 @@
+// lm_driver.hip -- host side of the MI355X-native Levenberg-Marquardt solver and its C ABI.
+//
+// The control flow mirrors optimizeLeastSquaresImplGeneric!T
+// (/root/reference/source/mir/optim/least_squares.d:877-1176, cited as LS:nnn below) pass for
+// pass -- validation order, Jacobian ageing, Broyden/full refresh, gradient test, damping,
+// BOXCQP solve, step guard, trial acceptance, lambda/mu schedule, convergence tests -- but every
+// floating-point operation of the loop runs in a HIP kernel (jtj_kernel.h, solve_kernel.h,
+// misc_kernels.h). The host only sequences kernels on integer/boolean control state that it
+// mirrors from a small device-resident LmState after each decision point.
+//
+// There is NO CPU fallback: without a usable HIP device the solve entry points print a
+// diagnostic and return status = numericError.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/mir_optim_amd.h"
+#include "comm.h"
+#include "common.h"
+#include "jtj_kernel.h"
+#include "misc_kernels.h"
+#include "solve_kernel.h"
+
+using namespace mirlsq;
+
+// ------------------------------------------------------------------------------------------
+// ABI pins
+// ------------------------------------------------------------------------------------------
+static_assert(sizeof(mir_least_squares_settings_d) == 128, "Settings_d must be 128 bytes");
+static_assert(offsetof(mir_least_squares_settings_d, jacobianEpsilon) == 8, "");
+static_assert(offsetof(mir_least_squares_settings_d, lambdaDecrease) == 96, "");
+static_assert(offsetof(mir_least_squares_settings_d, qpSettings) == 104, "");
+static_assert(sizeof(mir_least_squares_settings_s) == 68, "Settings_s must be 68 bytes");
+static_assert(offsetof(mir_least_squares_settings_s, qpSettings) == 56, "");
+static_assert(sizeof(mir_least_squares_result_d) == 32, "Result_d must be 32 bytes");
+static_assert(offsetof(mir_least_squares_result_d, residual) == 16, "");
+static_assert(sizeof(mir_least_squares_result_s) == 24, "Result_s must be 24 bytes");
+static_assert(sizeof(mir_slice_d) == 16 && sizeof(mir_least_squares_task) == 16, "");
+
+struct mir_lsq_workspace {
+    size_t m = 0, n = 0, elem = 0;
+    void* dev = nullptr;       // one device allocation, carved below
+    size_t dev_bytes = 0;
+    void* ypanel = nullptr;    // lazily allocated FD panel (device mode)
+    size_t ypanel_bytes = 0;
+    void* pinned = nullptr;    // small pinned host block (state + trial readback)
+    void* pinned_y = nullptr;  // m-vector staging (host-callback mode), lazily allocated
+    void* pinned_J = nullptr;  // m*n staging for host analytic Jacobians, lazily allocated
+    int num_cu = 256;
+};
+
+namespace {
+
+template <typename T> struct Abi;
+template <> struct Abi<double> {
+    using Settings = mir_least_squares_settings_d;
+    using Result = mir_least_squares_result_d;
+    using F = mir_least_squares_function_d;
+    using G = mir_least_squares_jacobian_d;
+    using FB = mir_lsq_batched_function_d;
+};
+template <> struct Abi<float> {
+    using Settings = mir_least_squares_settings_s;
+    using Result = mir_least_squares_result_s;
+    using F = mir_least_squares_function_s;
+    using G = mir_least_squares_jacobian_s;
+    using FB = mir_lsq_batched_function_s;
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+bool device_available()
+{
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) {
+        std::fprintf(stderr, "[mir_optim_amd] no usable HIP device: the MI355X kernels cannot run "
+                             "(this library has no CPU fallback)\n");
+        return false;
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// J^T J launch plan
+// ------------------------------------------------------------------------------------------
+struct JtjPlan {
+    int ncb = 0;
+    int nblk = 0;
+    int slab_len = 0;
+    size_t lds = 0;
+};
+
+template <typename T>
+JtjPlan jtj_plan(size_t m, int n, int num_cu)
+{
+    JtjPlan p;
+    p.ncb = (n + 15) / 16;
+    const int nacc = p.ncb * (p.ncb + 1) / 2;
+    p.slab_len = (nacc * 4 + p.ncb) * kWave;
+    const int rpb = 4 * (int)(sizeof(T) / 4);
+    const int roles = jtj_roles_rt(p.ncb, rpb);
+    p.lds = (size_t)(roles == 4 ? 0 : (roles == 2 ? 1 : 2)) * p.slab_len * sizeof(T);
+    // workgroups per CU: LDS- and register-limited (one workgroup = one wave per SIMD)
+    int per_cu = p.lds ? (int)((160 * 1024) / p.lds) : 8;
+    const int reg_waves = (nacc * rpb / roles > 40) ? 2 : 4;   // matches jtj_min_waves
+    if (per_cu > reg_waves) per_cu = reg_waves;
+    if (per_cu < 1) per_cu = 1;
+    const size_t G = (m + 3) / 4;
+    const size_t slots_per_blk = kJtjWaves / roles;
+    size_t want = (G + slots_per_blk * 8 - 1) / (slots_per_blk * 8);     // at least ~8 row groups per wave
+    size_t cap = (size_t)num_cu * per_cu;
+    p.nblk = (int)(want < cap ? (want ? want : 1) : cap);
+    return p;
+}
+
+template <typename T, int NCB, bool BR>
+hipError_t jtj_launch_one(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
+{
+    auto kern = k_jtj<T, NCB, BR>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(256), p.lds, s, a);
+    return hipGetLastError();
+}
+
+template <typename T, bool BR>
+hipError_t jtj_launch_br(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
+{
+    switch (p.ncb) {
+    case 1: return jtj_launch_one<T, 1, BR>(p, a, s);
+    case 2: return jtj_launch_one<T, 2, BR>(p, a, s);
+    case 3: return jtj_launch_one<T, 3, BR>(p, a, s);
+    case 4: return jtj_launch_one<T, 4, BR>(p, a, s);
+    case 5: return jtj_launch_one<T, 5, BR>(p, a, s);
+    case 6: return jtj_launch_one<T, 6, BR>(p, a, s);
+    case 7: return jtj_launch_one<T, 7, BR>(p, a, s);
+    case 8: return jtj_launch_one<T, 8, BR>(p, a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// fused [Broyden] + JtJ + Jty -> packed[ n(n+1)/2 + n ]
+template <typename T>
+hipError_t jtj_run(const JtjPlan& p, const JtjArgs<T>& a, bool broyden, T* packed, hipStream_t s)
+{
+    hipError_t e = broyden ? jtj_launch_br<T, true>(p, a, s) : jtj_launch_br<T, false>(p, a, s);
+    if (e != hipSuccess) return e;
+    const int rb = (p.slab_len + 31) / 32;
+    hipLaunchKernelGGL(k_jtj_slab_reduce<T>, dim3(rb), dim3(256), 0, s, a.slabs, p.nblk, p.slab_len, p.ncb, a.n, packed);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// device buffers carved from one allocation
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct Buffers {
+    T *J, *y, *mB, *ytmp;
+    T *X, *twh;
+    T *x, *lower, *upper, *dx, *trial, *Jy, *JJ, *packed, *partials, *sum;
+    LmState<T>* st;
+    T* slabs;
+    SolveScratch<T> sc;
+    size_t bytes;
+};
+
+constexpr int kPartials = 1024;
+
+template <typename T>
+Buffers<T> carve(void* base, size_t m, size_t n, const JtjPlan& plan)
+{
+    Buffers<T> b{};
+    size_t off = 0;
+    auto take = [&](size_t count, size_t elem) {
+        void* p = base ? static_cast<char*>(base) + off : nullptr;
+        off = align_up(off + count * elem, 256);
+        return p;
+    };
+    b.J = (T*)take(m * n, sizeof(T));
+    b.y = (T*)take(m, sizeof(T));
+    b.mB = (T*)take(m, sizeof(T));
+    b.ytmp = (T*)take(m, sizeof(T));
+    b.X = (T*)take(2 * n * n, sizeof(T));
+    b.twh = (T*)take(n, sizeof(T));
+    b.x = (T*)take(n, sizeof(T));
+    b.lower = (T*)take(n, sizeof(T));
+    b.upper = (T*)take(n, sizeof(T));
+    b.dx = (T*)take(n, sizeof(T));
+    b.trial = (T*)take(n, sizeof(T));
+    b.Jy = (T*)take(n, sizeof(T));
+    b.JJ = (T*)take(n * n, sizeof(T));
+    b.packed = (T*)take(n * (n + 1) / 2 + n + 8, sizeof(T));
+    b.partials = (T*)take(kPartials, sizeof(T));
+    b.sum = (T*)take(8, sizeof(T));
+    b.st = (LmState<T>*)take(1, sizeof(LmState<T>));
+    b.slabs = (T*)take((size_t)plan.nblk * plan.slab_len, sizeof(T));
+    b.sc.Pm = (T*)take(n * n, sizeof(T));
+    b.sc.A = (T*)take(n * n, sizeof(T));
+    b.sc.Fg = (T*)take(n * (n | 1), sizeof(T));
+    b.sc.vec = (T*)take(12 * n, sizeof(T));
+    b.sc.ivec = (int32_t*)take(2 * n, sizeof(int32_t));
+    b.bytes = off;
+    return b;
+}
+
+int query_num_cu()
+{
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+}
+
+template <typename T>
+mir_lsq_workspace* workspace_create(size_t m, size_t n)
+{
+    auto* ws = new mir_lsq_workspace();
+    ws->m = m; ws->n = n; ws->elem = sizeof(T);
+    ws->num_cu = query_num_cu();
+    const JtjPlan plan = jtj_plan<T>(m, (int)n, ws->num_cu);
+    const Buffers<T> sz = carve<T>(nullptr, m, n, plan);
+    ws->dev_bytes = sz.bytes;
+    if (hipMalloc(&ws->dev, ws->dev_bytes) != hipSuccess) {
+        std::fprintf(stderr, "[mir_optim_amd] hipMalloc(%zu bytes) failed\n", ws->dev_bytes);
+        delete ws;
+        return nullptr;
+    }
+    if (hipHostMalloc(&ws->pinned, sizeof(LmState<T>) + (2 * n + 8) * sizeof(T), hipHostMallocDefault) != hipSuccess) {
+        (void)hipFree(ws->dev);
+        delete ws;
+        return nullptr;
+    }
+    return ws;
+}
+
+void workspace_destroy(mir_lsq_workspace* ws)
+{
+    if (!ws) return;
+    if (ws->dev) (void)hipFree(ws->dev);
+    if (ws->ypanel) (void)hipFree(ws->ypanel);
+    if (ws->pinned) (void)hipHostFree(ws->pinned);
+    if (ws->pinned_y) (void)hipHostFree(ws->pinned_y);
+    if (ws->pinned_J) (void)hipHostFree(ws->pinned_J);
+    delete ws;
+}
+
+// ------------------------------------------------------------------------------------------
+// the solver
+// ------------------------------------------------------------------------------------------
+struct EventPair { hipEvent_t a, b; int kind; };   // kind: 0 jtj, 1 jtj+broyden, 2 solve
+
+template <typename T>
+struct Solver {
+    using Settings = typename Abi<T>::Settings;
+    using Result = typename Abi<T>::Result;
+    using F = typename Abi<T>::F;
+    using G = typename Abi<T>::G;
+    using FB = typename Abi<T>::FB;
+
+    const Settings* S;
+    size_t m;
+    uint32_t n;
+    T* xh;                 // caller's x (host), updated in place on accepted steps (LS:1135)
+    const T *lh, *uh;
+    void* fctx; F f;
+    void* gctx; G g;
+    void* tmctx; mir_least_squares_thread_manager tm;
+    void* fbctx; FB fb;
+    uint32_t fd_batch;
+    bool device_cb;
+    bool time_kernels;
+    mir_lsq_comm* comm;
+    mir_lsq_stats* stats;
+
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    mir_lsq_workspace* ws = nullptr;
+    bool own_ws = false;
+    Buffers<T> B;
+    JtjPlan plan;
+    LmSettingsDev<T> sd;
+    int f_in_lds = 0;
+    size_t solve_lds = 0;
+
+    LmState<T>* st_h;      // pinned mirror
+    T* trial_h;            // pinned, n
+    std::vector<T> twh_h;
+    std::vector<EventPair> events;
+    Result ret;
+
+    // host-callback finite differences (reference thread-manager contract, LS:1019-1048)
+    struct Slot { T* p = nullptr; T* yp = nullptr; T* ym = nullptr; };
+    std::vector<Slot> slots;
+    std::vector<int> slot_count;
+    std::mutex fd_mutex;
+    bool fd_failed = false;
+
+    bool ok(hipError_t e, const char* what)
+    {
+        if (e == hipSuccess) return true;
+        std::fprintf(stderr, "[mir_optim_amd] %s failed: %s\n", what, hipGetErrorName(e));
+        return false;
+    }
+
+    void ev_begin(int kind)
+    {
+        if (!time_kernels) return;
+        EventPair p{};
+        p.kind = kind;
+        (void)hipEventCreate(&p.a);
+        (void)hipEventCreate(&p.b);
+        (void)hipEventRecord(p.a, stream);
+        events.push_back(p);
+    }
+    void ev_end()
+    {
+        if (!time_kernels) return;
+        (void)hipEventRecord(events.back().b, stream);
+    }
+
+    bool setup()
+    {
+        if (!ws) {
+            ws = workspace_create<T>(m, n);
+            own_ws = true;
+            if (!ws) return false;
+        } else if (ws->m != m || ws->n != n || ws->elem != sizeof(T)) {
+            std::fprintf(stderr, "[mir_optim_amd] workspace shape mismatch\n");
+            ws = nullptr;
+            return false;
+        }
+        plan = jtj_plan<T>(m, (int)n, ws->num_cu);
+        B = carve<T>(ws->dev, m, n, plan);
+        st_h = reinterpret_cast<LmState<T>*>(ws->pinned);
+        trial_h = reinterpret_cast<T*>(static_cast<char*>(ws->pinned) + sizeof(LmState<T>));
+        if (!stream) {
+            if (!ok(hipStreamCreate(&stream), "hipStreamCreate")) return false;
+            own_stream = true;
+        }
+        sd.jacobianEpsilon = S->jacobianEpsilon; sd.absTolerance = S->absTolerance; sd.relTolerance = S->relTolerance;
+        sd.gradTolerance = S->gradTolerance; sd.maxGoodResidual = S->maxGoodResidual; sd.maxStep = S->maxStep;
+        sd.maxLambda = S->maxLambda; sd.minLambda = S->minLambda; sd.minStepQuality = S->minStepQuality;
+        sd.goodStepQuality = S->goodStepQuality; sd.lambdaIncrease = S->lambdaIncrease; sd.lambdaDecrease = S->lambdaDecrease;
+        sd.qpRelTolerance = S->qpSettings.relTolerance; sd.qpAbsTolerance = S->qpSettings.absTolerance;
+        sd.qpMaxIterations = S->qpSettings.maxIterations; sd.pad = 0;
+        const size_t fbytes = (size_t)(n | 1) * n * sizeof(T);
+        f_in_lds = fbytes <= (size_t)kSolveLdsBytes;
+        solve_lds = f_in_lds ? fbytes : 0;
+        if (solve_lds > 48 * 1024) {
+            if (!ok(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lm_solve<T>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds), "hipFuncSetAttribute"))
+                return false;
+        }
+        twh_h.resize(n);
+        return ok(hipMemcpyAsync(B.x, xh, n * sizeof(T), hipMemcpyHostToDevice, stream), "H2D x")
+            && ok(hipMemcpyAsync(B.lower, lh, n * sizeof(T), hipMemcpyHostToDevice, stream), "H2D l")
+            && ok(hipMemcpyAsync(B.upper, uh, n * sizeof(T), hipMemcpyHostToDevice, stream), "H2D u");
+    }
+
+    void teardown()
+    {
+        if (stream) (void)hipStreamSynchronize(stream);
+        if (stats) {
+            for (auto& e : events) {
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, e.a, e.b);
+                if (e.kind == 0) { stats->jtj_ms += ms; stats->jtj_launches++; }
+                else if (e.kind == 1) { stats->jtj_ms += ms; stats->jtj_launches++; stats->jtj_broyden_ms += ms; stats->jtj_broyden_launches++; }
+                else if (e.kind == 2) { stats->solve_ms += ms; stats->solve_launches++; }
+            }
+        }
+        for (auto& e : events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        events.clear();
+        for (auto& s : slots) {
+            if (s.p) std::free(s.p);
+            if (s.yp) (void)hipHostFree(s.yp);
+            if (s.ym) (void)hipHostFree(s.ym);
+        }
+        slots.clear();
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
+        if (own_ws && ws) workspace_destroy(ws);
+    }
+
+    // ---- residual evaluation f(x) -> y_dev.  x_dev / x_host describe the same point.
+    bool eval_f(const T* x_dev, const T* x_host, T* y_dev)
+    {
+        if (device_cb) {
+            f(fctx, m, n, x_dev, y_dev);
+            return true;
+        }
+        if (!ws->pinned_y && !ok(hipHostMalloc(&ws->pinned_y, m * sizeof(T), hipHostMallocDefault), "hipHostMalloc(y)")) return false;
+        T* yh = static_cast<T*>(ws->pinned_y);
+        f(fctx, m, n, x_host, yh);
+        return ok(hipMemcpyAsync(y_dev, yh, m * sizeof(T), hipMemcpyHostToDevice, stream), "H2D y")
+            && ok(hipStreamSynchronize(stream), "sync");
+    }
+
+    // ---- ||v||^2 -> B.sum[slot] on device (all-reduced over row shards)
+    bool sumsq(const T* v, int slot)
+    {
+        int nb = (int)((m + 4095) / 4096);
+        if (nb > kPartials) nb = kPartials;
+        if (nb < 1) nb = 1;
+        hipLaunchKernelGGL(k_sumsq_partial<T>, dim3(nb), dim3(256), 0, stream, v, m, B.partials);
+        hipLaunchKernelGGL(k_sumsq_final<T>, dim3(1), dim3(256), 0, stream, B.partials, nb, B.sum + slot);
+        if (comm && comm_allreduce<T>(comm, B.sum + slot, 1, stream) != 0) return false;
+        return ok(hipGetLastError(), "sumsq");
+    }
+
+    bool read_state(bool with_trial)
+    {
+        if (!ok(hipMemcpyAsync(st_h, B.st, sizeof(LmState<T>), hipMemcpyDeviceToHost, stream), "D2H state")) return false;
+        if (with_trial && !ok(hipMemcpyAsync(trial_h, B.trial, n * sizeof(T), hipMemcpyDeviceToHost, stream), "D2H trial")) return false;
+        return ok(hipStreamSynchronize(stream), "sync");
+    }
+
+    // ---- fused [Broyden] + J^T J + J^T y, all-reduce, unpack (LS:1003-1006, 1052, 1065)
+    bool jacobian_products(bool broyden, const T* y_dev, const T* yold_dev)
+    {
+        JtjArgs<T> a{};
+        a.J = B.J; a.Jout = B.J; a.y = y_dev; a.y_old = yold_dev; a.dx = B.dx; a.dx_dot = &B.st->dx_dot;
+        a.slabs = B.slabs; a.m = m; a.n = (int)n;
+        ev_begin(broyden ? 1 : 0);
+        if (!ok(jtj_run<T>(plan, a, broyden, B.packed, stream), "jtj kernel")) return false;
+        ev_end();
+        if (comm && comm_allreduce<T>(comm, B.packed, (size_t)n * (n + 1) / 2 + n, stream) != 0) return false;
+        hipLaunchKernelGGL(k_unpack_grad<T>, dim3(1), dim3(256), 0, stream, B.packed, (int)n, B.JJ, B.Jy, B.st);
+        return ok(hipGetLastError(), "unpack");
+    }
+
+    // ---- finite-difference Jacobian, device callbacks (LS:1016-1050 restructured: all perturbed
+    //      points are generated at once, evaluated one by one or in batches, and written to J in
+    //      coalesced column panels)
+    bool fd_device()
+    {
+        hipLaunchKernelGGL(k_fd_points<T>, dim3(n), dim3(64), 0, stream, B.x, B.lower, B.upper, sd.jacobianEpsilon, (int)n, B.X, B.twh);
+        for (uint32_t j = 0; j < n; ++j) {   // same arithmetic on the host, to skip collapsed intervals like LS:1033
+            const T save = xh[j];
+            T xmh = save - S->jacobianEpsilon, xph = save + S->jacobianEpsilon;
+            xmh = std::fmax(xmh, lh[j]);
+            xph = std::fmin(xph, uh[j]);
+            twh_h[j] = xph - xmh;
+        }
+        // panel width bounded by an 8 GiB scratch
+        size_t pb = n;
+        const size_t cap = (size_t)8 << 30;
+        if (2 * pb * m * sizeof(T) > cap) pb = cap / (2 * m * sizeof(T));
+        if (pb < 1) pb = 1;
+        if (fb && fd_batch && fd_batch / 2 < pb) pb = fd_batch / 2 ? fd_batch / 2 : 1;
+        const size_t need = 2 * pb * m * sizeof(T);
+        if (ws->ypanel_bytes < need) {
+            if (ws->ypanel) (void)hipFree(ws->ypanel);
+            ws->ypanel = nullptr; ws->ypanel_bytes = 0;
+            if (!ok(hipMalloc(&ws->ypanel, need), "hipMalloc(FD panel)")) return false;
+            ws->ypanel_bytes = need;
+        }
+        T* Y = static_cast<T*>(ws->ypanel);
+        for (size_t j0 = 0; j0 < n; j0 += pb) {
+            const size_t pc = (j0 + pb <= n) ? pb : n - j0;
+            if (fb) {
+                fb(fbctx, m, n, 2 * pc, B.X + 2 * j0 * n, Y);
+            } else {
+                for (size_t c = 0; c < pc; ++c) {
+                    if (twh_h[j0 + c] == 0) continue;
+                    f(fctx, m, n, B.X + (2 * (j0 + c)) * n, Y + (2 * c) * m);
+                    f(fctx, m, n, B.X + (2 * (j0 + c) + 1) * n, Y + (2 * c + 1) * m);
+                }
+            }
+            dim3 grid((unsigned)((m + 63) / 64), (unsigned)((pc + 31) / 32));
+            hipLaunchKernelGGL(k_fd_fill<T>, grid, dim3(256), 0, stream, Y, m, B.twh, B.J, m, (int)n, (int)j0, (int)pc);
+        }
+        ret.fCalls += n;    // LS:1024, LS:1049 (quirk Q5: +n although 2n evaluations are made)
+        return ok(hipGetLastError(), "fd fill");
+    }
+
+    // ---- finite-difference Jacobian, host callbacks: the reference's task body LS:1019-1048
+    static void fd_task_trampoline(mir_least_squares_task task, uint32_t totalThreads, uint32_t threadId, uint32_t j)
+    {
+        static_cast<Solver<T>*>(task.context)->fd_task(totalThreads, threadId, j);
+    }
+    void fd_task(uint32_t totalThreads, uint32_t threadId, uint32_t j)
+    {
+        const uint32_t idx = totalThreads >= n ? j : threadId;       // LS:1022
+        if (idx >= n || j >= n) { fd_failed = true; return; }
+        Slot* s;
+        {
+            std::lock_guard<std::mutex> lk(fd_mutex);
+            s = &slots[idx];
+            if (!s->p) {
+                s->p = static_cast<T*>(std::malloc(n * sizeof(T)));
+                if (hipHostMalloc((void**)&s->yp, m * sizeof(T), hipHostMallocDefault) != hipSuccess
+                    || hipHostMalloc((void**)&s->ym, m * sizeof(T), hipHostMallocDefault) != hipSuccess || !s->p) {
+                    fd_failed = true;
+                    return;
+                }
+            }
+            if (slot_count[idx]++ == 0) std::memcpy(s->p, xh, n * sizeof(T));   // LS:1024-1025
+        }
+        T* p = s->p;
+        const T save = p[j];                                         // LS:1027-1031
+        T xmh = save - S->jacobianEpsilon, xph = save + S->jacobianEpsilon;
+        xmh = std::fmax(xmh, lh[j]);
+        xph = std::fmin(xph, uh[j]);
+        const T twh = xph - xmh;
+        if (twh != 0) {                                              // LS:1033-1043
+            p[j] = xph;
+            f(fctx, m, n, p, s->yp);
+            p[j] = xmh;
+            f(fctx, m, n, p, s->ym);
+            p[j] = save;
+        }
+        std::lock_guard<std::mutex> lk(fd_mutex);
+        if (twh != 0) {
+            if (hipMemcpyAsync(B.mB, s->yp, m * sizeof(T), hipMemcpyHostToDevice, stream) != hipSuccess
+                || hipMemcpyAsync(B.ytmp, s->ym, m * sizeof(T), hipMemcpyHostToDevice, stream) != hipSuccess) {
+                fd_failed = true;
+                return;
+            }
+        }
+        hipLaunchKernelGGL(k_fd_fill_col<T>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream,
+                           B.mB, B.ytmp, twh, B.J, m, (int)n, (int)j);
+        if (hipStreamSynchronize(stream) != hipSuccess) fd_failed = true;
+    }
+    bool fd_host()
+    {
+        slots.resize(n);
+        slot_count.assign(n, 0);                                     // LS:1018
+        mir_least_squares_task task{this, nullptr};
+        if (tm) tm(tmctx, n, task, &fd_task_trampoline);             // LS:1019
+        else for (uint32_t j = 0; j < n; ++j) fd_task(1, 0, j);      // LS:947-951
+        uint32_t calls = 0;
+        for (uint32_t k = 0; k < n; ++k) calls += (uint32_t)slot_count[k];
+        ret.fCalls += calls;                                         // LS:1049
+        return !fd_failed;
+    }
+
+    bool analytic_jacobian()
+    {
+        if (device_cb) {
+            g(gctx, m, n, B.x, B.J);
+        } else {
+            if (!ws->pinned_J && !ok(hipHostMalloc(&ws->pinned_J, m * n * sizeof(T), hipHostMallocDefault), "hipHostMalloc(J)")) return false;
+            T* Jh = static_cast<T*>(ws->pinned_J);
+            g(gctx, m, n, xh, Jh);
+            if (!ok(hipMemcpyAsync(B.J, Jh, m * n * sizeof(T), hipMemcpyHostToDevice, stream), "H2D J")
+                || !ok(hipStreamSynchronize(stream), "sync")) return false;
+        }
+        ret.gCalls += 1;                                             // LS:1014
+        return true;
+    }
+
+    Result run()
+    {
+        ret.status = mir_ls_numericError; ret.iterations = 0; ret.fCalls = 0; ret.gCalls = 0;   // LS:132-142
+        ret.residual = Lim<T>::inf(); ret.lambda = 0;
+        const auto t_start = std::chrono::steady_clock::now();
+
+        // validation, LS:930-943 (quirk Q9) -- needs no device
+        {
+            bool finite = true;
+            for (uint32_t i = 0; i < n; ++i) if (!(-Lim<T>::inf() < xh[i] && xh[i] < Lim<T>::inf())) finite = false;
+            if (m == 0 || n == 0 || !finite) { ret.status = mir_ls_badGuess; return ret; }
+            for (uint32_t i = 0; i < n; ++i) if (!(lh[i] <= xh[i]) || !(xh[i] <= uh[i])) { ret.status = mir_ls_badBounds; return ret; }
+            if (!(0 <= S->minStepQuality && S->minStepQuality < 1)) { ret.status = mir_ls_badMinStepQuality; return ret; }
+            if (!(0 <= S->goodStepQuality && S->goodStepQuality <= 1)) { ret.status = mir_ls_badGoodStepQuality; return ret; }
+            if (!(S->minStepQuality < S->goodStepQuality)) { ret.status = mir_ls_badStepQuality; return ret; }
+            if (!(1 <= S->lambdaIncrease && S->lambdaIncrease <= std::sqrt(Lim<T>::max))) { ret.status = mir_ls_badLambdaParams; return ret; }
+            if (!(std::sqrt(Lim<T>::min_normal) <= S->lambdaDecrease && S->lambdaDecrease <= 1)) { ret.status = mir_ls_badLambdaParams; return ret; }
+        }
+        if (n > (uint32_t)kSolveMaxN || n > 128) {
+            std::fprintf(stderr, "[mir_optim_amd] n = %u is not supported by this build (n <= 128)\n", n);
+            return ret;
+        }
+        if (!device_available()) return ret;
+        if (!setup()) { teardown(); return ret; }
+
+        const uint32_t maxAge = S->maxAge ? S->maxAge : (g ? 3 : 2 * n);     // LS:945 (quirk Q4)
+
+        T* y = B.y;          // the reference swaps the contents of y and mBuffer (LS:1136); here the
+        T* mB = B.mB;        // two device buffers swap roles
+
+        bool fail = false;
+        do {   // single-exit block for device errors
+            if (!eval_f(B.x, xh, y)) { fail = true; break; }                 // LS:953
+            ++ret.fCalls;
+            if (!sumsq(y, 0)) { fail = true; break; }                        // LS:955
+            hipLaunchKernelGGL(k_init_state<T>, dim3(1), dim3(1), 0, stream, B.sum, B.st);
+            if (!read_state(false)) { fail = true; break; }
+        } while (false);
+        if (fail) { teardown(); ret.status = mir_ls_numericError; return ret; }
+
+        ret.residual = st_h->residual;
+        bool fConverged = ret.residual <= S->maxGoodResidual;                // LS:956
+        bool needJacobian = true;                                            // LS:959
+        uint32_t age = maxAge;
+        ret.lambda = 0;
+        T mu = 1;
+        const T suspiciousMu = 16;
+        ret.status = mir_ls_maxIterations;                                   // LS:971
+
+        do {
+            if (stats) stats->passes++;
+            if (fConverged) { ret.status = mir_ls_fConverged; break; }       // LS:974-978
+            if (!(ret.lambda <= S->maxLambda)) { ret.status = mir_ls_furtherImprovement; break; }   // LS:979-983
+            if (mu > suspiciousMu && age) {                                  // LS:984-989
+                needJacobian = true;
+                age = maxAge;
+                mu = 1;
+                hipLaunchKernelGGL(k_reset_mu<T>, dim3(1), dim3(1), 0, stream, B.st);
+            }
+            {                                                                // LS:990-995
+                bool nan = false;
+                for (uint32_t i = 0; i < n; ++i) if (!(xh[i] <= xh[i])) nan = true;
+                if (nan) { ret.status = mir_ls_numericError; break; }
+            }
+            bool newJacobian = false;
+            if (needJacobian) {                                              // LS:996-1063
+                needJacobian = false;
+                newJacobian = true;
+                if (age < maxAge) {                                          // Broyden, LS:999-1007
+                    age++;
+                    if (stats) stats->jacobian_broyden++;
+                    if (!jacobian_products(true, y, mB)) { fail = true; break; }
+                } else {
+                    age = 0;
+                    if (stats) stats->jacobian_full++;
+                    const auto t0 = std::chrono::steady_clock::now();
+                    bool okj;
+                    if (g) okj = analytic_jacobian();                        // LS:1011-1015
+                    else okj = device_cb ? fd_device() : fd_host();          // LS:1016-1050
+                    if (!okj) { fail = true; break; }
+                    if (stats) {
+                        (void)hipStreamSynchronize(stream);
+                        stats->fd_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                    }
+                    if (!jacobian_products(false, y, mB)) { fail = true; break; }
+                }
+            }
+
+            // LS:1053-1062 (gradient test, evaluated inside the kernel when a new Jy exists),
+            // LS:1067-1110, 1141-1142: damping, BOXCQP solve, step rounding, trial point, prediction
+            {
+                LmSolveArgs<T> a{};
+                a.JJ = B.JJ; a.Jy = B.Jy; a.x = B.x; a.lower = B.lower; a.upper = B.upper;
+                a.dx = B.dx; a.trial = B.trial; a.st = B.st; a.set = sd; a.sc = B.sc; a.n = (int)n;
+                a.f_in_lds = f_in_lds;
+                a.check_grad = newJacobian ? 1 : 0;
+                ev_begin(2);
+                hipLaunchKernelGGL(k_lm_solve<T>, dim3(1), dim3(kSolveThreads), solve_lds, stream, a);
+                ev_end();
+                if (!ok(hipGetLastError(), "solve kernel") || !read_state(true)) { fail = true; break; }
+            }
+            if (newJacobian && (st_h->flags & kFlagGradSmall)) {             // LS:1053-1062
+                if (age == 0) { ret.status = mir_ls_gConverged; break; }
+                age = maxAge;
+                continue;
+            }
+            ret.lambda = st_h->lambda;
+            if (st_h->qp_iterations > 0 && stats) stats->qp_active_set_passes++;
+            if (st_h->qp_status != 0) { ret.status = mir_ls_numericError; break; }      // LS:1080-1085
+            if (st_h->flags & kFlagDxNaN) { ret.status = mir_ls_numericError; break; }  // LS:1087-1092
+
+            if (st_h->flags & kFlagStepTooLong) {                            // LS:1101-1106
+                hipLaunchKernelGGL(k_bump_lambda<T>, dim3(1), dim3(1), 0, stream, B.st, sd.lambdaIncrease);
+                ret.lambda *= S->lambdaIncrease * mu;
+                mu *= 2;
+                if (stats) stats->step_guard_rejects++;
+                continue;
+            }
+
+            ++ret.fCalls;                                                    // LS:1112-1115
+            if (!eval_f(B.trial, trial_h, mB)) { fail = true; break; }
+            if (!sumsq(mB, 1)) { fail = true; break; }
+            hipLaunchKernelGGL(k_decide<T>, dim3(1), dim3(kSolveThreads), 0, stream, B.sum + 1, B.st, sd, B.x, B.trial, (int)n);
+            if (!ok(hipGetLastError(), "decide kernel") || !read_state(false)) { fail = true; break; }
+
+            const int dec = st_h->decision;
+            if (dec == kDecideNumericError) { ret.status = mir_ls_numericError; break; }   // LS:1117-1122
+            ret.lambda = st_h->lambda;
+            mu = st_h->mu;
+            if (dec == kDecideReject) {                                      // LS:1125-1130
+                if (stats) stats->rejected++;
+                continue;
+            }
+
+            needJacobian = true;                                             // LS:1132-1139
+            ret.iterations = st_h->iterations;
+            for (uint32_t i = 0; i < n; ++i) xh[i] = trial_h[i];
+            { T* t = y; y = mB; mB = t; }
+            ret.residual = st_h->residual;
+            fConverged = ret.residual <= S->maxGoodResidual;
+            if (stats) stats->accepted++;
+
+            if (dec == kDecideAcceptNoPrediction) { ret.status = mir_ls_furtherImprovement; break; }   // LS:1144-1148
+
+            const T dxn = std::sqrt(st_h->dx_dot);                           // LS:1164-1173 (quirk Q6)
+            if (!(dxn > S->absTolerance && st_h->trial_xnorm > dxn * S->relTolerance)) {
+                if (age == 0) { ret.status = mir_ls_xConverged; break; }
+                age = maxAge;
+                continue;
+            }
+        } while (ret.iterations < S->maxIterations);                         // LS:1175
+
+        if (fail) ret.status = mir_ls_numericError;
+        if (stats) stats->total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+        teardown();
+        return ret;
+    }
+};
+
+template <typename T>
+typename Abi<T>::Result solve_entry(const typename Abi<T>::Settings* settings, size_t m, size_t n, T* x, const T* l,
+                                    const T* u, const mir_lsq_gpu_options* opt, void* fctx, typename Abi<T>::F f,
+                                    void* gctx, typename Abi<T>::G g, void* tmctx, mir_least_squares_thread_manager tm)
+{
+    Solver<T> s{};
+    s.S = settings; s.m = m; s.n = (uint32_t)n; s.xh = x; s.lh = l; s.uh = u;
+    s.fctx = fctx; s.f = f; s.gctx = gctx; s.g = g; s.tmctx = tmctx; s.tm = tm;
+    if (opt) {
+        s.device_cb = (opt->flags & MIR_LSQ_DEVICE_CALLBACKS) != 0;
+        s.time_kernels = (opt->flags & MIR_LSQ_TIME_KERNELS) != 0 && opt->stats;
+        s.stream = static_cast<hipStream_t>(opt->stream);
+        s.comm = opt->comm;
+        s.ws = opt->workspace;
+        s.fbctx = opt->fbContext;
+        s.fb = s.device_cb ? reinterpret_cast<typename Abi<T>::FB>(opt->fb) : nullptr;
+        s.fd_batch = opt->fd_batch;
+        s.stats = opt->stats;
+    }
+    return s.run();
+}
+
+}  // namespace
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+size_t mir_box_qp_work_length(size_t n) { return n * n * 2 + n * 8; }                                  // QP:36-42
+size_t mir_box_qp_iwork_length(size_t n) { return n + (n / sizeof(int32_t) + (n % sizeof(int32_t) != 0)); }  // QP:47-50
+size_t mir_least_squares_work_length(size_t m, size_t n)                                               // LS:642-646
+{
+    return mir_box_qp_work_length(n) + n * 5 + n * n + n * m + m * 2;
+}
+size_t mir_least_squares_iwork_length(size_t m, size_t n)                                              // LS:651-656
+{
+    (void)m;
+    const size_t a = mir_box_qp_iwork_length(n);
+    return a > n ? a : n;
+}
+
+const char* mir_least_squares_status_string(mir_least_squares_status st)                               // LS:528-557, 666-669
+{
+    switch (st) {
+    case mir_ls_furtherImprovement: return "The algorithm cann't improve the solution";
+    case mir_ls_maxIterations: return "Maximum number of iterations reached";
+    case mir_ls_xConverged: return "X converged";
+    case mir_ls_gConverged: return "Jacobian converged";
+    case mir_ls_fConverged: return "Residual is small enough";
+    case mir_ls_badBounds: return "Initial guess must be within bounds.";
+    case mir_ls_badGuess: return "Initial guess must be an array of finite numbers.";
+    case mir_ls_badMinStepQuality: return "0 <= minStepQuality < 1 must hold.";
+    case mir_ls_badGoodStepQuality: return "0 < goodStepQuality <= 1 must hold.";
+    case mir_ls_badStepQuality: return "minStepQuality < goodStepQuality must hold.";
+    case mir_ls_badLambdaParams: return "1 <= lambdaIncrease && lambdaIncrease <= T.max.sqrt and T.min_normal.sqrt <= lambdaDecrease && lambdaDecrease <= 1 must hold.";
+    case mir_ls_numericError: return "Numeric Error";
+    }
+    return "";
+}
+
+void mir_least_squares_init_d(mir_least_squares_settings_d* s)                                         // LS:93-122, 761-764
+{
+    s->maxIterations = 1000; s->maxAge = 0;
+    s->jacobianEpsilon = 0x1p-26;            // 2 ^^ ((1 - 53) / 2) (quirk Q10)
+    s->absTolerance = DBL_EPSILON; s->relTolerance = 0; s->gradTolerance = DBL_EPSILON;
+    s->maxGoodResidual = DBL_EPSILON * DBL_EPSILON;
+    s->maxStep = std::sqrt(DBL_MAX) / 16; s->maxLambda = DBL_MAX / 16; s->minLambda = DBL_MIN * 16;
+    s->minStepQuality = 0.1; s->goodStepQuality = 0.5; s->lambdaIncrease = 2;
+    s->lambdaDecrease = (double)0.30901699437494742410229341718281905886L;   // 1 / (GoldenRatio * 2)
+    s->qpSettings.relTolerance = DBL_EPSILON * 16; s->qpSettings.absTolerance = DBL_EPSILON * 16;
+    s->qpSettings.maxIterations = 0;
+}
+void mir_least_squares_init_s(mir_least_squares_settings_s* s)                                         // LS:767-770
+{
+    s->maxIterations = 1000; s->maxAge = 0;
+    s->jacobianEpsilon = 0x1p-11f;           // 2 ^^ ((1 - 24) / 2), integer division
+    s->absTolerance = FLT_EPSILON; s->relTolerance = 0; s->gradTolerance = FLT_EPSILON;
+    s->maxGoodResidual = FLT_EPSILON * FLT_EPSILON;
+    s->maxStep = std::sqrt(FLT_MAX) / 16; s->maxLambda = FLT_MAX / 16; s->minLambda = FLT_MIN * 16;
+    s->minStepQuality = 0.1f; s->goodStepQuality = 0.5f; s->lambdaIncrease = 2;
+    s->lambdaDecrease = (float)0.30901699437494742410229341718281905886L;
+    s->qpSettings.relTolerance = FLT_EPSILON * 16; s->qpSettings.absTolerance = FLT_EPSILON * 16;
+    s->qpSettings.maxIterations = 0;
+}
+void mir_least_squares_reset_d(mir_least_squares_settings_d* s) { mir_least_squares_init_d(s); }        // LS:783-786
+void mir_least_squares_reset_s(mir_least_squares_settings_s* s) { mir_least_squares_init_s(s); }        // LS:789-792
+
+mir_least_squares_result_d mir_optimize_least_squares_d(                                               // LS:705-724
+    const mir_least_squares_settings_d* settings, size_t m, size_t n, double* x, const double* l, const double* u,
+    mir_slice_d work, mir_slice_i iwork, void* fContext, mir_least_squares_function_d f, void* gContext,
+    mir_least_squares_jacobian_d g, void* tmContext, mir_least_squares_thread_manager tm)
+{
+    (void)work; (void)iwork;
+    return solve_entry<double>(settings, m, n, x, l, u, nullptr, fContext, f, gContext, g, tmContext, tm);
+}
+
+mir_least_squares_result_s mir_optimize_least_squares_s(                                               // LS:729-748
+    const mir_least_squares_settings_s* settings, size_t m, size_t n, float* x, const float* l, const float* u,
+    mir_slice_s work, mir_slice_i iwork, void* fContext, mir_least_squares_function_s f, void* gContext,
+    mir_least_squares_jacobian_s g, void* tmContext, mir_least_squares_thread_manager tm)
+{
+    (void)work; (void)iwork;
+    return solve_entry<float>(settings, m, n, x, l, u, nullptr, fContext, f, gContext, g, tmContext, tm);
+}
+
+mir_least_squares_result_d mir_optimize_least_squares_gpu_d(
+    const mir_least_squares_settings_d* settings, size_t m, size_t n, double* x, const double* l, const double* u,
+    const mir_lsq_gpu_options* options, void* fContext, mir_least_squares_function_d f, void* gContext,
+    mir_least_squares_jacobian_d g, void* tmContext, mir_least_squares_thread_manager tm)
+{
+    return solve_entry<double>(settings, m, n, x, l, u, options, fContext, f, gContext, g, tmContext, tm);
+}
+
+mir_least_squares_result_s mir_optimize_least_squares_gpu_s(
+    const mir_least_squares_settings_s* settings, size_t m, size_t n, float* x, const float* l, const float* u,
+    const mir_lsq_gpu_options* options, void* fContext, mir_least_squares_function_s f, void* gContext,
+    mir_least_squares_jacobian_s g, void* tmContext, mir_least_squares_thread_manager tm)
+{
+    return solve_entry<float>(settings, m, n, x, l, u, options, fContext, f, gContext, g, tmContext, tm);
+}
+
+// ---- standalone BOXCQP ---------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+template <typename T, typename QS>
+int box_qp_entry(const QS* settings, size_t n_, const T* P, const T* q, const T* l, const T* u, T* x,
+                 int unconstrainedSolution, int* iterations)
+{
+    if (iterations) *iterations = 0;
+    if (n_ == 0) return mir_box_qp_solved;
+    if (n_ > (size_t)kSolveMaxN) { std::fprintf(stderr, "[mir_optim_amd] box qp: n > %d unsupported\n", kSolveMaxN); return mir_box_qp_numericError; }
+    if (!device_available()) return mir_box_qp_numericError;
+    const int n = (int)n_;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t oP = take(sizeof(T) * n * n), oq = take(sizeof(T) * n), ol = take(sizeof(T) * n), ou = take(sizeof(T) * n),
+                 ox = take(sizeof(T) * n), oPm = take(sizeof(T) * n * n), oA = take(sizeof(T) * n * n),
+                 oF = take(sizeof(T) * n * (n | 1)), ov = take(sizeof(T) * 12 * n), oi = take(sizeof(int32_t) * 2 * n),
+                 oo = take(sizeof(int) * 4);
+    char* base = nullptr;
+    if (hipMalloc((void**)&base, off) != hipSuccess) return mir_box_qp_numericError;
+    BoxQpArgs<T> a{};
+    a.P = (T*)(base + oP); a.q = (T*)(base + oq); a.l = (T*)(base + ol); a.u = (T*)(base + ou); a.x = (T*)(base + ox);
+    a.sc.Pm = (T*)(base + oPm); a.sc.A = (T*)(base + oA); a.sc.Fg = (T*)(base + oF); a.sc.vec = (T*)(base + ov);
+    a.sc.ivec = (int32_t*)(base + oi); a.out = (int*)(base + oo);
+    a.relTol = settings->relTolerance; a.absTol = settings->absTolerance; a.maxIterations = settings->maxIterations;
+    a.unconstrained = unconstrainedSolution; a.n = n;
+    const size_t fbytes = (size_t)(n | 1) * n * sizeof(T);
+    a.f_in_lds = fbytes <= (size_t)kSolveLdsBytes;
+    const size_t lds = a.f_in_lds ? fbytes : 0;
+    int out[2] = {mir_box_qp_numericError, 0};
+    bool good = hipMemcpy((void*)a.P, P, sizeof(T) * n * n, hipMemcpyHostToDevice) == hipSuccess
+        && hipMemcpy((void*)a.q, q, sizeof(T) * n, hipMemcpyHostToDevice) == hipSuccess
+        && hipMemcpy((void*)a.l, l, sizeof(T) * n, hipMemcpyHostToDevice) == hipSuccess
+        && hipMemcpy((void*)a.u, u, sizeof(T) * n, hipMemcpyHostToDevice) == hipSuccess
+        && hipMemcpy((void*)a.x, x, sizeof(T) * n, hipMemcpyHostToDevice) == hipSuccess;
+    if (good && lds > 48 * 1024)
+        good = hipFuncSetAttribute(reinterpret_cast<const void*>(k_box_qp<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    if (good) {
+        hipLaunchKernelGGL(k_box_qp<T>, dim3(1), dim3(kSolveThreads), lds, 0, a);
+        good = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess
+            && hipMemcpy(out, a.out, sizeof(out), hipMemcpyDeviceToHost) == hipSuccess
+            && hipMemcpy(x, a.x, sizeof(T) * n, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(base);
+    if (!good) return mir_box_qp_numericError;
+    if (iterations) *iterations = out[1];
+    return out[0];
+}
+
+template <typename T>
+int jtj_entry(size_t m, size_t n, T* J, const T* y, const T* y_old, const T* dx, int broyden, T* JJ, T* Jy,
+              void* stream_, float* kernel_ms)
+{
+    if (!device_available()) return -1;
+    if (n == 0 || n > 128 || m == 0) return -2;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const JtjPlan plan = jtj_plan<T>(m, (int)n, query_num_cu());
+    const size_t packed_len = n * (n + 1) / 2 + n + 8;
+    T *slabs = nullptr, *packed = nullptr, *dxdot = nullptr;
+    LmState<T>* st = nullptr;
+    if (hipMalloc((void**)&slabs, sizeof(T) * (size_t)plan.nblk * plan.slab_len) != hipSuccess) return -3;
+    if (hipMalloc((void**)&packed, sizeof(T) * packed_len) != hipSuccess) { (void)hipFree(slabs); return -3; }
+    if (hipMalloc((void**)&st, sizeof(LmState<T>) + sizeof(T) * 8) != hipSuccess) { (void)hipFree(slabs); (void)hipFree(packed); return -3; }
+    dxdot = reinterpret_cast<T*>(st + 1);
+    int rc = 0;
+    if (broyden) {
+        // ||dx||^2 on the device (n-vector, one block)
+        hipLaunchKernelGGL(k_sumsq_partial<T>, dim3(1), dim3(256), 0, stream, dx, n, packed);
+        hipLaunchKernelGGL(k_sumsq_final<T>, dim3(1), dim3(256), 0, stream, packed, 1, dxdot);
+    }
+    JtjArgs<T> a{};
+    a.J = J; a.Jout = J; a.y = y; a.y_old = y_old; a.dx = dx; a.dx_dot = dxdot; a.slabs = slabs; a.m = m; a.n = (int)n;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, stream);
+    if (jtj_run<T>(plan, a, broyden != 0, packed, stream) != hipSuccess) rc = -4;
+    (void)hipEventRecord(e1, stream);
+    hipLaunchKernelGGL(k_unpack_grad<T>, dim3(1), dim3(256), 0, stream, packed, (int)n, JJ, Jy, st);
+    if (hipStreamSynchronize(stream) != hipSuccess) rc = -5;
+    if (kernel_ms) { float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); *kernel_ms = ms; }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(slabs); (void)hipFree(packed); (void)hipFree(st);
+    return rc;
+}
+}  // namespace
+
+extern "C" {
+
+int mir_solve_box_qp_gpu_d(const mir_box_qp_settings_d* settings, size_t n, const double* P, const double* q,
+                           const double* l, const double* u, double* x, int unconstrainedSolution, int* iterations)
+{
+    return box_qp_entry<double>(settings, n, P, q, l, u, x, unconstrainedSolution, iterations);
+}
+int mir_solve_box_qp_gpu_s(const mir_box_qp_settings_s* settings, size_t n, const float* P, const float* q,
+                           const float* l, const float* u, float* x, int unconstrainedSolution, int* iterations)
+{
+    return box_qp_entry<float>(settings, n, P, q, l, u, x, unconstrainedSolution, iterations);
+}
+
+int mir_lsq_jtj_d(size_t m, size_t n, double* J, const double* y, const double* y_old, const double* dx, int broyden,
+                  double* JJ, double* Jy, void* stream, float* kernel_ms)
+{
+    return jtj_entry<double>(m, n, J, y, y_old, dx, broyden, JJ, Jy, stream, kernel_ms);
+}
+int mir_lsq_jtj_s(size_t m, size_t n, float* J, const float* y, const float* y_old, const float* dx, int broyden,
+                  float* JJ, float* Jy, void* stream, float* kernel_ms)
+{
+    return jtj_entry<float>(m, n, J, y, y_old, dx, broyden, JJ, Jy, stream, kernel_ms);
+}
+
+mir_lsq_workspace* mir_lsq_workspace_create(size_t m, size_t n, size_t elem_size)
+{
+    if (!device_available() || n == 0 || m == 0) return nullptr;
+    if (elem_size == 8) return workspace_create<double>(m, n);
+    if (elem_size == 4) return workspace_create<float>(m, n);
+    return nullptr;
+}
+void mir_lsq_workspace_destroy(mir_lsq_workspace* ws) { workspace_destroy(ws); }
+
+// ---- communicators ---------------------------------------------------------------------------
+int mir_lsq_rccl_unique_id(void* out)
+{
+    void* h = rccl_open();
+    if (!h) { std::fprintf(stderr, "[mir_optim_amd] librccl not found\n"); return -1; }
+    auto fn = reinterpret_cast<int (*)(NcclUniqueId*)>(dlsym(h, "ncclGetUniqueId"));
+    if (!fn) return -2;
+    return fn(static_cast<NcclUniqueId*>(out));
+}
+
+mir_lsq_comm* mir_lsq_comm_create_rccl(int nranks, int rank, const void* unique_id)
+{
+    void* h = rccl_open();
+    if (!h) { std::fprintf(stderr, "[mir_optim_amd] librccl not found\n"); return nullptr; }
+    auto init = reinterpret_cast<int (*)(void**, int, NcclUniqueId, int)>(dlsym(h, "ncclCommInitRank"));
+    auto ar = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(h, "ncclAllReduce"));
+    auto destroy = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommDestroy"));
+    if (!init || !ar || !destroy) return nullptr;
+    NcclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof id);
+    void* c = nullptr;
+    const int rc = init(&c, nranks, id, rank);
+    if (rc != 0) { std::fprintf(stderr, "[mir_optim_amd] ncclCommInitRank failed: %d\n", rc); return nullptr; }
+    auto* comm = new mir_lsq_comm();
+    comm->nranks = nranks; comm->rank = rank; comm->kind = 1; comm->lib = h; comm->nccl_comm = c;
+    comm->allreduce_fn = ar; comm->destroy_fn = destroy;
+    return comm;
+}
+
+mir_lsq_comm* mir_lsq_comm_create_callback(int nranks, int rank, mir_lsq_allreduce_fn fn, void* ctx)
+{
+    if (!fn) return nullptr;
+    auto* comm = new mir_lsq_comm();
+    comm->nranks = nranks; comm->rank = rank; comm->kind = 2; comm->cb = fn; comm->cb_ctx = ctx;
+    return comm;
+}
+
+void mir_lsq_comm_destroy(mir_lsq_comm* comm)
+{
+    if (!comm) return;
+    if (comm->kind == 1 && comm->destroy_fn && comm->nccl_comm) comm->destroy_fn(comm->nccl_comm);
+    delete comm;
+}
+
+// ---- small device utilities ------------------------------------------------------------------
+int mir_lsq_device_count(void)
+{
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt;
+}
+void* mir_lsq_device_malloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    return p;
+}
+void mir_lsq_device_free(void* p) { if (p) (void)hipFree(p); }
+int mir_lsq_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+    return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;
+}
+int mir_lsq_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;
+}
+void* mir_lsq_stream_create(void)
+{
+    hipStream_t s = nullptr;
+    if (hipStreamCreate(&s) != hipSuccess) return nullptr;
+    return s;
+}
+void mir_lsq_stream_destroy(void* stream) { if (stream) (void)hipStreamDestroy(static_cast<hipStream_t>(stream)); }
+int mir_lsq_stream_synchronize(void* stream) { return hipStreamSynchronize(static_cast<hipStream_t>(stream)) == hipSuccess ? 0 : -1; }
+const char* mir_lsq_version(void) { return "mir_optim_amd 0.1 (gfx950)"; }
+
+}  // extern "C"

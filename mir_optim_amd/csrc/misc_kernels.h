@@ -1,0 +1,217 @@
+// misc_kernels.h -- the m-vector and bookkeeping kernels of the LM pass.
+//
+// Replaces (/root/reference/source/mir/optim/least_squares.d):
+//   LS:955, LS:1115   dot(y, y)                          -> k_sumsq_partial + k_sumsq_final
+//   LS:1018-1048      finite-difference column fill      -> k_fd_points + k_fd_fill / k_fd_fill_col
+//   LS:1053           |Jy[iamax(Jy)]|                     -> k_unpack_grad
+//   LS:1117-1161      trial acceptance, rho, lambda/mu   -> k_decide
+//   LS:1103-1104      step-size guard lambda bump        -> k_bump_lambda
+#pragma once
+
+#include "common.h"
+#include "solve_kernel.h"
+
+namespace mirlsq {
+
+// ---- sum of squares, deterministic two-stage. Stage 1: gridDim.x partials.
+template <typename T>
+__global__ __launch_bounds__(256) void k_sumsq_partial(const T* __restrict__ v, size_t m, T* __restrict__ partials)
+{
+    __shared__ T red[4];
+    T s = 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    // contiguous chunk per block keeps the summation order independent of the grid-stride pattern
+    const size_t per = (m + gridDim.x - 1) / gridDim.x;
+    const size_t b0 = (size_t)blockIdx.x * per;
+    const size_t b1 = b0 + per < m ? b0 + per : m;
+    (void)stride;
+    for (size_t i = b0 + threadIdx.x; i < b1; i += blockDim.x) { const T t = v[i]; s += t * t; }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Stage 2: one block sums the partials in a fixed order into *out.
+template <typename T>
+__global__ __launch_bounds__(256) void k_sumsq_final(const T* __restrict__ partials, int nparts, T* __restrict__ out)
+{
+    __shared__ T red[4];
+    T s = 0;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += partials[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---- LS:953-971: state at entry. *sum = ||f(x0)||^2 (already all-reduced).
+template <typename T>
+__global__ void k_init_state(const T* sum, LmState<T>* st)
+{
+    LmState<T> s{};
+    s.lambda = 0;            // LS:966 (no warm start, quirk Q11)
+    s.mu = 1;                // LS:969
+    s.residual = *sum;       // LS:955
+    *st = s;
+}
+
+// ---- packed [JJ lower | Jy] -> full symmetric JJ, Jy, ||Jy||_inf (LS:1053).
+template <typename T>
+__global__ __launch_bounds__(256) void k_unpack_grad(const T* __restrict__ packed, int n, T* __restrict__ JJ,
+                                                     T* __restrict__ Jy, LmState<T>* st)
+{
+    __shared__ T red[4];
+    for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
+        const int i = idx / n, j = idx % n;
+        const int r = i >= j ? i : j, c = i >= j ? j : i;
+        JJ[idx] = packed[(size_t)r * (r + 1) / 2 + c];
+    }
+    T mx = 0;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        const T v = packed[(size_t)n * (n + 1) / 2 + j];
+        Jy[j] = v;
+        const T av = dabs(v);
+        // i?amax never selects a NaN after the first element; mirror "!(x > tol)" semantics by
+        // keeping NaN out of the max unless everything is NaN
+        if (av > mx) mx = av;
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T r = red[0];
+        for (int w = 1; w < 4; ++w) r = red[w] > r ? red[w] : r;
+        st->jy_inf = r;
+    }
+}
+
+// ---- finite-difference points, LS:1027-1031: X[2j] = x with x_j = min(x_j + eps, u_j),
+//      X[2j+1] = x with x_j = max(x_j - eps, l_j); twh[j] = xph - xmh.
+template <typename T>
+__global__ void k_fd_points(const T* __restrict__ x, const T* __restrict__ lower, const T* __restrict__ upper,
+                            T eps, int n, T* __restrict__ X, T* __restrict__ twh)
+{
+    const int j = blockIdx.x;
+    const T save = x[j];
+    T xmh = save - eps, xph = save + eps;
+    xmh = dfmax(xmh, lower[j]);
+    xph = dfmin(xph, upper[j]);
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        const T xv = x[k];
+        X[(size_t)(2 * j) * n + k] = k == j ? xph : xv;
+        X[(size_t)(2 * j + 1) * n + k] = k == j ? xmh : xv;
+    }
+    if (threadIdx.x == 0) twh[j] = xph - xmh;
+}
+
+// ---- LS:1037-1046 for a panel of columns [j0, j0 + pc): J[i][j] = (Y[2(j-j0)][i] - Y[2(j-j0)+1][i]) * (1 / twh[j])
+//      (zero when twh == 0). Y rows are m-vectors, row stride ldy. LDS transpose so that both the
+//      reads (along i) and the writes (along j) are coalesced. grid = (ceil(m/64), ceil(pc/32)).
+template <typename T>
+__global__ __launch_bounds__(256) void k_fd_fill(const T* __restrict__ Y, size_t ldy, const T* __restrict__ twh,
+                                                 T* __restrict__ J, size_t m, int n, int j0, int pc)
+{
+    __shared__ T tile[32][65];
+    const size_t i0 = (size_t)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 32;
+    const int lane = threadIdx.x & 63, cw = threadIdx.x >> 6;
+    for (int c = cw; c < 32; c += 4) {
+        const int cc = c0 + c;
+        T v = 0;
+        if (cc < pc && i0 + lane < m) {
+            const T t = twh[j0 + cc];
+            if (t != 0) {
+                const T a = Y[(size_t)(2 * cc) * ldy + i0 + lane];
+                const T b = Y[(size_t)(2 * cc + 1) * ldy + i0 + lane];
+                T d = a;          // copy(mBuffer, Jj)
+                d += T(-1) * b;   // axpy(-1, mBuffer, Jj)
+                v = d * (T(1) / t);   // scal(1 / twh, Jj)
+            }
+        }
+        tile[c][lane] = v;
+    }
+    __syncthreads();
+    const int ncol = (pc - c0) < 32 ? (pc - c0) : 32;
+    for (int idx = threadIdx.x; idx < 64 * 32; idx += 256) {
+        const int r = idx >> 5, c = idx & 31;
+        if (c < ncol && i0 + r < m) J[(i0 + r) * (size_t)n + j0 + c0 + c] = tile[c][r];
+    }
+}
+
+// single strided column (host-callback mode): J[:, j] = (yp - ym) * (1/twh) or 0
+template <typename T>
+__global__ __launch_bounds__(256) void k_fd_fill_col(const T* __restrict__ yp, const T* __restrict__ ym, T twh,
+                                                     T* __restrict__ J, size_t m, int n, int j)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    T v = 0;
+    if (twh != 0) { T d = yp[i]; d += T(-1) * ym[i]; v = d * (T(1) / twh); }
+    J[i * (size_t)n + j] = v;
+}
+
+// ---- LS:1117-1161: the floating-point side of step acceptance. One block of kSolveThreads.
+//      *trial_sum = ||f(trial)||^2 (already all-reduced). On acceptance x <- trial (LS:1135).
+template <typename T>
+__global__ __launch_bounds__(kSolveThreads) void k_decide(const T* trial_sum, LmState<T>* st, LmSettingsDev<T> set,
+                                                          T* x, const T* trial, int n)
+{
+    __shared__ int dec_s;
+    if (threadIdx.x == 0) {
+        LmState<T> s = *st;
+        const T tr = *trial_sum;
+        s.trial_residual = tr;
+        int dec;
+        if (!(tr <= Lim<T>::inf())) {                                 // LS:1117-1122
+            dec = kDecideNumericError;
+            s.flags |= kFlagTrialNotFinite;
+        } else {
+            const T improvement = s.residual - tr;                    // LS:1124
+            s.improvement = improvement;
+            if (!(improvement > 0)) {                                 // LS:1125-1130
+                s.lambda *= set.lambdaIncrease * s.mu;
+                s.mu *= 2;
+                dec = kDecideReject;
+            } else {                                                  // LS:1132-1139
+                s.mu = 1;
+                s.iterations++;
+                s.residual = tr;
+                s.dx_dot = s.new_dx_dot;
+                if (!(s.predicted > 0)) {                             // LS:1144-1148
+                    dec = kDecideAcceptNoPrediction;
+                } else {
+                    const T rho = s.predicted / improvement;          // LS:1150 (quirk Q2)
+                    s.rho = rho;
+                    if (rho < set.minStepQuality) {                   // LS:1152-1156
+                        s.lambda *= set.lambdaIncrease * s.mu;
+                        s.mu *= 2;
+                    } else if (rho >= set.goodStepQuality) {          // LS:1158-1161
+                        s.lambda = dfmax(set.lambdaDecrease * s.lambda * s.mu, set.minLambda);
+                    }
+                    dec = kDecideAccept;
+                }
+            }
+        }
+        s.decision = dec;
+        *st = s;
+        dec_s = dec;
+    }
+    __syncthreads();
+    if ((dec_s == kDecideAccept || dec_s == kDecideAcceptNoPrediction) && threadIdx.x < n)
+        x[threadIdx.x] = trial[threadIdx.x];                          // LS:1135
+}
+
+// ---- LS:1103-1104 (also used for nothing else): lambda *= lambdaIncrease * mu; mu *= 2
+template <typename T>
+__global__ void k_bump_lambda(LmState<T>* st, T lambdaIncrease)
+{
+    st->lambda *= lambdaIncrease * st->mu;
+    st->mu *= 2;
+}
+
+// ---- LS:984-989: forced refresh resets mu
+template <typename T>
+__global__ void k_reset_mu(LmState<T>* st) { st->mu = 1; }
+
+}  // namespace mirlsq

@@ -1,0 +1,516 @@
+// solve_kernel.h -- the n x n part of one LM pass as ONE single-workgroup kernel:
+//   damping (lambda_0, P = J^T J + lambda I), step bounds, the bound-constrained QP
+//   (equilibrated Cholesky solve with iterative refinement == LAPACK ?posvx('E','L'), then the
+//   BOXCQP active-set loop when a bound is violated), step rounding, trial point, predicted
+//   reduction and the guards of the reference.
+//
+// Replaces (/root/reference/source/mir/optim/):
+//   least_squares.d:1067-1079, 1087-1110, 1141-1142, 1164 (nrm2)      -> k_lm_solve
+//   boxcqp.d:122-379 (solveBoxQP), 404-410 (applyBounds)              -> box_qp_device
+//   mir-lapack posvx (un-vendored; Netlib ?posvx = ?poequ + ?laqsy + ?potrf + ?potrs + ?porfs)
+//                                                                     -> posvx_device
+// The reciprocal-condition estimate (?pocon) and the forward-error bound of ?porfs are not
+// computed: they only feed rcond/ferr and `info == n + 1`, which the reference ignores
+// (boxcqp.d:212, 323), so no result depends on them.
+//
+// MI355X mapping: one 256-thread workgroup; the Cholesky factor lives in LDS, column-major with an
+// odd leading dimension (both column and row walks are bank-conflict-free) when it fits
+// (n <= 128 in f64), else in an L2-resident global scratch; triangular solves run on one wave with
+// the vector in registers (no workgroup barrier on the critical path).
+#pragma once
+
+#include "common.h"
+
+namespace mirlsq {
+
+constexpr int kSolveThreads = 256;
+constexpr int kSolveMaxN = 256;          // n-vectors are handled one element per thread
+constexpr int kSolveLdsBytes = 150 * 1024;
+
+// Device-resident scalars of the LM loop. The host mirrors it after each decision point.
+template <typename T>
+struct LmState {
+    T lambda, mu, residual, trial_residual;
+    T dx_dot, new_dx_dot, predicted, trial_xnorm;
+    T jy_inf, improvement, rho, pad0;
+    int32_t qp_status, qp_iterations, flags, decision;
+    uint32_t iterations, pad1, pad2, pad3;
+};
+enum : int32_t { kFlagDxNaN = 1, kFlagXNaN = 2, kFlagStepTooLong = 4, kFlagTrialNotFinite = 8, kFlagGradSmall = 16 };
+enum : int32_t {
+    kDecideNone = 0, kDecideReject = 1, kDecideAccept = 2, kDecideAcceptNoPrediction = 3,
+    kDecideNumericError = 4
+};
+
+template <typename T>
+struct LmSettingsDev {   // the floating-point part of LeastSquaresSettings!T (LS:85-123)
+    T jacobianEpsilon, absTolerance, relTolerance, gradTolerance, maxGoodResidual, maxStep, maxLambda,
+      minLambda, minStepQuality, goodStepQuality, lambdaIncrease, lambdaDecrease, qpRelTolerance, qpAbsTolerance;
+    uint32_t qpMaxIterations, pad;
+};
+
+template <typename T>
+struct SolveScratch {    // global scratch, all L2 resident
+    T* Pm;      // n x n, P = JJ + lambda I, full symmetric (unscaled; BOXCQP reads it)
+    T* A;       // n x n, the (possibly equilibrated) matrix handed to posvx, full symmetric
+    T* Fg;      // n x (n|1) factor when it does not fit LDS
+    T* vec;     // 12 n-vectors: s, b, r, w, la, mu, sX, qpl, qpu, q, xq, spare
+    int32_t* ivec;  // 2 n: SI, flags
+};
+
+// ---------------------------------------------------------------- workgroup collectives
+template <typename T, typename Op>
+__device__ inline T block_reduce(T v, Op op, T* red /* >= 4 */)
+{
+#pragma unroll
+    for (int k = 1; k < kWave; k <<= 1) v = op(v, wave_shfl_xor(v, k));
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    T r = red[0];
+#pragma unroll
+    for (int w = 1; w < kSolveThreads / kWave; ++w) r = op(r, red[w]);
+    return r;
+}
+template <typename T> __device__ inline T block_sum(T v, T* red) { return block_reduce(v, [](T a, T b) { return a + b; }, red); }
+template <typename T> __device__ inline T block_max(T v, T* red) { return block_reduce(v, [](T a, T b) { return a > b ? a : b; }, red); }
+template <typename T> __device__ inline T block_min(T v, T* red) { return block_reduce(v, [](T a, T b) { return a < b ? a : b; }, red); }
+__device__ inline int block_or(int v, int* red)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) *red = 0;
+    __syncthreads();
+    if (v) atomicOr(red, v);
+    __syncthreads();
+    return *red;
+}
+
+// ---------------------------------------------------------------- ?potrs 'L' on one wave
+// F column-major (F(i,k) at F[i + k*ldf]), lower. xv: the right-hand side / solution in memory
+// visible to the workgroup. Must be called by all threads; wave 0 works, then a barrier.
+template <typename T>
+__device__ inline void potrs_wave(int n, const T* F, int ldf, T* xv)
+{
+    constexpr int K = kSolveMaxN / kWave;   // elements per lane
+    __syncthreads();
+    if (threadIdx.x < kWave) {
+        const int lane = threadIdx.x;
+        T xr[K];
+#pragma unroll
+        for (int t = 0; t < K; ++t) { const int k = lane + kWave * t; xr[t] = k < n ? xv[k] : T(0); }
+        // forward: L z = b
+        for (int i = 0; i < n; ++i) {
+            T col[K];
+#pragma unroll
+            for (int t = 0; t < K; ++t) { const int k = lane + kWave * t; col[t] = (k > i && k < n) ? F[k + (size_t)i * ldf] : T(0); }
+            const T dii = F[i + (size_t)i * ldf];
+            T xi = 0;
+#pragma unroll
+            for (int t = 0; t < K; ++t) if ((i >> 6) == t) xi = __shfl(xr[t], i & 63, kWave);
+            xi = xi / dii;
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                const int k = lane + kWave * t;
+                if (k == i) xr[t] = xi;
+                xr[t] -= col[t] * xi;
+            }
+        }
+        // backward: L^T x = z   (row i of L^T = column i of L read along k > i ... walk rows of L)
+        for (int i = n - 1; i >= 0; --i) {
+            T row[K];
+#pragma unroll
+            for (int t = 0; t < K; ++t) { const int k = lane + kWave * t; row[t] = (k < i) ? F[i + (size_t)k * ldf] : T(0); }
+            const T dii = F[i + (size_t)i * ldf];
+            T xi = 0;
+#pragma unroll
+            for (int t = 0; t < K; ++t) if ((i >> 6) == t) xi = __shfl(xr[t], i & 63, kWave);
+            xi = xi / dii;
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                const int k = lane + kWave * t;
+                if (k == i) xr[t] = xi;
+                xr[t] -= row[t] * xi;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < K; ++t) { const int k = lane + kWave * t; if (k < n) xv[k] = xr[t]; }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------- ?posvx('E','L'), nrhs = 1
+// A: n x n full symmetric, leading dimension lda (overwritten by its equilibrated form).
+// b: right-hand side (overwritten by the scaled rhs). x: solution. s,r,w: n-vectors.
+// F/ldf: factor storage (LDS or global). Returns info (0 = ok, k > 0 = leading minor k not
+// positive definite). Collective over the workgroup.
+template <typename T>
+__device__ int posvx_device(int n, T* A, int lda, T* F, int ldf, T* s, T* b, T* x, T* r, T* w, T* red)
+{
+    const int tid = threadIdx.x;
+    const T eps = Lim<T>::eps / 2;              // dlamch('Epsilon')
+    const T safmin = Lim<T>::min_normal;        // dlamch('Safe minimum')
+
+    // ?poequ
+    T di = tid < n ? A[tid + (size_t)tid * lda] : T(0);
+    const T smin = block_min(tid < n ? di : Lim<T>::inf(), red);
+    const T amax = block_max(tid < n ? di : -Lim<T>::inf(), red);
+    bool rcequ = false;
+    if (smin > 0) {
+        const T scond = dsqrt(smin) / dsqrt(amax);
+        if (tid < n) s[tid] = T(1) / dsqrt(di);
+        // ?laqsy
+        const T small = safmin / Lim<T>::eps, large = T(1) / small;
+        rcequ = !(scond >= T(0.1) && amax >= small && amax <= large);
+    }
+    __syncthreads();
+    if (rcequ) {
+        for (int idx = tid; idx < n * n; idx += kSolveThreads) {
+            const int i = idx % n, j = idx / n;
+            A[i + (size_t)j * lda] = s[j] * s[i] * A[i + (size_t)j * lda];
+        }
+        if (tid < n) b[tid] = s[tid] * b[tid];
+    }
+    __syncthreads();
+
+    // ?lacpy + ?potrf 'L' (right-looking, two barriers per column)
+    for (int idx = tid; idx < n * n; idx += kSolveThreads) {
+        const int i = idx % n, j = idx / n;
+        if (i >= j) F[i + (size_t)j * ldf] = A[i + (size_t)j * lda];
+    }
+    __syncthreads();
+    const int tx = tid & 63, ty = tid >> 6;
+    for (int j = 0; j < n; ++j) {
+        const T ajj = F[j + (size_t)j * ldf];
+        if (!(ajj > 0)) return j + 1;           // uniform: every thread reads the same value
+        const T d = dsqrt(ajj);
+        for (int i = j + 1 + tid; i < n; i += kSolveThreads) F[i + (size_t)j * ldf] /= d;
+        __syncthreads();
+        // F(j,j) is not read by the trailing update, so it can be overwritten in this phase
+        if (tid == 0) F[j + (size_t)j * ldf] = d;
+        for (int k = j + 1 + ty; k < n; k += kSolveThreads / kWave) {
+            const T fkj = F[k + (size_t)j * ldf];
+            for (int i = k + tx; i < n; i += kWave) F[i + (size_t)k * ldf] -= F[i + (size_t)j * ldf] * fkj;
+        }
+        __syncthreads();
+    }
+
+    // ?potrs
+    if (tid < n) x[tid] = b[tid];
+    potrs_wave(n, F, ldf, x);
+
+    // ?porfs: iterative refinement, ITMAX = 5
+    const T safe1 = T(n + 1) * safmin, safe2 = safe1 / eps;
+    T lstres = 3;
+    for (int count = 1;; ++count) {
+        // r = b - A x ; w = |b| + |A| |x|      (two threads per row)
+        {
+            const int i = tid >> 1, h = tid & 1;
+            T ri = 0, wi = 0;
+            if (i < n) {
+                const int k0 = h ? n / 2 : 0, k1 = h ? n : n / 2;
+                for (int k = k0; k < k1; ++k) {
+                    const T aik = A[i + (size_t)k * lda];
+                    const T xk = x[k];
+                    ri -= aik * xk;
+                    wi += dabs(aik) * dabs(xk);
+                }
+            }
+            ri += wave_shfl_xor(ri, 1);
+            wi += wave_shfl_xor(wi, 1);
+            if (i < n && h == 0) { r[i] = b[i] + ri; w[i] = dabs(b[i]) + wi; }
+        }
+        if (n > kSolveThreads / 2) {   // rows beyond the first 128 (n <= 256)
+            __syncthreads();
+            const int i = kSolveThreads / 2 + (tid >> 1), h = tid & 1;
+            T ri = 0, wi = 0;
+            if (i < n) {
+                const int k0 = h ? n / 2 : 0, k1 = h ? n : n / 2;
+                for (int k = k0; k < k1; ++k) {
+                    const T aik = A[i + (size_t)k * lda];
+                    const T xk = x[k];
+                    ri -= aik * xk;
+                    wi += dabs(aik) * dabs(xk);
+                }
+            }
+            ri += wave_shfl_xor(ri, 1);
+            wi += wave_shfl_xor(wi, 1);
+            if (i < n && h == 0) { r[i] = b[i] + ri; w[i] = dabs(b[i]) + wi; }
+        }
+        __syncthreads();
+        T qv = 0;
+        if (tid < n) qv = (w[tid] > safe2) ? dabs(r[tid]) / w[tid] : (dabs(r[tid]) + safe1) / (w[tid] + safe1);
+        const T berr = block_max(qv, red);
+        if (berr > eps && 2 * berr <= lstres && count <= 5) {
+            potrs_wave(n, F, ldf, r);
+            if (tid < n) x[tid] += r[tid];
+            lstres = berr;
+            __syncthreads();
+            continue;
+        }
+        break;
+    }
+    if (rcequ && tid < n) x[tid] = s[tid] * x[tid];
+    __syncthreads();
+    return 0;
+}
+
+// ---------------------------------------------------------------- solveBoxQP, boxcqp.d:122-379
+// Pm: n x n full symmetric (unscaled). q, l, u: n-vectors. x: in/out (holds the unconstrained
+// solution on entry when skip_unconstrained). Returns BoxQPStatus; *iters = active-set passes.
+template <typename T>
+__device__ int box_qp_device(int n, const T* Pm, const T* q, const T* l, const T* u, T* x,
+                             bool unconstrainedSolution, T relTol, T absTol, uint32_t maxIterations,
+                             SolveScratch<T>& sc, T* F, int ldf, T* red, int* ired, int* iters)
+{
+    const int tid = threadIdx.x;
+    T* s = sc.vec;
+    T* b = sc.vec + 1 * (size_t)n;
+    T* r = sc.vec + 2 * (size_t)n;
+    T* w = sc.vec + 3 * (size_t)n;
+    T* la = sc.vec + 4 * (size_t)n;
+    T* mu = sc.vec + 5 * (size_t)n;
+    T* sX = sc.vec + 6 * (size_t)n;
+    int32_t* SI = sc.ivec;
+    int32_t* flags = sc.ivec + n;
+    *iters = 0;
+    if (n == 0) return 0;                                           // QP:162-163
+
+    if (!unconstrainedSolution) {                                   // QP:168-214
+        for (int idx = tid; idx < n * n; idx += kSolveThreads) sc.A[idx] = Pm[idx];   // QP:186-189
+        if (tid < n) b[tid] = -q[tid];                              // QP:191
+        __syncthreads();
+        const int info = posvx_device(n, sc.A, n, F, ldf, s, b, x, r, w, red);
+        if (info != 0) return 1;                                    // QP:212-213 (info == n+1 is never produced)
+    }
+
+    {                                                               // QP:216-219
+        int bad = 0;
+        if (tid < n) bad = !(l[tid] <= x[tid] && x[tid] <= u[tid]);
+        if (!block_or(bad, ired)) return 0;
+    }
+
+    if (!maxIterations) maxIterations = (uint32_t)n * 10 + 100;     // QP:224-226
+    if (tid < n) { la[tid] = 0; mu[tid] = 0; }                      // QP:228-232
+    __syncthreads();
+
+    for (uint32_t step = 0; step < maxIterations; ++step) {         // QP:234
+        *iters = (int)step + 1;
+        // classification, QP:239-263 (element-parallel; the free-set list SI is built by a
+        // ballot prefix sum, which preserves the reference's ascending order)
+        int fl = 2;   // 2 = not an element
+        if (tid < n) {
+            const T xi = x[tid], li = l[tid], ui = u[tid];
+            const T xl = xi - li, ux = ui - xi;
+            if (xl < 0 || (xl < relTol + absTol * dabs(li) && la[tid] >= 0)) { fl = -1; x[tid] = li; mu[tid] = 0; }
+            else if (ux < 0 || (ux < relTol + absTol * dabs(ui) && mu[tid] >= 0)) { fl = 1; x[tid] = ui; la[tid] = 0; }
+            else { fl = 0; mu[tid] = 0; la[tid] = 0; }
+            flags[tid] = fl;
+        }
+        const unsigned long long bal = __ballot(fl == 0);
+        const int wave = tid >> 6, lane = tid & 63;
+        __syncthreads();
+        if (lane == 0) ired[1 + wave] = __popcll(bal);
+        __syncthreads();
+        int base = 0;
+        for (int wv = 0; wv < wave; ++wv) base += ired[1 + wv];
+        int sN = 0;
+        for (int wv = 0; wv < kSolveThreads / kWave; ++wv) sN += ired[1 + wv];
+        if (fl == 0) SI[base + __popcll(bal & ((1ull << lane) - 1))] = tid;
+        __syncthreads();
+        if (sN == n) break;                                         // QP:265-266 (quirk Q8)
+
+        // reduced system, QP:282-305: thread ii assembles row ii of A_s and b_ii with a
+        // Kahan-Babuska-Neumaier sum over the bound variables, j ascending as in the reference
+        if (tid < sN) {
+            const int i = SI[tid];
+            T ks = q[i], kc = 0;
+            int jj = 0;
+            for (int j = 0; j < n; ++j) {
+                const T pij = Pm[(size_t)j * n + i];
+                const int fj = flags[j];
+                if (fj) {
+                    const T v = pij * (fj < 0 ? l[j] : u[j]);
+                    const T t = ks + v;
+                    if (dabs(ks) >= dabs(v)) kc += (ks - t) + v; else kc += (v - t) + ks;
+                    ks = t;
+                } else {
+                    sc.A[(size_t)jj * sN + tid] = pij;              // A_s(tid, jj) (symmetric)
+                    ++jj;
+                }
+            }
+            b[tid] = -(ks + kc);
+        }
+        __syncthreads();
+        if (sN) {                                                   // QP:307-325
+            const int info = posvx_device(sN, sc.A, sN, F, ldf, s, b, sX, r, w, red);
+            if (info != 0) return 1;
+        }
+        if (tid < sN) x[SI[tid]] = sX[tid];                         // QP:327-329
+        __syncthreads();
+
+        // multipliers, QP:333-337
+        if (tid < n && flags[tid]) {
+            T v1 = 0, v2 = 0;
+            for (int j = 0; j < tid; ++j) v1 += Pm[(size_t)j * n + tid] * x[j];
+            for (int j = tid; j < n; ++j) v2 += Pm[(size_t)j * n + tid] * x[j];
+            const T val = v1 + v2 + q[tid];
+            if (flags[tid] < 0) la[tid] = val; else mu[tid] = -val;
+        }
+        __syncthreads();
+        int again = 0;                                              // QP:339-347
+        if (tid < n) {
+            const int fi = flags[tid];
+            if (fi < 0) again = !(la[tid] >= 0);
+            else if (fi > 0) again = !(mu[tid] >= 0);
+            else again = !(x[tid] >= l[tid] && x[tid] <= u[tid]);
+        }
+        if (block_or(again, ired)) continue;
+
+        if (tid < n) x[tid] = dfmax(dfmin(x[tid], u[tid]), l[tid]); // QP:349 applyBounds
+        __syncthreads();
+        return 0;
+    }
+    return 2;                                                       // QP:378
+}
+
+// ---------------------------------------------------------------- one LM pass, n x n part
+template <typename T>
+struct LmSolveArgs {
+    const T* JJ;       // n x n full symmetric, undamped
+    const T* Jy;       // n
+    const T* x;        // n current point
+    const T* lower;    // n
+    const T* upper;    // n
+    T* dx;             // n out: rounded step (LS:1096-1097)
+    T* trial;          // n out: clamp(x + dx) (LS:1108-1110)
+    LmState<T>* st;
+    LmSettingsDev<T> set;
+    SolveScratch<T> sc;
+    int n;
+    int f_in_lds;
+    int check_grad;    // a new Jy was just computed: apply the gradient test LS:1053 first
+};
+
+template <typename T>
+__global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ T red[8];
+    __shared__ int ired[8];
+    const int n = a.n, tid = threadIdx.x;
+    const int ldf = n | 1;
+    T* F = a.f_in_lds ? reinterpret_cast<T*>(smem_raw) : a.sc.Fg;
+    T* qpl = a.sc.vec + 7 * (size_t)n;
+    T* qpu = a.sc.vec + 8 * (size_t)n;
+    T* xq = a.sc.vec + 10 * (size_t)n;
+
+    // gradient test, LS:1053: stop before touching lambda when ||Jy||_inf <= gradTolerance
+    if (a.check_grad && !(a.st->jy_inf > a.set.gradTolerance)) {
+        if (tid == 0) { a.st->flags = kFlagGradSmall; a.st->qp_status = 0; a.st->qp_iterations = 0; }
+        return;
+    }
+
+    // lambda_0, LS:1067-1072 (first element of maximum |diag|, as i?amax picks it)
+    T lambda = a.st->lambda;
+    if (!(lambda >= a.set.minLambda)) {
+        const T dg = tid < n ? dabs(a.JJ[(size_t)tid * n + tid]) : T(-1);
+        const T mx = block_max(dg, red);
+        int cand = (tid < n && dg == mx) ? tid : 0x7fffffff;
+#pragma unroll
+        for (int k = 1; k < kWave; k <<= 1) { const int o = __shfl_xor(cand, k, kWave); cand = o < cand ? o : cand; }
+        __syncthreads();
+        if ((tid & 63) == 0) ired[4 + (tid >> 6)] = cand;
+        __syncthreads();
+        int first = ired[4];
+        for (int wv = 1; wv < kSolveThreads / kWave; ++wv) first = ired[4 + wv] < first ? ired[4 + wv] : first;
+        lambda = T(0.001) * a.JJ[(size_t)first * n + first];
+        if (!(lambda >= a.set.minLambda)) lambda = 1;
+    }
+
+    // step bounds LS:1074-1077, P = JJ + lambda I LS:1078-1079 (JJ itself is never modified, so
+    // the save/restore of its diagonal at LS:1078/1094 is not needed)
+    if (tid < n) { qpl[tid] = a.lower[tid] - a.x[tid]; qpu[tid] = a.upper[tid] - a.x[tid]; }
+    for (int idx = tid; idx < n * n; idx += kSolveThreads) {
+        const int i = idx / n, j = idx % n;
+        T v = a.JJ[idx];
+        if (i == j) v += lambda;
+        a.sc.Pm[idx] = v;
+    }
+    __syncthreads();
+
+    int qp_iters = 0;
+    const int qp = box_qp_device(n, a.sc.Pm, a.Jy, qpl, qpu, xq, false, a.set.qpRelTolerance, a.set.qpAbsTolerance,
+                                 a.set.qpMaxIterations, a.sc, F, ldf, red, ired, &qp_iters);   // LS:1080
+
+    int flags = 0;
+    T ndd = 0, pred = 0, xn = 0;
+    if (qp == 0) {
+        T d = 0, tr = 0;
+        if (tid < n) {
+            d = xq[tid];
+            if (!(d <= d)) flags = kFlagDxNaN;                       // LS:1087
+            const T xi = a.x[tid];
+            d = d + xi;                                              // LS:1096
+            d = d - xi;                                              // LS:1097
+            a.dx[tid] = d;
+            tr = dfmax(dfmin(d + xi, a.upper[tid]), a.lower[tid]);   // LS:1108-1110
+            a.trial[tid] = tr;
+            if (!(tr <= tr)) flags |= kFlagXNaN;
+        }
+        flags = block_or(flags, ired);
+        ndd = block_sum(d * d, red);                                 // LS:1099
+        // predicted reduction with the UNDAMPED JJ, LS:1141-1142: t = JJ dx + 2 Jy ; pred = -(t . dx)
+        T ti = 0;
+        if (tid < n) {
+            for (int j = 0; j < n; ++j) ti += a.JJ[(size_t)j * n + tid] * a.dx[j];
+            ti = ti + 2 * a.Jy[tid];
+            ti = ti * d;
+        }
+        pred = -block_sum(ti, red);
+        // ||trial||_2 for the relTolerance test, LS:1164 (scaled like ?nrm2)
+        const T amx = block_max(dabs(tr), red);
+        T sc2 = 0;
+        if (tid < n && amx > 0) { const T v = tr / amx; sc2 = v * v; }
+        xn = amx > 0 ? amx * dsqrt(block_sum(sc2, red)) : T(0);
+        if (!(dsqrt(ndd) < a.set.maxStep)) flags |= kFlagStepTooLong; // LS:1101
+    }
+    if (tid == 0) {
+        a.st->lambda = lambda;
+        a.st->qp_status = qp;
+        a.st->qp_iterations = qp_iters;
+        a.st->flags = flags;
+        a.st->new_dx_dot = ndd;
+        a.st->predicted = pred;
+        a.st->trial_xnorm = xn;
+    }
+}
+
+// standalone BOXCQP (mir_solve_box_qp_gpu_*)
+template <typename T>
+struct BoxQpArgs {
+    const T* P; const T* q; const T* l; const T* u; T* x;
+    T relTol, absTol; uint32_t maxIterations; int unconstrained;
+    SolveScratch<T> sc; int n; int f_in_lds; int* out;   // out[0] = status, out[1] = iterations
+};
+template <typename T>
+__global__ __launch_bounds__(kSolveThreads) void k_box_qp(BoxQpArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ T red[8];
+    __shared__ int ired[8];
+    const int n = a.n;
+    T* F = a.f_in_lds ? reinterpret_cast<T*>(smem_raw) : a.sc.Fg;
+    // symmetrise the lower triangle (QP:109: only the lower triangle of P is meaningful)
+    for (int idx = threadIdx.x; idx < n * n; idx += kSolveThreads) {
+        const int i = idx / n, j = idx % n;
+        a.sc.Pm[idx] = i >= j ? a.P[(size_t)i * n + j] : a.P[(size_t)j * n + i];
+    }
+    __syncthreads();
+    int it = 0;
+    const int st = box_qp_device(n, a.sc.Pm, a.q, a.l, a.u, a.x, a.unconstrained != 0, a.relTol, a.absTol,
+                                 a.maxIterations, a.sc, F, n | 1, red, ired, &it);
+    if (threadIdx.x == 0) { a.out[0] = st; a.out[1] = it; }
+}
+
+}  // namespace mirlsq

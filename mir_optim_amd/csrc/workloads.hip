@@ -1,0 +1,231 @@
+// workloads.hip -- DEVICE residual callbacks for the synthetic workloads of SURVEY.md section 8d
+// (the "user code" side of the boundary: these play the role of the caller's f / g / batched f,
+// LeastSquaresFunctionBetterC at /root/reference/source/mir/optim/least_squares.d:78-80, with the
+// device-pointer contract of MIR_LSQ_DEVICE_CALLBACKS). Built as a separate shared library
+// (libmir_optim_amd_workloads.so) so the solver library stays free of model code.
+//
+// Also holds the host-side counter RNG u(k) = (splitmix64(seed + k) >> 11) * 2^-53 used to build
+// bit-identical inputs for the GPU run and the CPU baseline.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+
+namespace {
+
+constexpr int kWave = 64;
+
+template <typename T> __device__ inline T sum16(T v)
+{
+    v += __shfl_xor(v, 1, kWave);
+    v += __shfl_xor(v, 2, kWave);
+    v += __shfl_xor(v, 4, kWave);
+    v += __shfl_xor(v, 8, kWave);
+    return v;
+}
+
+__device__ inline double dtanh(double v) { return tanh(v); }
+__device__ inline float dtanh(float v) { return tanhf(v); }
+__device__ inline double dexp(double v) { return exp(v); }
+__device__ inline float dexp(float v) { return expf(v); }
+
+// ---- tanh-linear: y_i = tanh(a_i . x) - b_i.  A wave handles 4 rows per step; lane (q, p) reads
+//      A[4g + q][16 c + p], i.e. every 16-lane group streams one full 128-byte line per load.
+//      MODE 0: residual; MODE 1: analytic Jacobian row (1 - tanh^2) a_i.
+template <typename T, int NCB, int MODE>
+__global__ __launch_bounds__(256) void k_tanh_linear(const T* __restrict__ A, const T* __restrict__ b,
+                                                     const T* __restrict__ x, T* __restrict__ out, size_t m, int n)
+{
+    const int lane = threadIdx.x & 63;
+    const int q = lane >> 4, p = lane & 15;
+    T xr[NCB];
+    int coff[NCB];
+    bool cok[NCB];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+        const int col = 16 * c + p;
+        cok[c] = col < n;
+        coff[c] = cok[c] ? col : n - 1;
+        const T t = x[coff[c]];
+        xr[c] = cok[c] ? t : T(0);
+    }
+    const size_t G = (m + 3) / 4;
+    const size_t wave_id = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t g = wave_id; g < G; g += nwaves) {
+        const size_t row = 4 * g + q;
+        const bool rok = row < m;
+        const T* rp = A + (rok ? row : m - 1) * (size_t)n;
+        T v[NCB];
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) v[c] = rp[coff[c]];
+        T s = 0;
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) s += v[c] * xr[c];
+        s = sum16(s);
+        const T t = dtanh(s);
+        if constexpr (MODE == 0) {
+            if (rok && p == 0) out[row] = t - b[row];
+        } else {
+            const T d = 1 - t * t;
+            T* op = out + (rok ? row : m - 1) * (size_t)n;
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) if (rok && cok[c]) op[coff[c]] = d * v[c];
+        }
+    }
+}
+
+template <typename T, int MODE>
+void launch_tanh_linear(const T* A, const T* b, const T* x, T* out, size_t m, int n, hipStream_t s)
+{
+    const size_t G = (m + 3) / 4;
+    size_t blocks = (G + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    const int ncb = (n + 15) / 16;
+    dim3 grid((unsigned)blocks), blk(256);
+    if (ncb <= 1) hipLaunchKernelGGL((k_tanh_linear<T, 1, MODE>), grid, blk, 0, s, A, b, x, out, m, n);
+    else if (ncb <= 2) hipLaunchKernelGGL((k_tanh_linear<T, 2, MODE>), grid, blk, 0, s, A, b, x, out, m, n);
+    else if (ncb <= 4) hipLaunchKernelGGL((k_tanh_linear<T, 4, MODE>), grid, blk, 0, s, A, b, x, out, m, n);
+    else if (ncb <= 8) hipLaunchKernelGGL((k_tanh_linear<T, 8, MODE>), grid, blk, 0, s, A, b, x, out, m, n);
+    else hipLaunchKernelGGL((k_tanh_linear<T, 16, MODE>), grid, blk, 0, s, A, b, x, out, m, n);
+}
+
+// ---- Gaussian-sum: n = 3K+1, x = [a | c | w | b]; y_i = sum_k a_k exp(-(t_i-c_k)^2/(2 w_k^2)) + b - data_i
+template <typename T>
+__global__ __launch_bounds__(256) void k_gauss_sum(const T* __restrict__ t, const T* __restrict__ data,
+                                                   const T* __restrict__ x, T* __restrict__ y, size_t m, int n)
+{
+    const int K = (n - 1) / 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (size_t)gridDim.x * blockDim.x) {
+        const T ti = t[i];
+        T s = x[3 * K];
+        for (int k = 0; k < K; ++k) {
+            const T d = ti - x[K + k], w = x[2 * K + k];
+            s += x[k] * dexp(-(d * d) / (2 * w * w));
+        }
+        y[i] = s - data[i];
+    }
+}
+
+// ---- exponential decay: kind 0: p0 exp(-t p1) - data ; kind 1: p0 exp(-t / p1) + p2 - data
+template <typename T>
+__global__ __launch_bounds__(256) void k_exp_decay(const T* __restrict__ t, const T* __restrict__ data,
+                                                   const T* __restrict__ x, T* __restrict__ y, size_t m, int kind)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (size_t)gridDim.x * blockDim.x) {
+        if (kind == 0) y[i] = x[0] * dexp(-t[i] * x[1]) - data[i];
+        else y[i] = x[0] * dexp(-t[i] / x[1]) + x[2] - data[i];
+    }
+}
+
+inline unsigned blocks_for(size_t m)
+{
+    size_t b = (m + 255) / 256;
+    if (b > 256 * 8) b = 256 * 8;
+    return (unsigned)(b ? b : 1);
+}
+
+inline uint64_t splitmix64_mix(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+}  // namespace
+
+extern "C" {
+
+// contexts: device data pointers + the stream the solver was given (mir_lsq_gpu_options.stream)
+struct wl_tanh_linear_ctx { const void* A; const void* b; void* stream; };
+struct wl_curve_ctx { const void* t; const void* data; void* stream; int kind; };
+
+void wl_tanh_linear_f_d(void* vctx, size_t m, size_t n, const double* x, double* y)
+{
+    auto* c = static_cast<wl_tanh_linear_ctx*>(vctx);
+    launch_tanh_linear<double, 0>((const double*)c->A, (const double*)c->b, x, y, m, (int)n, (hipStream_t)c->stream);
+}
+void wl_tanh_linear_g_d(void* vctx, size_t m, size_t n, const double* x, double* J)
+{
+    auto* c = static_cast<wl_tanh_linear_ctx*>(vctx);
+    launch_tanh_linear<double, 1>((const double*)c->A, (const double*)c->b, x, J, m, (int)n, (hipStream_t)c->stream);
+}
+// batched residual (mir_lsq_batched_function_d): p points. First version: one sweep per point.
+void wl_tanh_linear_fb_d(void* vctx, size_t m, size_t n, size_t p, const double* X, double* Y)
+{
+    auto* c = static_cast<wl_tanh_linear_ctx*>(vctx);
+    for (size_t k = 0; k < p; ++k)
+        launch_tanh_linear<double, 0>((const double*)c->A, (const double*)c->b, X + k * n, Y + k * m, m, (int)n, (hipStream_t)c->stream);
+}
+void wl_tanh_linear_f_s(void* vctx, size_t m, size_t n, const float* x, float* y)
+{
+    auto* c = static_cast<wl_tanh_linear_ctx*>(vctx);
+    launch_tanh_linear<float, 0>((const float*)c->A, (const float*)c->b, x, y, m, (int)n, (hipStream_t)c->stream);
+}
+void wl_tanh_linear_g_s(void* vctx, size_t m, size_t n, const float* x, float* J)
+{
+    auto* c = static_cast<wl_tanh_linear_ctx*>(vctx);
+    launch_tanh_linear<float, 1>((const float*)c->A, (const float*)c->b, x, J, m, (int)n, (hipStream_t)c->stream);
+}
+
+void wl_gauss_sum_f_d(void* vctx, size_t m, size_t n, const double* x, double* y)
+{
+    auto* c = static_cast<wl_curve_ctx*>(vctx);
+    hipLaunchKernelGGL(k_gauss_sum<double>, dim3(blocks_for(m)), dim3(256), 0, (hipStream_t)c->stream,
+                       (const double*)c->t, (const double*)c->data, x, y, m, (int)n);
+}
+void wl_gauss_sum_f_s(void* vctx, size_t m, size_t n, const float* x, float* y)
+{
+    auto* c = static_cast<wl_curve_ctx*>(vctx);
+    hipLaunchKernelGGL(k_gauss_sum<float>, dim3(blocks_for(m)), dim3(256), 0, (hipStream_t)c->stream,
+                       (const float*)c->t, (const float*)c->data, x, y, m, (int)n);
+}
+void wl_exp_decay_f_d(void* vctx, size_t m, size_t n, const double* x, double* y)
+{
+    (void)n;
+    auto* c = static_cast<wl_curve_ctx*>(vctx);
+    hipLaunchKernelGGL(k_exp_decay<double>, dim3(blocks_for(m)), dim3(256), 0, (hipStream_t)c->stream,
+                       (const double*)c->t, (const double*)c->data, x, y, m, c->kind);
+}
+void wl_exp_decay_f_s(void* vctx, size_t m, size_t n, const float* x, float* y)
+{
+    (void)n;
+    auto* c = static_cast<wl_curve_ctx*>(vctx);
+    hipLaunchKernelGGL(k_exp_decay<float>, dim3(blocks_for(m)), dim3(256), 0, (hipStream_t)c->stream,
+                       (const float*)c->t, (const float*)c->data, x, y, m, c->kind);
+}
+
+// host: out[k] = u(seed + offset + k)
+void wl_uniform(uint64_t seed, uint64_t offset, size_t count, double* out)
+{
+    for (size_t k = 0; k < count; ++k) out[k] = (double)(splitmix64_mix(seed + offset + (uint64_t)k) >> 11) * 0x1p-53;
+}
+
+// host: the tanh-linear data set of SURVEY.md 8d for rows [row_offset, row_offset + m):
+//   A_ij = (2u(10; i n + j) - 1) sqrt(3/n),  x* = 2u(11) - 1,  b = tanh(A x*) + noise (2u(12; i) - 1),
+//   x0 = x* + 0.1 (2u(13) - 1).  A: m*n, b: m, xstar: n, x0: n (host buffers).
+void wl_tanh_linear_generate(size_t m, size_t n, size_t row_offset, double noise, double* A, double* b,
+                             double* xstar, double* x0)
+{
+    const double sc = std::sqrt(3.0 / (double)n);
+    for (size_t j = 0; j < n; ++j) {
+        xstar[j] = 2 * ((double)(splitmix64_mix(11 + j) >> 11) * 0x1p-53) - 1;
+        x0[j] = xstar[j] + 0.1 * (2 * ((double)(splitmix64_mix(13 + j) >> 11) * 0x1p-53) - 1);
+    }
+#pragma omp parallel for schedule(static)
+    for (ptrdiff_t i = 0; i < (ptrdiff_t)m; ++i) {
+        const uint64_t gi = (uint64_t)row_offset + (uint64_t)i;
+        double* a = A + (size_t)i * n;
+        double s = 0;
+        for (size_t j = 0; j < n; ++j) {
+            a[j] = (2 * ((double)(splitmix64_mix(10 + gi * n + j) >> 11) * 0x1p-53) - 1) * sc;
+            s += a[j] * xstar[j];
+        }
+        b[i] = std::tanh(s) + noise * (2 * ((double)(splitmix64_mix(12 + gi) >> 11) * 0x1p-53) - 1);
+    }
+}
+
+}  // extern "C"

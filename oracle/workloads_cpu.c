@@ -22,7 +22,7 @@ static inline uint64_t splitmix64_mix(uint64_t z)
 }
 void wlc_uniform(uint64_t seed, uint64_t offset, size_t count, double* out)
 {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (count > 200000)
     for (ptrdiff_t k = 0; k < (ptrdiff_t)count; ++k)
         out[k] = (double)(splitmix64_mix(seed + offset + (uint64_t)k) >> 11) * 0x1p-53;
 }
@@ -33,7 +33,7 @@ typedef struct { const double* A; const double* b; } wlc_tanh_linear_ctx;
 void wlc_tanh_linear_f(void* vctx, size_t m, size_t n, const double* x, double* y)
 {
     const wlc_tanh_linear_ctx* c = (const wlc_tanh_linear_ctx*)vctx;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (m * n > 200000)
     for (ptrdiff_t i = 0; i < (ptrdiff_t)m; ++i) {
         const double* a = c->A + (size_t)i * n;
         double s = 0;
@@ -45,7 +45,7 @@ void wlc_tanh_linear_f(void* vctx, size_t m, size_t n, const double* x, double* 
 void wlc_tanh_linear_g(void* vctx, size_t m, size_t n, const double* x, double* J)
 {
     const wlc_tanh_linear_ctx* c = (const wlc_tanh_linear_ctx*)vctx;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (m * n > 200000)
     for (ptrdiff_t i = 0; i < (ptrdiff_t)m; ++i) {
         const double* a = c->A + (size_t)i * n;
         double s = 0;
@@ -65,7 +65,7 @@ void wlc_gauss_sum_f(void* vctx, size_t m, size_t n, const double* x, double* y)
 {
     const wlc_gauss_sum_ctx* c = (const wlc_gauss_sum_ctx*)vctx;
     const size_t K = (n - 1) / 3;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (m * n > 200000)
     for (ptrdiff_t i = 0; i < (ptrdiff_t)m; ++i) {
         double t = c->t[i], s = x[3 * K];
         for (size_t k = 0; k < K; ++k) {
