@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- LM iterations/sec on the BASELINE.json headline workload.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+Workload (cfg 3): tanh-linear synthetic NLS, r_i(x) = tanh(a_i . x) - b_i,
+m = 1e6 rows PER GPU x n = 128 parameters, fp64, finite-difference Jacobian through the user
+residual callback, defaults except absTolerance = 1e-9; rank r owns global rows
+[r * 1e6, (r + 1) * 1e6) (weak scaling; one fused RCCL all-reduce of [J^T J | J^T y] per
+Jacobian-changing pass, one scalar all-reduce per trial step).
+
+A "step" is one complete LM solve (mir_optimize_least_squares_gpu_d from x0 to termination):
+residual + FD Jacobian callbacks, Broyden updates, J^T J / J^T y, damped BOXCQP solves, step
+acceptance -- nothing is skipped or cached between solves. `value` = (accepted LM iterations of the
+K timed solves) x N / time: LM iterations per second per 1e6 x 128 row block, aggregated over ranks
+(at N = 1 it is plainly the solver's LM iterations/sec).
+
+The JSON line also carries
+  roofline     -- the solver's dominant kernel (fused Broyden + J^T J + J^T y), HIP-event timed on
+                  the solver's stream inside the timed region; algorithmic bytes = 8 (2 m n + 3 m)
+  cpu_baseline -- the oracle (CPU port of the reference algorithm, OpenBLAS for syrk/gemv/ger/posvx)
+                  on a bounded sample of the same workload, rank 0, N = 1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--m", type=int, default=1_000_000, help="rows per GPU")
+    ap.add_argument("--n", type=int, default=128)
+    ap.add_argument("--fd", choices=["batched", "serial"], default="batched",
+                    help="finite differences through the batched residual callback or one call per point")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iterations", type=int, default=6, help="accepted iterations of the CPU sample")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 64)))   # CPU baseline leg (oracle, OpenMP)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import mir_optim_amd as M
+    from mir_optim_amd import api, workloads as W
+
+    if not torch.cuda.is_available() or M.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: mir_optim_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    comm = None
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        uid = np.zeros(128, dtype=np.uint8)
+        if rank == 0 and api.lib().mir_lsq_rccl_unique_id(uid.ctypes.data) != 0:
+            raise SystemExit("ncclGetUniqueId failed")
+        t = torch.from_numpy(uid).cuda()
+        dist.broadcast(t, 0)
+        uid = t.cpu().numpy()
+        comm = api.lib().mir_lsq_comm_create_rccl(world, rank, uid.ctypes.data)
+        if not comm:
+            raise SystemExit("RCCL communicator creation failed")
+
+    m, n = args.m, args.n
+    data = W.tanh_linear_data(m, n, row_offset=rank * m)
+    prob = W.TanhLinear(data["A"], data["b"])
+    settings = M.LeastSquaresSettings()
+    settings.absTolerance = 1e-9
+    ws = api.lib().mir_lsq_workspace_create(m, n, 8)
+    if not ws:
+        raise SystemExit("workspace allocation failed")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def solve(stats=None, flags=0):
+        return prob.solve(data["x0"], settings=settings, stats=stats, flags=flags, comm=comm, workspace=ws,
+                          batched=(args.fd == "batched"))
+
+    for _ in range(args.warmup):
+        res, x = solve()
+    stats = M.Stats()
+    iters = 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, x = solve(stats=stats, flags=M.TIME_KERNELS)
+        iters += res.iterations
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if res.status < 0:
+        raise SystemExit(f"solver failed: {res}")
+
+    out = None
+    if rank == 0:
+        st = stats.as_dict()
+        value = iters * world / dt
+        nb = max(1, st["jtj_broyden_launches"])
+        kern_ms = st["jtj_broyden_ms"] / nb
+        alg_bytes = 8.0 * (2.0 * m * n + 3.0 * m)            # T (2 m n + 3 m), Broyden pass fused
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if st["jtj_broyden_launches"] else 0.0
+        out = {
+            "metric": "LM iterations/sec", "value": value, "unit": "iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"cfg3 tanh-linear NLS m={m}/GPU x n={n} fp64, FD Jacobian ({args.fd} residual callback), "
+                            "absTolerance=1e-9, whole solves x0 -> termination",
+                "m_per_gpu": m, "m_total": m * world, "n": n, "parallelism": f"rows sharded x{world}, RCCL all-reduce",
+                "iterations_per_solve": iters / args.steps, "status": res.status.name,
+                "passes_per_solve": st["passes"] / args.steps, "fcalls_per_solve": res.fCalls,
+                "jacobian_full_per_solve": st["jacobian_full"] / args.steps,
+                "global_lm_iterations_per_sec": iters / dt, "residual": res.residual,
+                "time_split_ms_per_solve": {
+                    "fd_refresh": st["fd_ms"] / args.steps, "jtj_kernels": st["jtj_ms"] / args.steps,
+                    "solve_kernel": st["solve_ms"] / args.steps, "total": st["total_ms"] / args.steps},
+            },
+            "roofline": {
+                "kernel": "k_jtj<double,8,true> (fused Broyden + J^T J + J^T y)", "bound": "hbm",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms,
+                "launches": st["jtj_broyden_launches"],
+                "mfma_tflops": (m * n * (n + 1.0) + 6.0 * m * n) / (kern_ms * 1e-3) / 1e12 if kern_ms else 0.0,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(data, m, n, args.cpu_iterations)
+        print(json.dumps(out), flush=True)
+    if comm:
+        api.lib().mir_lsq_comm_destroy(comm)
+    api.lib().mir_lsq_workspace_destroy(ws)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(data, m, n, iterations):
+    """The oracle (port of the reference algorithm; OpenBLAS from scipy for syrk/gemv/ger/posvx -- the
+    library class the reference links) on the same inputs, bounded to `iterations` accepted steps."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    ob = O.load_openblas(threads=threads)
+    so = O.default_settings()
+    so.absTolerance = 1e-9
+    so.maxIterations = iterations
+    ctx = O.TanhLinearCtx(data["A"].ctypes.data, data["b"].ctypes.data)
+    t0 = time.perf_counter()
+    ro, xo = O.optimize(O.native_fn("wlc_tanh_linear_f"), m, data["x0"], settings=so, fctx=C.addressof(ctx),
+                        use_openblas=ob)
+    dt = time.perf_counter() - t0
+    return {"value": ro.iterations / dt, "unit": "iterations/s", "cores": threads, "kind": "port",
+            "sample": f"first {ro.iterations} accepted LM iterations of the same m={m} x n={n} solve "
+                      f"(1 FD Jacobian = {2 * n} residual calls + Broyden passes), {dt:.1f} s, "
+                      f"OpenBLAS={'yes' if ob else 'no (plain loops)'}, residual calls OpenMP x{threads}",
+            "seconds": dt, "fcalls": ro.fCalls}
+
+
+if __name__ == "__main__":
+    main()
