@@ -260,6 +260,7 @@ __global__ __launch_bounds__(256) void k_jtj_slab_reduce(const T* __restrict__ s
     if (e < slab_len) {
         const int per = (nslabs + 7) / 8;
         const int b0 = sp * per, b1 = (b0 + per < nslabs) ? b0 + per : nslabs;
+#pragma unroll 8
         for (int b = b0; b < b1; ++b) s += slabs[(size_t)b * slab_len + e];
     }
     part[sp][es] = s;

@@ -290,6 +290,7 @@ struct Solver {
     JtjPlan plan;
     LmSettingsDev<T> sd;
     int f_in_lds = 0;
+    int solve_nb_ = 0;
     size_t solve_lds = 0;
 
     LmState<T>* st_h;      // pinned mirror
@@ -353,14 +354,9 @@ struct Solver {
         sd.goodStepQuality = S->goodStepQuality; sd.lambdaIncrease = S->lambdaIncrease; sd.lambdaDecrease = S->lambdaDecrease;
         sd.qpRelTolerance = S->qpSettings.relTolerance; sd.qpAbsTolerance = S->qpSettings.absTolerance;
         sd.qpMaxIterations = S->qpSettings.maxIterations; sd.pad = 0;
-        const size_t fbytes = (size_t)(n | 1) * n * sizeof(T);
-        f_in_lds = fbytes <= (size_t)kSolveLdsBytes;
-        solve_lds = f_in_lds ? fbytes : 0;
-        if (solve_lds > 48 * 1024) {
-            if (!ok(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lm_solve<T>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds), "hipFuncSetAttribute"))
-                return false;
-        }
+        solve_nb_ = solve_nb((int)n, (int)sizeof(T));
+        f_in_lds = solve_nb_ > 0;
+        solve_lds = solve_lds_bytes((int)n, (int)sizeof(T));
         twh_h.resize(n);
         return ok(hipMemcpyAsync(B.x, xh, n * sizeof(T), hipMemcpyHostToDevice, stream), "H2D x")
             && ok(hipMemcpyAsync(B.lower, lh, n * sizeof(T), hipMemcpyHostToDevice, stream), "H2D l")
@@ -405,6 +401,30 @@ struct Solver {
             && ok(hipStreamSynchronize(stream), "sync");
     }
 
+    template <int NB>
+    hipError_t launch_solve_nb(const LmSolveArgs<T>& a)
+    {
+        auto kern = k_lm_solve<T, NB>;
+        static bool attr_done = false;
+        if (!attr_done && solve_lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(1), dim3(kSolveThreads), solve_lds, stream, a);
+        return hipGetLastError();
+    }
+    hipError_t launch_solve(const LmSolveArgs<T>& a)
+    {
+        switch (solve_nb_) {
+        case 1: return launch_solve_nb<1>(a);
+        case 2: return launch_solve_nb<2>(a);
+        case 4: return launch_solve_nb<4>(a);
+        case 8: return launch_solve_nb<8>(a);
+        default: return launch_solve_nb<0>(a);
+        }
+    }
+
     // ---- ||v||^2 -> B.sum[slot] on device (all-reduced over row shards)
     bool sumsq(const T* v, int slot)
     {
@@ -434,7 +454,7 @@ struct Solver {
         if (!ok(jtj_run<T>(plan, a, broyden, B.packed, stream), "jtj kernel")) return false;
         ev_end();
         if (comm && comm_allreduce<T>(comm, B.packed, (size_t)n * (n + 1) / 2 + n, stream) != 0) return false;
-        hipLaunchKernelGGL(k_unpack_grad<T>, dim3(1), dim3(256), 0, stream, B.packed, (int)n, B.JJ, B.Jy, B.st);
+        hipLaunchKernelGGL(k_unpack_grad<T>, dim3(n + 1), dim3(128), 0, stream, B.packed, (int)n, B.JJ, B.Jy, B.st);
         return ok(hipGetLastError(), "unpack");
     }
 
@@ -656,7 +676,7 @@ struct Solver {
                 a.f_in_lds = f_in_lds;
                 a.check_grad = newJacobian ? 1 : 0;
                 ev_begin(2);
-                hipLaunchKernelGGL(k_lm_solve<T>, dim3(1), dim3(kSolveThreads), solve_lds, stream, a);
+                if (!ok(launch_solve(a), "solve launch")) { fail = true; break; }
                 ev_end();
                 if (!ok(hipGetLastError(), "solve kernel") || !read_state(true)) { fail = true; break; }
             }
@@ -867,19 +887,32 @@ int box_qp_entry(const QS* settings, size_t n_, const T* P, const T* q, const T*
     a.sc.ivec = (int32_t*)(base + oi); a.out = (int*)(base + oo);
     a.relTol = settings->relTolerance; a.absTol = settings->absTolerance; a.maxIterations = settings->maxIterations;
     a.unconstrained = unconstrainedSolution; a.n = n;
-    const size_t fbytes = (size_t)(n | 1) * n * sizeof(T);
-    a.f_in_lds = fbytes <= (size_t)kSolveLdsBytes;
-    const size_t lds = a.f_in_lds ? fbytes : 0;
+    const int nb = solve_nb(n, (int)sizeof(T));
+    a.f_in_lds = nb > 0;
+    const size_t lds = solve_lds_bytes(n, (int)sizeof(T));
     int out[2] = {mir_box_qp_numericError, 0};
     bool good = hipMemcpy((void*)a.P, P, sizeof(T) * n * n, hipMemcpyHostToDevice) == hipSuccess
         && hipMemcpy((void*)a.q, q, sizeof(T) * n, hipMemcpyHostToDevice) == hipSuccess
         && hipMemcpy((void*)a.l, l, sizeof(T) * n, hipMemcpyHostToDevice) == hipSuccess
         && hipMemcpy((void*)a.u, u, sizeof(T) * n, hipMemcpyHostToDevice) == hipSuccess
         && hipMemcpy((void*)a.x, x, sizeof(T) * n, hipMemcpyHostToDevice) == hipSuccess;
-    if (good && lds > 48 * 1024)
-        good = hipFuncSetAttribute(reinterpret_cast<const void*>(k_box_qp<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
     if (good) {
-        hipLaunchKernelGGL(k_box_qp<T>, dim3(1), dim3(kSolveThreads), lds, 0, a);
+        auto launch = [&](auto kern) {
+            if (lds > 48 * 1024
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess)
+                return false;
+            hipLaunchKernelGGL(kern, dim3(1), dim3(kSolveThreads), lds, 0, a);
+            return true;
+        };
+        switch (nb) {
+        case 1: good = launch(k_box_qp<T, 1>); break;
+        case 2: good = launch(k_box_qp<T, 2>); break;
+        case 4: good = launch(k_box_qp<T, 4>); break;
+        case 8: good = launch(k_box_qp<T, 8>); break;
+        default: good = launch(k_box_qp<T, 0>); break;
+        }
+    }
+    if (good) {
         good = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess
             && hipMemcpy(out, a.out, sizeof(out), hipMemcpyDeviceToHost) == hipSuccess
             && hipMemcpy(x, a.x, sizeof(T) * n, hipMemcpyDeviceToHost) == hipSuccess;
@@ -918,7 +951,7 @@ int jtj_entry(size_t m, size_t n, T* J, const T* y, const T* y_old, const T* dx,
     (void)hipEventRecord(e0, stream);
     if (jtj_run<T>(plan, a, broyden != 0, packed, stream) != hipSuccess) rc = -4;
     (void)hipEventRecord(e1, stream);
-    hipLaunchKernelGGL(k_unpack_grad<T>, dim3(1), dim3(256), 0, stream, packed, (int)n, JJ, Jy, st);
+    hipLaunchKernelGGL(k_unpack_grad<T>, dim3((unsigned)n + 1), dim3(128), 0, stream, packed, (int)n, JJ, Jy, st);
     if (hipStreamSynchronize(stream) != hipSuccess) rc = -5;
     if (kernel_ms) { float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); *kernel_ms = ms; }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

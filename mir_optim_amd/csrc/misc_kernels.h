@@ -57,23 +57,25 @@ __global__ void k_init_state(const T* sum, LmState<T>* st)
 }
 
 // ---- packed [JJ lower | Jy] -> full symmetric JJ, Jy, ||Jy||_inf (LS:1053).
+//      grid = n + 1 blocks: block i < n expands row i of JJ, block n handles Jy and its max.
 template <typename T>
 __global__ __launch_bounds__(256) void k_unpack_grad(const T* __restrict__ packed, int n, T* __restrict__ JJ,
                                                      T* __restrict__ Jy, LmState<T>* st)
 {
     __shared__ T red[4];
-    for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
-        const int i = idx / n, j = idx % n;
-        const int r = i >= j ? i : j, c = i >= j ? j : i;
-        JJ[idx] = packed[(size_t)r * (r + 1) / 2 + c];
+    const int i = blockIdx.x;
+    if (i < n) {
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {
+            const int r = i >= j ? i : j, c = i >= j ? j : i;
+            JJ[(size_t)i * n + j] = packed[(size_t)r * (r + 1) / 2 + c];
+        }
+        return;
     }
     T mx = 0;
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
         const T v = packed[(size_t)n * (n + 1) / 2 + j];
         Jy[j] = v;
         const T av = dabs(v);
-        // i?amax never selects a NaN after the first element; mirror "!(x > tol)" semantics by
-        // keeping NaN out of the max unless everything is NaN
         if (av > mx) mx = av;
     }
     mx = wave_max(mx);
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void k_unpack_grad(const T* __restrict__ packe
     __syncthreads();
     if (threadIdx.x == 0) {
         T r = red[0];
-        for (int w = 1; w < 4; ++w) r = red[w] > r ? red[w] : r;
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = red[w] > r ? red[w] : r;
         st->jy_inf = r;
     }
 }

@@ -139,14 +139,155 @@ __device__ inline void potrs_wave(int n, const T* F, int ldf, T* xv)
     __syncthreads();
 }
 
+// ---------------------------------------------------------------- fast path: factor resident in LDS
+// Register-tiled right-looking Cholesky for n <= 16 NB on the 16 x 16 thread grid (tr = tid & 15,
+// tc = tid >> 4): thread (tr, tc) keeps F(16 a + tr, 16 b + tc), a, b < NB, in registers for the
+// whole factorisation; per column only the finished column (n values) crosses LDS. Two barriers per
+// column, no memory round trip for the trailing matrix. On exit F (column-major, ldf odd) holds L
+// and rdiag[i] = 1 / L(i,i). colbuf, rdiag: n values each; sh: 1 value. All three in LDS.
+template <typename T, int NB>
+__device__ __forceinline__ int potrf_tiled(int n, const T* A, int lda, T* F, int ldf, T* colbuf, T* rdiag, T* sh)
+{
+    const int tid = threadIdx.x;
+    const int tr = tid & 15, tc = tid >> 4;
+    T f[NB][NB];
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int i = 16 * a + tr, k = 16 * b + tc;
+            f[a][b] = (b <= a && i < n && k < n) ? A[i + (size_t)k * lda] : T(0);
+        }
+    int info = 0;
+#pragma unroll
+    for (int JB = 0; JB < NB; ++JB) {
+        if (info != 0 || 16 * JB >= n) break;
+        for (int jc = 0; jc < 16; ++jc) {
+            const int j = 16 * JB + jc;
+            if (j >= n) break;
+            if (tr == jc && tc == jc) *sh = f[JB][JB];
+            __syncthreads();
+            const T ajj = *sh;
+            if (!(ajj > 0)) { info = j + 1; break; }      // uniform
+            const T d = dsqrt(ajj);
+            if (tc == jc) {
+#pragma unroll
+                for (int a = JB; a < NB; ++a) {
+                    const int i = 16 * a + tr;
+                    if (i > j && i < n) { f[a][JB] = f[a][JB] / d; colbuf[i] = f[a][JB]; }
+                    else if (i == j) { f[a][JB] = d; rdiag[j] = T(1) / d; }
+                }
+            }
+            __syncthreads();
+            T ci[NB], ck[NB];
+#pragma unroll
+            for (int a = JB; a < NB; ++a) {
+                const int i = 16 * a + tr, k = 16 * a + tc;
+                ci[a] = (i > j && i < n) ? colbuf[i] : T(0);
+                ck[a] = (k > j && k < n) ? colbuf[k] : T(0);
+            }
+#pragma unroll
+            for (int a = JB; a < NB; ++a)
+#pragma unroll
+                for (int b = JB; b <= a; ++b) f[a][b] -= ci[a] * ck[b];
+        }
+    }
+    if (info != 0) return info;
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            const int i = 16 * a + tr, k = 16 * b + tc;
+            if (i < n && k < n && i >= k) F[i + (size_t)k * ldf] = f[a][b];
+        }
+    __syncthreads();
+    return 0;
+}
+
+// ?potrs 'L' on one wave, factor in LDS, vector in registers (K = ceil(n / 64) values per lane),
+// columns/rows of L prefetched 8 steps ahead, reciprocal diagonal instead of a division on the
+// loop-carried path. Collective: all threads call; wave 0 works.
+template <typename T, int K>
+__device__ __forceinline__ void potrs_fast(int n, const T* F, int ldf, const T* rdiag, T* xv)
+{
+    __syncthreads();
+    if (threadIdx.x < kWave) {
+        const int lane = threadIdx.x;
+        T xr[K], rd[K];
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            const int k = lane + kWave * t;
+            xr[t] = k < n ? xv[k] : T(0);
+            rd[t] = k < n ? rdiag[k] : T(0);
+        }
+        for (int i0 = 0; i0 < n; i0 += 8) {             // forward: L z = b
+            T col[8][K];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int t = 0; t < K; ++t) {
+                    const int i = i0 + u, k = lane + kWave * t;
+                    col[u][t] = (i < n && k > i && k < n) ? F[k + (size_t)i * ldf] : T(0);
+                }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u;
+                if (i < n) {
+                    T xi = 0;
+#pragma unroll
+                    for (int t = 0; t < K; ++t) if ((i >> 6) == t) xi = __shfl(xr[t] * rd[t], i & 63, kWave);
+#pragma unroll
+                    for (int t = 0; t < K; ++t) {
+                        if (lane + kWave * t == i) xr[t] = xi;
+                        xr[t] -= col[u][t] * xi;
+                    }
+                }
+            }
+        }
+        for (int i0 = ((n - 1) | 7); i0 >= 0; i0 -= 8) { // backward: L^T x = z, i = i0, i0-1, ..., i0-7
+            T row[8][K];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int t = 0; t < K; ++t) {
+                    const int i = i0 - u, k = lane + kWave * t;
+                    row[u][t] = (i < n && k < i) ? F[i + (size_t)k * ldf] : T(0);
+                }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 - u;
+                if (i < n) {
+                    T xi = 0;
+#pragma unroll
+                    for (int t = 0; t < K; ++t) if ((i >> 6) == t) xi = __shfl(xr[t] * rd[t], i & 63, kWave);
+#pragma unroll
+                    for (int t = 0; t < K; ++t) {
+                        if (lane + kWave * t == i) xr[t] = xi;
+                        xr[t] -= row[u][t] * xi;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < K; ++t) { const int k = lane + kWave * t; if (k < n) xv[k] = xr[t]; }
+    }
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------- ?posvx('E','L'), nrhs = 1
 // A: n x n full symmetric, leading dimension lda (overwritten by its equilibrated form).
 // b: right-hand side (overwritten by the scaled rhs). x: solution. s,r,w: n-vectors.
 // F/ldf: factor storage (LDS or global). Returns info (0 = ok, k > 0 = leading minor k not
 // positive definite). Collective over the workgroup.
-template <typename T>
+template <typename T, int NB>
 __device__ int posvx_device(int n, T* A, int lda, T* F, int ldf, T* s, T* b, T* x, T* r, T* w, T* red)
 {
+    // fast path (NB > 0): LDS scratch behind the factor
+    T* colbuf = F + (size_t)ldf * (16 * (NB > 0 ? NB : 1));
+    T* rdiag = colbuf + 16 * (NB > 0 ? NB : 1);
+    T* shv = rdiag + 16 * (NB > 0 ? NB : 1);
+    (void)colbuf; (void)rdiag; (void)shv;
     const int tid = threadIdx.x;
     const T eps = Lim<T>::eps / 2;              // dlamch('Epsilon')
     const T safmin = Lim<T>::min_normal;        // dlamch('Safe minimum')
@@ -165,39 +306,48 @@ __device__ int posvx_device(int n, T* A, int lda, T* F, int ldf, T* s, T* b, T* 
     }
     __syncthreads();
     if (rcequ) {
-        for (int idx = tid; idx < n * n; idx += kSolveThreads) {
-            const int i = idx % n, j = idx / n;
-            A[i + (size_t)j * lda] = s[j] * s[i] * A[i + (size_t)j * lda];
+        // column j handled by the threads of one quarter-wave stride: no integer division
+        for (int j = tid >> 6; j < n; j += kSolveThreads / kWave) {
+            const T cj = s[j];
+#pragma unroll 4
+            for (int i = tid & 63; i < n; i += kWave) A[i + (size_t)j * lda] = cj * s[i] * A[i + (size_t)j * lda];
         }
         if (tid < n) b[tid] = s[tid] * b[tid];
     }
     __syncthreads();
 
-    // ?lacpy + ?potrf 'L' (right-looking, two barriers per column)
-    for (int idx = tid; idx < n * n; idx += kSolveThreads) {
-        const int i = idx % n, j = idx / n;
-        if (i >= j) F[i + (size_t)j * ldf] = A[i + (size_t)j * lda];
-    }
-    __syncthreads();
-    const int tx = tid & 63, ty = tid >> 6;
-    for (int j = 0; j < n; ++j) {
-        const T ajj = F[j + (size_t)j * ldf];
-        if (!(ajj > 0)) return j + 1;           // uniform: every thread reads the same value
-        const T d = dsqrt(ajj);
-        for (int i = j + 1 + tid; i < n; i += kSolveThreads) F[i + (size_t)j * ldf] /= d;
-        __syncthreads();
-        // F(j,j) is not read by the trailing update, so it can be overwritten in this phase
-        if (tid == 0) F[j + (size_t)j * ldf] = d;
-        for (int k = j + 1 + ty; k < n; k += kSolveThreads / kWave) {
-            const T fkj = F[k + (size_t)j * ldf];
-            for (int i = k + tx; i < n; i += kWave) F[i + (size_t)k * ldf] -= F[i + (size_t)j * ldf] * fkj;
+    // ?lacpy + ?potrf 'L'
+    if constexpr (NB > 0) {
+        const int info = potrf_tiled<T, NB>(n, A, lda, F, ldf, colbuf, rdiag, shv);
+        if (info != 0) return info;
+    } else {
+        // generic path (factor in global memory): right-looking, two barriers per column
+        for (int idx = tid; idx < n * n; idx += kSolveThreads) {
+            const int i = idx % n, j = idx / n;
+            if (i >= j) F[i + (size_t)j * ldf] = A[i + (size_t)j * lda];
         }
         __syncthreads();
+        const int tx = tid & 63, ty = tid >> 6;
+        for (int j = 0; j < n; ++j) {
+            const T ajj = F[j + (size_t)j * ldf];
+            if (!(ajj > 0)) return j + 1;           // uniform: every thread reads the same value
+            const T d = dsqrt(ajj);
+            for (int i = j + 1 + tid; i < n; i += kSolveThreads) F[i + (size_t)j * ldf] /= d;
+            __syncthreads();
+            // F(j,j) is not read by the trailing update, so it can be overwritten in this phase
+            if (tid == 0) F[j + (size_t)j * ldf] = d;
+            for (int k = j + 1 + ty; k < n; k += kSolveThreads / kWave) {
+                const T fkj = F[k + (size_t)j * ldf];
+                for (int i = k + tx; i < n; i += kWave) F[i + (size_t)k * ldf] -= F[i + (size_t)j * ldf] * fkj;
+            }
+            __syncthreads();
+        }
     }
 
     // ?potrs
     if (tid < n) x[tid] = b[tid];
-    potrs_wave(n, F, ldf, x);
+    if constexpr (NB > 0) potrs_fast<T, (NB > 4 ? 2 : 1)>(n, F, ldf, rdiag, x);
+    else potrs_wave(n, F, ldf, x);
 
     // ?porfs: iterative refinement, ITMAX = 5
     const T safe1 = T(n + 1) * safmin, safe2 = safe1 / eps;
@@ -209,6 +359,7 @@ __device__ int posvx_device(int n, T* A, int lda, T* F, int ldf, T* s, T* b, T* 
             T ri = 0, wi = 0;
             if (i < n) {
                 const int k0 = h ? n / 2 : 0, k1 = h ? n : n / 2;
+#pragma unroll 16
                 for (int k = k0; k < k1; ++k) {
                     const T aik = A[i + (size_t)k * lda];
                     const T xk = x[k];
@@ -226,6 +377,7 @@ __device__ int posvx_device(int n, T* A, int lda, T* F, int ldf, T* s, T* b, T* 
             T ri = 0, wi = 0;
             if (i < n) {
                 const int k0 = h ? n / 2 : 0, k1 = h ? n : n / 2;
+#pragma unroll 16
                 for (int k = k0; k < k1; ++k) {
                     const T aik = A[i + (size_t)k * lda];
                     const T xk = x[k];
@@ -242,7 +394,8 @@ __device__ int posvx_device(int n, T* A, int lda, T* F, int ldf, T* s, T* b, T* 
         if (tid < n) qv = (w[tid] > safe2) ? dabs(r[tid]) / w[tid] : (dabs(r[tid]) + safe1) / (w[tid] + safe1);
         const T berr = block_max(qv, red);
         if (berr > eps && 2 * berr <= lstres && count <= 5) {
-            potrs_wave(n, F, ldf, r);
+            if constexpr (NB > 0) potrs_fast<T, (NB > 4 ? 2 : 1)>(n, F, ldf, rdiag, r);
+            else potrs_wave(n, F, ldf, r);
             if (tid < n) x[tid] += r[tid];
             lstres = berr;
             __syncthreads();
@@ -258,7 +411,7 @@ __device__ int posvx_device(int n, T* A, int lda, T* F, int ldf, T* s, T* b, T* 
 // ---------------------------------------------------------------- solveBoxQP, boxcqp.d:122-379
 // Pm: n x n full symmetric (unscaled). q, l, u: n-vectors. x: in/out (holds the unconstrained
 // solution on entry when skip_unconstrained). Returns BoxQPStatus; *iters = active-set passes.
-template <typename T>
+template <typename T, int NB>
 __device__ int box_qp_device(int n, const T* Pm, const T* q, const T* l, const T* u, T* x,
                              bool unconstrainedSolution, T relTol, T absTol, uint32_t maxIterations,
                              SolveScratch<T>& sc, T* F, int ldf, T* red, int* ired, int* iters)
@@ -277,10 +430,11 @@ __device__ int box_qp_device(int n, const T* Pm, const T* q, const T* l, const T
     if (n == 0) return 0;                                           // QP:162-163
 
     if (!unconstrainedSolution) {                                   // QP:168-214
+#pragma unroll 16
         for (int idx = tid; idx < n * n; idx += kSolveThreads) sc.A[idx] = Pm[idx];   // QP:186-189
         if (tid < n) b[tid] = -q[tid];                              // QP:191
         __syncthreads();
-        const int info = posvx_device(n, sc.A, n, F, ldf, s, b, x, r, w, red);
+        const int info = posvx_device<T, NB>(n, sc.A, n, F, ldf, s, b, x, r, w, red);
         if (info != 0) return 1;                                    // QP:212-213 (info == n+1 is never produced)
     }
 
@@ -343,7 +497,7 @@ __device__ int box_qp_device(int n, const T* Pm, const T* q, const T* l, const T
         }
         __syncthreads();
         if (sN) {                                                   // QP:307-325
-            const int info = posvx_device(sN, sc.A, sN, F, ldf, s, b, sX, r, w, red);
+            const int info = posvx_device<T, NB>(sN, sc.A, sN, F, ldf, s, b, sX, r, w, red);
             if (info != 0) return 1;
         }
         if (tid < sN) x[SI[tid]] = sX[tid];                         // QP:327-329
@@ -375,6 +529,21 @@ __device__ int box_qp_device(int n, const T* Pm, const T* q, const T* l, const T
 }
 
 // ---------------------------------------------------------------- one LM pass, n x n part
+// fast-path tile count for n (0 = generic path with the factor in global memory) and its LDS bytes:
+// factor (n|1) x 16 NB, then colbuf, rdiag (16 NB each) and one scalar
+__host__ __device__ inline int solve_nb(int n, int elem)
+{
+    const int nb = n <= 16 ? 1 : (n <= 32 ? 2 : (n <= 64 ? 4 : (n <= 128 ? 8 : 0)));
+    if (nb == 0) return 0;
+    const long bytes = ((long)(n | 1) * 16 * nb + 32 * nb + 2) * elem;
+    return bytes <= kSolveLdsBytes ? nb : 0;
+}
+__host__ __device__ inline size_t solve_lds_bytes(int n, int elem)
+{
+    const int nb = solve_nb(n, elem);
+    return nb ? (size_t)((long)(n | 1) * 16 * nb + 32 * nb + 2) * elem : 0;
+}
+
 template <typename T>
 struct LmSolveArgs {
     const T* JJ;       // n x n full symmetric, undamped
@@ -392,7 +561,7 @@ struct LmSolveArgs {
     int check_grad;    // a new Jy was just computed: apply the gradient test LS:1053 first
 };
 
-template <typename T>
+template <typename T, int NB>
 __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -400,7 +569,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
     __shared__ int ired[8];
     const int n = a.n, tid = threadIdx.x;
     const int ldf = n | 1;
-    T* F = a.f_in_lds ? reinterpret_cast<T*>(smem_raw) : a.sc.Fg;
+    T* F;
+    if constexpr (NB > 0) F = reinterpret_cast<T*>(smem_raw); else F = a.sc.Fg;
     T* qpl = a.sc.vec + 7 * (size_t)n;
     T* qpu = a.sc.vec + 8 * (size_t)n;
     T* xq = a.sc.vec + 10 * (size_t)n;
@@ -431,16 +601,14 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
     // step bounds LS:1074-1077, P = JJ + lambda I LS:1078-1079 (JJ itself is never modified, so
     // the save/restore of its diagonal at LS:1078/1094 is not needed)
     if (tid < n) { qpl[tid] = a.lower[tid] - a.x[tid]; qpu[tid] = a.upper[tid] - a.x[tid]; }
-    for (int idx = tid; idx < n * n; idx += kSolveThreads) {
-        const int i = idx / n, j = idx % n;
-        T v = a.JJ[idx];
-        if (i == j) v += lambda;
-        a.sc.Pm[idx] = v;
-    }
+#pragma unroll 16
+    for (int idx = tid; idx < n * n; idx += kSolveThreads) a.sc.Pm[idx] = a.JJ[idx];
+    __syncthreads();
+    if (tid < n) a.sc.Pm[(size_t)tid * (n + 1)] = a.JJ[(size_t)tid * (n + 1)] + lambda;
     __syncthreads();
 
     int qp_iters = 0;
-    const int qp = box_qp_device(n, a.sc.Pm, a.Jy, qpl, qpu, xq, false, a.set.qpRelTolerance, a.set.qpAbsTolerance,
+    const int qp = box_qp_device<T, NB>(n, a.sc.Pm, a.Jy, qpl, qpu, xq, false, a.set.qpRelTolerance, a.set.qpAbsTolerance,
                                  a.set.qpMaxIterations, a.sc, F, ldf, red, ired, &qp_iters);   // LS:1080
 
     int flags = 0;
@@ -462,10 +630,17 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
         ndd = block_sum(d * d, red);                                 // LS:1099
         // predicted reduction with the UNDAMPED JJ, LS:1141-1142: t = JJ dx + 2 Jy ; pred = -(t . dx)
         T ti = 0;
-        if (tid < n) {
-            for (int j = 0; j < n; ++j) ti += a.JJ[(size_t)j * n + tid] * a.dx[j];
-            ti = ti + 2 * a.Jy[tid];
-            ti = ti * d;
+        {
+            // thread pair (i, h) sums half of row i (n <= 128) or thread i sums the whole row
+            const bool pair = n <= kSolveThreads / 2;
+            const int i = pair ? tid >> 1 : tid, h = pair ? tid & 1 : 0;
+            if (i < n) {
+                const int j0 = pair && h ? n / 2 : 0, j1 = pair && !h ? n / 2 : n;
+#pragma unroll 16
+                for (int j = j0; j < j1; ++j) ti += a.JJ[(size_t)j * n + i] * a.dx[j];
+                if (h == 0) ti = ti + 2 * a.Jy[i];
+                ti = ti * a.dx[i];
+            }
         }
         pred = -block_sum(ti, red);
         // ||trial||_2 for the relTolerance test, LS:1164 (scaled like ?nrm2)
@@ -493,14 +668,15 @@ struct BoxQpArgs {
     T relTol, absTol; uint32_t maxIterations; int unconstrained;
     SolveScratch<T> sc; int n; int f_in_lds; int* out;   // out[0] = status, out[1] = iterations
 };
-template <typename T>
+template <typename T, int NB>
 __global__ __launch_bounds__(kSolveThreads) void k_box_qp(BoxQpArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ T red[8];
     __shared__ int ired[8];
     const int n = a.n;
-    T* F = a.f_in_lds ? reinterpret_cast<T*>(smem_raw) : a.sc.Fg;
+    T* F;
+    if constexpr (NB > 0) F = reinterpret_cast<T*>(smem_raw); else F = a.sc.Fg;
     // symmetrise the lower triangle (QP:109: only the lower triangle of P is meaningful)
     for (int idx = threadIdx.x; idx < n * n; idx += kSolveThreads) {
         const int i = idx / n, j = idx % n;
@@ -508,7 +684,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_box_qp(BoxQpArgs<T> a)
     }
     __syncthreads();
     int it = 0;
-    const int st = box_qp_device(n, a.sc.Pm, a.q, a.l, a.u, a.x, a.unconstrained != 0, a.relTol, a.absTol,
+    const int st = box_qp_device<T, NB>(n, a.sc.Pm, a.q, a.l, a.u, a.x, a.unconstrained != 0, a.relTol, a.absTol,
                                  a.maxIterations, a.sc, F, n | 1, red, ired, &it);
     if (threadIdx.x == 0) { a.out[0] = st; a.out[1] = it; }
 }

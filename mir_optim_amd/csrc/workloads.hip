@@ -120,6 +120,96 @@ __global__ __launch_bounds__(256) void k_exp_decay(const T* __restrict__ t, cons
     }
 }
 
+
+// ---- batched tanh-linear residuals: Y[p][i] = tanh(a_i . X[p]) - b_i for p < P points in ONE
+//      sweep over A (the finite-difference Jacobian evaluates its 2n perturbed points together).
+//      It is a tall GEMM A[m x n] X^T[n x P] on v_mfma_f64_16x16x4_f64:
+//        * workgroup = 16 waves; wave w owns points [16 w, 16 w + 16) of a 256-point chunk and keeps
+//          their X fragments (B operand, NK k-steps) in registers for the whole sweep;
+//        * the workgroup streams 16-row tiles of A through a double-buffered, padded LDS image
+//          (row pitch n + 2 doubles -> the 16-row x 4-column A-operand read is bank-conflict free);
+//          every byte of A is read from HBM once per 256 points;
+//        * epilogue: tanh - b on the accumulator, stored along the row index (4 x 32-byte runs per
+//          point and tile, merged into full lines in L2).
+template <int NK>
+__global__ __launch_bounds__(1024) void k_tanh_linear_batched(const double* __restrict__ A, const double* __restrict__ b,
+                                                               const double* __restrict__ X, double* __restrict__ Y,
+                                                               size_t m, int n, int P)
+{
+    using Acc = __attribute__((ext_vector_type(4))) double;
+    constexpr int NPAD = 4 * NK;            // padded column count
+    constexpr int PITCH = NPAD + 2;         // doubles
+    __shared__ __attribute__((aligned(16))) double tile[2][16 * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // zero the padding columns once (never overwritten afterwards)
+    for (int idx = tid; idx < 2 * 16 * PITCH; idx += 1024) (&tile[0][0])[idx] = 0.0;
+    __syncthreads();
+
+    // piece -> (row, 16-byte column pair) of a 16-row tile; tile rows are contiguous in memory
+    const int ppr = n / 2;                  // 16-byte pieces per row (n even)
+    const bool has_piece = tid < 16 * ppr;
+    const int prow = has_piece ? tid / ppr : 0, pcol = has_piece ? tid % ppr : 0;
+    const size_t ntiles = (m + 15) / 16;
+
+    for (int pbase = 0; pbase < P; pbase += 256) {
+        const int pl = pbase + wave * 16 + fr;                  // this lane's point
+        const bool pok = pl < P;
+        double xf[NK];
+#pragma unroll
+        for (int s = 0; s < NK; ++s) {
+            const int col = 4 * s + fq;
+            xf[s] = (pok && col < n) ? X[(size_t)pl * n + col] : 0.0;
+        }
+        double2 stage = make_double2(0.0, 0.0);
+        auto gload = [&](size_t t) {
+            const size_t row = t * 16 + prow;
+            if (has_piece && row < m) stage = *reinterpret_cast<const double2*>(A + row * (size_t)n + 2 * pcol);
+            else stage = make_double2(0.0, 0.0);
+        };
+        auto lstore = [&](int buf) {
+            if (has_piece) *reinterpret_cast<double2*>(&tile[buf][prow * PITCH + 2 * pcol]) = stage;
+        };
+        size_t t = blockIdx.x;
+        if (t < ntiles) { gload(t); lstore(0); }
+        if (t + gridDim.x < ntiles) gload(t + gridDim.x);
+        __syncthreads();
+        int buf = 0;
+        for (; t < ntiles; t += gridDim.x) {
+            Acc acc = {0.0, 0.0, 0.0, 0.0};
+            const double* tp = &tile[buf][fr * PITCH + fq];
+#pragma unroll
+            for (int s = 0; s < NK; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tp[4 * s], xf[s], acc, 0, 0, 0);
+            // D: col = lane & 15 = point, row = (lane >> 4) + 4 r
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t row = t * 16 + fq + 4 * r;
+                if (pok && row < m) Y[(size_t)pl * m + row] = tanh(acc[r]) - b[row];
+            }
+            // stage tile t + grid into the other buffer (its last readers passed the previous barrier)
+            if (t + gridDim.x < ntiles) lstore(buf ^ 1);
+            if (t + 2 * (size_t)gridDim.x < ntiles) gload(t + 2 * (size_t)gridDim.x);
+            __syncthreads();
+            buf ^= 1;
+        }
+        __syncthreads();
+    }
+}
+
+bool launch_tanh_linear_batched(const double* A, const double* b, const double* X, double* Y, size_t m, int n, int P,
+                                hipStream_t s)
+{
+    if (n % 2 != 0 || n > 128 || n < 4) return false;
+    const size_t ntiles = (m + 15) / 16;
+    unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
+    if (n <= 16) hipLaunchKernelGGL(k_tanh_linear_batched<4>, dim3(grid), dim3(1024), 0, s, A, b, X, Y, m, n, P);
+    else if (n <= 32) hipLaunchKernelGGL(k_tanh_linear_batched<8>, dim3(grid), dim3(1024), 0, s, A, b, X, Y, m, n, P);
+    else if (n <= 64) hipLaunchKernelGGL(k_tanh_linear_batched<16>, dim3(grid), dim3(1024), 0, s, A, b, X, Y, m, n, P);
+    else hipLaunchKernelGGL(k_tanh_linear_batched<32>, dim3(grid), dim3(1024), 0, s, A, b, X, Y, m, n, P);
+    return true;
+}
+
 inline unsigned blocks_for(size_t m)
 {
     size_t b = (m + 255) / 256;
@@ -153,10 +243,12 @@ void wl_tanh_linear_g_d(void* vctx, size_t m, size_t n, const double* x, double*
     auto* c = static_cast<wl_tanh_linear_ctx*>(vctx);
     launch_tanh_linear<double, 1>((const double*)c->A, (const double*)c->b, x, J, m, (int)n, (hipStream_t)c->stream);
 }
-// batched residual (mir_lsq_batched_function_d): p points. First version: one sweep per point.
+// batched residual (mir_lsq_batched_function_d): p points in one sweep over A (MFMA GEMM); shapes the
+// GEMM kernel does not cover fall back to one sweep per point.
 void wl_tanh_linear_fb_d(void* vctx, size_t m, size_t n, size_t p, const double* X, double* Y)
 {
     auto* c = static_cast<wl_tanh_linear_ctx*>(vctx);
+    if (launch_tanh_linear_batched((const double*)c->A, (const double*)c->b, X, Y, m, (int)n, (int)p, (hipStream_t)c->stream)) return;
     for (size_t k = 0; k < p; ++k)
         launch_tanh_linear<double, 0>((const double*)c->A, (const double*)c->b, X + k * n, Y + k * m, m, (int)n, (hipStream_t)c->stream);
 }

@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the oracle's OpenMP regions: a 256-thread GPU-box host gains nothing beyond a few threads here
+os.environ.setdefault("OMP_NUM_THREADS", "16")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
