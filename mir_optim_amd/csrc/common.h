@@ -53,12 +53,29 @@ template <> struct Mma<float> {
 
 template <typename T> __device__ inline T wave_shfl_xor(T v, int mask) { return __shfl_xor(v, mask, kWave); }
 
-// sum over the 16 lanes that share lane >> 4
+// rotate within each row of 16 lanes by N (DPP row_ror:N) -- a VALU lane crossbar move, ~10x
+// cheaper in latency than ds_bpermute (which is what __shfl_xor lowers to)
+template <int N> __device__ inline int dpp_row_ror(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x120 + N, 0xF, 0xF, false);
+}
+template <int N> __device__ inline double dpp_row_ror(double v)
+{
+    const int lo = dpp_row_ror<N>(__double2loint(v));
+    const int hi = dpp_row_ror<N>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+template <int N> __device__ inline float dpp_row_ror(float v)
+{
+    return __int_as_float(dpp_row_ror<N>(__float_as_int(v)));
+}
+
+// sum over the 16 lanes that share lane >> 4 (every lane receives the total): rotate-and-add
 template <typename T> __device__ inline T sum16(T v) {
-    v += wave_shfl_xor(v, 1);
-    v += wave_shfl_xor(v, 2);
-    v += wave_shfl_xor(v, 4);
-    v += wave_shfl_xor(v, 8);
+    v += dpp_row_ror<8>(v);
+    v += dpp_row_ror<4>(v);
+    v += dpp_row_ror<2>(v);
+    v += dpp_row_ror<1>(v);
     return v;
 }
 template <typename T> __device__ inline T wave_sum(T v) {
@@ -74,6 +91,18 @@ template <typename T> __device__ inline T wave_max(T v) {
         v = o > v ? o : v;
     }
     return v;
+}
+
+// broadcast lane `src` (wave-uniform) of v to every lane through SGPRs (v_readlane), not through LDS
+__device__ inline double lane_bcast(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline float lane_bcast(float v, int src)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
 __device__ inline double dsqrt(double v) { return sqrt(v); }

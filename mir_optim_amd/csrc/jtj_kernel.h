@@ -287,4 +287,191 @@ __global__ __launch_bounds__(256) void k_jtj_slab_reduce(const T* __restrict__ s
     }
 }
 
+// =========================================================================================
+// v2: the same fused pass with an LDS-DMA ring (f64, n = 16 NCB).
+//
+// v1 above keeps only one 4-row group per wave in flight, so a CU has a few KB of J outstanding and
+// the kernel runs at HBM *latency* (measured 1.4 TB/s algorithmic at m = 1e6, n = 128). Here a
+// dedicated loader wave streams J through a ring of NS LDS slots with `global_load_lds_dwordx4`
+// (no VGPRs, up to 60 KB in flight per workgroup, counted `s_waitcnt vmcnt(N)`, one raw
+// `s_barrier` per stage), and the four compute waves ("roles", each owning a quarter of the
+// accumulator blocks) read their MFMA fragments from the slot with ds_read_b64:
+//   lane (q, p) reads row 4 g + q, column 16 c + p  ->  exactly the A/B operand layout.
+// y / y_old are ordinary vector loads in the compute waves only (the loader wave never issues a
+// VGPR-destination load, so its vmcnt counts nothing but its own DMA).
+// =========================================================================================
+typedef __attribute__((address_space(3))) void* jtj_lds_ptr;
+typedef const __attribute__((address_space(1))) void* jtj_gbl_ptr;
+
+template <int NCB> struct Jtj2Cfg {
+    static constexpr int RS = (NCB == 1) ? 16 : ((NCB % 2 == 0 && NCB >= 6) ? 4 : 8);   // rows per stage
+    static constexpr int GPS = RS / 4;                                                     // 4-row groups per stage
+    static constexpr int IPS = RS * NCB / 8;                                               // 1 KB DMA instructions per stage
+    static constexpr int D = (60 / IPS) > 15 ? 15 : (60 / IPS);                            // stages in flight
+    static constexpr int NS = D + 2;                                                       // ring slots
+    static constexpr int SLOT_BYTES = IPS * 1024;
+    static constexpr int RING_BYTES = NS * SLOT_BYTES;
+    // y / y_old travel through their own small rings: one 1 KB DMA instruction = 128 rows = SPC stages
+    static constexpr int SPC = 128 / RS;            // stages per y chunk
+    static constexpr int YNS = 4;                   // y ring slots (chunks c .. c+2 may be live)
+    static constexpr int Y_OFF = RING_BYTES;
+    static constexpr int YO_OFF = RING_BYTES + YNS * 1024;
+    static constexpr int LDS_BYTES = RING_BYTES + 2 * YNS * 1024;
+};
+constexpr int kJtj2Threads = 5 * kWave;     // 4 compute waves + 1 loader wave
+
+template <int NCB, bool BROYDEN, int ROLE>
+__device__ __forceinline__ void jtj2_compute(const JtjArgs<double>& a, const unsigned char* smem, int lane,
+                                             size_t s0, size_t S)
+{
+    using T = double;
+    using Acc = typename Mma<T>::Acc;
+    using C = Jtj2Cfg<NCB>;
+    constexpr int NACC = jtj_nacc<NCB>();
+    const int q = lane >> 4, p = lane & 15;
+    const size_t m = a.m;
+    constexpr int n = 16 * NCB;
+
+    Acc acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = Acc{0, 0, 0, 0};
+    T jy[NCB], dxr[NCB];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+        jy[c] = 0;
+        dxr[c] = 0;
+        if constexpr (BROYDEN) dxr[c] = a.dx[16 * c + p];
+    }
+    T neg_d = 0;
+    if constexpr (BROYDEN) neg_d = -(T(1) / *a.dx_dot);
+
+    for (size_t s = 0; s < S; ++s) {
+        __builtin_amdgcn_s_barrier();                       // stage s has landed (loader waited for it)
+        const T* slot = reinterpret_cast<const T*>(smem + (s % C::NS) * C::SLOT_BYTES);
+#pragma unroll
+        for (int gi = 0; gi < C::GPS; ++gi) {
+            const size_t row = (s0 + s) * C::RS + 4 * gi + q;
+            const bool rok = row < m;
+            const size_t rc = rok ? row : m - 1;
+            (void)rc;
+            T v[NCB];
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) {
+                const T t = slot[(4 * gi + q) * n + 16 * c + p];
+                v[c] = rok ? t : T(0);
+            }
+            const int yidx = (int)((s / C::SPC) % C::YNS) * 128 + (int)(s % C::SPC) * C::RS + 4 * gi + q;
+            T yv = reinterpret_cast<const T*>(smem + C::Y_OFF)[yidx];
+            yv = rok ? yv : T(0);
+            if constexpr (BROYDEN) {
+                T yo = reinterpret_cast<const T*>(smem + C::YO_OFF)[yidx];
+                yo = rok ? yo : T(0);
+                T part = 0;
+#pragma unroll
+                for (int c = 0; c < NCB; ++c) part += v[c] * dxr[c];
+                part = sum16(part);
+                const T t = (yo - yv) + part;            // LS:1003-1004
+                const T u = neg_d * t;                   // LS:1005
+                T* wp = a.Jout + rc * (size_t)n;
+#pragma unroll
+                for (int c = 0; c < NCB; ++c) {
+                    v[c] = v[c] + u * dxr[c];            // LS:1006
+                    if constexpr (ROLE == 0) { if (rok) wp[16 * c + p] = v[c]; }
+                }
+            }
+            if constexpr (ROLE == 0) {
+#pragma unroll
+                for (int c = 0; c < NCB; ++c) jy[c] += v[c] * yv;     // LS:1052
+            }
+#pragma unroll
+            for (int I = 0; I < NCB; ++I)
+#pragma unroll
+                for (int Jb = 0; Jb <= I; ++Jb)
+                    if (jtj_owns<NCB, 4, ROLE>(I * (I + 1) / 2 + Jb))
+                        acc[I * (I + 1) / 2 + Jb] = Mma<T>::mma(v[I], v[Jb], acc[I * (I + 1) / 2 + Jb]);   // LS:1065
+        }
+    }
+
+    // every compute wave owns a disjoint part of the workgroup's slab: no LDS reduction needed
+    T* dst = a.slabs + (size_t)blockIdx.x * jtj_slab_len<NCB>();
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+        if (jtj_owns<NCB, 4, ROLE>(i)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(i * 4 + r) * kWave + lane] = acc[i][r];
+        }
+    if constexpr (ROLE == 0) {
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            jy[c] += wave_shfl_xor(jy[c], 16);
+            jy[c] += wave_shfl_xor(jy[c], 32);
+            dst[(NACC * 4 + c) * kWave + lane] = jy[c];
+        }
+    }
+}
+
+template <int NCB, bool BROYDEN>
+__global__ __launch_bounds__(kJtj2Threads) void k_jtj2(JtjArgs<double> a)
+{
+    using C = Jtj2Cfg<NCB>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int n = 16 * NCB;
+
+    // contiguous range of stages for this workgroup
+    const size_t Stot = (a.m + C::RS - 1) / C::RS;
+    const size_t per = (Stot + gridDim.x - 1) / gridDim.x;
+    const size_t s0 = (size_t)blockIdx.x * per < Stot ? (size_t)blockIdx.x * per : Stot;
+    const size_t s1 = s0 + per < Stot ? s0 + per : Stot;
+    const size_t S = s1 - s0;
+
+    if (wave == 4) {
+        // ---- loader wave: LDS-DMA ring, counted waits, one barrier per stage
+        const unsigned char* Jb = reinterpret_cast<const unsigned char*>(a.J);
+        const size_t total = a.m * (size_t)n * sizeof(double);
+        auto issue = [&](size_t s) {
+            const size_t base = (s0 + s) * (size_t)C::RS * n * sizeof(double);
+            unsigned char* slot = smem2 + (s % C::NS) * C::SLOT_BYTES;
+#pragma unroll
+            for (int ins = 0; ins < C::IPS; ++ins) {
+                size_t off = base + (size_t)(ins * 64 + lane) * 16;
+                if (off + 16 > total) off = base;            // rows past m: any valid bytes (masked by the consumers)
+                __builtin_amdgcn_global_load_lds((jtj_gbl_ptr)(Jb + off), (jtj_lds_ptr)(slot + ins * 1024), 16, 0, 0);
+            }
+        };
+        // y / y_old chunks (128 rows each) ride in the same in-order DMA queue, two chunks ahead
+        const unsigned char* yb = reinterpret_cast<const unsigned char*>(a.y);
+        const unsigned char* yob = reinterpret_cast<const unsigned char*>(a.y_old);
+        const size_t ytotal = a.m * sizeof(double);
+        const size_t nchunks = (S + C::SPC - 1) / C::SPC;
+        auto issue_y = [&](size_t c) {
+            size_t off = ((s0 * C::RS) + c * 128) * sizeof(double) + (size_t)lane * 16;
+            if (off + 16 > ytotal) off = 0;
+            __builtin_amdgcn_global_load_lds((jtj_gbl_ptr)(yb + off), (jtj_lds_ptr)(smem2 + C::Y_OFF + (c % C::YNS) * 1024), 16, 0, 0);
+            if constexpr (BROYDEN)
+                __builtin_amdgcn_global_load_lds((jtj_gbl_ptr)(yob + off), (jtj_lds_ptr)(smem2 + C::YO_OFF + (c % C::YNS) * 1024), 16, 0, 0);
+        };
+        if (nchunks > 0) issue_y(0);
+        if (nchunks > 1) issue_y(1);
+        const size_t pre = S < (size_t)C::D ? S : (size_t)C::D;
+        for (size_t s = 0; s < pre; ++s) issue(s);
+        for (size_t s = 0; s < S; ++s) {
+            if (s % C::SPC == 0 && s / C::SPC + 2 < nchunks) issue_y(s / C::SPC + 2);
+            if (s + C::D < S) {
+                issue(s + C::D);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::D * C::IPS) : "memory");   // everything up to stage s landed
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+    if (wave == 0) jtj2_compute<NCB, BROYDEN, 0>(a, smem2, lane, s0, S);
+    else if (wave == 1) jtj2_compute<NCB, BROYDEN, 1>(a, smem2, lane, s0, S);
+    else if (wave == 2) jtj2_compute<NCB, BROYDEN, 2>(a, smem2, lane, s0, S);
+    else jtj2_compute<NCB, BROYDEN, 3>(a, smem2, lane, s0, S);
+}
+
 }  // namespace mirlsq

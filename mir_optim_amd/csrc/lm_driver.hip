@@ -93,7 +93,26 @@ struct JtjPlan {
     int nblk = 0;
     int slab_len = 0;
     size_t lds = 0;
+    bool v2 = false;      // LDS-DMA ring kernel (f64, n = 16 ncb)
 };
+
+template <int NCB> constexpr size_t jtj2_lds() { return Jtj2Cfg<NCB>::LDS_BYTES; }
+inline size_t jtj2_lds_rt(int ncb)
+{
+    switch (ncb) {
+    case 1: return jtj2_lds<1>(); case 2: return jtj2_lds<2>(); case 3: return jtj2_lds<3>(); case 4: return jtj2_lds<4>();
+    case 5: return jtj2_lds<5>(); case 6: return jtj2_lds<6>(); case 7: return jtj2_lds<7>(); case 8: return jtj2_lds<8>();
+    }
+    return 0;
+}
+inline int jtj2_rs_rt(int ncb)
+{
+    switch (ncb) {
+    case 1: return Jtj2Cfg<1>::RS; case 2: return Jtj2Cfg<2>::RS; case 3: return Jtj2Cfg<3>::RS; case 4: return Jtj2Cfg<4>::RS;
+    case 5: return Jtj2Cfg<5>::RS; case 6: return Jtj2Cfg<6>::RS; case 7: return Jtj2Cfg<7>::RS; case 8: return Jtj2Cfg<8>::RS;
+    }
+    return 4;
+}
 
 template <typename T>
 JtjPlan jtj_plan(size_t m, int n, int num_cu)
@@ -102,6 +121,16 @@ JtjPlan jtj_plan(size_t m, int n, int num_cu)
     p.ncb = (n + 15) / 16;
     const int nacc = p.ncb * (p.ncb + 1) / 2;
     p.slab_len = (nacc * 4 + p.ncb) * kWave;
+    static const bool no_v2 = std::getenv("MIR_LSQ_JTJ_V1") != nullptr;
+    if (sizeof(T) == 8 && n % 16 == 0 && n <= 128 && m % 2 == 0 && !no_v2) {
+        p.v2 = true;
+        p.lds = jtj2_lds_rt(p.ncb);
+        const size_t stot = (m + jtj2_rs_rt(p.ncb) - 1) / jtj2_rs_rt(p.ncb);
+        size_t want = (stot + 7) / 8;                          // at least ~8 stages per workgroup
+        const size_t cap = (size_t)num_cu * 2;
+        p.nblk = (int)(want < cap ? (want ? want : 1) : cap);
+        return p;
+    }
     const int rpb = 4 * (int)(sizeof(T) / 4);
     const int roles = jtj_roles_rt(p.ncb, rpb);
     p.lds = (size_t)(roles == 4 ? 0 : (roles == 2 ? 1 : 2)) * p.slab_len * sizeof(T);
@@ -133,9 +162,46 @@ hipError_t jtj_launch_one(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
     return hipGetLastError();
 }
 
+template <int NCB, bool BR>
+hipError_t jtj2_launch_one(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t s)
+{
+    auto kern = k_jtj2<NCB, BR>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(kJtj2Threads), p.lds, s, a);
+    return hipGetLastError();
+}
+template <bool BR>
+hipError_t jtj2_launch(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t s)
+{
+    switch (p.ncb) {
+    case 1: return jtj2_launch_one<1, BR>(p, a, s);
+    case 2: return jtj2_launch_one<2, BR>(p, a, s);
+    case 3: return jtj2_launch_one<3, BR>(p, a, s);
+    case 4: return jtj2_launch_one<4, BR>(p, a, s);
+    case 5: return jtj2_launch_one<5, BR>(p, a, s);
+    case 6: return jtj2_launch_one<6, BR>(p, a, s);
+    case 7: return jtj2_launch_one<7, BR>(p, a, s);
+    case 8: return jtj2_launch_one<8, BR>(p, a, s);
+    }
+    return hipErrorInvalidValue;
+}
+template <typename T, bool BR>
+hipError_t jtj2_dispatch(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
+{
+    if constexpr (sizeof(T) == 8) return jtj2_launch<BR>(p, a, s);
+    else return hipErrorInvalidValue;
+}
+
 template <typename T, bool BR>
 hipError_t jtj_launch_br(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
 {
+    if (p.v2) return jtj2_dispatch<T, BR>(p, a, s);
     switch (p.ncb) {
     case 1: return jtj_launch_one<T, 1, BR>(p, a, s);
     case 2: return jtj_launch_one<T, 2, BR>(p, a, s);
@@ -180,6 +246,7 @@ template <typename T>
 Buffers<T> carve(void* base, size_t m, size_t n, const JtjPlan& plan)
 {
     Buffers<T> b{};
+    long long* dbg_all = nullptr;
     size_t off = 0;
     auto take = [&](size_t count, size_t elem) {
         void* p = base ? static_cast<char*>(base) + off : nullptr;
@@ -209,6 +276,9 @@ Buffers<T> carve(void* base, size_t m, size_t n, const JtjPlan& plan)
     b.sc.Fg = (T*)take(n * (n | 1), sizeof(T));
     b.sc.vec = (T*)take(12 * n, sizeof(T));
     b.sc.ivec = (int32_t*)take(2 * n, sizeof(int32_t));
+    b.sc.dbg = (long long*)take(16, sizeof(long long));
+    dbg_all = b.sc.dbg;
+    (void)dbg_all;
     b.bytes = off;
     return b;
 }
@@ -289,6 +359,7 @@ struct Solver {
     Buffers<T> B;
     JtjPlan plan;
     LmSettingsDev<T> sd;
+    bool dbg_solve = std::getenv("MIR_LSQ_DEBUG_SOLVE") != nullptr;
     int f_in_lds = 0;
     int solve_nb_ = 0;
     size_t solve_lds = 0;
@@ -675,10 +746,17 @@ struct Solver {
                 a.dx = B.dx; a.trial = B.trial; a.st = B.st; a.set = sd; a.sc = B.sc; a.n = (int)n;
                 a.f_in_lds = f_in_lds;
                 a.check_grad = newJacobian ? 1 : 0;
+                if (!dbg_solve) a.sc.dbg = nullptr;
                 ev_begin(2);
                 if (!ok(launch_solve(a), "solve launch")) { fail = true; break; }
                 ev_end();
                 if (!ok(hipGetLastError(), "solve kernel") || !read_state(true)) { fail = true; break; }
+            }
+            if (dbg_solve) {
+                long long h[16];
+                if (hipMemcpy(h, B.sc.dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
+                    std::fprintf(stderr, "[solve dbg] (10ns ticks) build %lld  copy/equil %lld  scale %lld  potrf %lld  potrs %lld  refine %lld  epilogue %lld  total %lld  shader MHz %.0f  [matvec1 %lld berr %lld]\n",
+                                 h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[8] - h[7], h[8] - h[0], (double)(h[10] - h[9]) / (double)(h[8] - h[0]) * 100.0, h[11] - h[5], h[12] - h[11]);
             }
             if (newJacobian && (st_h->flags & kFlagGradSmall)) {             // LS:1053-1062
                 if (age == 0) { ret.status = mir_ls_gConverged; break; }
@@ -884,7 +962,7 @@ int box_qp_entry(const QS* settings, size_t n_, const T* P, const T* q, const T*
     BoxQpArgs<T> a{};
     a.P = (T*)(base + oP); a.q = (T*)(base + oq); a.l = (T*)(base + ol); a.u = (T*)(base + ou); a.x = (T*)(base + ox);
     a.sc.Pm = (T*)(base + oPm); a.sc.A = (T*)(base + oA); a.sc.Fg = (T*)(base + oF); a.sc.vec = (T*)(base + ov);
-    a.sc.ivec = (int32_t*)(base + oi); a.out = (int*)(base + oo);
+    a.sc.ivec = (int32_t*)(base + oi); a.out = (int*)(base + oo); a.sc.dbg = nullptr;
     a.relTol = settings->relTolerance; a.absTol = settings->absTolerance; a.maxIterations = settings->maxIterations;
     a.unconstrained = unconstrainedSolution; a.n = n;
     const int nb = solve_nb(n, (int)sizeof(T));

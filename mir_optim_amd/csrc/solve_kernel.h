@@ -56,7 +56,10 @@ struct SolveScratch {    // global scratch, all L2 resident
     T* Fg;      // n x (n|1) factor when it does not fit LDS
     T* vec;     // 12 n-vectors: s, b, r, w, la, mu, sX, qpl, qpu, q, xq, spare
     int32_t* ivec;  // 2 n: SI, flags
+    long long* dbg; // optional phase stamps (diagnostic builds of the host pass a buffer; else nullptr)
 };
+
+#define MIRLSQ_STAMP(ptr, k) do { if ((ptr) && threadIdx.x == 0) (ptr)[k] = wall_clock64(); } while (0)
 
 // ---------------------------------------------------------------- workgroup collectives
 template <typename T, typename Op>
@@ -90,7 +93,7 @@ __device__ inline int block_or(int v, int* red)
 // F column-major (F(i,k) at F[i + k*ldf]), lower. xv: the right-hand side / solution in memory
 // visible to the workgroup. Must be called by all threads; wave 0 works, then a barrier.
 template <typename T>
-__device__ inline void potrs_wave(int n, const T* F, int ldf, T* xv)
+__device__ __forceinline__ void potrs_wave(int n, const T* F, int ldf, T* xv)
 {
     constexpr int K = kSolveMaxN / kWave;   // elements per lane
     __syncthreads();
@@ -156,7 +159,12 @@ __device__ __forceinline__ int potrf_tiled(int n, const T* A, int lda, T* F, int
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int i = 16 * a + tr, k = 16 * b + tc;
-            f[a][b] = (b <= a && i < n && k < n) ? A[i + (size_t)k * lda] : T(0);
+            if (b <= a) {   // compile-time after unrolling; addresses clamped so the loads need no branch
+                const T v = A[(i < n ? i : n - 1) + (size_t)(k < n ? k : n - 1) * lda];
+                f[a][b] = (i < n && k < n) ? v : T(0);
+            } else {
+                f[a][b] = T(0);
+            }
         }
     int info = 0;
 #pragma unroll
@@ -170,12 +178,15 @@ __device__ __forceinline__ int potrf_tiled(int n, const T* A, int lda, T* F, int
             const T ajj = *sh;
             if (!(ajj > 0)) { info = j + 1; break; }      // uniform
             const T d = dsqrt(ajj);
+            const T rinv = T(1) / d;                      // ?potf2 scales the column by ONE / AJJ
+            // (sqrt and the reciprocal are independent of each other's result only through d; both
+            //  sit on the per-column critical path -- see DESIGN.md "solve kernel")
             if (tc == jc) {
 #pragma unroll
                 for (int a = JB; a < NB; ++a) {
                     const int i = 16 * a + tr;
-                    if (i > j && i < n) { f[a][JB] = f[a][JB] / d; colbuf[i] = f[a][JB]; }
-                    else if (i == j) { f[a][JB] = d; rdiag[j] = T(1) / d; }
+                    if (i > j && i < n) { f[a][JB] = f[a][JB] * rinv; colbuf[i] = f[a][JB]; }
+                    else if (i == j) { f[a][JB] = d; rdiag[j] = rinv; }
                 }
             }
             __syncthreads();
@@ -183,8 +194,9 @@ __device__ __forceinline__ int potrf_tiled(int n, const T* A, int lda, T* F, int
 #pragma unroll
             for (int a = JB; a < NB; ++a) {
                 const int i = 16 * a + tr, k = 16 * a + tc;
-                ci[a] = (i > j && i < n) ? colbuf[i] : T(0);
-                ck[a] = (k > j && k < n) ? colbuf[k] : T(0);
+                const T vi = colbuf[i < n ? i : n - 1], vk = colbuf[k < n ? k : n - 1];
+                ci[a] = (i > j && i < n) ? vi : T(0);
+                ck[a] = (k > j && k < n) ? vk : T(0);
             }
 #pragma unroll
             for (int a = JB; a < NB; ++a)
@@ -228,7 +240,8 @@ __device__ __forceinline__ void potrs_fast(int n, const T* F, int ldf, const T* 
 #pragma unroll
                 for (int t = 0; t < K; ++t) {
                     const int i = i0 + u, k = lane + kWave * t;
-                    col[u][t] = (i < n && k > i && k < n) ? F[k + (size_t)i * ldf] : T(0);
+                    const T v = F[(k < n ? k : n - 1) + (size_t)(i < n ? i : n - 1) * ldf];
+                    col[u][t] = (i < n && k > i && k < n) ? v : T(0);
                 }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -236,7 +249,7 @@ __device__ __forceinline__ void potrs_fast(int n, const T* F, int ldf, const T* 
                 if (i < n) {
                     T xi = 0;
 #pragma unroll
-                    for (int t = 0; t < K; ++t) if ((i >> 6) == t) xi = __shfl(xr[t] * rd[t], i & 63, kWave);
+                    for (int t = 0; t < K; ++t) if ((i >> 6) == t) xi = lane_bcast(xr[t] * rd[t], i & 63);
 #pragma unroll
                     for (int t = 0; t < K; ++t) {
                         if (lane + kWave * t == i) xr[t] = xi;
@@ -252,15 +265,17 @@ __device__ __forceinline__ void potrs_fast(int n, const T* F, int ldf, const T* 
 #pragma unroll
                 for (int t = 0; t < K; ++t) {
                     const int i = i0 - u, k = lane + kWave * t;
-                    row[u][t] = (i < n && k < i) ? F[i + (size_t)k * ldf] : T(0);
+                    const int ic = i < 0 ? 0 : (i < n ? i : n - 1);
+                    const T v = F[ic + (size_t)(k < n ? k : n - 1) * ldf];
+                    row[u][t] = (i >= 0 && i < n && k < i) ? v : T(0);
                 }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = i0 - u;
-                if (i < n) {
+                if (i >= 0 && i < n) {
                     T xi = 0;
 #pragma unroll
-                    for (int t = 0; t < K; ++t) if ((i >> 6) == t) xi = __shfl(xr[t] * rd[t], i & 63, kWave);
+                    for (int t = 0; t < K; ++t) if ((i >> 6) == t) xi = lane_bcast(xr[t] * rd[t], i & 63);
 #pragma unroll
                     for (int t = 0; t < K; ++t) {
                         if (lane + kWave * t == i) xr[t] = xi;
@@ -281,8 +296,9 @@ __device__ __forceinline__ void potrs_fast(int n, const T* F, int ldf, const T* 
 // F/ldf: factor storage (LDS or global). Returns info (0 = ok, k > 0 = leading minor k not
 // positive definite). Collective over the workgroup.
 template <typename T, int NB>
-__device__ int posvx_device(int n, T* A, int lda, T* F, int ldf, T* s, T* b, T* x, T* r, T* w, T* red)
+__device__ __forceinline__ int posvx_device(int n, T* A, int lda, T* F, int ldf, T* s, T* b, T* x, T* r, T* w, T* red, long long* dbg = nullptr)
 {
+    MIRLSQ_STAMP(dbg, 2);
     // fast path (NB > 0): LDS scratch behind the factor
     T* colbuf = F + (size_t)ldf * (16 * (NB > 0 ? NB : 1));
     T* rdiag = colbuf + 16 * (NB > 0 ? NB : 1);
@@ -316,6 +332,7 @@ __device__ int posvx_device(int n, T* A, int lda, T* F, int ldf, T* s, T* b, T* 
     }
     __syncthreads();
 
+    MIRLSQ_STAMP(dbg, 3);
     // ?lacpy + ?potrf 'L'
     if constexpr (NB > 0) {
         const int info = potrf_tiled<T, NB>(n, A, lda, F, ldf, colbuf, rdiag, shv);
@@ -344,55 +361,47 @@ __device__ int posvx_device(int n, T* A, int lda, T* F, int ldf, T* s, T* b, T* 
         }
     }
 
+    MIRLSQ_STAMP(dbg, 4);
     // ?potrs
     if (tid < n) x[tid] = b[tid];
     if constexpr (NB > 0) potrs_fast<T, (NB > 4 ? 2 : 1)>(n, F, ldf, rdiag, x);
     else potrs_wave(n, F, ldf, x);
 
+    MIRLSQ_STAMP(dbg, 5);
     // ?porfs: iterative refinement, ITMAX = 5
     const T safe1 = T(n + 1) * safmin, safe2 = safe1 / eps;
     T lstres = 3;
     for (int count = 1;; ++count) {
-        // r = b - A x ; w = |b| + |A| |x|      (two threads per row)
-        {
-            const int i = tid >> 1, h = tid & 1;
+        // r = b - A x ; w = |b| + |A| |x|      (two threads per row, 16 loads in flight per thread)
+        for (int base = 0; base < n; base += kSolveThreads / 2) {
+            const int i = base + (tid >> 1), h = tid & 1;
+            const int ic = i < n ? i : n - 1;
+            const int k0 = h ? n / 2 : 0, k1 = h ? n : n / 2;
+            const T* __restrict__ Ap = A;
+            const T* __restrict__ xp = x;
             T ri = 0, wi = 0;
-            if (i < n) {
-                const int k0 = h ? n / 2 : 0, k1 = h ? n : n / 2;
-#pragma unroll 16
-                for (int k = k0; k < k1; ++k) {
-                    const T aik = A[i + (size_t)k * lda];
-                    const T xk = x[k];
-                    ri -= aik * xk;
-                    wi += dabs(aik) * dabs(xk);
+            for (int kb = k0; kb < k1; kb += 16) {
+                T av[16], xv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int k = kb + u < k1 ? kb + u : k1 - 1;
+                    av[u] = Ap[ic + (size_t)k * lda];
+                    xv[u] = xp[k];
                 }
-            }
-            ri += wave_shfl_xor(ri, 1);
-            wi += wave_shfl_xor(wi, 1);
-            if (i < n && h == 0) { r[i] = b[i] + ri; w[i] = dabs(b[i]) + wi; }
-        }
-        if (n > kSolveThreads / 2) {   // rows beyond the first 128 (n <= 256)
-            __syncthreads();
-            const int i = kSolveThreads / 2 + (tid >> 1), h = tid & 1;
-            T ri = 0, wi = 0;
-            if (i < n) {
-                const int k0 = h ? n / 2 : 0, k1 = h ? n : n / 2;
-#pragma unroll 16
-                for (int k = k0; k < k1; ++k) {
-                    const T aik = A[i + (size_t)k * lda];
-                    const T xk = x[k];
-                    ri -= aik * xk;
-                    wi += dabs(aik) * dabs(xk);
-                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (kb + u < k1) { ri -= av[u] * xv[u]; wi += dabs(av[u]) * dabs(xv[u]); }
             }
             ri += wave_shfl_xor(ri, 1);
             wi += wave_shfl_xor(wi, 1);
             if (i < n && h == 0) { r[i] = b[i] + ri; w[i] = dabs(b[i]) + wi; }
         }
         __syncthreads();
+        if (count == 1) MIRLSQ_STAMP(dbg, 11);
         T qv = 0;
         if (tid < n) qv = (w[tid] > safe2) ? dabs(r[tid]) / w[tid] : (dabs(r[tid]) + safe1) / (w[tid] + safe1);
         const T berr = block_max(qv, red);
+        if (count == 1) MIRLSQ_STAMP(dbg, 12);
         if (berr > eps && 2 * berr <= lstres && count <= 5) {
             if constexpr (NB > 0) potrs_fast<T, (NB > 4 ? 2 : 1)>(n, F, ldf, rdiag, r);
             else potrs_wave(n, F, ldf, r);
@@ -405,6 +414,7 @@ __device__ int posvx_device(int n, T* A, int lda, T* F, int ldf, T* s, T* b, T* 
     }
     if (rcequ && tid < n) x[tid] = s[tid] * x[tid];
     __syncthreads();
+    MIRLSQ_STAMP(dbg, 6);
     return 0;
 }
 
@@ -412,9 +422,9 @@ __device__ int posvx_device(int n, T* A, int lda, T* F, int ldf, T* s, T* b, T* 
 // Pm: n x n full symmetric (unscaled). q, l, u: n-vectors. x: in/out (holds the unconstrained
 // solution on entry when skip_unconstrained). Returns BoxQPStatus; *iters = active-set passes.
 template <typename T, int NB>
-__device__ int box_qp_device(int n, const T* Pm, const T* q, const T* l, const T* u, T* x,
+__device__ __forceinline__ int box_qp_device(int n, const T* Pm, const T* q, const T* l, const T* u, T* x,
                              bool unconstrainedSolution, T relTol, T absTol, uint32_t maxIterations,
-                             SolveScratch<T>& sc, T* F, int ldf, T* red, int* ired, int* iters)
+                             SolveScratch<T>& sc, T* F, int ldf, T* red, int* ired, int* iters, bool a_prefilled = false)
 {
     const int tid = threadIdx.x;
     T* s = sc.vec;
@@ -430,11 +440,21 @@ __device__ int box_qp_device(int n, const T* Pm, const T* q, const T* l, const T
     if (n == 0) return 0;                                           // QP:162-163
 
     if (!unconstrainedSolution) {                                   // QP:168-214
-#pragma unroll 16
-        for (int idx = tid; idx < n * n; idx += kSolveThreads) sc.A[idx] = Pm[idx];   // QP:186-189
+        if (!a_prefilled) {                                            // QP:186-189
+            const T* __restrict__ src = Pm;
+            T* __restrict__ da = sc.A;
+            const int nn = n * n;
+            for (int base = tid; base < nn; base += 16 * kSolveThreads) {
+                T v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { const int idx = base + u * kSolveThreads; v[u] = src[idx < nn ? idx : nn - 1]; }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { const int idx = base + u * kSolveThreads; if (idx < nn) da[idx] = v[u]; }
+            }
+        }
         if (tid < n) b[tid] = -q[tid];                              // QP:191
         __syncthreads();
-        const int info = posvx_device<T, NB>(n, sc.A, n, F, ldf, s, b, x, r, w, red);
+        const int info = posvx_device<T, NB>(n, sc.A, n, F, ldf, s, b, x, r, w, red, sc.dbg);
         if (info != 0) return 1;                                    // QP:212-213 (info == n+1 is never produced)
     }
 
@@ -575,6 +595,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
     T* qpu = a.sc.vec + 8 * (size_t)n;
     T* xq = a.sc.vec + 10 * (size_t)n;
 
+    MIRLSQ_STAMP(a.sc.dbg, 0);
+    if (a.sc.dbg && threadIdx.x == 0) a.sc.dbg[9] = clock64();
     // gradient test, LS:1053: stop before touching lambda when ||Jy||_inf <= gradTolerance
     if (a.check_grad && !(a.st->jy_inf > a.set.gradTolerance)) {
         if (tid == 0) { a.st->flags = kFlagGradSmall; a.st->qp_status = 0; a.st->qp_iterations = 0; }
@@ -601,16 +623,35 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
     // step bounds LS:1074-1077, P = JJ + lambda I LS:1078-1079 (JJ itself is never modified, so
     // the save/restore of its diagonal at LS:1078/1094 is not needed)
     if (tid < n) { qpl[tid] = a.lower[tid] - a.x[tid]; qpu[tid] = a.upper[tid] - a.x[tid]; }
-#pragma unroll 16
-    for (int idx = tid; idx < n * n; idx += kSolveThreads) a.sc.Pm[idx] = a.JJ[idx];
-    __syncthreads();
-    if (tid < n) a.sc.Pm[(size_t)tid * (n + 1)] = a.JJ[(size_t)tid * (n + 1)] + lambda;
+    {   // Pm = A = JJ + lambda I, 16 loads in flight per thread (a plain copy loop serialises on
+        // may-alias load/store ordering)
+        const T* __restrict__ src = a.JJ;
+        T* __restrict__ dp = a.sc.Pm;
+        T* __restrict__ da = a.sc.A;
+        const int nn = n * n;
+        for (int base = tid; base < nn; base += 16 * kSolveThreads) {
+            T v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int idx = base + u * kSolveThreads; v[u] = src[idx < nn ? idx : nn - 1]; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int idx = base + u * kSolveThreads;
+                if (idx < nn) {
+                    const T t = (idx % (n + 1) == 0) ? v[u] + lambda : v[u];
+                    dp[idx] = t;
+                    da[idx] = t;
+                }
+            }
+        }
+    }
     __syncthreads();
 
+    MIRLSQ_STAMP(a.sc.dbg, 1);
     int qp_iters = 0;
     const int qp = box_qp_device<T, NB>(n, a.sc.Pm, a.Jy, qpl, qpu, xq, false, a.set.qpRelTolerance, a.set.qpAbsTolerance,
-                                 a.set.qpMaxIterations, a.sc, F, ldf, red, ired, &qp_iters);   // LS:1080
+                                 a.set.qpMaxIterations, a.sc, F, ldf, red, ired, &qp_iters, true);   // LS:1080
 
+    MIRLSQ_STAMP(a.sc.dbg, 7);
     int flags = 0;
     T ndd = 0, pred = 0, xn = 0;
     if (qp == 0) {
@@ -650,6 +691,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
         xn = amx > 0 ? amx * dsqrt(block_sum(sc2, red)) : T(0);
         if (!(dsqrt(ndd) < a.set.maxStep)) flags |= kFlagStepTooLong; // LS:1101
     }
+    MIRLSQ_STAMP(a.sc.dbg, 8);
+    if (a.sc.dbg && threadIdx.x == 0) a.sc.dbg[10] = clock64();
     if (tid == 0) {
         a.st->lambda = lambda;
         a.st->qp_status = qp;
