@@ -26,6 +26,8 @@
 //     all-reduce uses.
 #pragma once
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace mirlsq {
@@ -288,49 +290,91 @@ __global__ __launch_bounds__(256) void k_jtj_slab_reduce(const T* __restrict__ s
 }
 
 // =========================================================================================
-// v2: the same fused pass with an LDS-DMA ring (f64, n = 16 NCB).
+// v2: the same fused pass with an LDS-DMA ring (f64, n = 16 NCB, m even).
 //
 // v1 above keeps only one 4-row group per wave in flight, so a CU has a few KB of J outstanding and
-// the kernel runs at HBM *latency* (measured 1.4 TB/s algorithmic at m = 1e6, n = 128). Here a
-// dedicated loader wave streams J through a ring of NS LDS slots with `global_load_lds_dwordx4`
-// (no VGPRs, up to 60 KB in flight per workgroup, counted `s_waitcnt vmcnt(N)`, one raw
-// `s_barrier` per stage), and the four compute waves ("roles", each owning a quarter of the
-// accumulator blocks) read their MFMA fragments from the slot with ds_read_b64:
-//   lane (q, p) reads row 4 g + q, column 16 c + p  ->  exactly the A/B operand layout.
-// y / y_old are ordinary vector loads in the compute waves only (the loader wave never issues a
-// VGPR-destination load, so its vmcnt counts nothing but its own DMA).
+// the kernel runs at HBM *latency* (measured 1.4 TB/s algorithmic at m = 1e6, n = 128). Here the
+// four waves of a workgroup ("roles", each owning a quarter of the accumulator blocks and walking the
+// same rows) stream J through a ring of NS LDS slots with `global_load_lds_dwordx4`: no VGPRs are
+// spent on data in flight, up to D stages (~60 KB) per workgroup are outstanding, each wave issues
+// its share of a stage's 1 KB DMA instructions, waits for its own with a COUNTED `s_waitcnt
+// vmcnt(N)` (N = D x the VMEM operations the wave issues per stage, DMA + Broyden stores) and one
+// raw `s_barrier` per stage publishes the stage to the other waves. The MFMA fragments are read
+// from the slot with ds_read_b64: lane (q, p) reads row 4 g + q, column 16 c + p -> exactly the
+// A/B operand layout. y / y_old ride in two small rings of their own (one 1 KB DMA per 128 rows),
+// so the main loop contains no VGPR-destination global load at all.
 // =========================================================================================
 typedef __attribute__((address_space(3))) void* jtj_lds_ptr;
 typedef const __attribute__((address_space(1))) void* jtj_gbl_ptr;
 
-template <int NCB> struct Jtj2Cfg {
-    static constexpr int RS = (NCB == 1) ? 16 : ((NCB % 2 == 0 && NCB >= 6) ? 4 : 8);   // rows per stage
+template <int NCB, bool BROYDEN> struct Jtj2Cfg {
+    // rows per stage: ~16 KB stages so that one barrier is amortised over 4+ row groups (a probe on
+    // MI355X: 4 KB stages 0.33 ms, 16 KB stages 0.27 ms for the n = 128 MFMA work; scripts/probes)
+    static constexpr int RS = NCB <= 4 ? 32 : (NCB == 5 ? 24 : (NCB == 6 ? 20 : 16));
     static constexpr int GPS = RS / 4;                                                     // 4-row groups per stage
     static constexpr int IPS = RS * NCB / 8;                                               // 1 KB DMA instructions per stage
-    static constexpr int D = (60 / IPS) > 15 ? 15 : (60 / IPS);                            // stages in flight
-    static constexpr int NS = D + 2;                                                       // ring slots
     static constexpr int SLOT_BYTES = IPS * 1024;
+    // DMA instructions the busier of the two loading waves issues per stage (waves 0, 1 issue every
+    // DMA and never store; waves 2, 3 do every Broyden write-back and issue no DMA: a counted vmcnt
+    // wait is only reliable over operations of one kind -- mixing stores into the count made the
+    // DMA wait pass early now and then, a run-to-run nondeterminism caught by scripts/diag_determinism.py)
+    static constexpr int MAX_OPS = (IPS + 1) / 2;
+    static constexpr int D0 = 60 / MAX_OPS;                                                // vmcnt is 6 bits
+    static constexpr int D1 = (64 * 1024) / SLOT_BYTES - 2;                                // 64 KB ring
+    static constexpr int D2 = D0 < D1 ? D0 : D1;
+    static constexpr int D = D2 < 1 ? 1 : (D2 > 15 ? 15 : D2);                             // stages in flight
+    static constexpr int NS = D + 2;                                                       // ring slots
     static constexpr int RING_BYTES = NS * SLOT_BYTES;
-    // y / y_old travel through their own small rings: one 1 KB DMA instruction = 128 rows = SPC stages
-    static constexpr int SPC = 128 / RS;            // stages per y chunk
-    static constexpr int YNS = 4;                   // y ring slots (chunks c .. c+2 may be live)
+    // y / y_old travel through their own small rings: one 1 KB DMA instruction = one chunk of 128 rows
+    static constexpr int YNS = 4;                   // y ring slots (chunks c-1 .. c+2 may be live)
     static constexpr int Y_OFF = RING_BYTES;
     static constexpr int YO_OFF = RING_BYTES + YNS * 1024;
     static constexpr int LDS_BYTES = RING_BYTES + 2 * YNS * 1024;
 };
-constexpr int kJtj2Threads = 5 * kWave;     // 4 compute waves + 1 loader wave
+constexpr int kJtj2Threads = 4 * kWave;
 
 template <int NCB, bool BROYDEN, int ROLE>
-__device__ __forceinline__ void jtj2_compute(const JtjArgs<double>& a, const unsigned char* smem, int lane,
-                                             size_t s0, size_t S)
+__device__ __forceinline__ void jtj2_body(const JtjArgs<double>& a, unsigned char* smem, int lane, size_t s0, size_t S)
 {
     using T = double;
     using Acc = typename Mma<T>::Acc;
-    using C = Jtj2Cfg<NCB>;
+    using C = Jtj2Cfg<NCB, BROYDEN>;
     constexpr int NACC = jtj_nacc<NCB>();
+    constexpr int n = 16 * NCB;
+    // this wave's share of a stage: waves 0, 1 issue the DMA instructions (ROLE, ROLE + 2, ...) and never
+    // store; waves 2, 3 write back the Broyden-updated column blocks c = ROLE (mod 2) and never load
+    constexpr bool LOADER = ROLE < 2;
+    constexpr int MYI = LOADER ? (C::IPS + 1 - ROLE) / 2 : 0;
+    constexpr int OPS = MYI;
     const int q = lane >> 4, p = lane & 15;
     const size_t m = a.m;
-    constexpr int n = 16 * NCB;
+
+    const unsigned char* Jb = reinterpret_cast<const unsigned char*>(a.J);
+    const size_t total = m * (size_t)n * sizeof(T);
+    auto issue = [&](size_t s) {
+        const size_t base = (s0 + s) * (size_t)C::RS * n * sizeof(T);
+        unsigned char* slot = smem + (s % C::NS) * C::SLOT_BYTES;
+#pragma unroll
+        for (int k = 0; k < MYI; ++k) {
+            const int ins = ROLE + 2 * k;
+            size_t off = base + (size_t)(ins * 64 + lane) * 16;
+            if (off + 16 > total) off = base;            // rows past m: any valid bytes (masked by the consumers)
+            __builtin_amdgcn_global_load_lds((jtj_gbl_ptr)(Jb + off), (jtj_lds_ptr)(slot + ins * 1024), 16, 0, 0);
+        }
+    };
+    // y / y_old chunks (128 rows each) are issued by role 1, two chunks ahead, in the same in-order queue
+    const unsigned char* yb = reinterpret_cast<const unsigned char*>(a.y);
+    const unsigned char* yob = reinterpret_cast<const unsigned char*>(a.y_old);
+    const size_t ytotal = m * sizeof(T);
+    const size_t nchunks = (S * C::RS + 127) / 128;
+    size_t next_chunk = 0;
+    auto issue_y = [&](size_t c) {
+        size_t off = ((s0 * C::RS) + c * 128) * sizeof(T) + (size_t)lane * 16;
+        if (off + 16 > ytotal) off = 0;
+        __builtin_amdgcn_global_load_lds((jtj_gbl_ptr)(yb + off), (jtj_lds_ptr)(smem + C::Y_OFF + (c % C::YNS) * 1024), 16, 0, 0);
+        if constexpr (BROYDEN)
+            __builtin_amdgcn_global_load_lds((jtj_gbl_ptr)(yob + off), (jtj_lds_ptr)(smem + C::YO_OFF + (c % C::YNS) * 1024), 16, 0, 0);
+    };
 
     Acc acc[NACC];
 #pragma unroll
@@ -344,55 +388,103 @@ __device__ __forceinline__ void jtj2_compute(const JtjArgs<double>& a, const uns
     }
     T neg_d = 0;
     if constexpr (BROYDEN) neg_d = -(T(1) / *a.dx_dot);
+    // the loads above must have retired before the counted waits below start counting
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    if constexpr (ROLE == 1) {
+        while (next_chunk < 3 && next_chunk < nchunks) issue_y(next_chunk++);
+    }
+    const size_t pre = S < (size_t)C::D ? S : (size_t)C::D;
+    for (size_t s = 0; s < pre; ++s) issue(s);
 
     for (size_t s = 0; s < S; ++s) {
-        __builtin_amdgcn_s_barrier();                       // stage s has landed (loader waited for it)
+        if constexpr (ROLE == 1) {
+            // keep the chunk holding this stage's first row plus two more in flight / resident
+            while (next_chunk <= (s * C::RS) / 128 + 2 && next_chunk < nchunks) issue_y(next_chunk++);
+        }
+        if (s + C::D < S) {
+            issue(s + C::D);
+            // my DMA of stage s (and everything older) has landed once at most D * OPS younger ops remain
+            if constexpr (OPS > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::D * OPS) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                       // stage s is complete in LDS for every wave
         const T* slot = reinterpret_cast<const T*>(smem + (s % C::NS) * C::SLOT_BYTES);
+        const T* yring = reinterpret_cast<const T*>(smem + C::Y_OFF);
+        const T* yoring = reinterpret_cast<const T*>(smem + C::YO_OFF);
+        const size_t row0 = (s0 + s) * C::RS;               // first global row of the stage
+
+        // One group = 4 rows: fragments v[NCB] (+ y, y_old). Software pipeline inside the stage:
+        //   read(g + 1) is issued before the MFMAs of g, and prepare(g + 1) -- masking, Broyden update,
+        //   write-back, J^T y -- is independent VALU work the scheduler can slot between those MFMAs.
+        struct Grp { T v[NCB]; T y, yo; };
+        auto read = [&](int gi, Grp& g) {
 #pragma unroll
-        for (int gi = 0; gi < C::GPS; ++gi) {
-            const size_t row = (s0 + s) * C::RS + 4 * gi + q;
-            const bool rok = row < m;
-            const size_t rc = rok ? row : m - 1;
-            (void)rc;
-            T v[NCB];
+            for (int c = 0; c < NCB; ++c) g.v[c] = slot[(4 * gi + q) * n + 16 * c + p];
+            const size_t lr = s * C::RS + 4 * gi + q;       // row index local to this workgroup
+            const int yidx = (int)((lr >> 7) % C::YNS) * 128 + (int)(lr & 127);
+            g.y = yring[yidx];
+            g.yo = 0;
+            if constexpr (BROYDEN) g.yo = yoring[yidx];
+        };
+        auto prepare = [&](int gi, Grp& g, auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            const size_t row = row0 + 4 * gi + q;
+            const bool rok = FULL ? true : row < m;
+            if constexpr (!FULL) {
 #pragma unroll
-            for (int c = 0; c < NCB; ++c) {
-                const T t = slot[(4 * gi + q) * n + 16 * c + p];
-                v[c] = rok ? t : T(0);
+                for (int c = 0; c < NCB; ++c) g.v[c] = rok ? g.v[c] : T(0);
+                g.y = rok ? g.y : T(0);
+                g.yo = rok ? g.yo : T(0);
             }
-            const int yidx = (int)((s / C::SPC) % C::YNS) * 128 + (int)(s % C::SPC) * C::RS + 4 * gi + q;
-            T yv = reinterpret_cast<const T*>(smem + C::Y_OFF)[yidx];
-            yv = rok ? yv : T(0);
             if constexpr (BROYDEN) {
-                T yo = reinterpret_cast<const T*>(smem + C::YO_OFF)[yidx];
-                yo = rok ? yo : T(0);
                 T part = 0;
 #pragma unroll
-                for (int c = 0; c < NCB; ++c) part += v[c] * dxr[c];
+                for (int c = 0; c < NCB; ++c) part += g.v[c] * dxr[c];
                 part = sum16(part);
-                const T t = (yo - yv) + part;            // LS:1003-1004
-                const T u = neg_d * t;                   // LS:1005
-                T* wp = a.Jout + rc * (size_t)n;
+                const T t = (g.yo - g.y) + part;          // LS:1003-1004
+                const T u = neg_d * t;                    // LS:1005
+                T* wp = a.Jout + (rok ? row : m - 1) * (size_t)n;
 #pragma unroll
                 for (int c = 0; c < NCB; ++c) {
-                    v[c] = v[c] + u * dxr[c];            // LS:1006
-                    if constexpr (ROLE == 0) { if (rok) wp[16 * c + p] = v[c]; }
+                    g.v[c] = g.v[c] + u * dxr[c];         // LS:1006
+                    if constexpr (!LOADER) { if (c % 2 == ROLE - 2) { if (rok) wp[16 * c + p] = g.v[c]; } }
                 }
             }
             if constexpr (ROLE == 0) {
 #pragma unroll
-                for (int c = 0; c < NCB; ++c) jy[c] += v[c] * yv;     // LS:1052
+                for (int c = 0; c < NCB; ++c) jy[c] += g.v[c] * g.y;     // LS:1052
             }
+        };
+        auto mfmas = [&](const Grp& g) {
 #pragma unroll
             for (int I = 0; I < NCB; ++I)
 #pragma unroll
-                for (int Jb = 0; Jb <= I; ++Jb)
-                    if (jtj_owns<NCB, 4, ROLE>(I * (I + 1) / 2 + Jb))
-                        acc[I * (I + 1) / 2 + Jb] = Mma<T>::mma(v[I], v[Jb], acc[I * (I + 1) / 2 + Jb]);   // LS:1065
-        }
+                for (int Jb2 = 0; Jb2 <= I; ++Jb2)
+                    if (jtj_owns<NCB, 4, ROLE>(I * (I + 1) / 2 + Jb2))
+                        acc[I * (I + 1) / 2 + Jb2] = Mma<T>::mma(g.v[I], g.v[Jb2], acc[I * (I + 1) / 2 + Jb2]);   // LS:1065
+        };
+        auto stage = [&](auto full_tag) {
+            Grp ga, gb;
+            read(0, ga);
+            prepare(0, ga, full_tag);
+#pragma unroll
+            for (int gi = 0; gi < C::GPS; gi += 2) {
+                if (gi + 1 < C::GPS) read(gi + 1, gb);
+                mfmas(ga);
+                if (gi + 1 < C::GPS) {
+                    prepare(gi + 1, gb, full_tag);
+                    if (gi + 2 < C::GPS) read(gi + 2, ga);
+                    mfmas(gb);
+                    if (gi + 2 < C::GPS) prepare(gi + 2, ga, full_tag);
+                }
+            }
+        };
+        if (row0 + C::RS <= m) stage(std::true_type{}); else stage(std::false_type{});
     }
 
-    // every compute wave owns a disjoint part of the workgroup's slab: no LDS reduction needed
+    // every wave owns a disjoint part of the workgroup's slab: no LDS reduction needed
     T* dst = a.slabs + (size_t)blockIdx.x * jtj_slab_len<NCB>();
 #pragma unroll
     for (int i = 0; i < NACC; ++i)
@@ -411,13 +503,12 @@ __device__ __forceinline__ void jtj2_compute(const JtjArgs<double>& a, const uns
 }
 
 template <int NCB, bool BROYDEN>
-__global__ __launch_bounds__(kJtj2Threads) void k_jtj2(JtjArgs<double> a)
+__global__ __launch_bounds__(kJtj2Threads, 2) void k_jtj2(JtjArgs<double> a)
 {
-    using C = Jtj2Cfg<NCB>;
+    using C = Jtj2Cfg<NCB, BROYDEN>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int n = 16 * NCB;
 
     // contiguous range of stages for this workgroup
     const size_t Stot = (a.m + C::RS - 1) / C::RS;
@@ -426,52 +517,10 @@ __global__ __launch_bounds__(kJtj2Threads) void k_jtj2(JtjArgs<double> a)
     const size_t s1 = s0 + per < Stot ? s0 + per : Stot;
     const size_t S = s1 - s0;
 
-    if (wave == 4) {
-        // ---- loader wave: LDS-DMA ring, counted waits, one barrier per stage
-        const unsigned char* Jb = reinterpret_cast<const unsigned char*>(a.J);
-        const size_t total = a.m * (size_t)n * sizeof(double);
-        auto issue = [&](size_t s) {
-            const size_t base = (s0 + s) * (size_t)C::RS * n * sizeof(double);
-            unsigned char* slot = smem2 + (s % C::NS) * C::SLOT_BYTES;
-#pragma unroll
-            for (int ins = 0; ins < C::IPS; ++ins) {
-                size_t off = base + (size_t)(ins * 64 + lane) * 16;
-                if (off + 16 > total) off = base;            // rows past m: any valid bytes (masked by the consumers)
-                __builtin_amdgcn_global_load_lds((jtj_gbl_ptr)(Jb + off), (jtj_lds_ptr)(slot + ins * 1024), 16, 0, 0);
-            }
-        };
-        // y / y_old chunks (128 rows each) ride in the same in-order DMA queue, two chunks ahead
-        const unsigned char* yb = reinterpret_cast<const unsigned char*>(a.y);
-        const unsigned char* yob = reinterpret_cast<const unsigned char*>(a.y_old);
-        const size_t ytotal = a.m * sizeof(double);
-        const size_t nchunks = (S + C::SPC - 1) / C::SPC;
-        auto issue_y = [&](size_t c) {
-            size_t off = ((s0 * C::RS) + c * 128) * sizeof(double) + (size_t)lane * 16;
-            if (off + 16 > ytotal) off = 0;
-            __builtin_amdgcn_global_load_lds((jtj_gbl_ptr)(yb + off), (jtj_lds_ptr)(smem2 + C::Y_OFF + (c % C::YNS) * 1024), 16, 0, 0);
-            if constexpr (BROYDEN)
-                __builtin_amdgcn_global_load_lds((jtj_gbl_ptr)(yob + off), (jtj_lds_ptr)(smem2 + C::YO_OFF + (c % C::YNS) * 1024), 16, 0, 0);
-        };
-        if (nchunks > 0) issue_y(0);
-        if (nchunks > 1) issue_y(1);
-        const size_t pre = S < (size_t)C::D ? S : (size_t)C::D;
-        for (size_t s = 0; s < pre; ++s) issue(s);
-        for (size_t s = 0; s < S; ++s) {
-            if (s % C::SPC == 0 && s / C::SPC + 2 < nchunks) issue_y(s / C::SPC + 2);
-            if (s + C::D < S) {
-                issue(s + C::D);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::D * C::IPS) : "memory");   // everything up to stage s landed
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();
-        }
-        return;
-    }
-    if (wave == 0) jtj2_compute<NCB, BROYDEN, 0>(a, smem2, lane, s0, S);
-    else if (wave == 1) jtj2_compute<NCB, BROYDEN, 1>(a, smem2, lane, s0, S);
-    else if (wave == 2) jtj2_compute<NCB, BROYDEN, 2>(a, smem2, lane, s0, S);
-    else jtj2_compute<NCB, BROYDEN, 3>(a, smem2, lane, s0, S);
+    if (wave == 0) jtj2_body<NCB, BROYDEN, 0>(a, smem2, lane, s0, S);
+    else if (wave == 1) jtj2_body<NCB, BROYDEN, 1>(a, smem2, lane, s0, S);
+    else if (wave == 2) jtj2_body<NCB, BROYDEN, 2>(a, smem2, lane, s0, S);
+    else jtj2_body<NCB, BROYDEN, 3>(a, smem2, lane, s0, S);
 }
 
 }  // namespace mirlsq

@@ -96,20 +96,26 @@ struct JtjPlan {
     bool v2 = false;      // LDS-DMA ring kernel (f64, n = 16 ncb)
 };
 
-template <int NCB> constexpr size_t jtj2_lds() { return Jtj2Cfg<NCB>::LDS_BYTES; }
-inline size_t jtj2_lds_rt(int ncb)
+inline size_t jtj2_lds_rt(int ncb, bool br)
 {
     switch (ncb) {
-    case 1: return jtj2_lds<1>(); case 2: return jtj2_lds<2>(); case 3: return jtj2_lds<3>(); case 4: return jtj2_lds<4>();
-    case 5: return jtj2_lds<5>(); case 6: return jtj2_lds<6>(); case 7: return jtj2_lds<7>(); case 8: return jtj2_lds<8>();
+    case 1: return br ? Jtj2Cfg<1, true>::LDS_BYTES : Jtj2Cfg<1, false>::LDS_BYTES;
+    case 2: return br ? Jtj2Cfg<2, true>::LDS_BYTES : Jtj2Cfg<2, false>::LDS_BYTES;
+    case 3: return br ? Jtj2Cfg<3, true>::LDS_BYTES : Jtj2Cfg<3, false>::LDS_BYTES;
+    case 4: return br ? Jtj2Cfg<4, true>::LDS_BYTES : Jtj2Cfg<4, false>::LDS_BYTES;
+    case 5: return br ? Jtj2Cfg<5, true>::LDS_BYTES : Jtj2Cfg<5, false>::LDS_BYTES;
+    case 6: return br ? Jtj2Cfg<6, true>::LDS_BYTES : Jtj2Cfg<6, false>::LDS_BYTES;
+    case 7: return br ? Jtj2Cfg<7, true>::LDS_BYTES : Jtj2Cfg<7, false>::LDS_BYTES;
+    case 8: return br ? Jtj2Cfg<8, true>::LDS_BYTES : Jtj2Cfg<8, false>::LDS_BYTES;
     }
     return 0;
 }
 inline int jtj2_rs_rt(int ncb)
 {
     switch (ncb) {
-    case 1: return Jtj2Cfg<1>::RS; case 2: return Jtj2Cfg<2>::RS; case 3: return Jtj2Cfg<3>::RS; case 4: return Jtj2Cfg<4>::RS;
-    case 5: return Jtj2Cfg<5>::RS; case 6: return Jtj2Cfg<6>::RS; case 7: return Jtj2Cfg<7>::RS; case 8: return Jtj2Cfg<8>::RS;
+    case 1: return Jtj2Cfg<1, false>::RS; case 2: return Jtj2Cfg<2, false>::RS; case 3: return Jtj2Cfg<3, false>::RS;
+    case 4: return Jtj2Cfg<4, false>::RS; case 5: return Jtj2Cfg<5, false>::RS; case 6: return Jtj2Cfg<6, false>::RS;
+    case 7: return Jtj2Cfg<7, false>::RS; case 8: return Jtj2Cfg<8, false>::RS;
     }
     return 4;
 }
@@ -124,7 +130,7 @@ JtjPlan jtj_plan(size_t m, int n, int num_cu)
     static const bool no_v2 = std::getenv("MIR_LSQ_JTJ_V1") != nullptr;
     if (sizeof(T) == 8 && n % 16 == 0 && n <= 128 && m % 2 == 0 && !no_v2) {
         p.v2 = true;
-        p.lds = jtj2_lds_rt(p.ncb);
+        p.lds = jtj2_lds_rt(p.ncb, false);
         const size_t stot = (m + jtj2_rs_rt(p.ncb) - 1) / jtj2_rs_rt(p.ncb);
         size_t want = (stot + 7) / 8;                          // at least ~8 stages per workgroup
         const size_t cap = (size_t)num_cu * 2;
@@ -166,14 +172,15 @@ template <int NCB, bool BR>
 hipError_t jtj2_launch_one(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t s)
 {
     auto kern = k_jtj2<NCB, BR>;
+    constexpr size_t lds = Jtj2Cfg<NCB, BR>::LDS_BYTES;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(kJtj2Threads), p.lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(kJtj2Threads), lds, s, a);
     return hipGetLastError();
 }
 template <bool BR>
@@ -201,7 +208,9 @@ hipError_t jtj2_dispatch(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
 template <typename T, bool BR>
 hipError_t jtj_launch_br(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
 {
-    if (p.v2) return jtj2_dispatch<T, BR>(p, a, s);
+    static const char* v1sel = std::getenv("MIR_LSQ_JTJ_V1_ONLY");   // diagnostics: "br" / "nobr" use v1 for that variant
+    const bool force_v1 = v1sel && ((BR && v1sel[0] == 'b') || (!BR && v1sel[0] == 'n'));
+    if (p.v2 && !force_v1) return jtj2_dispatch<T, BR>(p, a, s);
     switch (p.ncb) {
     case 1: return jtj_launch_one<T, 1, BR>(p, a, s);
     case 2: return jtj_launch_one<T, 2, BR>(p, a, s);

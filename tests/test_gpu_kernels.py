@@ -79,11 +79,15 @@ def test_jtj_float32():
     assert np.array_equal(JJ, Ji.T @ Ji) and np.array_equal(Jy, Ji.T @ yi)
 
 
-def test_jtj_determinism():
+@pytest.mark.parametrize("m", [100003, 100000])     # odd m: register-streaming kernel; even m: LDS-DMA ring kernel
+def test_jtj_determinism(m):
     rng = np.random.default_rng(1)
-    J = rng.standard_normal((100003, 128)); y = rng.standard_normal(100003)
+    J = rng.standard_normal((m, 128)); y = rng.standard_normal(m)
+    yo = y + 0.01 * rng.standard_normal(m); dx = 1e-3 * rng.standard_normal(128)
     a = M.jtj(J, y); b = M.jtj(J, y)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    a = M.jtj(J, y, y_old=yo, dx=dx); b = M.jtj(J, y, y_old=yo, dx=dx)
+    assert all(np.array_equal(u, v) for u, v in zip(a[:3], b[:3]))
 
 
 # ------------------------------------------------------------------ BOXCQP / posvx on the device

@@ -223,6 +223,24 @@ def test_batched_residual_callback_matches_pointwise(m, n):
         assert np.max(np.abs(Yb - ref)) < 1e-13 and np.max(np.abs(Y1 - ref)) < 1e-13
 
 
+def test_repeated_solve_is_bit_reproducible():
+    """The whole path is deterministic (fixed-order reductions, no float atomics): repeated solves are
+    bitwise equal. m even and n = 128 select the LDS-DMA ring kernel; an earlier version of it mixed
+    stores into a counted vmcnt wait and was caught by exactly this check."""
+    w = P.tanh_linear(60000, 128)
+    prob = W.TanhLinear(w["A"], w["b"])
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
+    ref = None
+    for rep in range(6):
+        res, x = prob.solve(w["x0"], settings=s, batched=(rep % 2 == 0))
+        key = (res.iterations, res.fCalls, res.residual, x.tobytes())
+        if rep < 2:
+            ref = ref or {}
+            ref[rep % 2] = key
+        else:
+            assert key == ref[rep % 2], f"solve {rep} differs from solve {rep % 2}"
+
+
 def test_stats_and_reentrancy(oracle):
     """two different problems interleaved on their own streams/workspaces give the same answers as alone."""
     w1, w2 = P.tanh_linear(5000, 16), P.tanh_linear(7000, 32)
