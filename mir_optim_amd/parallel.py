@@ -1,0 +1,77 @@
+"""Row-shard data parallelism for the LM solver: rank r owns a contiguous block of
+the m residual rows; x, dx, lambda, J^T J, J^T y and every scalar are replicated and every rank runs the same
+control flow (the n x n solve is replicated too: its inputs are bit-identical after the all-reduce, so no
+broadcast is needed). The only exchange is a sum all-reduce of the packed [J^T J lower | J^T y] buffer per
+Jacobian-changing pass and of one scalar per residual evaluation.
+
+Two communicators exist in the C library: RCCL (one process per GPU over xGMI; the production path) and a
+callback communicator whose all-reduce is supplied by the host program -- used here with torch.distributed
+`gloo` so that the sharded path can be exercised with world_size 2 on a single GPU or on CPU-only hosts."""
+import ctypes as C
+
+import numpy as np
+
+from . import api
+
+
+def row_shard(m_total, world, rank):
+    """Contiguous, balanced row blocks: (row_offset, m_local). The first m_total % world ranks get one extra row."""
+    base, extra = divmod(int(m_total), int(world))
+    m_local = base + (1 if rank < extra else 0)
+    offset = rank * base + min(rank, extra)
+    return offset, m_local
+
+
+def packed_length(n):
+    """Doubles in the fused all-reduce payload: n(n+1)/2 (J^T J lower) + n (J^T y)."""
+    return n * (n + 1) // 2 + n
+
+
+def rccl_comm(world, rank, broadcast_bytes):
+    """Create the RCCL communicator. `broadcast_bytes(buf: np.ndarray[uint8, 128]) -> np.ndarray` must return rank
+    0's buffer on every rank (any out-of-band channel: torch.distributed, MPI, a file ...)."""
+    L = api.lib()
+    uid = np.zeros(128, dtype=np.uint8)
+    if rank == 0 and L.mir_lsq_rccl_unique_id(uid.ctypes.data) != 0:
+        raise RuntimeError("ncclGetUniqueId failed")
+    uid = np.ascontiguousarray(broadcast_bytes(uid), dtype=np.uint8)
+    comm = L.mir_lsq_comm_create_rccl(world, rank, uid.ctypes.data)
+    if not comm:
+        raise RuntimeError("ncclCommInitRank failed")
+    return comm
+
+
+class HostAllreduceComm:
+    """Callback communicator: device buffer -> host -> `allreduce_numpy(buf)` (in place, sum) -> device."""
+
+    def __init__(self, world, rank, allreduce_numpy):
+        self.allreduce_numpy = allreduce_numpy
+        L = api.lib()
+
+        def cb(_ctx, dev_ptr, count, stream):
+            host = np.empty(count, dtype=np.float64)
+            if L.mir_lsq_memcpy_d2h(host.ctypes.data, dev_ptr, count * 8, stream) != 0:
+                raise RuntimeError("D2H failed in all-reduce callback")
+            self.allreduce_numpy(host)
+            if L.mir_lsq_memcpy_h2d(dev_ptr, host.ctypes.data, count * 8, stream) != 0:
+                raise RuntimeError("H2D failed in all-reduce callback")
+
+        self._cb = api.ALLREDUCE_FN(cb)
+        self.handle = L.mir_lsq_comm_create_callback(world, rank, self._cb, None)
+        if not self.handle:
+            raise RuntimeError("mir_lsq_comm_create_callback failed")
+
+    def close(self):
+        if self.handle:
+            api.lib().mir_lsq_comm_destroy(self.handle)
+            self.handle = None
+
+
+def torch_allreduce_numpy(dist):
+    """`allreduce_numpy` over a torch.distributed process group (gloo on CPU tensors)."""
+    import torch
+
+    def f(buf):
+        t = torch.from_numpy(buf)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return f

@@ -91,7 +91,10 @@ def tanh_linear(m, n, row_offset=0, m_total=None, noise=1e-3):
     """cfg 3 / cfg 4 family: r_i(x) = tanh(a_i . x) - b_i, seeds 10..13. Rows [row_offset, row_offset+m)."""
     A = ((2 * splitmix64_uniform(10, m * n, row_offset * n) - 1) * np.sqrt(3.0 / n)).reshape(m, n)
     xs = 2 * splitmix64_uniform(11, n) - 1
-    b = np.tanh(A @ xs) + noise * (2 * splitmix64_uniform(12, m, row_offset) - 1)
+    dots = np.zeros(m)
+    for j in range(n):                      # fixed summation order: a row's value does not depend on the shard it is in
+        dots += A[:, j] * xs[j]
+    b = np.tanh(dots) + noise * (2 * splitmix64_uniform(12, m, row_offset) - 1)
     x0 = xs + 0.1 * (2 * splitmix64_uniform(13, n) - 1)
     return dict(A=np.ascontiguousarray(A), b=b, xstar=xs, x0=x0, m=m, n=n)
 

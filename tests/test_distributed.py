@@ -1,0 +1,83 @@
+"""N > 1 path: rows sharded over ranks, sum all-reduce of [J^T J | J^T y] and of the residual
+scalars, everything else replicated. world_size 2 over gloo on 127.0.0.1.
+  CPU  : host logic (row_shard, payload length) + the oracle's sharded restatement == the unsharded oracle
+  GPU  : the HIP path with the callback communicator, two processes sharing the GPU == the unsharded oracle"""
+import ctypes as C
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import problems as P
+from mir_optim_amd import parallel as PAR
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch(mode, m_total, n, tmp_path, world=2):
+    out = str(tmp_path / "result")
+    port = str(free_port())
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   LOCAL_RANK=str(r), OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), mode, str(m_total), str(n), out],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    return [json.load(open(f"{out}.{r}")) for r in range(world)]
+
+
+def unsharded_oracle(oracle, m_total, n):
+    w = P.tanh_linear(m_total, n)
+    s = oracle.default_settings(); s.absTolerance = 1e-9
+    ctx = oracle.TanhLinearCtx(w["A"].ctypes.data, w["b"].ctypes.data)
+    return oracle.optimize(oracle.native_fn("wlc_tanh_linear_f"), m_total, w["x0"], settings=s, fctx=C.addressof(ctx))
+
+
+def test_row_shard_partition():
+    for m_total, world in [(10, 2), (11, 2), (1000000, 8), (7, 8), (8000000, 8), (5, 3)]:
+        blocks = [PAR.row_shard(m_total, world, r) for r in range(world)]
+        assert blocks[0][0] == 0 and sum(b[1] for b in blocks) == m_total
+        for (o0, l0), (o1, _) in zip(blocks, blocks[1:]):
+            assert o0 + l0 == o1                                  # contiguous, no gap / overlap
+        assert max(b[1] for b in blocks) - min(b[1] for b in blocks) <= 1
+    assert PAR.packed_length(128) == 8384 and PAR.packed_length(256) == 33152   # 66 KB / 259 KB payloads
+    # shards concatenate to the unsharded data set (bit-identical inputs across world sizes)
+    full = P.tanh_linear(1001, 8)
+    parts = [P.tanh_linear(l, 8, row_offset=o) for o, l in (PAR.row_shard(1001, 3, r) for r in range(3))]
+    assert np.array_equal(np.vstack([p["A"] for p in parts]), full["A"])
+    assert np.array_equal(np.concatenate([p["b"] for p in parts]), full["b"])
+
+
+def test_sharded_oracle_matches_unsharded_gloo(oracle, tmp_path):
+    m_total, n = 6001, 12
+    res = launch("oracle", m_total, n, tmp_path)
+    ro, xo = unsharded_oracle(oracle, m_total, n)
+    assert res[0]["x"] == res[1]["x"] and res[0]["iterations"] == res[1]["iterations"]    # replicas agree bit for bit
+    assert np.allclose(res[0]["x"], xo, rtol=1e-7, atol=1e-10)
+    assert np.isclose(res[0]["residual"], ro.residual, rtol=1e-10)
+    assert (res[0]["status"] not in ("maxIterations", "numericError")) and ro.status >= 0
+
+
+@pytest.mark.gpu
+def test_sharded_gpu_path_matches_unsharded_oracle(oracle, tmp_path):
+    m_total, n = 40000, 64
+    res = launch("gpu", m_total, n, tmp_path)
+    ro, xo = unsharded_oracle(oracle, m_total, n)
+    assert res[0]["x"] == res[1]["x"] and res[0]["iterations"] == res[1]["iterations"]    # replicas agree bit for bit
+    assert np.allclose(res[0]["x"], xo, rtol=1e-6, atol=1e-9)
+    assert np.isclose(res[0]["residual"], ro.residual, rtol=1e-9)
+    assert res[0]["status"] not in ("maxIterations", "numericError")
