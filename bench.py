@@ -35,6 +35,23 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def pmc_traffic(kernel, m, n):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/rNN/pmc_traffic.json,
+    made by scripts/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command).
+    PMC counters cannot be read from inside the timed run, so this is the stored measurement; None if absent or
+    if the run's shape differs from the profiled one (m = 1e6, n = 128)."""
+    import glob
+    if (m, n) != (1_000_000, 128):
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1]))["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (KeyError, ValueError):
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,9 +159,9 @@ def main():
                     "solve_kernel": st["solve_ms"] / args.steps, "total": st["total_ms"] / args.steps},
             },
             "roofline": {
-                "kernel": "k_jtj<double,8,true> (fused Broyden + J^T J + J^T y)", "bound": "hbm",
+                "kernel": "mirlsq::k_jtj2<8, true> (fused Broyden + J^T J + J^T y, LDS-DMA ring)", "bound": "hbm",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms,
+                "traffic": pmc_traffic("mirlsq::k_jtj2<8, true>", m, n), "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms,
                 "launches": st["jtj_broyden_launches"],
                 "mfma_tflops": (m * n * (n + 1.0) + 6.0 * m * n) / (kern_ms * 1e-3) / 1e12 if kern_ms else 0.0,
             },
