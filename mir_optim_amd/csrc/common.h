@@ -105,6 +105,24 @@ __device__ inline float lane_bcast(float v, int src)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
+// 1/sqrt(a) and sqrt(a) to full precision from the hardware rsq estimate + Newton steps (shorter
+// dependent chain than sqrt() followed by a division; used on the Cholesky pivot path)
+__device__ inline void rsqrt_sqrt(double a, double& rinv, double& d)
+{
+    double r = __builtin_amdgcn_rsq(a);
+    r = r * (1.5 - 0.5 * a * r * r);
+    r = r * (1.5 - 0.5 * a * r * r);
+    double s = a * r;
+    s = fma(0.5 * r, fma(-s, s, a), s);          // sqrt: one correction step
+    r = fma(r, fma(-s, r, 1.0), r);              // 1/sqrt consistent with s
+    rinv = r; d = s;
+}
+__device__ inline void rsqrt_sqrt(float a, float& rinv, float& d)
+{
+    d = sqrtf(a);
+    rinv = 1.0f / d;
+}
+
 __device__ inline double dsqrt(double v) { return sqrt(v); }
 __device__ inline float dsqrt(float v) { return sqrtf(v); }
 __device__ inline double dabs(double v) { return fabs(v); }

@@ -25,7 +25,7 @@ namespace mirlsq {
 
 constexpr int kSolveThreads = 256;
 constexpr int kSolveMaxN = 256;          // n-vectors are handled one element per thread
-constexpr int kSolveLdsBytes = 150 * 1024;
+constexpr int kSolveLdsBytes = 159 * 1024;
 
 // Device-resident scalars of the LM loop. The host mirrors it after each decision point.
 template <typename T>
@@ -290,6 +290,208 @@ __device__ __forceinline__ void potrs_fast(int n, const T* F, int ldf, const T* 
     __syncthreads();
 }
 
+// ---------------------------------------------------------------- v2 of the LDS fast path
+// potrf_tiled2: same register tiling as potrf_tiled but ONE barrier per column. The 16 threads that
+// hold column j (already updated by columns < j) publish it UNSCALED, pivot included, into one of two
+// column buffers; after the barrier every thread reads the pivot and the entries it needs, computes
+// 1/sqrt(pivot) itself (no second exchange) and applies the scaled rank-1 update; the holders of
+// column j + 1 then publish into the other buffer. colbuf: 2 n values.
+template <typename T, int NB>
+__device__ __forceinline__ int potrf_tiled2(int n, const T* A, int lda, T* F, int ldf, T* colbuf, T* rdiag)
+{
+    // The matrix is padded to 16 NB with an identity block ([[A, 0], [0, I]] factors as [[L, 0], [0, I]]),
+    // so the inner loops need no "row < n" masks; the loop stops at column n - 1.
+    const int tid = threadIdx.x;
+    const int tr = tid & 15, tc = tid >> 4;
+    T f[NB][NB];
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int i = 16 * a + tr, k = 16 * b + tc;
+            if (b <= a) {
+                const T v = A[(i < n ? i : n - 1) + (size_t)(k < n ? k : n - 1) * lda];
+                f[a][b] = (i < n && k < n) ? v : ((i == k) ? T(1) : T(0));
+            } else {
+                f[a][b] = T(0);
+            }
+        }
+    if (tc == 0) {                                             // publish column 0
+#pragma unroll
+        for (int a = 0; a < NB; ++a) colbuf[16 * a + tr] = f[a][0];
+    }
+    int info = 0;
+#pragma unroll
+    for (int JB = 0; JB < NB; ++JB) {
+        if (info != 0 || 16 * JB >= n) break;
+        for (int jc = 0; jc < 16; ++jc) {
+            const int j = 16 * JB + jc;
+            if (j >= n) break;
+            const T* cb = colbuf + (j & 1) * (16 * NB);
+            __syncthreads();                                   // column j (unscaled) is published
+            const T ajj = cb[j];
+            T cvi[NB], cvk[NB];
+#pragma unroll
+            for (int a = JB; a < NB; ++a) { cvi[a] = cb[16 * a + tr]; cvk[a] = cb[16 * a + tc]; }
+            if (!(ajj > 0)) { info = j + 1; break; }           // uniform: every thread reads the same value
+            T rinv, d;
+            rsqrt_sqrt(ajj, rinv, d);
+            T ci[NB], ck[NB];
+#pragma unroll
+            for (int a = JB; a < NB; ++a) { ci[a] = cvi[a] * rinv; ck[a] = cvk[a] * rinv; }
+            ci[JB] = tr > jc ? ci[JB] : T(0);                   // only rows / columns below the pivot take part
+            ck[JB] = tc > jc ? ck[JB] : T(0);
+            if (tc == jc) {                                    // holders of column j keep the final values
+#pragma unroll
+                for (int a = JB + 1; a < NB; ++a) f[a][JB] = ci[a];
+                f[JB][JB] = tr > jc ? ci[JB] : (tr == jc ? d : f[JB][JB]);
+                if (tr == jc) rdiag[j] = rinv;
+            }
+#pragma unroll
+            for (int a = JB; a < NB; ++a)
+#pragma unroll
+                for (int b = JB; b <= a; ++b) f[a][b] -= ci[a] * ck[b];
+            // publish column j + 1 into the other buffer
+            if (j + 1 < n) {
+                T* nb = colbuf + ((j + 1) & 1) * (16 * NB);
+                if (jc < 15) {
+                    if (tc == jc + 1) {
+#pragma unroll
+                        for (int a = JB; a < NB; ++a) nb[16 * a + tr] = f[a][JB];
+                    }
+                } else if (JB + 1 < NB) {
+                    if (tc == 0) {
+#pragma unroll
+                        for (int a = JB + 1; a < NB; ++a) nb[16 * a + tr] = f[a][JB + 1];
+                    }
+                }
+            }
+        }
+    }
+    if (info != 0) return info;
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            const int i = 16 * a + tr, k = 16 * b + tc;
+            if (i < n && k < n && i >= k) F[i + (size_t)k * ldf] = f[a][b];
+        }
+    __syncthreads();
+    return 0;
+}
+
+// Inverses of the 16 x 16 diagonal blocks of L (lower triangular), one thread per (block, column):
+// column c of inv(L_kk) is the forward substitution L_kk x = e_c. Dinv block k at Dinv + k * 272,
+// element (r, c) at [r + 17 c] (leading dimension 17: row- and column-wise walks are conflict-free).
+template <typename T, int NB>
+__device__ __forceinline__ void invert_diag_blocks(int n, const T* F, int ldf, T* Dinv)
+{
+    const int tid = threadIdx.x;
+    if (tid < 16 * NB) {
+        const int k = tid >> 4, c = tid & 15;
+        const int base = 16 * k;
+        T x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            T s = (r == c) ? T(1) : T(0);
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (q < r) {
+                    const int ir = base + r < n ? base + r : n - 1, iq = base + q < n ? base + q : n - 1;
+                    s -= F[ir + (size_t)iq * ldf] * x[q];
+                }
+            const int ir = base + r < n ? base + r : n - 1;
+            const T dr = F[ir + (size_t)ir * ldf];
+            // rows past n (partial last block) are treated as an identity extension
+            x[r] = (base + r < n) ? ((r >= c) ? s / dr : T(0)) : ((r == c) ? T(1) : T(0));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Dinv[k * 272 + r + 17 * c] = x[r];
+    }
+    __syncthreads();
+}
+
+// Blocked ?potrs on one wave: x_k = inv(L_kk) z_k by a 16 x 16 product with the precomputed inverse,
+// then z_i -= L_ik x_k for the remaining rows; 2 NB dependent block steps instead of 2 n scalar ones.
+// Lane l holds rows l and l + 64 (K = 2) or l (K = 1). Collective: all threads call; wave 0 works.
+template <typename T, int NB>
+__device__ __forceinline__ void potrs_blocked(int n, const T* F, int ldf, const T* Dinv, T* xv)
+{
+    constexpr int K = NB > 4 ? 2 : 1;
+    __syncthreads();
+    if (threadIdx.x < kWave) {
+        const int lane = threadIdx.x, r = lane & 15;
+        T xr[K];
+#pragma unroll
+        for (int t = 0; t < K; ++t) { const int k = lane + kWave * t; xr[t] = k < n ? xv[k] : T(0); }
+        // ---- forward: L z = b
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            if (16 * kb < n) {
+                constexpr int dummy = 0; (void)dummy;
+                const int t = kb >> 2, q4 = kb & 3;          // block kb lives in register t, lanes 16 q4 .. 16 q4 + 15
+                T zb[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) zb[c] = lane_bcast(xr[t], 16 * q4 + c);
+                T xn = 0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) xn += Dinv[kb * 272 + r + 17 * c] * zb[c];   // entries above the diagonal are 0
+                if ((lane >> 4) == q4) xr[t] = xn;
+                T xb[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) xb[c] = lane_bcast(xr[t], 16 * q4 + c);
+#pragma unroll
+                for (int t2 = 0; t2 < K; ++t2) {
+                    const int i = lane + kWave * t2;
+                    const bool below = i >= 16 * (kb + 1) && i < n;
+                    const int ic = i < n ? i : n - 1;
+                    T acc = 0;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        const int col = 16 * kb + c < n ? 16 * kb + c : n - 1;
+                        acc += F[ic + (size_t)col * ldf] * ((16 * kb + c < n) ? xb[c] : T(0));
+                    }
+                    if (below) xr[t2] -= acc;
+                }
+            }
+        }
+        // ---- backward: L^T x = z
+#pragma unroll
+        for (int kb = NB - 1; kb >= 0; --kb) {
+            if (16 * kb < n) {
+                const int t = kb >> 2, q4 = kb & 3;
+                T zb[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) zb[c] = lane_bcast(xr[t], 16 * q4 + c);
+                T xn = 0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) xn += Dinv[kb * 272 + c + 17 * r] * zb[c];   // (inv L_kk)^T (r, c) = inv(c, r)
+                if ((lane >> 4) == q4) xr[t] = xn;
+                T xb[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) xb[c] = lane_bcast(xr[t], 16 * q4 + c);
+#pragma unroll
+                for (int t2 = 0; t2 < K; ++t2) {
+                    const int i = lane + kWave * t2;
+                    const bool above = i < 16 * kb;
+                    const int ic = i < n ? i : n - 1;
+                    T acc = 0;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        const int row = 16 * kb + c < n ? 16 * kb + c : n - 1;
+                        acc += F[row + (size_t)ic * ldf] * ((16 * kb + c < n) ? xb[c] : T(0));   // L(16 kb + c, i)
+                    }
+                    if (above) xr[t2] -= acc;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < K; ++t) { const int k = lane + kWave * t; if (k < n) xv[k] = xr[t]; }
+    }
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------- ?posvx('E','L'), nrhs = 1
 // A: n x n full symmetric, leading dimension lda (overwritten by its equilibrated form).
 // b: right-hand side (overwritten by the scaled rhs). x: solution. s,r,w: n-vectors.
@@ -299,11 +501,11 @@ template <typename T, int NB>
 __device__ __forceinline__ int posvx_device(int n, T* A, int lda, T* F, int ldf, T* s, T* b, T* x, T* r, T* w, T* red, long long* dbg = nullptr)
 {
     MIRLSQ_STAMP(dbg, 2);
-    // fast path (NB > 0): LDS scratch behind the factor
+    // fast path (NB > 0): LDS scratch behind the factor: colbuf (2 x 16 NB), rdiag (16 NB), Dinv (NB x 272)
     T* colbuf = F + (size_t)ldf * (16 * (NB > 0 ? NB : 1));
-    T* rdiag = colbuf + 16 * (NB > 0 ? NB : 1);
-    T* shv = rdiag + 16 * (NB > 0 ? NB : 1);
-    (void)colbuf; (void)rdiag; (void)shv;
+    T* rdiag = colbuf + 32 * (NB > 0 ? NB : 1);
+    T* Dinv = rdiag + 16 * (NB > 0 ? NB : 1);
+    (void)colbuf; (void)rdiag; (void)Dinv;
     const int tid = threadIdx.x;
     const T eps = Lim<T>::eps / 2;              // dlamch('Epsilon')
     const T safmin = Lim<T>::min_normal;        // dlamch('Safe minimum')
@@ -335,8 +537,9 @@ __device__ __forceinline__ int posvx_device(int n, T* A, int lda, T* F, int ldf,
     MIRLSQ_STAMP(dbg, 3);
     // ?lacpy + ?potrf 'L'
     if constexpr (NB > 0) {
-        const int info = potrf_tiled<T, NB>(n, A, lda, F, ldf, colbuf, rdiag, shv);
+        const int info = potrf_tiled2<T, NB>(n, A, lda, F, ldf, colbuf, rdiag);
         if (info != 0) return info;
+        invert_diag_blocks<T, NB>(n, F, ldf, Dinv);
     } else {
         // generic path (factor in global memory): right-looking, two barriers per column
         for (int idx = tid; idx < n * n; idx += kSolveThreads) {
@@ -364,7 +567,7 @@ __device__ __forceinline__ int posvx_device(int n, T* A, int lda, T* F, int ldf,
     MIRLSQ_STAMP(dbg, 4);
     // ?potrs
     if (tid < n) x[tid] = b[tid];
-    if constexpr (NB > 0) potrs_fast<T, (NB > 4 ? 2 : 1)>(n, F, ldf, rdiag, x);
+    if constexpr (NB > 0) potrs_blocked<T, NB>(n, F, ldf, Dinv, x);
     else potrs_wave(n, F, ldf, x);
 
     MIRLSQ_STAMP(dbg, 5);
@@ -403,7 +606,7 @@ __device__ __forceinline__ int posvx_device(int n, T* A, int lda, T* F, int ldf,
         const T berr = block_max(qv, red);
         if (count == 1) MIRLSQ_STAMP(dbg, 12);
         if (berr > eps && 2 * berr <= lstres && count <= 5) {
-            if constexpr (NB > 0) potrs_fast<T, (NB > 4 ? 2 : 1)>(n, F, ldf, rdiag, r);
+            if constexpr (NB > 0) potrs_blocked<T, NB>(n, F, ldf, Dinv, r);
             else potrs_wave(n, F, ldf, r);
             if (tid < n) x[tid] += r[tid];
             lstres = berr;
@@ -555,13 +758,13 @@ __host__ __device__ inline int solve_nb(int n, int elem)
 {
     const int nb = n <= 16 ? 1 : (n <= 32 ? 2 : (n <= 64 ? 4 : (n <= 128 ? 8 : 0)));
     if (nb == 0) return 0;
-    const long bytes = ((long)(n | 1) * 16 * nb + 32 * nb + 2) * elem;
+    const long bytes = ((long)(n | 1) * 16 * nb + 48 * nb + 272 * nb) * elem;
     return bytes <= kSolveLdsBytes ? nb : 0;
 }
 __host__ __device__ inline size_t solve_lds_bytes(int n, int elem)
 {
     const int nb = solve_nb(n, elem);
-    return nb ? (size_t)((long)(n | 1) * 16 * nb + 32 * nb + 2) * elem : 0;
+    return nb ? (size_t)((long)(n | 1) * 16 * nb + 48 * nb + 272 * nb) * elem : 0;
 }
 
 template <typename T>
