@@ -86,17 +86,20 @@ def main():
         raise SystemExit("bench.py needs a GPU: mir_optim_amd has no CPU path")
     torch.cuda.set_device(local_rank)
     comm = None
-    if world > 1:
+    distributed = world > 1 or os.environ.get("MIR_LSQ_FORCE_COMM") == "1"   # the env knob exercises the N > 1 code path on one GPU
+    if distributed:
+        from mir_optim_amd import parallel as PAR
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        uid = np.zeros(128, dtype=np.uint8)
-        if rank == 0 and api.lib().mir_lsq_rccl_unique_id(uid.ctypes.data) != 0:
-            raise SystemExit("ncclGetUniqueId failed")
-        t = torch.from_numpy(uid).cuda()
-        dist.broadcast(t, 0)
-        uid = t.cpu().numpy()
-        comm = api.lib().mir_lsq_comm_create_rccl(world, rank, uid.ctypes.data)
-        if not comm:
-            raise SystemExit("RCCL communicator creation failed")
+
+        def bcast(buf):
+            t = torch.from_numpy(buf).cuda()
+            dist.broadcast(t, 0)
+            return t.cpu().numpy()
+        comm = PAR.rccl_comm(world, rank, bcast)     # the solver's own RCCL communicator (xGMI), id via torch.distributed
 
     m, n = args.m, args.n
     data = W.tanh_linear_data(m, n, row_offset=rank * m)
@@ -108,7 +111,7 @@ def main():
         raise SystemExit("workspace allocation failed")
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -127,7 +130,7 @@ def main():
         iters += res.iterations
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -172,7 +175,7 @@ def main():
     if comm:
         api.lib().mir_lsq_comm_destroy(comm)
     api.lib().mir_lsq_workspace_destroy(ws)
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

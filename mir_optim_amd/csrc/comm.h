@@ -33,7 +33,11 @@ struct NcclUniqueId { char internal[128]; };
 
 inline void* rccl_open()
 {
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    // prefer an RCCL that the host program has already loaded (e.g. the one bundled with PyTorch): two
+    // RCCL instances in one process work but double the IPC/bootstrap state
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     return h;

@@ -81,3 +81,19 @@ def test_sharded_gpu_path_matches_unsharded_oracle(oracle, tmp_path):
     assert np.allclose(res[0]["x"], xo, rtol=1e-6, atol=1e-9)
     assert np.isclose(res[0]["residual"], ro.residual, rtol=1e-9)
     assert res[0]["status"] not in ("maxIterations", "numericError")
+
+
+@pytest.mark.gpu
+def test_rccl_communicator_world_size_1(oracle):
+    """The production communicator (RCCL via dlopen) on the one visible GPU: id creation, ncclCommInitRank,
+    fp64 sum all-reduce of the packed buffer and of the residual scalar on the solver's stream, destroy."""
+    import mir_optim_amd as M
+    from mir_optim_amd import workloads as W
+    comm = PAR.rccl_comm(1, 0, lambda buf: buf)
+    w = P.tanh_linear(30000, 32)
+    prob = W.TanhLinear(w["A"], w["b"])
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
+    r1, x1 = prob.solve(w["x0"], settings=s, comm=comm)
+    r0, x0 = prob.solve(w["x0"], settings=s)
+    M.api.lib().mir_lsq_comm_destroy(comm)
+    assert r1.status >= 0 and np.array_equal(x1, x0) and r1.iterations == r0.iterations   # sum over one rank = identity
