@@ -1,0 +1,236 @@
+// jtj_wide.h -- J^T J (lower) + J^T y (+ Broyden) for 128 < n <= 256 (BASELINE cfg 4: n = 256).
+//
+// Same fragment scheme as jtj_kernel.h (lane (q, p) holds J[4g + q][16 c + p] = MFMA A and B operand), but the
+// 16 x 16-block output grid no longer fits one workgroup's registers, so it is cut into 4 x 4-block tiles
+// (64 x 64 outputs, 16 accumulators per wave): job (TI, TJ), TJ <= TI, streams all rows and loads only the
+// column blocks of its two panels. Diagonal jobs also produce their panel's part of J^T y.
+// The Broyden rank-1 update (LS:1003-1006) needs the whole row for its dot product, so it is a separate
+// HBM-bound pass (k_broyden_wide) in front of the products.
+// First version: register streaming like k_jtj (correctness and coverage first; the LDS-DMA ring of k_jtj2
+// is the obvious next step for this path).
+#pragma once
+
+#include "common.h"
+
+namespace mirlsq {
+
+constexpr int kWideTile = 4;                                             // blocks per tile side
+constexpr int kWideSlabLen = (kWideTile * kWideTile * 4 + kWideTile) * kWave;   // 16 blocks x 4 regs + 4 jy regs, x 64 lanes
+
+template <typename T>
+struct JtjWideArgs {
+    const T* J;
+    const T* y;
+    T* slabs;          // [job][workgroup][kWideSlabLen]
+    size_t m;
+    int n;
+    int nt;            // tiles per side = ceil(ceil(n / 16) / 4)
+};
+
+__host__ __device__ inline void wide_job_to_tile(int job, int& ti, int& tj)
+{
+    ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= job) ++ti;
+    tj = job - ti * (ti + 1) / 2;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_jtj_wide(JtjWideArgs<T> a)
+{
+    using Acc = typename Mma<T>::Acc;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+    T* red = reinterpret_cast<T*>(smem_w);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 4, p = lane & 15;
+    int ti, tj;
+    wide_job_to_tile(blockIdx.y, ti, tj);
+    const bool diag = ti == tj;
+    const size_t m = a.m;
+    const int n = a.n;
+
+    const size_t G = (m + 3) / 4;
+    const size_t nslots = (size_t)gridDim.x * 4;
+    const size_t per = (G + nslots - 1) / nslots;
+    const size_t slot = (size_t)blockIdx.x * 4 + wave;
+    const size_t g0 = slot * per < G ? slot * per : G;
+    const size_t g1 = g0 + per < G ? g0 + per : G;
+
+    Acc acc[kWideTile][kWideTile];
+#pragma unroll
+    for (int i = 0; i < kWideTile; ++i)
+#pragma unroll
+        for (int j = 0; j < kWideTile; ++j) acc[i][j] = Acc{0, 0, 0, 0};
+    T jy[kWideTile];
+    int ci[kWideTile], cj[kWideTile];
+    bool oki[kWideTile], okj[kWideTile];
+#pragma unroll
+    for (int c = 0; c < kWideTile; ++c) {
+        jy[c] = 0;
+        const int coli = 16 * (kWideTile * ti + c) + p, colj = 16 * (kWideTile * tj + c) + p;
+        oki[c] = coli < n; okj[c] = colj < n;
+        ci[c] = oki[c] ? coli : n - 1;
+        cj[c] = okj[c] ? colj : n - 1;
+    }
+    struct Frag { T vi[kWideTile], vj[kWideTile], y; };
+    auto load = [&](size_t g, Frag& f) {
+        const size_t row = 4 * g + q;
+        const bool rok = row < m;
+        const size_t rc = rok ? row : m - 1;
+        const T* rp = a.J + rc * (size_t)n;
+#pragma unroll
+        for (int c = 0; c < kWideTile; ++c) {
+            const T t = rp[ci[c]];
+            f.vi[c] = (rok && oki[c]) ? t : T(0);
+        }
+#pragma unroll
+        for (int c = 0; c < kWideTile; ++c) {
+            const T t = rp[cj[c]];
+            f.vj[c] = (rok && okj[c]) ? t : T(0);
+        }
+        const T t = a.y[rc];
+        f.y = rok ? t : T(0);
+    };
+    auto compute = [&](const Frag& f) {
+        if (diag) {
+#pragma unroll
+            for (int c = 0; c < kWideTile; ++c) jy[c] += f.vi[c] * f.y;       // LS:1052
+        }
+#pragma unroll
+        for (int i = 0; i < kWideTile; ++i)
+#pragma unroll
+            for (int j = 0; j < kWideTile; ++j) acc[i][j] = Mma<T>::mma(f.vi[i], f.vj[j], acc[i][j]);   // LS:1065
+    };
+    Frag fa, fb;
+    size_t g = g0;
+    if (g < g1) load(g, fa);
+    while (g < g1) {
+        if (g + 1 < g1) load(g + 1, fb);
+        compute(fa);
+        ++g;
+        if (g >= g1) break;
+        if (g + 1 < g1) load(g + 1, fa);
+        compute(fb);
+        ++g;
+    }
+#pragma unroll
+    for (int c = 0; c < kWideTile; ++c) {
+        jy[c] += wave_shfl_xor(jy[c], 16);
+        jy[c] += wave_shfl_xor(jy[c], 32);
+    }
+    // workgroup reduction through LDS in a fixed order: (w0 + w2) + (w1 + w3)
+    constexpr int SL = kWideSlabLen;
+    auto put = [&](T* dst) {
+#pragma unroll
+        for (int i = 0; i < kWideTile; ++i)
+#pragma unroll
+            for (int j = 0; j < kWideTile; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[((i * kWideTile + j) * 4 + r) * kWave + lane] = acc[i][j][r];
+#pragma unroll
+        for (int c = 0; c < kWideTile; ++c) dst[(kWideTile * kWideTile * 4 + c) * kWave + lane] = jy[c];
+    };
+    auto add = [&](const T* src) {
+#pragma unroll
+        for (int i = 0; i < kWideTile; ++i)
+#pragma unroll
+            for (int j = 0; j < kWideTile; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += src[((i * kWideTile + j) * 4 + r) * kWave + lane];
+#pragma unroll
+        for (int c = 0; c < kWideTile; ++c) jy[c] += src[(kWideTile * kWideTile * 4 + c) * kWave + lane];
+    };
+    if (wave >= 2) put(red + (size_t)(wave - 2) * SL);
+    __syncthreads();
+    if (wave < 2) add(red + (size_t)wave * SL);
+    __syncthreads();
+    if (wave == 1) put(red);
+    __syncthreads();
+    if (wave == 0) {
+        add(red);
+        put(a.slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * SL);
+    }
+}
+
+// fixed-order sum over workgroups, scatter into packed [JJ lower | Jy]. grid = (ceil(SL / 32), jobs), 256 threads.
+template <typename T>
+__global__ __launch_bounds__(256) void k_jtj_wide_reduce(const T* __restrict__ slabs, int nwg, int n, T* __restrict__ packed)
+{
+    __shared__ T part[8][32];
+    constexpr int SL = kWideSlabLen;
+    const int es = threadIdx.x & 31, sp = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + es;
+    const int job = blockIdx.y;
+    T s = 0;
+    if (e < SL) {
+        const int per = (nwg + 7) / 8;
+        const int b0 = sp * per, b1 = (b0 + per < nwg) ? b0 + per : nwg;
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) s += slabs[((size_t)job * nwg + b) * SL + e];
+    }
+    part[sp][es] = s;
+    __syncthreads();
+    if (sp == 0 && e < SL) {
+        T tot = part[0][es];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) tot += part[k][es];
+        int ti, tj;
+        wide_job_to_tile(job, ti, tj);
+        const int reg = e / kWave, lane = e % kWave;
+        if (reg < kWideTile * kWideTile * 4) {
+            const int blk = reg >> 2, r = reg & 3;
+            const int bi = blk / kWideTile, bj = blk % kWideTile;
+            const int row = 16 * (kWideTile * ti + bi) + Mma<T>::row(lane, r);
+            const int col = 16 * (kWideTile * tj + bj) + (lane & 15);
+            if (row < n && col <= row) packed[(size_t)row * (row + 1) / 2 + col] = tot;
+        } else if (ti == tj) {
+            const int c = reg - kWideTile * kWideTile * 4;
+            const int col = 16 * (kWideTile * ti + c) + lane;
+            if (lane < 16 && col < n) packed[(size_t)n * (n + 1) / 2 + col] = tot;
+        }
+    }
+}
+
+// Broyden update for wide rows, LS:1002-1006: J[i,:] += ((y_i - yold_i - J[i,:].dx) / dx.dx) dx^T. HBM-bound.
+template <typename T>
+__global__ __launch_bounds__(256) void k_broyden_wide(T* __restrict__ J, const T* __restrict__ y, const T* __restrict__ y_old,
+                                                      const T* __restrict__ dx, const T* __restrict__ dx_dot, size_t m, int n)
+{
+    constexpr int NCBW = 16;
+    const int lane = threadIdx.x & 63;
+    const int q = lane >> 4, p = lane & 15;
+    T dxr[NCBW];
+    int co[NCBW];
+    bool ok[NCBW];
+#pragma unroll
+    for (int c = 0; c < NCBW; ++c) {
+        const int col = 16 * c + p;
+        ok[c] = col < n;
+        co[c] = ok[c] ? col : n - 1;
+        const T t = dx[co[c]];
+        dxr[c] = ok[c] ? t : T(0);
+    }
+    const T neg_d = -(T(1) / *dx_dot);
+    const size_t G = (m + 3) / 4;
+    const size_t wave_id = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t g = wave_id; g < G; g += nwaves) {
+        const size_t row = 4 * g + q;
+        const bool rok = row < m;
+        T* rp = J + (rok ? row : m - 1) * (size_t)n;
+        T v[NCBW];
+#pragma unroll
+        for (int c = 0; c < NCBW; ++c) { const T t = rp[co[c]]; v[c] = (rok && ok[c]) ? t : T(0); }
+        const T yv = rok ? y[rok ? row : 0] : T(0), yo = rok ? y_old[rok ? row : 0] : T(0);
+        T part = 0;
+#pragma unroll
+        for (int c = 0; c < NCBW; ++c) part += v[c] * dxr[c];
+        part = sum16(part);
+        const T t = (yo - yv) + part;
+        const T u = neg_d * t;
+#pragma unroll
+        for (int c = 0; c < NCBW; ++c) if (rok && ok[c]) rp[co[c]] = v[c] + u * dxr[c];
+    }
+}
+
+}  // namespace mirlsq

@@ -23,6 +23,7 @@
 #include "comm.h"
 #include "common.h"
 #include "jtj_kernel.h"
+#include "jtj_wide.h"
 #include "misc_kernels.h"
 #include "solve_kernel.h"
 
@@ -94,6 +95,8 @@ struct JtjPlan {
     int slab_len = 0;
     size_t lds = 0;
     bool v2 = false;      // LDS-DMA ring kernel (f64, n = 16 ncb)
+    bool wide = false;    // 128 < n <= 256: tiled jobs (jtj_wide.h)
+    int njobs = 1;
 };
 
 inline size_t jtj2_lds_rt(int ncb, bool br)
@@ -127,6 +130,19 @@ JtjPlan jtj_plan(size_t m, int n, int num_cu)
     p.ncb = (n + 15) / 16;
     const int nacc = p.ncb * (p.ncb + 1) / 2;
     p.slab_len = (nacc * 4 + p.ncb) * kWave;
+    if (n > 128) {
+        p.wide = true;
+        const int nt = (p.ncb + kWideTile - 1) / kWideTile;
+        p.njobs = nt * (nt + 1) / 2;
+        p.slab_len = kWideSlabLen;
+        p.lds = (size_t)2 * kWideSlabLen * sizeof(T);
+        const size_t G = (m + 3) / 4;
+        size_t want = (G + 4 * 8 - 1) / (4 * 8);
+        size_t cap = (size_t)num_cu * 4 / p.njobs;
+        if (cap < 1) cap = 1;
+        p.nblk = (int)(want < cap ? (want ? want : 1) : cap);
+        return p;
+    }
     static const bool no_v2 = std::getenv("MIR_LSQ_JTJ_V1") != nullptr;
     if (sizeof(T) == 8 && n % 16 == 0 && n <= 128 && m % 2 == 0 && !no_v2) {
         p.v2 = true;
@@ -226,8 +242,32 @@ hipError_t jtj_launch_br(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
 
 // fused [Broyden] + JtJ + Jty -> packed[ n(n+1)/2 + n ]
 template <typename T>
+hipError_t jtj_run_wide(const JtjPlan& p, const JtjArgs<T>& a, bool broyden, T* packed, hipStream_t s)
+{
+    if (broyden) {
+        const size_t G = (a.m + 3) / 4;
+        size_t blocks = (G + 3) / 4;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_broyden_wide<T>, dim3((unsigned)blocks), dim3(256), 0, s, a.Jout, a.y, a.y_old, a.dx, a.dx_dot, a.m, a.n);
+    }
+    JtjWideArgs<T> w{};
+    w.J = a.J; w.y = a.y; w.slabs = a.slabs; w.m = a.m; w.n = a.n;
+    w.nt = ((a.n + 15) / 16 + kWideTile - 1) / kWideTile;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_jtj_wide<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_jtj_wide<T>, dim3(p.nblk, p.njobs), dim3(256), p.lds, s, w);
+    hipLaunchKernelGGL(k_jtj_wide_reduce<T>, dim3((kWideSlabLen + 31) / 32, p.njobs), dim3(256), 0, s, a.slabs, p.nblk, a.n, packed);
+    return hipGetLastError();
+}
+
+template <typename T>
 hipError_t jtj_run(const JtjPlan& p, const JtjArgs<T>& a, bool broyden, T* packed, hipStream_t s)
 {
+    if (p.wide) return jtj_run_wide<T>(p, a, broyden, packed, s);
     hipError_t e = broyden ? jtj_launch_br<T, true>(p, a, s) : jtj_launch_br<T, false>(p, a, s);
     if (e != hipSuccess) return e;
     const int rb = (p.slab_len + 31) / 32;
@@ -279,7 +319,7 @@ Buffers<T> carve(void* base, size_t m, size_t n, const JtjPlan& plan)
     b.partials = (T*)take(kPartials, sizeof(T));
     b.sum = (T*)take(8, sizeof(T));
     b.st = (LmState<T>*)take(1, sizeof(LmState<T>));
-    b.slabs = (T*)take((size_t)plan.nblk * plan.slab_len, sizeof(T));
+    b.slabs = (T*)take((size_t)plan.nblk * plan.njobs * plan.slab_len, sizeof(T));
     b.sc.Pm = (T*)take(n * n, sizeof(T));
     b.sc.A = (T*)take(n * n, sizeof(T));
     b.sc.Fg = (T*)take(n * (n | 1), sizeof(T));
@@ -677,8 +717,8 @@ struct Solver {
             if (!(1 <= S->lambdaIncrease && S->lambdaIncrease <= std::sqrt(Lim<T>::max))) { ret.status = mir_ls_badLambdaParams; return ret; }
             if (!(std::sqrt(Lim<T>::min_normal) <= S->lambdaDecrease && S->lambdaDecrease <= 1)) { ret.status = mir_ls_badLambdaParams; return ret; }
         }
-        if (n > (uint32_t)kSolveMaxN || n > 128) {
-            std::fprintf(stderr, "[mir_optim_amd] n = %u is not supported by this build (n <= 128)\n", n);
+        if (n > (uint32_t)kSolveMaxN) {
+            std::fprintf(stderr, "[mir_optim_amd] n = %u is not supported by this build (n <= %d)\n", n, kSolveMaxN);
             return ret;
         }
         if (!device_available()) return ret;
@@ -1015,13 +1055,13 @@ int jtj_entry(size_t m, size_t n, T* J, const T* y, const T* y_old, const T* dx,
               void* stream_, float* kernel_ms)
 {
     if (!device_available()) return -1;
-    if (n == 0 || n > 128 || m == 0) return -2;
+    if (n == 0 || n > (size_t)kSolveMaxN || m == 0) return -2;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const JtjPlan plan = jtj_plan<T>(m, (int)n, query_num_cu());
     const size_t packed_len = n * (n + 1) / 2 + n + 8;
     T *slabs = nullptr, *packed = nullptr, *dxdot = nullptr;
     LmState<T>* st = nullptr;
-    if (hipMalloc((void**)&slabs, sizeof(T) * (size_t)plan.nblk * plan.slab_len) != hipSuccess) return -3;
+    if (hipMalloc((void**)&slabs, sizeof(T) * (size_t)plan.nblk * plan.njobs * plan.slab_len) != hipSuccess) return -3;
     if (hipMalloc((void**)&packed, sizeof(T) * packed_len) != hipSuccess) { (void)hipFree(slabs); return -3; }
     if (hipMalloc((void**)&st, sizeof(LmState<T>) + sizeof(T) * 8) != hipSuccess) { (void)hipFree(slabs); (void)hipFree(packed); return -3; }
     dxdot = reinterpret_cast<T*>(st + 1);

@@ -31,6 +31,32 @@ def test_jtj_and_jty_match_numpy(m, n):
     assert np.max(np.abs(Jy - Jyr)) < 1e-13 * np.sqrt(m) * np.linalg.norm(J, axis=0).max() * np.abs(y).max()
 
 
+@pytest.mark.parametrize("m,n", [(1000, 129), (5000, 160), (3001, 200), (20000, 256), (777, 255)])
+def test_jtj_wide_n_matches_numpy(m, n):
+    """128 < n <= 256 (cfg 4's n = 256): tiled jobs + separate Broyden pass (jtj_wide.h)."""
+    rng = np.random.default_rng(m + n)
+    J = rng.standard_normal((m, n))
+    J[:, 1] = np.arange(m) % 5 - 2.0
+    y = rng.standard_normal(m)
+    JJ, Jy, J_after, _ = M.jtj(J, y)
+    JJr, Jyr = ref_products(J, y)
+    scale = np.sqrt(np.outer(np.diag(JJr), np.diag(JJr)))
+    assert np.array_equal(J_after, J) and np.array_equal(JJ, JJ.T)
+    assert np.max(np.abs(JJ - JJr) / scale) < 1e-13
+    assert np.allclose(Jy, Jyr, rtol=1e-11, atol=1e-11 * np.abs(Jyr).max())
+    y_old = y + 0.1 * rng.standard_normal(m)
+    dx = 0.05 * rng.standard_normal(n)
+    JJ, Jy, J_after, _ = M.jtj(J, y, y_old=y_old, dx=dx)
+    d = 1.0 / (dx @ dx)
+    Jn = J + np.outer(-d * (J @ dx + (y_old - y)), dx)
+    assert np.max(np.abs(J_after - Jn)) < 1e-13 * max(1.0, np.abs(Jn).max())
+    JJr, Jyr = ref_products(J_after, y)
+    assert np.max(np.abs(JJ - JJr) / np.sqrt(np.outer(np.diag(JJr), np.diag(JJr)))) < 1e-13
+    Ji = rng.integers(-4, 5, size=(2000, 144)).astype(np.float64); yi = rng.integers(-4, 5, size=2000).astype(np.float64)
+    JJ, Jy, _, _ = M.jtj(Ji, yi)
+    assert np.array_equal(JJ, Ji.T @ Ji) and np.array_equal(Jy, Ji.T @ yi)
+
+
 def test_jtj_exact_integers():
     """small integers: every partial sum is exact, so the result must be bit-exact."""
     rng = np.random.default_rng(5)

@@ -134,7 +134,8 @@ def oracle_tanh(oracle, w, settings, lower=None, upper=None, analytic=False):
                            g=oracle.native_fn("wlc_tanh_linear_g") if analytic else None, gctx=C.addressof(ctx))
 
 
-@pytest.mark.parametrize("m,n", [(64, 4), (512, 8), (4096, 16), (20000, 32), (30000, 64), (50000, 128), (9973, 100)])
+@pytest.mark.parametrize("m,n", [(64, 4), (512, 8), (4096, 16), (20000, 32), (30000, 64), (50000, 128), (9973, 100),
+                                 (20000, 160), (30000, 256)])
 def test_tanh_linear_fd_matches_oracle(oracle, m, n):
     w = P.tanh_linear(m, n)
     prob = W.TanhLinear(w["A"], w["b"])
