@@ -224,6 +224,21 @@ def test_batched_residual_callback_matches_pointwise(m, n):
         assert np.max(np.abs(Yb - ref)) < 1e-13 and np.max(np.abs(Y1 - ref)) < 1e-13
 
 
+def test_cfg2_gauss_sum_full_size(oracle):
+    """BASELINE cfg 2: Gaussian-sum curve fit, m = 1e5 residuals x n = 16 parameters, fp64, width bounds, FD Jacobian."""
+    import ctypes as C
+    g = P.gauss_sum(100000, K=5)
+    assert g["n"] == 16
+    prob = W.Curve("gauss_sum", g["t"], g["data"])
+    res, x = prob.solve(g["x0"], g["lower"], g["upper"])
+    ctx = oracle.GaussSumCtx(g["t"].ctypes.data, g["data"].ctypes.data)
+    ro, xo = oracle.optimize(oracle.native_fn("wlc_gauss_sum_f"), g["m"], g["x0"], lower=g["lower"], upper=g["upper"],
+                             fctx=C.addressof(ctx))
+    assert res.status >= 0 and ro.status >= 0
+    assert np.allclose(x, xo, rtol=1e-6, atol=1e-9) and np.isclose(res.residual, ro.residual, rtol=1e-8)
+    assert np.allclose(x, g["truth"], rtol=5e-3, atol=1e-3)
+
+
 def test_repeated_solve_is_bit_reproducible():
     """The whole path is deterministic (fixed-order reductions, no float atomics): repeated solves are
     bitwise equal. m even and n = 128 select the LDS-DMA ring kernel; an earlier version of it mixed
