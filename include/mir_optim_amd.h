@@ -227,6 +227,20 @@ int mir_solve_box_qp_gpu_s(const mir_box_qp_settings_s* settings, size_t n, cons
                            const float* q, const float* l, const float* u, float* x,
                            int unconstrainedSolution, int* iterations);
 
+/* Batched small fits, ONE WAVEFRONT PER PROBLEM (BASELINE cfg 5): `count` independent problems of the same shape
+ * with a built-in residual model r_i = model(t_i; x) - data_i evaluated inside the kernel (no callback):
+ *   MIR_LSQ_MODEL_EXP_DECAY   n = 3   p0 exp(-t p1) + p2
+ *   MIR_LSQ_MODEL_EXP3_AFFINE n = 8   p0 exp(-t p1) + p2 exp(-t p3) + p4 exp(-t p5) + p6 + p7 t
+ * x: count x n (in/out), lower/upper: n (shared), t: m values shared by all problems (t_stride = 0) or count x m
+ * (t_stride = m), data: count x m, results: count. All HOST pointers. The LM algorithm, statuses and counters are
+ * those of mir_optimize_least_squares_s; problems whose step reaches a finite bound are completed by the general
+ * solver (BOXCQP active set) transparently. Returns 0, or a negative value when no device / bad arguments. */
+enum { MIR_LSQ_MODEL_EXP_DECAY = 0, MIR_LSQ_MODEL_EXP3_AFFINE = 1 };
+int mir_optimize_least_squares_batched_s(const mir_least_squares_settings_s* settings, size_t count, size_t m, int model,
+                                         float* x, const float* lower, const float* upper,
+                                         const float* t, size_t t_stride, const float* data,
+                                         mir_least_squares_result_s* results);
+
 /* Unit-level access to the hot kernels (parity tests and micro-benchmarks). All pointers are
  * DEVICE pointers; stream may be NULL (default stream; the call synchronises before returning).
  * JJ: n x n row-major, full symmetric on return. broyden != 0 first applies

@@ -29,8 +29,12 @@ __all__ = [
     "LeastSquaresException", "optimize", "optimizeLeastSquares", "solveBoxQP", "leastSquaresStatusString",
     "mir_least_squares_work_length", "mir_least_squares_iwork_length", "mir_box_qp_work_length",
     "mir_box_qp_iwork_length", "GpuOptions", "Stats", "lib", "workloads_lib", "device_count",
-    "DeviceBuffer", "Stream", "jtj", "DEVICE_CALLBACKS", "TIME_KERNELS",
+    "DeviceBuffer", "Stream", "jtj", "DEVICE_CALLBACKS", "TIME_KERNELS", "optimizeLeastSquaresBatched",
+    "MODEL_EXP_DECAY", "MODEL_EXP3_AFFINE",
 ]
+
+MODEL_EXP_DECAY = 0      # n = 3: p0 exp(-t p1) + p2
+MODEL_EXP3_AFFINE = 1    # n = 8: p0 exp(-t p1) + p2 exp(-t p3) + p4 exp(-t p5) + p6 + p7 t
 
 DEVICE_CALLBACKS = 1
 TIME_KERNELS = 2
@@ -181,6 +185,9 @@ def lib():
             fn.restype = C.c_int
             fn.argtypes = [sz, sz, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                            C.c_void_p, C.POINTER(C.c_float)]
+        L.mir_optimize_least_squares_batched_s.restype = C.c_int
+        L.mir_optimize_least_squares_batched_s.argtypes = [C.POINTER(_Ss), sz, sz, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                           C.c_void_p, sz, C.c_void_p, C.c_void_p]
         L.mir_lsq_workspace_create.restype = C.c_void_p
         L.mir_lsq_workspace_create.argtypes = [sz, sz, sz]
         L.mir_lsq_workspace_destroy.argtypes = [C.c_void_p]
@@ -427,6 +434,29 @@ def optimize(f, m, x, l=None, u=None, g=None, tm=None, settings=None, dtype=np.f
     if res.status < 0:
         raise LeastSquaresException(res.status, res)
     return res, xo
+
+
+def optimizeLeastSquaresBatched(model, x, t, data, l=None, u=None, settings=None):
+    """Many independent small fits, one wavefront per problem (mir_optimize_least_squares_batched_s, fp32).
+    x: count x n starts (a copy is updated and returned), t: m (shared) or count x m, data: count x m.
+    Returns (list of LeastSquaresResult, x)."""
+    L = lib()
+    x = np.array(x, dtype=np.float32, order="C")
+    count, n = x.shape
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    m = data.shape[1]
+    t = np.ascontiguousarray(t, dtype=np.float32)
+    t_stride = 0 if t.ndim == 1 else m
+    lo = np.full(n, -np.inf, dtype=np.float32) if l is None else np.ascontiguousarray(l, dtype=np.float32)
+    up = np.full(n, np.inf, dtype=np.float32) if u is None else np.ascontiguousarray(u, dtype=np.float32)
+    if settings is None:
+        settings = LeastSquaresSettings(np.float32)
+    raw = (_Rs * count)()
+    rc = L.mir_optimize_least_squares_batched_s(C.byref(settings), count, m, int(model), x.ctypes.data, lo.ctypes.data,
+                                                up.ctypes.data, t.ctypes.data, t_stride, data.ctypes.data, raw)
+    if rc != 0:
+        raise RuntimeError(f"mir_optimize_least_squares_batched_s failed: {rc}")
+    return [LeastSquaresResult(r) for r in raw], x
 
 
 def solveBoxQP(P, q, l, u, x=None, settings=None, dtype=np.float64, unconstrainedSolution=False):

@@ -24,6 +24,7 @@
 #include "common.h"
 #include "jtj_kernel.h"
 #include "jtj_wide.h"
+#include "batched_kernel.h"
 #include "misc_kernels.h"
 #include "solve_kernel.h"
 
@@ -1088,6 +1089,109 @@ int jtj_entry(size_t m, size_t n, T* J, const T* y, const T* y_old, const T* dx,
 }  // namespace
 
 extern "C" {
+
+// ---- batched one-wave-per-problem entry (cfg 5) ------------------------------------------------
+namespace {
+struct BatchedFallbackCtx { const float* t; const float* d; hipStream_t stream; int model; };
+void batched_fallback_f(void* vctx, size_t m, size_t n, const float* x, float* y)
+{
+    (void)n;
+    auto* c = static_cast<BatchedFallbackCtx*>(vctx);
+    const unsigned blocks = (unsigned)((m + 255) / 256);
+    if (c->model == kModelExpDecay)
+        hipLaunchKernelGGL(k_batched_model_eval<kModelExpDecay>, dim3(blocks), dim3(256), 0, c->stream, c->t, c->d, x, y, (int)m);
+    else
+        hipLaunchKernelGGL(k_batched_model_eval<kModelExp3Affine>, dim3(blocks), dim3(256), 0, c->stream, c->t, c->d, x, y, (int)m);
+}
+}  // namespace
+
+int mir_optimize_least_squares_batched_s(const mir_least_squares_settings_s* S, size_t count, size_t m, int model,
+                                         float* x, const float* lower, const float* upper,
+                                         const float* t, size_t t_stride, const float* data,
+                                         mir_least_squares_result_s* results)
+{
+    if (!S || !x || !lower || !upper || !t || !data || !results) return -1;
+    const int n = model == kModelExpDecay ? 3 : (model == kModelExp3Affine ? 8 : 0);
+    if (n == 0 || (t_stride != 0 && t_stride != m)) return -1;
+    for (size_t i = 0; i < count; ++i) {       // defaults of LeastSquaresResult!T, LS:132-142
+        results[i].status = mir_ls_numericError; results[i].iterations = results[i].fCalls = results[i].gCalls = 0;
+        results[i].residual = Lim<float>::inf(); results[i].lambda = 0;
+    }
+    if (count == 0) return 0;
+    // settings validation LS:934-943, common to all problems (codes reported per problem)
+    int bad = 0;
+    if (!(0 <= S->minStepQuality && S->minStepQuality < 1)) bad = mir_ls_badMinStepQuality;
+    else if (!(0 <= S->goodStepQuality && S->goodStepQuality <= 1)) bad = mir_ls_badGoodStepQuality;
+    else if (!(S->minStepQuality < S->goodStepQuality)) bad = mir_ls_badStepQuality;
+    else if (!(1 <= S->lambdaIncrease && S->lambdaIncrease <= std::sqrt(FLT_MAX))) bad = mir_ls_badLambdaParams;
+    else if (!(std::sqrt(FLT_MIN) <= S->lambdaDecrease && S->lambdaDecrease <= 1)) bad = mir_ls_badLambdaParams;
+    if (!device_available()) return -2;
+    const size_t lds = (size_t)4 * (n + 2) * m * sizeof(float);
+    if (m == 0 || lds > 160 * 1024 - 512) {
+        std::fprintf(stderr, "[mir_optim_amd] batched entry: m = %zu does not fit one wave's LDS slice\n", m);
+        return -3;
+    }
+    BatchedArgs a{};
+    a.set.jacobianEpsilon = S->jacobianEpsilon; a.set.absTolerance = S->absTolerance; a.set.relTolerance = S->relTolerance;
+    a.set.gradTolerance = S->gradTolerance; a.set.maxGoodResidual = S->maxGoodResidual; a.set.maxStep = S->maxStep;
+    a.set.maxLambda = S->maxLambda; a.set.minLambda = S->minLambda; a.set.minStepQuality = S->minStepQuality;
+    a.set.goodStepQuality = S->goodStepQuality; a.set.lambdaIncrease = S->lambdaIncrease; a.set.lambdaDecrease = S->lambdaDecrease;
+    a.set.qpRelTolerance = S->qpSettings.relTolerance; a.set.qpAbsTolerance = S->qpSettings.absTolerance;
+    a.set.qpMaxIterations = S->qpSettings.maxIterations;
+    a.maxIterations = S->maxIterations; a.maxAge = S->maxAge; a.count = (int)count; a.m = (int)m;
+    a.t_stride = (int)t_stride;
+    const size_t tb = (t_stride ? count : 1) * m * sizeof(float), db = count * m * sizeof(float), xb = count * n * sizeof(float);
+    char* base = nullptr;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t ot = take(tb), od = take(db), ox = take(xb), ol = take(n * sizeof(float)), ou = take(n * sizeof(float)),
+                 orr = take(count * sizeof(BatchedResult));
+    if (hipMalloc((void**)&base, off) != hipSuccess) return -4;
+    bool good = hipMemcpy(base + ot, t, tb, hipMemcpyHostToDevice) == hipSuccess
+        && hipMemcpy(base + od, data, db, hipMemcpyHostToDevice) == hipSuccess
+        && hipMemcpy(base + ox, x, xb, hipMemcpyHostToDevice) == hipSuccess
+        && hipMemcpy(base + ol, lower, n * sizeof(float), hipMemcpyHostToDevice) == hipSuccess
+        && hipMemcpy(base + ou, upper, n * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+    a.t = (const float*)(base + ot); a.data = (const float*)(base + od); a.x = (float*)(base + ox);
+    a.lower = (const float*)(base + ol); a.upper = (const float*)(base + ou); a.results = (BatchedResult*)(base + orr);
+    std::vector<BatchedResult> res(count);
+    std::vector<float> x0(x, x + count * n);       // starts, for the fallback problems
+    if (good && !bad) {
+        const unsigned blocks = (unsigned)((count + 3) / 4);
+        auto launch = [&](auto kern) {
+            if (lds > 48 * 1024
+                && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return false;
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, a);
+            return hipGetLastError() == hipSuccess;
+        };
+        good = model == kModelExpDecay ? launch(k_lm_batched<kModelExpDecay>) : launch(k_lm_batched<kModelExp3Affine>);
+        good = good && hipDeviceSynchronize() == hipSuccess
+            && hipMemcpy(res.data(), a.results, count * sizeof(BatchedResult), hipMemcpyDeviceToHost) == hipSuccess
+            && hipMemcpy(x, a.x, xb, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (good) {
+        for (size_t i = 0; i < count; ++i) {
+            if (bad) { results[i].status = bad; continue; }
+            results[i].status = res[i].status; results[i].iterations = res[i].iterations; results[i].fCalls = res[i].fCalls;
+            results[i].gCalls = res[i].gCalls; results[i].residual = res[i].residual; results[i].lambda = res[i].lambda;
+            if (res[i].status == kBatchedNeedsGeneral) {
+                // bounded step: complete this problem with the general solver (device callbacks, BOXCQP on the device)
+                hipStream_t st = nullptr;
+                if (hipStreamCreate(&st) != hipSuccess) { good = false; break; }
+                BatchedFallbackCtx c{a.t + (t_stride ? i * m : 0), a.data + i * m, st, model};
+                mir_lsq_gpu_options o{};
+                o.struct_size = sizeof o; o.flags = MIR_LSQ_DEVICE_CALLBACKS; o.stream = st;
+                std::memcpy(x + i * n, x0.data() + i * n, n * sizeof(float));
+                results[i] = mir_optimize_least_squares_gpu_s(S, m, n, x + i * n, lower, upper, &o, &c, batched_fallback_f,
+                                                              nullptr, nullptr, nullptr, nullptr);
+                (void)hipStreamDestroy(st);
+            }
+        }
+    }
+    (void)hipFree(base);
+    return good ? 0 : -5;
+}
 
 int mir_solve_box_qp_gpu_d(const mir_box_qp_settings_d* settings, size_t n, const double* P, const double* q,
                            const double* l, const double* u, double* x, int unconstrainedSolution, int* iterations)
