@@ -50,6 +50,7 @@ struct mir_lsq_workspace {
     size_t dev_bytes = 0;
     void* ypanel = nullptr;    // lazily allocated FD panel (device mode)
     size_t ypanel_bytes = 0;
+    void* ytrial = nullptr;    // lazily allocated kChainMax x m trial residuals (speculative lambda ladder)
     void* pinned = nullptr;    // small pinned host block (state + trial readback)
     void* pinned_y = nullptr;  // m-vector staging (host-callback mode), lazily allocated
     void* pinned_J = nullptr;  // m*n staging for host analytic Jacobians, lazily allocated
@@ -283,10 +284,11 @@ template <typename T>
 struct Buffers {
     T *J, *y, *mB, *ytmp;
     T *X, *twh;
-    T *x, *lower, *upper, *dx, *trial, *Jy, *JJ, *packed, *partials, *sum;
+    T *x, *lower, *upper, *dx, *dx_acc, *trial, *Jy, *JJ, *packed, *partials, *sum;
     LmState<T>* st;
+    ChainRec<T>* rec;
     T* slabs;
-    SolveScratch<T> sc;
+    SolveScratch<T> sc[kChainMax];
     size_t bytes;
 };
 
@@ -312,22 +314,27 @@ Buffers<T> carve(void* base, size_t m, size_t n, const JtjPlan& plan)
     b.x = (T*)take(n, sizeof(T));
     b.lower = (T*)take(n, sizeof(T));
     b.upper = (T*)take(n, sizeof(T));
-    b.dx = (T*)take(n, sizeof(T));
-    b.trial = (T*)take(n, sizeof(T));
+    b.dx = (T*)take(kChainMax * n, sizeof(T));
+    b.dx_acc = (T*)take(n, sizeof(T));
+    b.trial = (T*)take(kChainMax * n, sizeof(T));
     b.Jy = (T*)take(n, sizeof(T));
     b.JJ = (T*)take(n * n, sizeof(T));
     b.packed = (T*)take(n * (n + 1) / 2 + n + 8, sizeof(T));
-    b.partials = (T*)take(kPartials, sizeof(T));
-    b.sum = (T*)take(8, sizeof(T));
+    b.partials = (T*)take((size_t)kChainMax * kPartials, sizeof(T));
+    b.sum = (T*)take(8 + kChainMax, sizeof(T));
     b.st = (LmState<T>*)take(1, sizeof(LmState<T>));
+    b.rec = (ChainRec<T>*)take(kChainMax, sizeof(ChainRec<T>));
     b.slabs = (T*)take((size_t)plan.nblk * plan.njobs * plan.slab_len, sizeof(T));
-    b.sc.Pm = (T*)take(n * n, sizeof(T));
-    b.sc.A = (T*)take(n * n, sizeof(T));
-    b.sc.Fg = (T*)take(n * (n | 1), sizeof(T));
-    b.sc.vec = (T*)take(12 * n, sizeof(T));
-    b.sc.ivec = (int32_t*)take(2 * n, sizeof(int32_t));
-    b.sc.dbg = (long long*)take(16, sizeof(long long));
-    dbg_all = b.sc.dbg;
+    for (int k = 0; k < kChainMax; ++k) {
+        b.sc[k].Pm = (T*)take(n * n, sizeof(T));
+        b.sc[k].A = (T*)take(n * n, sizeof(T));
+        b.sc[k].Fg = (T*)take(n * (n | 1), sizeof(T));
+        b.sc[k].vec = (T*)take(12 * n, sizeof(T));
+        b.sc[k].ivec = (int32_t*)take(2 * n, sizeof(int32_t));
+        b.sc[k].dbg = nullptr;
+    }
+    b.sc[0].dbg = (long long*)take(16, sizeof(long long));
+    dbg_all = b.sc[0].dbg;
     (void)dbg_all;
     b.bytes = off;
     return b;
@@ -368,6 +375,7 @@ void workspace_destroy(mir_lsq_workspace* ws)
     if (!ws) return;
     if (ws->dev) (void)hipFree(ws->dev);
     if (ws->ypanel) (void)hipFree(ws->ypanel);
+    if (ws->ytrial) (void)hipFree(ws->ytrial);
     if (ws->pinned) (void)hipHostFree(ws->pinned);
     if (ws->pinned_y) (void)hipHostFree(ws->pinned_y);
     if (ws->pinned_J) (void)hipHostFree(ws->pinned_J);
@@ -410,6 +418,7 @@ struct Solver {
     JtjPlan plan;
     LmSettingsDev<T> sd;
     bool dbg_solve = std::getenv("MIR_LSQ_DEBUG_SOLVE") != nullptr;
+    bool no_speculation = std::getenv("MIR_LSQ_NO_SPECULATION") != nullptr;
     int f_in_lds = 0;
     int solve_nb_ = 0;
     size_t solve_lds = 0;
@@ -523,7 +532,7 @@ struct Solver {
     }
 
     template <int NB>
-    hipError_t launch_solve_nb(const LmSolveArgs<T>& a)
+    hipError_t launch_solve_nb(const LmSolveArgs<T>& a, int ks)
     {
         auto kern = k_lm_solve<T, NB>;
         static bool attr_done = false;
@@ -532,36 +541,37 @@ struct Solver {
             if (e != hipSuccess) return e;
             attr_done = true;
         }
-        hipLaunchKernelGGL(kern, dim3(1), dim3(kSolveThreads), solve_lds, stream, a);
+        hipLaunchKernelGGL(kern, dim3(ks), dim3(kSolveThreads), solve_lds, stream, a);
         return hipGetLastError();
     }
-    hipError_t launch_solve(const LmSolveArgs<T>& a)
+    hipError_t launch_solve(const LmSolveArgs<T>& a, int ks)
     {
         switch (solve_nb_) {
-        case 1: return launch_solve_nb<1>(a);
-        case 2: return launch_solve_nb<2>(a);
-        case 4: return launch_solve_nb<4>(a);
-        case 8: return launch_solve_nb<8>(a);
-        default: return launch_solve_nb<0>(a);
+        case 1: return launch_solve_nb<1>(a, ks);
+        case 2: return launch_solve_nb<2>(a, ks);
+        case 4: return launch_solve_nb<4>(a, ks);
+        case 8: return launch_solve_nb<8>(a, ks);
+        default: return launch_solve_nb<0>(a, ks);
         }
     }
 
-    // ---- ||v||^2 -> B.sum[slot] on device (all-reduced over row shards)
-    bool sumsq(const T* v, int slot)
+    // ---- ||v_k||^2 for k < count vectors (stride vstride) -> B.sum[slot + k] on device (all-reduced over row shards)
+    bool sumsq(const T* v, int slot, int count = 1, size_t vstride = 0)
     {
         int nb = (int)((m + 4095) / 4096);
         if (nb > kPartials) nb = kPartials;
         if (nb < 1) nb = 1;
-        hipLaunchKernelGGL(k_sumsq_partial<T>, dim3(nb), dim3(256), 0, stream, v, m, B.partials);
-        hipLaunchKernelGGL(k_sumsq_final<T>, dim3(1), dim3(256), 0, stream, B.partials, nb, B.sum + slot);
-        if (comm && comm_allreduce<T>(comm, B.sum + slot, 1, stream) != 0) return false;
+        hipLaunchKernelGGL(k_sumsq_partial<T>, dim3(nb, count), dim3(256), 0, stream, v, m, B.partials, vstride, kPartials);
+        hipLaunchKernelGGL(k_sumsq_final<T>, dim3(count), dim3(256), 0, stream, B.partials, nb, B.sum + slot, kPartials);
+        if (comm && comm_allreduce<T>(comm, B.sum + slot, (size_t)count, stream) != 0) return false;
         return ok(hipGetLastError(), "sumsq");
     }
 
-    bool read_state(bool with_trial)
+    // mirror the device state (and optionally n values: the current x after a decision, or trial 0 before a host callback)
+    bool read_state(const T* vec_dev)
     {
         if (!ok(hipMemcpyAsync(st_h, B.st, sizeof(LmState<T>), hipMemcpyDeviceToHost, stream), "D2H state")) return false;
-        if (with_trial && !ok(hipMemcpyAsync(trial_h, B.trial, n * sizeof(T), hipMemcpyDeviceToHost, stream), "D2H trial")) return false;
+        if (vec_dev && !ok(hipMemcpyAsync(trial_h, vec_dev, n * sizeof(T), hipMemcpyDeviceToHost, stream), "D2H vec")) return false;
         return ok(hipStreamSynchronize(stream), "sync");
     }
 
@@ -569,7 +579,7 @@ struct Solver {
     bool jacobian_products(bool broyden, const T* y_dev, const T* yold_dev)
     {
         JtjArgs<T> a{};
-        a.J = B.J; a.Jout = B.J; a.y = y_dev; a.y_old = yold_dev; a.dx = B.dx; a.dx_dot = &B.st->dx_dot;
+        a.J = B.J; a.Jout = B.J; a.y = y_dev; a.y_old = yold_dev; a.dx = B.dx_acc; a.dx_dot = &B.st->dx_dot;
         a.slabs = B.slabs; a.m = m; a.n = (int)n;
         ev_begin(broyden ? 1 : 0);
         if (!ok(jtj_run<T>(plan, a, broyden, B.packed, stream), "jtj kernel")) return false;
@@ -601,6 +611,7 @@ struct Solver {
         const size_t need = 2 * pb * m * sizeof(T);
         if (ws->ypanel_bytes < need) {
             if (ws->ypanel) (void)hipFree(ws->ypanel);
+    if (ws->ytrial) (void)hipFree(ws->ytrial);
             ws->ypanel = nullptr; ws->ypanel_bytes = 0;
             if (!ok(hipMalloc(&ws->ypanel, need), "hipMalloc(FD panel)")) return false;
             ws->ypanel_bytes = need;
@@ -736,13 +747,15 @@ struct Solver {
             ++ret.fCalls;
             if (!sumsq(y, 0)) { fail = true; break; }                        // LS:955
             hipLaunchKernelGGL(k_init_state<T>, dim3(1), dim3(1), 0, stream, B.sum, B.st);
-            if (!read_state(false)) { fail = true; break; }
+            if (!read_state(nullptr)) { fail = true; break; }
         } while (false);
         if (fail) { teardown(); ret.status = mir_ls_numericError; return ret; }
 
         ret.residual = st_h->residual;
         bool fConverged = ret.residual <= S->maxGoodResidual;                // LS:956
         bool needJacobian = true;                                            // LS:959
+        bool last_rejected = false;
+        const bool speculate = device_cb && fb != nullptr && !no_speculation;
         uint32_t age = maxAge;
         ret.lambda = 0;
         T mu = 1;
@@ -768,6 +781,7 @@ struct Solver {
             if (needJacobian) {                                              // LS:996-1063
                 needJacobian = false;
                 newJacobian = true;
+                last_rejected = false;
                 if (age < maxAge) {                                          // Broyden, LS:999-1007
                     age++;
                     if (stats) stats->jacobian_broyden++;
@@ -788,62 +802,105 @@ struct Solver {
                 }
             }
 
-            // LS:1053-1062 (gradient test, evaluated inside the kernel when a new Jy exists),
-            // LS:1067-1110, 1141-1142: damping, BOXCQP solve, step rounding, trial point, prediction
+            // ---- one ROUND: the n x n solve for a ladder of lambdas, the trial residuals, the decision.
+            // LS:1053-1062 (gradient test, inside the kernel when a new Jy exists), LS:1067-1110, 1141-1142
+            // (damping, BOXCQP, step rounding, trial point, prediction), LS:1112-1161 (trial residual, acceptance).
+            //
+            // Speculation: after a rejection the reference re-solves with lambda * lambdaIncrease * mu, mu * 2
+            // (LS:1103, 1127) and J^T J, J^T y unchanged -- the whole ladder lambda_0 .. lambda_{ks-1} is known in
+            // advance. When a batched residual callback exists, workgroup k solves with lambda_k, all trial points
+            // are evaluated in one sweep and k_decide_chain walks them in the reference's order; entries after the
+            // first accepted one are discarded, so results, counters and callback-visible semantics of accepted
+            // points are unchanged. The ladder stops where the reference's top-of-loop checks would intervene
+            // (lambda > maxLambda LS:979, forced refresh LS:984).
+            const bool lambda_from_state = !(ret.lambda >= S->minLambda);     // first pass: lambda_0 rule inside the kernel
+            int ks = 1;
+            T lam[kChainMax];
+            lam[0] = ret.lambda;
+            if (speculate && !newJacobian && !lambda_from_state && last_rejected) {
+                T l2 = ret.lambda, m2 = mu;
+                while (ks < kChainMax) {
+                    l2 *= S->lambdaIncrease * m2;
+                    m2 *= 2;
+                    if (!(l2 <= S->maxLambda)) break;                         // LS:979 would exit there
+                    if (m2 > suspiciousMu && age) break;                      // LS:984 would force a refresh there
+                    lam[ks++] = l2;
+                }
+            }
             {
                 LmSolveArgs<T> a{};
                 a.JJ = B.JJ; a.Jy = B.Jy; a.x = B.x; a.lower = B.lower; a.upper = B.upper;
-                a.dx = B.dx; a.trial = B.trial; a.st = B.st; a.set = sd; a.sc = B.sc; a.n = (int)n;
+                a.dx = B.dx; a.trial = B.trial; a.st = B.st; a.rec = B.rec; a.set = sd; a.n = (int)n;
+                for (int k = 0; k < kChainMax; ++k) { a.sc[k] = B.sc[k]; a.lam[k] = k < ks ? lam[k] : T(0); }
                 a.f_in_lds = f_in_lds;
                 a.check_grad = newJacobian ? 1 : 0;
-                if (!dbg_solve) a.sc.dbg = nullptr;
+                a.lambda_from_state = lambda_from_state ? 1 : 0;
+                if (!dbg_solve) a.sc[0].dbg = nullptr;
                 ev_begin(2);
-                if (!ok(launch_solve(a), "solve launch")) { fail = true; break; }
+                if (!ok(launch_solve(a, ks), "solve launch")) { fail = true; break; }
                 ev_end();
-                if (!ok(hipGetLastError(), "solve kernel") || !read_state(true)) { fail = true; break; }
             }
             if (dbg_solve) {
                 long long h[16];
-                if (hipMemcpy(h, B.sc.dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
+                if (hipMemcpy(h, B.sc[0].dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
                     std::fprintf(stderr, "[solve dbg] (10ns ticks) build %lld  copy/equil %lld  scale %lld  potrf %lld  potrs %lld  refine %lld  epilogue %lld  total %lld  shader MHz %.0f  [matvec1 %lld berr %lld]\n",
                                  h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[8] - h[7], h[8] - h[0], (double)(h[10] - h[9]) / (double)(h[8] - h[0]) * 100.0, h[11] - h[5], h[12] - h[11]);
             }
-            if (newJacobian && (st_h->flags & kFlagGradSmall)) {             // LS:1053-1062
+
+            // trial residuals -> ytr (k-th vector at ytr + k * m); with one trial they go straight into mB
+            T* ytr = mB;
+            if (ks > 1) {
+                if (!ws->ytrial && !ok(hipMalloc(&ws->ytrial, (size_t)kChainMax * m * sizeof(T)), "hipMalloc(trial residuals)")) { fail = true; break; }
+                ytr = static_cast<T*>(ws->ytrial);
+            }
+            if (device_cb) {
+                // no host round trip before the residual: it is evaluated speculatively even when the record will
+                // forbid it (gradient converged, QP failure, step guard) -- the decision kernel then ignores it
+                if (ks > 1) fb(fbctx, m, n, (size_t)ks, B.trial, ytr);
+                else f(fctx, m, n, B.trial, ytr);
+            } else {
+                // reference contract: the callback needs the trial point on the host
+                ChainRec<T> r0;
+                if (!ok(hipMemcpyAsync(&r0, B.rec, sizeof r0, hipMemcpyDeviceToHost, stream), "D2H rec") || !read_state(B.trial)) { fail = true; break; }
+                const bool no_f = (newJacobian && (r0.flags & kFlagGradSmall)) || r0.qp_status != 0
+                    || (r0.flags & (kFlagDxNaN | kFlagStepTooLong));
+                if (!no_f && !eval_f(B.trial, trial_h, ytr)) { fail = true; break; }
+            }
+            if (!sumsq(ytr, 1, ks, m)) { fail = true; break; }
+            {
+                DecideArgs<T> d{};
+                d.sums = B.sum + 1; d.rec = B.rec; d.st = B.st; d.set = sd; d.x = B.x; d.trial = B.trial; d.dx_chain = B.dx;
+                d.dx_acc = B.dx_acc; d.n = (int)n; d.ks = ks; d.check_grad = newJacobian ? 1 : 0;
+                d.lambda_from_state = lambda_from_state ? 1 : 0;
+                hipLaunchKernelGGL(k_decide_chain<T>, dim3(1), dim3(kSolveThreads), 0, stream, d);
+            }
+            if (!ok(hipGetLastError(), "decide kernel") || !read_state(B.x)) { fail = true; break; }
+
+            const int dec = st_h->decision;
+            ret.fCalls += st_h->fcalls;                                      // LS:1112
+            if (stats) {
+                if (st_h->consumed > 1) stats->passes += st_h->consumed - 1;
+                stats->rejected += st_h->rejects;
+                stats->step_guard_rejects += st_h->guards;
+                stats->qp_active_set_passes += st_h->qp_active;
+            }
+            if (dec == kDecideGradSmall) {                                   // LS:1053-1062
                 if (age == 0) { ret.status = mir_ls_gConverged; break; }
                 age = maxAge;
                 continue;
             }
             ret.lambda = st_h->lambda;
-            if (st_h->qp_iterations > 0 && stats) stats->qp_active_set_passes++;
-            if (st_h->qp_status != 0) { ret.status = mir_ls_numericError; break; }      // LS:1080-1085
-            if (st_h->flags & kFlagDxNaN) { ret.status = mir_ls_numericError; break; }  // LS:1087-1092
-
-            if (st_h->flags & kFlagStepTooLong) {                            // LS:1101-1106
-                hipLaunchKernelGGL(k_bump_lambda<T>, dim3(1), dim3(1), 0, stream, B.st, sd.lambdaIncrease);
-                ret.lambda *= S->lambdaIncrease * mu;
-                mu *= 2;
-                if (stats) stats->step_guard_rejects++;
-                continue;
-            }
-
-            ++ret.fCalls;                                                    // LS:1112-1115
-            if (!eval_f(B.trial, trial_h, mB)) { fail = true; break; }
-            if (!sumsq(mB, 1)) { fail = true; break; }
-            hipLaunchKernelGGL(k_decide<T>, dim3(1), dim3(kSolveThreads), 0, stream, B.sum + 1, B.st, sd, B.x, B.trial, (int)n);
-            if (!ok(hipGetLastError(), "decide kernel") || !read_state(false)) { fail = true; break; }
-
-            const int dec = st_h->decision;
-            if (dec == kDecideNumericError) { ret.status = mir_ls_numericError; break; }   // LS:1117-1122
-            ret.lambda = st_h->lambda;
             mu = st_h->mu;
-            if (dec == kDecideReject) {                                      // LS:1125-1130
-                if (stats) stats->rejected++;
-                continue;
-            }
+            if (dec == kDecideNumericError) { ret.status = mir_ls_numericError; break; }   // LS:1080-1092, 1117-1122
+            if (dec == kDecideReject) { last_rejected = true; continue; }    // LS:1101-1106, 1125-1130
+            last_rejected = false;
 
             needJacobian = true;                                             // LS:1132-1139
             ret.iterations = st_h->iterations;
-            for (uint32_t i = 0; i < n; ++i) xh[i] = trial_h[i];
+            for (uint32_t i = 0; i < n; ++i) xh[i] = trial_h[i];             // trial_h holds the new x (read_state(B.x))
+            if (ytr != mB) {
+                if (!ok(hipMemcpyAsync(mB, ytr + (size_t)st_h->accepted_k * m, m * sizeof(T), hipMemcpyDeviceToDevice, stream), "D2D y")) { fail = true; break; }
+            }
             { T* t = y; y = mB; mB = t; }
             ret.residual = st_h->residual;
             fConverged = ret.residual <= S->maxGoodResidual;

@@ -4,8 +4,8 @@
 //   LS:955, LS:1115   dot(y, y)                          -> k_sumsq_partial + k_sumsq_final
 //   LS:1018-1048      finite-difference column fill      -> k_fd_points + k_fd_fill / k_fd_fill_col
 //   LS:1053           |Jy[iamax(Jy)]|                     -> k_unpack_grad
-//   LS:1117-1161      trial acceptance, rho, lambda/mu   -> k_decide
-//   LS:1103-1104      step-size guard lambda bump        -> k_bump_lambda
+//   LS:1080-1161      QP/NaN guards, step guard, trial acceptance, rho, lambda/mu over a chain of
+//                     speculative trials                                -> k_decide_chain
 #pragma once
 
 #include "common.h"
@@ -14,10 +14,14 @@
 namespace mirlsq {
 
 // ---- sum of squares, deterministic two-stage. Stage 1: gridDim.x partials.
+// blockIdx.y selects one of several m-vectors (stride vstride) and its block of pstride partials.
 template <typename T>
-__global__ __launch_bounds__(256) void k_sumsq_partial(const T* __restrict__ v, size_t m, T* __restrict__ partials)
+__global__ __launch_bounds__(256) void k_sumsq_partial(const T* __restrict__ v0, size_t m, T* __restrict__ partials0,
+                                                       size_t vstride = 0, int pstride = 0)
 {
     __shared__ T red[4];
+    const T* __restrict__ v = v0 + (size_t)blockIdx.y * vstride;
+    T* __restrict__ partials = partials0 + (size_t)blockIdx.y * pstride;
     T s = 0;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     // contiguous chunk per block keeps the summation order independent of the grid-stride pattern
@@ -34,15 +38,16 @@ __global__ __launch_bounds__(256) void k_sumsq_partial(const T* __restrict__ v, 
 
 // Stage 2: one block sums the partials in a fixed order into *out.
 template <typename T>
-__global__ __launch_bounds__(256) void k_sumsq_final(const T* __restrict__ partials, int nparts, T* __restrict__ out)
+__global__ __launch_bounds__(256) void k_sumsq_final(const T* __restrict__ partials0, int nparts, T* __restrict__ out, int pstride = 0)
 {
     __shared__ T red[4];
+    const T* __restrict__ partials = partials0 + (size_t)blockIdx.x * pstride;
     T s = 0;
     for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += partials[i];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) *out = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // ---- LS:953-971: state at entry. *sum = ||f(x0)||^2 (already all-reduced).
@@ -153,63 +158,90 @@ __global__ __launch_bounds__(256) void k_fd_fill_col(const T* __restrict__ yp, c
     J[i * (size_t)n + j] = v;
 }
 
-// ---- LS:1117-1161: the floating-point side of step acceptance. One block of kSolveThreads.
-//      *trial_sum = ||f(trial)||^2 (already all-reduced). On acceptance x <- trial (LS:1135).
+// ---- LS:1080-1161 for a chain of ks speculative trials: walks the lambda ladder in the reference's order --
+//      QP failure / NaN step (LS:1080-1092), step-size guard (LS:1101-1106), trial residual (LS:1117), rejection
+//      (LS:1125-1130) -- until the first accepted trial, whose x, dx and scalars become the state (LS:1132-1161).
+//      sums[k] = ||f(trial_k)||^2 (already all-reduced). Later chain entries are simply discarded: they were
+//      computed on the assumption that every earlier entry is rejected, which is exactly when the reference would
+//      have computed them. One block of kSolveThreads.
 template <typename T>
-__global__ __launch_bounds__(kSolveThreads) void k_decide(const T* trial_sum, LmState<T>* st, LmSettingsDev<T> set,
-                                                          T* x, const T* trial, int n)
+struct DecideArgs {
+    const T* sums;
+    const ChainRec<T>* rec;
+    LmState<T>* st;
+    LmSettingsDev<T> set;
+    T* x;               // n: current point, overwritten by the accepted trial (LS:1135)
+    const T* trial;     // ks x n
+    const T* dx_chain;  // ks x n
+    T* dx_acc;          // n: accepted step, kept for the next Broyden update (LS:1004-1006)
+    int n, ks, check_grad, lambda_from_state;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kSolveThreads) void k_decide_chain(DecideArgs<T> a)
 {
-    __shared__ int dec_s;
+    __shared__ int acc_s;
     if (threadIdx.x == 0) {
-        LmState<T> s = *st;
-        const T tr = *trial_sum;
-        s.trial_residual = tr;
-        int dec;
-        if (!(tr <= Lim<T>::inf())) {                                 // LS:1117-1122
-            dec = kDecideNumericError;
-            s.flags |= kFlagTrialNotFinite;
-        } else {
-            const T improvement = s.residual - tr;                    // LS:1124
-            s.improvement = improvement;
-            if (!(improvement > 0)) {                                 // LS:1125-1130
-                s.lambda *= set.lambdaIncrease * s.mu;
+        LmState<T> s = *a.st;
+        int dec = kDecideReject, acc = -1;
+        uint32_t consumed = 0, fcalls = 0, rejects = 0, guards = 0, qpact = 0;
+        for (int k = 0; k < a.ks; ++k) {
+            const ChainRec<T> r = a.rec[k];
+            if (k == 0 && a.check_grad && (r.flags & kFlagGradSmall)) { dec = kDecideGradSmall; break; }   // LS:1053
+            ++consumed;
+            if (k == 0 && a.lambda_from_state) s.lambda = r.lambda;           // lambda_0, LS:1067-1072
+            if (r.qp_iterations > 0) ++qpact;
+            s.qp_status = r.qp_status; s.qp_iterations = r.qp_iterations; s.flags = r.flags;
+            if (r.qp_status != 0 || (r.flags & kFlagDxNaN)) { dec = kDecideNumericError; break; }   // LS:1080-1092
+            if (r.flags & kFlagStepTooLong) {                                 // LS:1101-1106
+                s.lambda *= a.set.lambdaIncrease * s.mu;
                 s.mu *= 2;
-                dec = kDecideReject;
-            } else {                                                  // LS:1132-1139
-                s.mu = 1;
-                s.iterations++;
-                s.residual = tr;
-                s.dx_dot = s.new_dx_dot;
-                if (!(s.predicted > 0)) {                             // LS:1144-1148
-                    dec = kDecideAcceptNoPrediction;
-                } else {
-                    const T rho = s.predicted / improvement;          // LS:1150 (quirk Q2)
-                    s.rho = rho;
-                    if (rho < set.minStepQuality) {                   // LS:1152-1156
-                        s.lambda *= set.lambdaIncrease * s.mu;
-                        s.mu *= 2;
-                    } else if (rho >= set.goodStepQuality) {          // LS:1158-1161
-                        s.lambda = dfmax(set.lambdaDecrease * s.lambda * s.mu, set.minLambda);
-                    }
-                    dec = kDecideAccept;
-                }
+                ++guards;
+                continue;
             }
+            ++fcalls;                                                         // LS:1112
+            const T tr = a.sums[k];
+            s.trial_residual = tr;
+            if (!(tr <= Lim<T>::inf())) { dec = kDecideNumericError; s.flags |= kFlagTrialNotFinite; break; }   // LS:1117
+            const T improvement = s.residual - tr;                            // LS:1124
+            s.improvement = improvement;
+            if (!(improvement > 0)) {                                         // LS:1125-1130
+                s.lambda *= a.set.lambdaIncrease * s.mu;
+                s.mu *= 2;
+                ++rejects;
+                continue;
+            }
+            s.mu = 1;                                                         // LS:1132-1139
+            s.iterations++;
+            s.residual = tr;
+            s.dx_dot = r.new_dx_dot;
+            s.new_dx_dot = r.new_dx_dot;
+            s.predicted = r.predicted;
+            s.trial_xnorm = r.trial_xnorm;
+            acc = k;
+            if (!(r.predicted > 0)) { dec = kDecideAcceptNoPrediction; break; }   // LS:1144-1148
+            const T rho = r.predicted / improvement;                          // LS:1150 (quirk Q2)
+            s.rho = rho;
+            if (rho < a.set.minStepQuality) {                                 // LS:1152-1156
+                s.lambda *= a.set.lambdaIncrease * s.mu;
+                s.mu *= 2;
+            } else if (rho >= a.set.goodStepQuality) {                        // LS:1158-1161
+                s.lambda = dfmax(a.set.lambdaDecrease * s.lambda * s.mu, a.set.minLambda);
+            }
+            dec = kDecideAccept;
+            break;
         }
-        s.decision = dec;
-        *st = s;
-        dec_s = dec;
+        s.decision = dec; s.accepted_k = acc; s.consumed = consumed; s.fcalls = fcalls;
+        s.rejects = rejects; s.guards = guards; s.qp_active = qpact;
+        *a.st = s;
+        acc_s = acc;
     }
     __syncthreads();
-    if ((dec_s == kDecideAccept || dec_s == kDecideAcceptNoPrediction) && threadIdx.x < n)
-        x[threadIdx.x] = trial[threadIdx.x];                          // LS:1135
-}
-
-// ---- LS:1103-1104 (also used for nothing else): lambda *= lambdaIncrease * mu; mu *= 2
-template <typename T>
-__global__ void k_bump_lambda(LmState<T>* st, T lambdaIncrease)
-{
-    st->lambda *= lambdaIncrease * st->mu;
-    st->mu *= 2;
+    const int acc = acc_s;
+    if (acc >= 0 && threadIdx.x < a.n) {
+        a.x[threadIdx.x] = a.trial[(size_t)acc * a.n + threadIdx.x];          // LS:1135
+        a.dx_acc[threadIdx.x] = a.dx_chain[(size_t)acc * a.n + threadIdx.x];
+    }
 }
 
 // ---- LS:984-989: forced refresh resets mu

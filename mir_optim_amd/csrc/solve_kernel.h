@@ -34,12 +34,24 @@ struct LmState {
     T dx_dot, new_dx_dot, predicted, trial_xnorm;
     T jy_inf, improvement, rho, pad0;
     int32_t qp_status, qp_iterations, flags, decision;
-    uint32_t iterations, pad1, pad2, pad3;
+    uint32_t iterations;
+    int32_t accepted_k;        // chain index of the accepted trial (-1: none)
+    uint32_t consumed;         // chain steps the reference would have executed this round
+    uint32_t fcalls;           // residual evaluations among them (LS:1112)
+    uint32_t rejects, guards, qp_active, pad1;
+};
+
+// One solve of the lambda ladder (chain step k): everything the acceptance logic needs about it.
+constexpr int kChainMax = 8;
+template <typename T>
+struct ChainRec {
+    T lambda, new_dx_dot, predicted, trial_xnorm;
+    int32_t qp_status, qp_iterations, flags, pad;
 };
 enum : int32_t { kFlagDxNaN = 1, kFlagXNaN = 2, kFlagStepTooLong = 4, kFlagTrialNotFinite = 8, kFlagGradSmall = 16 };
 enum : int32_t {
     kDecideNone = 0, kDecideReject = 1, kDecideAccept = 2, kDecideAcceptNoPrediction = 3,
-    kDecideNumericError = 4
+    kDecideNumericError = 4, kDecideGradSmall = 5
 };
 
 template <typename T>
@@ -774,14 +786,17 @@ struct LmSolveArgs {
     const T* x;        // n current point
     const T* lower;    // n
     const T* upper;    // n
-    T* dx;             // n out: rounded step (LS:1096-1097)
-    T* trial;          // n out: clamp(x + dx) (LS:1108-1110)
+    T* dx;             // kChainMax x n out: rounded step (LS:1096-1097) of chain step blockIdx.x
+    T* trial;          // kChainMax x n out: clamp(x + dx) (LS:1108-1110)
     LmState<T>* st;
+    ChainRec<T>* rec;  // kChainMax
     LmSettingsDev<T> set;
-    SolveScratch<T> sc;
+    SolveScratch<T> sc[kChainMax];
+    T lam[kChainMax];  // the lambda ladder lambda_k = lambda after k bumps (LS:1103/1127); workgroup k solves with lam[k]
     int n;
     int f_in_lds;
-    int check_grad;    // a new Jy was just computed: apply the gradient test LS:1053 first
+    int check_grad;        // a new Jy was just computed: apply the gradient test LS:1053 first (chain of 1)
+    int lambda_from_state; // step 0 takes st->lambda and applies the lambda_0 rule LS:1067-1072
 };
 
 template <typename T, int NB>
@@ -792,23 +807,27 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
     __shared__ int ired[8];
     const int n = a.n, tid = threadIdx.x;
     const int ldf = n | 1;
+    const int kc = blockIdx.x;                       // chain step
+    SolveScratch<T> sc = a.sc[kc];
+    T* dx_out = a.dx + (size_t)kc * n;
+    T* trial_out = a.trial + (size_t)kc * n;
     T* F;
-    if constexpr (NB > 0) F = reinterpret_cast<T*>(smem_raw); else F = a.sc.Fg;
-    T* qpl = a.sc.vec + 7 * (size_t)n;
-    T* qpu = a.sc.vec + 8 * (size_t)n;
-    T* xq = a.sc.vec + 10 * (size_t)n;
+    if constexpr (NB > 0) F = reinterpret_cast<T*>(smem_raw); else F = sc.Fg;
+    T* qpl = sc.vec + 7 * (size_t)n;
+    T* qpu = sc.vec + 8 * (size_t)n;
+    T* xq = sc.vec + 10 * (size_t)n;
 
-    MIRLSQ_STAMP(a.sc.dbg, 0);
-    if (a.sc.dbg && threadIdx.x == 0) a.sc.dbg[9] = clock64();
+    MIRLSQ_STAMP(sc.dbg, 0);
+    if (sc.dbg && threadIdx.x == 0) sc.dbg[9] = clock64();
     // gradient test, LS:1053: stop before touching lambda when ||Jy||_inf <= gradTolerance
     if (a.check_grad && !(a.st->jy_inf > a.set.gradTolerance)) {
-        if (tid == 0) { a.st->flags = kFlagGradSmall; a.st->qp_status = 0; a.st->qp_iterations = 0; }
+        if (tid == 0) { ChainRec<T> r{}; r.flags = kFlagGradSmall; a.rec[kc] = r; }
         return;
     }
 
     // lambda_0, LS:1067-1072 (first element of maximum |diag|, as i?amax picks it)
-    T lambda = a.st->lambda;
-    if (!(lambda >= a.set.minLambda)) {
+    T lambda = (kc == 0 && a.lambda_from_state) ? a.st->lambda : a.lam[kc];
+    if (kc == 0 && a.lambda_from_state && !(lambda >= a.set.minLambda)) {
         const T dg = tid < n ? dabs(a.JJ[(size_t)tid * n + tid]) : T(-1);
         const T mx = block_max(dg, red);
         int cand = (tid < n && dg == mx) ? tid : 0x7fffffff;
@@ -829,8 +848,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
     {   // Pm = A = JJ + lambda I, 16 loads in flight per thread (a plain copy loop serialises on
         // may-alias load/store ordering)
         const T* __restrict__ src = a.JJ;
-        T* __restrict__ dp = a.sc.Pm;
-        T* __restrict__ da = a.sc.A;
+        T* __restrict__ dp = sc.Pm;
+        T* __restrict__ da = sc.A;
         const int nn = n * n;
         for (int base = tid; base < nn; base += 16 * kSolveThreads) {
             T v[16];
@@ -849,12 +868,12 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
     }
     __syncthreads();
 
-    MIRLSQ_STAMP(a.sc.dbg, 1);
+    MIRLSQ_STAMP(sc.dbg, 1);
     int qp_iters = 0;
-    const int qp = box_qp_device<T, NB>(n, a.sc.Pm, a.Jy, qpl, qpu, xq, false, a.set.qpRelTolerance, a.set.qpAbsTolerance,
-                                 a.set.qpMaxIterations, a.sc, F, ldf, red, ired, &qp_iters, true);   // LS:1080
+    const int qp = box_qp_device<T, NB>(n, sc.Pm, a.Jy, qpl, qpu, xq, false, a.set.qpRelTolerance, a.set.qpAbsTolerance,
+                                 a.set.qpMaxIterations, sc, F, ldf, red, ired, &qp_iters, true);   // LS:1080
 
-    MIRLSQ_STAMP(a.sc.dbg, 7);
+    MIRLSQ_STAMP(sc.dbg, 7);
     int flags = 0;
     T ndd = 0, pred = 0, xn = 0;
     if (qp == 0) {
@@ -865,9 +884,9 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
             const T xi = a.x[tid];
             d = d + xi;                                              // LS:1096
             d = d - xi;                                              // LS:1097
-            a.dx[tid] = d;
+            dx_out[tid] = d;
             tr = dfmax(dfmin(d + xi, a.upper[tid]), a.lower[tid]);   // LS:1108-1110
-            a.trial[tid] = tr;
+            trial_out[tid] = tr;
             if (!(tr <= tr)) flags |= kFlagXNaN;
         }
         flags = block_or(flags, ired);
@@ -881,9 +900,9 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
             if (i < n) {
                 const int j0 = pair && h ? n / 2 : 0, j1 = pair && !h ? n / 2 : n;
 #pragma unroll 16
-                for (int j = j0; j < j1; ++j) ti += a.JJ[(size_t)j * n + i] * a.dx[j];
+                for (int j = j0; j < j1; ++j) ti += a.JJ[(size_t)j * n + i] * dx_out[j];
                 if (h == 0) ti = ti + 2 * a.Jy[i];
-                ti = ti * a.dx[i];
+                ti = ti * dx_out[i];
             }
         }
         pred = -block_sum(ti, red);
@@ -894,16 +913,13 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
         xn = amx > 0 ? amx * dsqrt(block_sum(sc2, red)) : T(0);
         if (!(dsqrt(ndd) < a.set.maxStep)) flags |= kFlagStepTooLong; // LS:1101
     }
-    MIRLSQ_STAMP(a.sc.dbg, 8);
-    if (a.sc.dbg && threadIdx.x == 0) a.sc.dbg[10] = clock64();
+    MIRLSQ_STAMP(sc.dbg, 8);
+    if (sc.dbg && threadIdx.x == 0) sc.dbg[10] = clock64();
     if (tid == 0) {
-        a.st->lambda = lambda;
-        a.st->qp_status = qp;
-        a.st->qp_iterations = qp_iters;
-        a.st->flags = flags;
-        a.st->new_dx_dot = ndd;
-        a.st->predicted = pred;
-        a.st->trial_xnorm = xn;
+        ChainRec<T> r{};
+        r.lambda = lambda; r.new_dx_dot = ndd; r.predicted = pred; r.trial_xnorm = xn;
+        r.qp_status = qp; r.qp_iterations = qp_iters; r.flags = flags;
+        a.rec[kc] = r;
     }
 }
 

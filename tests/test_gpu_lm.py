@@ -257,6 +257,27 @@ def test_repeated_solve_is_bit_reproducible():
             assert key == ref[rep % 2], f"solve {rep} differs from solve {rep % 2}"
 
 
+@pytest.mark.parametrize("m,n", [(3000, 17), (9000, 33), (20001, 9)])
+def test_speculative_lambda_ladder_is_bitwise_equivalent(m, n, monkeypatch):
+    """After a rejection the solver evaluates a ladder of up to 8 lambdas at once (batched residual callback) and
+    walks them in the reference's order. With a batched callback that is numerically the same function as the
+    single-point one (odd n: workloads.hip falls back to one sweep per point) the result must be bit-identical
+    to the one-trial-per-pass execution: same x, residual, lambda, iterations, fCalls, pass count."""
+    w = P.tanh_linear(m, n)
+    prob = W.TanhLinear(w["A"], w["b"])
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-12          # force the long noisy rejection tail (quirk Q3)
+    st1, st0 = M.Stats(), M.Stats()
+    r1, x1 = prob.solve(w["x0"], settings=s, batched=True, stats=st1, flags=M.TIME_KERNELS)
+    monkeypatch.setenv("MIR_LSQ_NO_SPECULATION", "1")
+    r0, x0 = prob.solve(w["x0"], settings=s, batched=True, stats=st0, flags=M.TIME_KERNELS)
+    monkeypatch.delenv("MIR_LSQ_NO_SPECULATION")
+    assert st0.rejected >= 5                                       # the ladder really had something to do
+    assert np.array_equal(x1, x0) and r1.residual == r0.residual and r1.lambda_ == r0.lambda_
+    assert (r1.status, r1.iterations, r1.fCalls) == (r0.status, r0.iterations, r0.fCalls)
+    assert (st1.passes, st1.accepted, st1.rejected, st1.step_guard_rejects) == (st0.passes, st0.accepted, st0.rejected, st0.step_guard_rejects)
+    assert st1.solve_launches < st0.solve_launches                 # fewer rounds than passes
+
+
 def test_stats_and_reentrancy(oracle):
     """two different problems interleaved on their own streams/workspaces give the same answers as alone."""
     w1, w2 = P.tanh_linear(5000, 16), P.tanh_linear(7000, 32)
