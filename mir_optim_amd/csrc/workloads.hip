@@ -214,18 +214,26 @@ __global__ __launch_bounds__(1024) void k_tanh_linear_batched(const double* __re
         if (t + gridDim.x < ntiles) gload(t + gridDim.x);
         __syncthreads();
         int buf = 0;
+        // software pipeline over tiles: the tanh / store epilogue of tile t - 1 is independent VALU work placed in
+        // the same basic block as the (dependent, latency-bound) MFMA chain of tile t, so the scheduler overlaps them
+        Acc prev = {0.0, 0.0, 0.0, 0.0};
+        size_t tprev = ntiles;                                  // "no previous tile"
+        auto epilogue = [&](const Acc& acc, size_t tt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t row = tt * 16 + fq + 4 * r;
+                if (pok && tt < ntiles && row < m) Y[(size_t)pl * m + row] = dtanh(acc[r]) - b[row];
+            }
+        };
         for (; t < ntiles; t += gridDim.x) {
             if (wave_active) {                                  // waves whose 16 points are all >= P only help staging
                 Acc acc = {0.0, 0.0, 0.0, 0.0};
                 const double* tp = &tile[buf][fr * PITCH + fq];
 #pragma unroll
                 for (int s = 0; s < NK; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tp[4 * s], xf[s], acc, 0, 0, 0);
-                // D: col = lane & 15 = point, row = (lane >> 4) + 4 r
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const size_t row = t * 16 + fq + 4 * r;
-                    if (pok && row < m) Y[(size_t)pl * m + row] = dtanh(acc[r]) - b[row];
-                }
+                epilogue(prev, tprev);                          // D: col = lane & 15 = point, row = (lane >> 4) + 4 r
+                prev = acc;
+                tprev = t;
             }
             // stage tile t + grid into the other buffer (its last readers passed the previous barrier)
             if (t + gridDim.x < ntiles) lstore(buf ^ 1);
@@ -233,6 +241,7 @@ __global__ __launch_bounds__(1024) void k_tanh_linear_batched(const double* __re
             __syncthreads();
             buf ^= 1;
         }
+        if (wave_active) epilogue(prev, tprev);
         __syncthreads();
     }
 }
