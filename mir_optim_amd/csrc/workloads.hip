@@ -11,6 +11,8 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -246,10 +248,249 @@ __global__ __launch_bounds__(1024) void k_tanh_linear_batched(const double* __re
     }
 }
 
+
+// ---- batched residuals, LDS-DMA version (n = 32, 64, 128): same GEMM, restructured like the solver's J^T J kernel.
+//      The first version above stages A through VGPRs and its waves wait, every 16-row tile, on a vmcnt that also
+//      covers their own scattered Y stores (measured 2.1 ms for m = 1e6, n = p = 128: 15 TFLOP/s). Here
+//        * waves 0..7 compute (wave w owns points [16 w, 16 w + 16) of a 128-point chunk) and issue NO loads in the
+//          sweep: their Y stores are fire-and-forget;
+//        * waves 8, 9 only issue `global_load_lds_dwordx4` DMA into a ring of NS stages of 32 rows (D stages in flight,
+//          counted vmcnt over DMA only, one raw s_barrier per stage); b rides in a small ring of its own;
+//        * LDS layout: row-major without padding, 16-byte pieces XOR-swizzled with the row (the DMA picks the SOURCE
+//          row and piece per lane, the LDS side of a DMA is always lane x 16 B). The K index of the MFMA chain is
+//          permuted so that one ds_read_b128 (4 LDS cycles, conflict-free with this swizzle) is the A operand of two
+//          k-steps; ds_read2_b64, which the compiler forms from paired 8-byte reads, costs 8 cycles and 2-way conflicts;
+//        * LDS row i of a tile holds memory row rho(i), so that a lane's four accumulator rows are two adjacent row
+//          pairs: the epilogue stores 16-byte pairs, 64 contiguous bytes per point and instruction;
+//        * two independent accumulator chains (two 16-row tiles of the stage) per wave keep the MFMA pipe full; the two
+//          compute waves of a SIMD run out of phase (MFMA-then-epilogue vs epilogue-then-MFMA).
+typedef __attribute__((address_space(3))) void* wl_lds_ptr;
+typedef const __attribute__((address_space(1))) void* wl_gbl_ptr;
+
+// MFMA row i of a 16-row tile holds memory row rho(i): D row fq + 4 r  <->  memory row (r >> 1) * 8 + 2 fq + (r & 1)
+__device__ __forceinline__ constexpr int tlb_rho(int i) { return ((i >> 2) >> 1) * 8 + 2 * (i & 3) + ((i >> 2) & 1); }
+// 16-byte piece p of LDS row i is stored at piece position p ^ sigma(i): with it the 4 x 16-lane groups of a
+// ds_read_b128 A-operand fetch ({0-3, 12-15, 20-27}, ...) each touch 16 distinct 16-byte bank slots
+__device__ __forceinline__ constexpr int tlb_sigma(int i) { return (i + 12) & 15; }
+
+template <int NK> struct TlbCfg {
+    static constexpr int N = 4 * NK;
+    static constexpr int PPR = N / 2;                       // 16-byte pieces per row
+    static constexpr int RPI = 64 / PPR;                    // rows per 1 KB DMA instruction
+    static constexpr int ROWS = 32;                         // rows per stage (two MFMA row tiles)
+    static constexpr int IPS = ROWS / RPI;                  // A instructions per stage
+    static constexpr int STAGE_BYTES = ROWS * N * 8;
+    static constexpr int NS = 4, D = 2, NSB = 8;
+    static constexpr int B_OFF = NS * STAGE_BYTES;
+    static constexpr int LDS_BYTES = B_OFF + NSB * 256;
+    static constexpr int COMPUTE_WAVES = 8, LOADER_WAVES = 2;
+    static constexpr int THREADS = 64 * (COMPUTE_WAVES + LOADER_WAVES);
+};
+
+template <int NK, int LOADER>
+__device__ __forceinline__ void tlb_loader(const double* __restrict__ A, const double* __restrict__ b, size_t m,
+                                           unsigned char* smem, int lane, size_t S, size_t F)
+{
+    using C = TlbCfg<NK>;
+    constexpr int MYI = C::IPS / 2;
+    constexpr int OPS = MYI + (LOADER == 1 ? 1 : 0);
+    const unsigned char* Ab = reinterpret_cast<const unsigned char*>(A);
+    const unsigned char* bb = reinterpret_cast<const unsigned char*>(b);
+    const int rin = lane / C::PPR, sp = lane % C::PPR;
+    auto issue = [&](size_t f) {
+        const size_t stage = blockIdx.x + (f % S) * (size_t)gridDim.x;
+        const size_t row0 = stage * C::ROWS;
+        unsigned char* slot = smem + (f % C::NS) * C::STAGE_BYTES;
+#pragma unroll
+        for (int k = 0; k < MYI; ++k) {
+            const int ins = LOADER + 2 * k;
+            const int R = ins * C::RPI + rin;                   // LDS row within the stage = 16 tile + MFMA row
+            size_t row = row0 + (R & 16) + tlb_rho(R & 15);     // the memory row that feeds it
+            row = row < m ? row : m - 1;                        // rows past m: valid bytes, never stored
+            const int piece = sp ^ tlb_sigma(R & 15);
+            __builtin_amdgcn_global_load_lds((wl_gbl_ptr)(Ab + (row * C::N + 2 * piece) * 8),
+                                             (wl_lds_ptr)(slot + ins * 1024), 16, 0, 0);
+        }
+        if constexpr (LOADER == 1) {
+            size_t row = row0 + (lane >> 1);
+            row = row < m ? row : m - 1;
+            __builtin_amdgcn_global_load_lds((wl_gbl_ptr)(bb + row * 8 + (lane & 1) * 4),
+                                             (wl_lds_ptr)(smem + C::B_OFF + (f % C::NSB) * 256), 4, 0, 0);
+        }
+    };
+    const size_t pre = F < (size_t)C::D ? F : (size_t)C::D;
+    for (size_t f = 0; f < pre; ++f) issue(f);
+    for (size_t f = 0; f < F; ++f) {
+        if (f + C::D < F) {
+            issue(f + C::D);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::D * OPS) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+template <int NK, bool ALIGNED, int GROUP>
+__device__ __forceinline__ void tlb_compute(const double* __restrict__ X, double* __restrict__ Y, size_t m, int P,
+                                            unsigned char* smem, int lane, int wave, size_t S, int nchunks)
+{
+    using C = TlbCfg<NK>;
+    using Acc = __attribute__((ext_vector_type(4))) double;
+    const int fr = lane & 15, fq = lane >> 4;
+    // k-step s = 2 j + e of the MFMA chain multiplies column 8 j + 2 fq + e: one ds_read_b128 (piece 4 j + fq of LDS
+    // row fr) feeds two k-steps, and X is read as the matching column pairs
+    const int v = fq ^ tlb_sigma(fr);
+    int laddr[4];                                               // byte offsets of j = 0..3 (mod 4) in a stage
+#pragma unroll
+    for (int k = 0; k < 4; ++k) laddr[k] = fr * C::N * 8 + ((4 * k) ^ v) * 16;
+
+    size_t f = 0;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const bool wave_active = ch * 128 + wave * 16 < P;      // wave-uniform
+        if (!wave_active) {                                     // nothing to compute: keep the barrier count
+            for (size_t s = 0; s < S; ++s) __builtin_amdgcn_s_barrier();
+            f += S;
+            continue;
+        }
+        // lanes past P duplicate point P - 1 (same inputs, same outputs, same addresses): the stores of the sweep
+        // need no per-lane predicate and the MFMA + epilogue body stays one basic block
+        int pl = ch * 128 + wave * 16 + fr;
+        pl = pl < P ? pl : P - 1;
+        double xf[NK];
+#pragma unroll
+        for (int s = 0; s < NK; ++s) xf[s] = X[(size_t)pl * C::N + 8 * (s >> 1) + 2 * fq + (s & 1)];
+        double* yp = Y + (size_t)pl * m;
+
+        auto mfma_stage = [&](size_t ff, Acc& acc0, Acc& acc1) {
+            const unsigned char* slot = smem + (ff % C::NS) * C::STAGE_BYTES;
+            acc0 = Acc{0, 0, 0, 0};
+            acc1 = Acc{0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < NK / 2; ++j) {
+                const int off = laddr[j & 3] + (j >> 2) * 256;  // (4 j & ~15) * 16 bytes
+                const double2 a0 = *reinterpret_cast<const double2*>(slot + off);
+                const double2 a1 = *reinterpret_cast<const double2*>(slot + off + 16 * C::N * 8);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, xf[2 * j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, xf[2 * j], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, xf[2 * j + 1], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, xf[2 * j + 1], acc1, 0, 0, 0);
+            }
+        };
+        // rows row0 + 2 fq + {0, 1} and row0 + 8 + 2 fq + {0, 1} of one 16-row tile
+        auto epilogue_tile = [&](const Acc& acc, size_t row0, const unsigned char* bslot, auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            const double2 b0 = *reinterpret_cast<const double2*>(bslot + 16 * fq);
+            const double2 b1 = *reinterpret_cast<const double2*>(bslot + 64 + 16 * fq);
+            const double y0 = dtanh(acc[0]) - b0.x, y1 = dtanh(acc[1]) - b0.y;
+            const double y2 = dtanh(acc[2]) - b1.x, y3 = dtanh(acc[3]) - b1.y;
+            const size_t ra = row0 + 2 * fq, rb = row0 + 8 + 2 * fq;
+            if constexpr (FULL && ALIGNED) {
+                *reinterpret_cast<double2*>(yp + ra) = make_double2(y0, y1);
+                *reinterpret_cast<double2*>(yp + rb) = make_double2(y2, y3);
+            } else if constexpr (FULL) {
+                yp[ra] = y0;
+                yp[ra + 1] = y1;
+                yp[rb] = y2;
+                yp[rb + 1] = y3;
+            } else {
+                if (ra < m) yp[ra] = y0;
+                if (ra + 1 < m) yp[ra + 1] = y1;
+                if (rb < m) yp[rb] = y2;
+                if (rb + 1 < m) yp[rb + 1] = y3;
+            }
+        };
+        auto epilogue = [&](const Acc& e0, const Acc& e1, size_t s, size_t ff, auto full_tag) {
+            const size_t row0 = (blockIdx.x + s * (size_t)gridDim.x) * C::ROWS;
+            const unsigned char* bs = smem + C::B_OFF + (ff % C::NSB) * 256;
+            epilogue_tile(e0, row0, bs, full_tag);
+            __builtin_amdgcn_sched_barrier(0);                  // one tile at a time: bounds the live tanh temporaries
+            epilogue_tile(e1, row0 + 16, bs + 128, full_tag);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // The two compute waves of a SIMD (w and w + 4) run out of phase: waves 0..3 do MFMA(s) then epilogue(s),
+        // waves 4..7 do epilogue(s - 1) then MFMA(s), so one wave's tanh / store VALU work overlaps the other's
+        // MFMA chains without relying on instruction scheduling. Only the last stage of a workgroup can be
+        // partial (stages ascend).
+        Acc acc0, acc1;
+        if constexpr (GROUP == 0) {
+            for (size_t s = 0; s + 1 < S; ++s, ++f) {
+                __builtin_amdgcn_s_barrier();                   // stage f is complete in LDS
+                mfma_stage(f, acc0, acc1);
+                epilogue(acc0, acc1, s, f, std::true_type{});
+            }
+            __builtin_amdgcn_s_barrier();
+            mfma_stage(f, acc0, acc1);
+            epilogue(acc0, acc1, S - 1, f, std::false_type{});
+            ++f;
+        } else {
+            __builtin_amdgcn_s_barrier();
+            mfma_stage(f, acc0, acc1);
+            ++f;
+            for (size_t s = 1; s < S; ++s, ++f) {
+                __builtin_amdgcn_s_barrier();
+                epilogue(acc0, acc1, s - 1, f - 1, std::true_type{});
+                mfma_stage(f, acc0, acc1);
+            }
+            epilogue(acc0, acc1, S - 1, f - 1, std::false_type{});
+        }
+    }
+}
+
+template <int NK>
+__global__ __launch_bounds__(TlbCfg<NK>::THREADS) void k_tanh_linear_batched_dma(const double* __restrict__ A,
+                                                                                  const double* __restrict__ b,
+                                                                                  const double* __restrict__ X,
+                                                                                  double* __restrict__ Y, size_t m, int P)
+{
+    using C = TlbCfg<NK>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tlb_smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t Stot = (m + C::ROWS - 1) / C::ROWS;
+    const size_t S = blockIdx.x < Stot ? (Stot - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;   // stages blockIdx.x + k grid
+    const int nchunks = (P + 127) / 128;
+    const size_t F = S * (size_t)nchunks;                       // flat (chunk, stage) sequence: the ring never drains
+    if (S == 0) return;
+    if (wave == C::COMPUTE_WAVES) tlb_loader<NK, 0>(A, b, m, tlb_smem, lane, S, F);
+    else if (wave == C::COMPUTE_WAVES + 1) tlb_loader<NK, 1>(A, b, m, tlb_smem, lane, S, F);
+    else {
+        const bool aligned = ((m & 1) == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
+        if (wave < 4) {
+            if (aligned) tlb_compute<NK, true, 0>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
+            else tlb_compute<NK, false, 0>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
+        } else {
+            if (aligned) tlb_compute<NK, true, 1>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
+            else tlb_compute<NK, false, 1>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
+        }
+    }
+}
+
+template <int NK>
+bool launch_tlb_dma(const double* A, const double* b, const double* X, double* Y, size_t m, int P, hipStream_t s)
+{
+    using C = TlbCfg<NK>;
+    static bool attr_ok = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k_tanh_linear_batched_dma<NK>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) == hipSuccess;
+    }();
+    if (!attr_ok) return false;
+    const size_t Stot = (m + C::ROWS - 1) / C::ROWS;
+    const unsigned grid = (unsigned)(Stot < 256 ? Stot : 256);
+    hipLaunchKernelGGL((k_tanh_linear_batched_dma<NK>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, s, A, b, X, Y, m, P);
+    return true;
+}
+
 bool launch_tanh_linear_batched(const double* A, const double* b, const double* X, double* Y, size_t m, int n, int P,
                                 hipStream_t s)
 {
     if (n % 2 != 0 || n > 128 || n < 4) return false;
+    static const bool v1_only = std::getenv("WL_BATCHED_V1") != nullptr;
+    if (!v1_only && m >= 32) {
+        if (n == 128 && launch_tlb_dma<32>(A, b, X, Y, m, P, s)) return true;
+        if (n == 64 && launch_tlb_dma<16>(A, b, X, Y, m, P, s)) return true;
+        if (n == 32 && launch_tlb_dma<8>(A, b, X, Y, m, P, s)) return true;
+    }
     const size_t ntiles = (m + 15) / 16;
     unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
     if (n <= 16) hipLaunchKernelGGL(k_tanh_linear_batched<4>, dim3(grid), dim3(1024), 0, s, A, b, X, Y, m, n, P);

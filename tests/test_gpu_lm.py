@@ -199,7 +199,8 @@ def test_gauss_sum_cfg2_family(oracle):
     assert np.allclose(x, g["truth"], rtol=5e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("m,n", [(1000, 4), (5000, 16), (3001, 30), (20000, 64), (40000, 128), (777, 100)])
+@pytest.mark.parametrize("m,n", [(1000, 4), (5000, 16), (3001, 30), (20000, 64), (40000, 128), (777, 100),
+                                 (4000, 32), (40001, 128), (50, 64), (300001, 128), (70000, 32)])
 def test_batched_residual_callback_matches_pointwise(m, n):
     """workloads.hip: the batched MFMA residual kernel == the per-point kernel (user-code side)."""
     import ctypes as C
