@@ -189,6 +189,26 @@ typedef struct mir_lsq_stats {
     uint64_t qp_active_set_passes;   /* passes in which BOXCQP's active-set loop ran */
 } mir_lsq_stats;
 
+/* Optional per-pass trace (not in the reference; a parity-pinning aid: tests compare it event by event with the
+ * oracle's trace). One record per Jacobian update and per executed loop pass, in the reference's order -- passes
+ * evaluated speculatively and then discarded are not recorded.
+ *   event 0: Jacobian refreshed in full (LS:1008-1050)   1: Broyden update (LS:999-1007)
+ *         2: pass rejected (LS:1125-1130)                3: pass accepted (LS:1132-1139)
+ *         4: step-size guard (LS:1101-1106)
+ * lambda is the damping the pass solved with; residual the current (event 3: the new) sum of squares;
+ * trial_residual ||f(trial)||^2 (0 for events 0, 1, 4); dx_dot = dx.dx of the pass (events 0, 1: of the last
+ * accepted step). `count` counts every event even when it exceeds `capacity` (only the first `capacity` are stored). */
+typedef struct mir_lsq_trace_record {
+    int32_t event;
+    uint32_t iterations;
+    double lambda, residual, trial_residual, dx_dot;
+} mir_lsq_trace_record;
+typedef struct mir_lsq_trace {
+    mir_lsq_trace_record* records;
+    uint64_t capacity;
+    uint64_t count;
+} mir_lsq_trace;
+
 typedef struct mir_lsq_gpu_options {
     uint32_t struct_size;            /* = sizeof(mir_lsq_gpu_options) */
     uint32_t flags;
@@ -200,6 +220,8 @@ typedef struct mir_lsq_gpu_options {
     uint32_t fd_batch;               /* max points per fb call (0 = 2n) */
     uint32_t reserved;
     mir_lsq_stats* stats;            /* optional out */
+    mir_lsq_trace* trace;            /* optional out; read only when struct_size covers it (costs one extra
+                                        device-to-host copy per pass) */
 } mir_lsq_gpu_options;
 
 /* Same algorithm and result contract as mir_optimize_least_squares_{d,s}; x/l/u stay host

@@ -30,7 +30,7 @@ __all__ = [
     "mir_least_squares_work_length", "mir_least_squares_iwork_length", "mir_box_qp_work_length",
     "mir_box_qp_iwork_length", "GpuOptions", "Stats", "lib", "workloads_lib", "device_count",
     "DeviceBuffer", "Stream", "jtj", "DEVICE_CALLBACKS", "TIME_KERNELS", "optimizeLeastSquaresBatched",
-    "MODEL_EXP_DECAY", "MODEL_EXP3_AFFINE",
+    "MODEL_EXP_DECAY", "MODEL_EXP3_AFFINE", "Trace", "TraceRecord",
 ]
 
 MODEL_EXP_DECAY = 0      # n = 3: p0 exp(-t p1) + p2
@@ -121,10 +121,37 @@ class Stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class TraceRecord(C.Structure):
+    _fields_ = [("event", C.c_int32), ("iterations", C.c_uint32), ("lambda_", C.c_double), ("residual", C.c_double),
+                ("trial_residual", C.c_double), ("dx_dot", C.c_double)]
+
+
+class _TraceHeader(C.Structure):
+    _fields_ = [("records", C.POINTER(TraceRecord)), ("capacity", C.c_uint64), ("count", C.c_uint64)]
+
+
+class Trace:
+    """mir_lsq_trace: per-pass records (event, iterations, lambda, residual, trial_residual, dx_dot)."""
+
+    EVENTS = {0: "jacobian_full", 1: "jacobian_broyden", 2: "rejected", 3: "accepted", 4: "step_guard"}
+
+    def __init__(self, capacity=4096):
+        self._buf = (TraceRecord * capacity)()
+        self.header = _TraceHeader(C.cast(self._buf, C.POINTER(TraceRecord)), capacity, 0)
+
+    @property
+    def count(self):
+        return int(self.header.count)
+
+    def records(self):
+        k = min(self.count, int(self.header.capacity))
+        return [(r.event, r.iterations, r.lambda_, r.residual, r.trial_residual, r.dx_dot) for r in self._buf[:k]]
+
+
 class GpuOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("flags", C.c_uint32), ("stream", C.c_void_p), ("comm", C.c_void_p),
                 ("workspace", C.c_void_p), ("fbContext", C.c_void_p), ("fb", C.c_void_p), ("fd_batch", C.c_uint32),
-                ("reserved", C.c_uint32), ("stats", C.POINTER(Stats))]
+                ("reserved", C.c_uint32), ("stats", C.POINTER(Stats)), ("trace", C.POINTER(_TraceHeader))]
 
     def __init__(self, **kw):
         super().__init__(**kw)

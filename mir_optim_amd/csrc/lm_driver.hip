@@ -409,6 +409,7 @@ struct Solver {
     bool time_kernels;
     mir_lsq_comm* comm;
     mir_lsq_stats* stats;
+    mir_lsq_trace* trace = nullptr;
 
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -568,6 +569,39 @@ struct Solver {
     }
 
     // mirror the device state (and optionally n values: the current x after a decision, or trial 0 before a host callback)
+    // ---- optional per-pass trace (mir_lsq_trace)
+    void trace_emit(int event, uint32_t iterations, T lambda, T residual, T trial_residual, T dx_dot)
+    {
+        if (!trace) return;
+        if (trace->count < trace->capacity && trace->records) {
+            mir_lsq_trace_record& r = trace->records[trace->count];
+            r.event = event; r.iterations = iterations; r.lambda = (double)lambda; r.residual = (double)residual;
+            r.trial_residual = (double)trial_residual; r.dx_dot = (double)dx_dot;
+        }
+        trace->count++;
+    }
+    // the passes of one round the reference would have executed, from the chain records and the trial sums
+    bool trace_round(int ks, T residual_before, uint32_t iterations_before)
+    {
+        ChainRec<T> rec[kChainMax];
+        T sums[kChainMax];
+        if (!ok(hipMemcpyAsync(rec, B.rec, (size_t)ks * sizeof(ChainRec<T>), hipMemcpyDeviceToHost, stream), "D2H rec")
+            || !ok(hipMemcpyAsync(sums, B.sum + 1, (size_t)ks * sizeof(T), hipMemcpyDeviceToHost, stream), "D2H sums")
+            || !ok(hipStreamSynchronize(stream), "sync"))
+            return false;
+        const int dec = st_h->decision;
+        if (dec == kDecideGradSmall || dec == kDecideNumericError) return true;
+        for (uint32_t k = 0; k < st_h->consumed && k < (uint32_t)ks; ++k) {
+            if (rec[k].flags & kFlagStepTooLong)
+                trace_emit(4, iterations_before, rec[k].lambda, residual_before, 0, rec[k].new_dx_dot);
+            else if ((int)k != st_h->accepted_k)
+                trace_emit(2, iterations_before, rec[k].lambda, residual_before, sums[k], rec[k].new_dx_dot);
+            else
+                trace_emit(3, iterations_before + 1, rec[k].lambda, sums[k], sums[k], rec[k].new_dx_dot);
+        }
+        return true;
+    }
+
     bool read_state(const T* vec_dev)
     {
         if (!ok(hipMemcpyAsync(st_h, B.st, sizeof(LmState<T>), hipMemcpyDeviceToHost, stream), "D2H state")) return false;
@@ -786,6 +820,7 @@ struct Solver {
                     age++;
                     if (stats) stats->jacobian_broyden++;
                     if (!jacobian_products(true, y, mB)) { fail = true; break; }
+                    trace_emit(1, ret.iterations, ret.lambda, ret.residual, 0, st_h->dx_dot);
                 } else {
                     age = 0;
                     if (stats) stats->jacobian_full++;
@@ -799,6 +834,7 @@ struct Solver {
                         stats->fd_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
                     }
                     if (!jacobian_products(false, y, mB)) { fail = true; break; }
+                    trace_emit(0, ret.iterations, ret.lambda, ret.residual, 0, st_h->dx_dot);
                 }
             }
 
@@ -876,6 +912,7 @@ struct Solver {
             }
             if (!ok(hipGetLastError(), "decide kernel") || !read_state(B.x)) { fail = true; break; }
 
+            if (trace && !trace_round(ks, ret.residual, ret.iterations)) { fail = true; break; }
             const int dec = st_h->decision;
             ret.fCalls += st_h->fcalls;                                      // LS:1112
             if (stats) {
@@ -941,6 +978,8 @@ typename Abi<T>::Result solve_entry(const typename Abi<T>::Settings* settings, s
         s.fb = s.device_cb ? reinterpret_cast<typename Abi<T>::FB>(opt->fb) : nullptr;
         s.fd_batch = opt->fd_batch;
         s.stats = opt->stats;
+        if (opt->struct_size >= offsetof(mir_lsq_gpu_options, trace) + sizeof(void*)) s.trace = opt->trace;
+        if (s.trace) s.trace->count = 0;
     }
     return s.run();
 }

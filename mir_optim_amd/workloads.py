@@ -43,7 +43,7 @@ class DeviceProblem:
 
     suffix = "d"
 
-    def options(self, flags=0, stats=None, comm=None, workspace=None, batched=False, fd_batch=0):
+    def options(self, flags=0, stats=None, comm=None, workspace=None, batched=False, fd_batch=0, trace=None):
         o = api.GpuOptions()
         o.flags = api.DEVICE_CALLBACKS | flags
         o.stream = self.stream.handle
@@ -55,6 +55,8 @@ class DeviceProblem:
             o.fd_batch = fd_batch
         if stats is not None:
             o.stats = C.pointer(stats)
+        if trace is not None:
+            o.trace = C.pointer(trace.header)
         return o
 
     def solve(self, x0, l=None, u=None, settings=None, analytic=False, **opt_kw):

@@ -114,3 +114,14 @@ def test_no_gpu_means_loud_numeric_error_not_a_cpu_path(capfd):
     assert "no usable HIP device" in capfd.readouterr().err
     st, _, _ = M.solveBoxQP(np.eye(2), [1.0, 1.0], [-1.0, -1.0], [1.0, 1.0])
     assert st == M.BoxQPStatus.numericError
+
+
+def test_gpu_options_trace_field_is_appended():
+    """mir_lsq_gpu_options is versioned by struct_size: `trace` was appended after `stats`, older callers (64-byte
+    struct) stay valid. Offsets as declared in include/mir_optim_amd.h."""
+    import ctypes as C
+    from mir_optim_amd import api
+    assert C.sizeof(api.GpuOptions) == 72 and api.GpuOptions.stats.offset == 56 and api.GpuOptions.trace.offset == 64
+    assert C.sizeof(api.TraceRecord) == 40
+    t = api.Trace(8)
+    assert t.count == 0 and t.records() == []

@@ -31,6 +31,20 @@ def same_class(a, b):
     return (int(a) >= 0) == (int(b) >= 0)
 
 
+def first_noisy_pass(recs):
+    """Index of the first pass whose trial residual differs from the current one by less than ~1e-10 relative: from
+    there on `improvement > 0` (LS:1125) and the step quality rho (LS:1150) compare rounding noise of two different
+    summation orders and two runs may legitimately branch differently. len(recs) if there is none."""
+    prev = None
+    for k, r in enumerate(recs):
+        if r[0] in (2, 3):
+            before = r[3] if r[0] == 2 else prev
+            if before is not None and abs(before - r[4]) <= 1e-10 * abs(before):
+                return k
+        prev = r[3]
+    return len(recs)
+
+
 def test_T1_with_jacobian(oracle):
     p = P.t1()
     res, x = run_host(p)
@@ -98,6 +112,37 @@ def test_T6_underdetermined_bounded(oracle):
     assert res.iterations == 1 and abs(res.residual - 0.5) < 1e-12
 
 
+@pytest.mark.parametrize("name", ["t1", "t2", "t3a", "t3b", "t4", "t6"])
+def test_reference_unittests_trace_equals_oracle_trace(oracle, name):
+    """Host-callback mode on the reference's own unittest problems (m <= 20, n <= 3): here the GPU path and the oracle
+    run the same few flops per reduction, so the complete trace -- every event, counter and lambda; 51 rejected passes
+    for T3b -- must be the same. Values agree to ~1e-14 until the first finite-difference refresh after a step and to
+    ~1e-7 after it: with the reference's absolute step 2^-26 (Q10) the FD Jacobian carries eps |f| / h ~ 1e-8 of
+    rounding noise that any 1e-14 change of x re-draws."""
+    p = getattr(P, name)()
+    tr = M.Trace()
+    opt = M.GpuOptions()
+    import ctypes as C
+    opt.trace = C.pointer(tr.header)
+    res, x = M.optimizeLeastSquares(p["f"], p["m"], np.array(p["x0"], dtype=float), p["lower"], p["upper"], g=p["g"], options=opt)
+    ev = []
+    ro, xo = run_oracle(oracle, p, trace=lambda *a: ev.append(a))
+    got = tr.records()
+    assert tr.count == len(got)
+    if name in ("t1", "t2", "t3a", "t3b", "t6"):
+        assert int(res.status) == ro.status and (res.iterations, res.fCalls, res.gCalls) == (ro.iterations, ro.fCalls, ro.gCalls)
+        assert len(got) == len(ev)
+    else:       # noisy data, nonzero residual: the tail of the fit decides on rounding noise (see first_noisy_pass)
+        K = min(first_noisy_pass(got), first_noisy_pass(ev), len(got), len(ev))
+        assert K >= 5 or K == len(ev) == len(got), (K, len(got), len(ev))
+        got, ev = got[:K], ev[:K]
+        assert res.status >= 0 and ro.status >= 0 and np.allclose(x, xo, rtol=1e-6, atol=1e-9)
+    assert [g[:2] for g in got] == [e[:2] for e in ev]
+    for g, e in zip(got, ev):
+        assert np.isclose(g[2], e[2], rtol=1e-12), (g, e)                # lambda: products of exact constants
+        assert np.allclose(g[3:], e[3:], rtol=2e-5, atol=1e-10 * (1 + ev[0][3])), (g, e)   # atol: noise floor of a zero-residual fit
+
+
 def test_nothrow_tier_and_exception(oracle):
     """optimize throws for status < 0 (LS:175-179), optimizeLeastSquares returns the status."""
     s = M.LeastSquaresSettings()
@@ -147,6 +192,55 @@ def test_tanh_linear_fd_matches_oracle(oracle, m, n):
     assert np.allclose(x, xo, rtol=1e-6, atol=1e-9)
     assert np.isclose(res.residual, ro.residual, rtol=1e-9)
     assert res.iterations > 2 and res.fCalls >= n
+
+
+def _oracle_trace(oracle, w, so, lower=None, upper=None, analytic=False):
+    ev = []
+    import ctypes as C
+    ctx = oracle.TanhLinearCtx(w["A"].ctypes.data, w["b"].ctypes.data)
+    ro, xo = oracle.optimize(oracle.native_fn("wlc_tanh_linear_f"), w["m"], w["x0"], lower=lower, upper=upper,
+                             settings=so, fctx=C.addressof(ctx), trace=lambda *a: ev.append(a),
+                             g=oracle.native_fn("wlc_tanh_linear_g") if analytic else None, gctx=C.addressof(ctx))
+    return ro, xo, ev
+
+
+@pytest.mark.parametrize("m,n,bounded,mode", [(4096, 16, False, "fd"), (20000, 32, False, "batched"), (3000, 16, True, "fd"),
+                                              (6000, 24, False, "analytic"), (50000, 128, False, "batched")])
+def test_pass_by_pass_trajectory_matches_oracle(oracle, m, n, bounded, mode):
+    """The reference pins no intermediate quantity; this pins the whole trajectory on the oracle: the
+    SAME sequence of events (Jacobian refresh / Broyden update / step guard / rejection / acceptance), the same
+    iteration counter and, pass by pass, the same damping, residuals and step lengths -- speculative lambda-ladder
+    rounds included (mode "batched"), whose discarded trials must leave no record."""
+    w = P.tanh_linear(m, n)
+    lo = up = None
+    if bounded:
+        lo = w["xstar"] - 0.02
+        lo[::3] = w["xstar"][::3] + 0.01
+        up = w["xstar"] + 0.5
+        w["x0"] = np.clip(w["x0"], lo, up)
+    prob = W.TanhLinear(w["A"], w["b"])
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
+    so = oracle.default_settings(); so.absTolerance = 1e-9
+    tr = M.Trace()
+    res, x = prob.solve(w["x0"].copy(), lo, up, settings=s, trace=tr, batched=(mode == "batched"), analytic=(mode == "analytic"))
+    ro, xo, ev = _oracle_trace(oracle, w, so, lo, up, analytic=(mode == "analytic"))
+    got = tr.records()
+    assert tr.count == len(got)
+
+    # everything before the first noise-level decision must agree; after it only the end result is compared
+    K = min(first_noisy_pass(got), first_noisy_pass(ev), len(got), len(ev))
+    assert K >= 9, (K, len(got), len(ev))
+    assert [g[0] for g in got[:K]] == [e[0] for e in ev[:K]]            # event kinds
+    assert [g[1] for g in got[:K]] == [e[1] for e in ev[:K]]            # iteration counter
+    kinds = {g[0] for g in got[:K]}
+    assert {0, 1, 3} <= kinds
+    for k, (g, e) in enumerate(zip(got[:K], ev[:K])):
+        assert np.isclose(g[2], e[2], rtol=1e-6), ("lambda", k, g, e)
+        assert np.isclose(g[3], e[3], rtol=1e-7), ("residual", k, g, e)
+        assert np.isclose(g[4], e[4], rtol=1e-7, atol=1e-300), ("trial residual", k, g, e)
+        assert np.isclose(g[5], e[5], rtol=1e-3, atol=1e-22), ("dx_dot", k, g, e)
+    assert res.status >= 0 and ro.status >= 0
+    assert np.allclose(x, xo, rtol=1e-6, atol=1e-9) and np.isclose(res.residual, ro.residual, rtol=1e-9)
 
 
 def test_tanh_linear_analytic_and_batched(oracle):
