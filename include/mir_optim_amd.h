@@ -297,6 +297,37 @@ void mir_lsq_stream_destroy(void* stream);
 int mir_lsq_stream_synchronize(void* stream);
 const char* mir_lsq_version(void);
 
+/* =====================================================================================================
+ * Part 3 -- a caller of the path: fitSpline (/root/reference/source/mir/optim/fit_splie.d:26-85).
+ *
+ * Fits the VALUES of a cubic spline at fixed knots x[nx] to scattered points by least squares through the
+ * library's own LM entry (n = nx, m = npoints + (lambda == 0)). The spline is mir.interpolate.spline's default
+ * configuration (mir-algorithm, un-vendored): C2 cubic, not-a-knot ends, kept in Hermite form (values + first
+ * derivatives). Quirks of the reference kept on purpose (its unittest FS:88-141 pins them):
+ *   - the smoothness penalty integrates the spline's FIRST derivative at the knots (FS:74, FS:77 index [1]);
+ *   - y[m-1] is always overwritten by the penalty term (FS:83): with lambda != 0 the last point is ignored.
+ * points: npoints x 2 row-major {abscissa, value}; l, u: bounds on the spline values; dist: optional replacement of
+ * the reference's `alias d = "a - b"` (NULL = a - b); splineY (out, nx): fitted values, started from 0 (FS:56-57);
+ * splineD (out, nx, optional): first derivatives. Returns MIR_FIT_SPLINE_*; the LM status is in *result (the D
+ * function throws for result->status < 0 through `optimize`, LS:175-179, and for TOO_FEW_POINTS, FS:47-51).
+ * ===================================================================================================== */
+enum { MIR_FIT_SPLINE_OK = 0, MIR_FIT_SPLINE_TOO_FEW_POINTS = 1, MIR_FIT_SPLINE_BAD_ARGUMENT = 2 };
+
+int mir_fit_spline_d(const mir_least_squares_settings_d* settings, size_t npoints, const double* points, size_t nx,
+                     const double* x, const double* l, const double* u, double lambda, double (*dist)(double, double),
+                     double* splineY, double* splineD, mir_least_squares_result_d* result);
+int mir_fit_spline_s(const mir_least_squares_settings_s* settings, size_t npoints, const float* points, size_t nx,
+                     const float* x, const float* l, const float* u, float lambda, float (*dist)(float, float),
+                     float* splineY, float* splineD, mir_least_squares_result_s* result);
+/* the residual function fitSpline minimises (FS:60-84), exposed so that tests can hand the same function to the oracle */
+void mir_fit_spline_residuals_d(size_t npoints, const double* points, size_t nx, const double* x, double lambda,
+                                const double* splineY, size_t m, double* y);
+/* C2 not-a-knot cubic spline: first derivatives at the knots; value / 1st / 2nd derivative at t (out3[3]) */
+void mir_spline_c2_derivatives_d(size_t n, const double* x, const double* y, double* d);
+void mir_spline_c2_derivatives_s(size_t n, const float* x, const float* y, float* d);
+void mir_spline_eval_d(size_t n, const double* x, const double* y, const double* d, double t, double* out3);
+void mir_spline_eval_s(size_t n, const float* x, const float* y, const float* d, float t, float* out3);
+
 #ifdef __cplusplus
 }
 #endif

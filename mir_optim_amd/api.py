@@ -30,7 +30,8 @@ __all__ = [
     "mir_least_squares_work_length", "mir_least_squares_iwork_length", "mir_box_qp_work_length",
     "mir_box_qp_iwork_length", "GpuOptions", "Stats", "lib", "workloads_lib", "device_count",
     "DeviceBuffer", "Stream", "jtj", "DEVICE_CALLBACKS", "TIME_KERNELS", "optimizeLeastSquaresBatched",
-    "MODEL_EXP_DECAY", "MODEL_EXP3_AFFINE", "Trace", "TraceRecord",
+    "MODEL_EXP_DECAY", "MODEL_EXP3_AFFINE", "Trace", "TraceRecord", "Spline", "FitSplineResult", "fitSpline",
+    "fit_spline_residuals",
 ]
 
 MODEL_EXP_DECAY = 0      # n = 3: p0 exp(-t p1) + p2
@@ -237,6 +238,14 @@ def lib():
         L.mir_lsq_stream_synchronize.restype = C.c_int
         L.mir_lsq_stream_synchronize.argtypes = [C.c_void_p]
         L.mir_lsq_version.restype = C.c_char_p
+        for suf, S, R, ct in (("d", _Sd, _Rd, C.c_double), ("s", _Ss, _Rs, C.c_float)):
+            fn = getattr(L, "mir_fit_spline_" + suf)
+            fn.restype = C.c_int
+            fn.argtypes = [C.POINTER(S), sz, C.c_void_p, sz, C.c_void_p, C.c_void_p, C.c_void_p, ct, C.c_void_p,
+                           C.c_void_p, C.c_void_p, C.POINTER(R)]
+            getattr(L, "mir_spline_c2_derivatives_" + suf).argtypes = [sz, C.c_void_p, C.c_void_p, C.c_void_p]
+            getattr(L, "mir_spline_eval_" + suf).argtypes = [sz, C.c_void_p, C.c_void_p, C.c_void_p, ct, C.c_void_p]
+        L.mir_fit_spline_residuals_d.argtypes = [sz, C.c_void_p, sz, C.c_void_p, C.c_double, C.c_void_p, sz, C.c_void_p]
         _lib = L
     return _lib
 
@@ -527,3 +536,78 @@ def jtj(J, y, y_old=None, dx=None, dtype=np.float64):
     for b in (dJ, dy, dyo, ddx, dJJ, dJy):
         b.free()
     return out
+
+
+# ---- fitSpline (fit_splie.d:26-85): a caller of the LM path -----------------------------------------------
+
+class Spline:
+    """C2 cubic spline with not-a-knot ends in Hermite form (what mir.interpolate.spline's default configuration
+    builds); evaluation and derivatives go through the library's host code (mir_spline_*)."""
+
+    def __init__(self, x, values, dtype=np.float64):
+        self.dtype = dtype
+        self.x = np.ascontiguousarray(x, dtype=dtype)
+        self.values = np.ascontiguousarray(values, dtype=dtype)
+        self.derivatives = np.zeros_like(self.values)
+        suf = "d" if dtype == np.float64 else "s"
+        getattr(lib(), "mir_spline_c2_derivatives_" + suf)(self.x.size, self.x.ctypes.data, self.values.ctypes.data,
+                                                         self.derivatives.ctypes.data)
+        self._eval = getattr(lib(), "mir_spline_eval_" + suf)
+
+    def withTwoDerivatives(self, t):
+        out = np.zeros(3, dtype=self.dtype)
+        self._eval(self.x.size, self.x.ctypes.data, self.values.ctypes.data, self.derivatives.ctypes.data, t, out.ctypes.data)
+        return out
+
+    def __call__(self, t):
+        if np.ndim(t) == 0:
+            return self.withTwoDerivatives(float(t))[0]
+        return np.array([self.withTwoDerivatives(float(v))[0] for v in np.asarray(t).ravel()]).reshape(np.shape(t))
+
+
+class FitSplineResult:
+    """FitSplineResult!T (fit_splie.d:7-13)."""
+
+    def __init__(self, leastSquaresResult, spline):
+        self.leastSquaresResult = leastSquaresResult
+        self.spline = spline
+
+
+def fit_spline_residuals(points, x, lambda_, splineY):
+    """The residual vector fitSpline minimises (FS:60-84), from the library's host code (double)."""
+    points = np.ascontiguousarray(points, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    v = np.ascontiguousarray(splineY, dtype=np.float64)
+    m = points.shape[0] + (1 if lambda_ == 0 else 0)
+    y = np.zeros(m)
+    lib().mir_fit_spline_residuals_d(points.shape[0], points.ctypes.data, x.size, x.ctypes.data, lambda_, v.ctypes.data, m,
+                                     y.ctypes.data)
+    return y
+
+
+def fitSpline(settings, points, x, l, u, lambda_=0.0, dtype=np.float64):
+    """fitSpline (fit_splie.d:26-85): least-squares fit of the spline values at the fixed knots `x` to `points`
+    (k x 2), bounds l <= spline(x) <= u, optional smoothness weight lambda_. Raises like the reference: Exception for
+    too few points (FS:47-51), LeastSquaresException for a negative LM status (through `optimize`, LS:175-179)."""
+    L = lib()
+    points = np.ascontiguousarray(points, dtype=dtype)
+    x = np.ascontiguousarray(x, dtype=dtype)
+    lo = np.ascontiguousarray(l, dtype=dtype)
+    up = np.ascontiguousarray(u, dtype=dtype)
+    if not lambda_ >= 0:
+        raise ValueError("fitSpline: lambda has to be non-negative")        # the reference's in-contract
+    y = np.zeros(x.size, dtype=dtype)
+    d = np.zeros(x.size, dtype=dtype)
+    dbl = dtype == np.float64
+    raw = (_Rd if dbl else _Rs)()
+    fn = L.mir_fit_spline_d if dbl else L.mir_fit_spline_s
+    rc = fn(C.byref(settings) if settings is not None else None, points.shape[0], points.ctypes.data, x.size,
+            x.ctypes.data, lo.ctypes.data, up.ctypes.data, lambda_, None, y.ctypes.data, d.ctypes.data, C.byref(raw))
+    if rc == 1:
+        raise Exception("fitSpline: points.length has to be greater or equal x.length when lambda is 0.0")
+    if rc != 0:
+        raise ValueError("fitSpline: bad argument")
+    res = LeastSquaresResult(raw)
+    if res.status < 0:
+        raise LeastSquaresException(int(res.status), res)
+    return FitSplineResult(res, Spline(x, y, dtype))

@@ -35,7 +35,7 @@ def build(force=False, verbose=False):
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "mir_optim_amd.h"))
     jobs = [
-        (SOLVER_LIB, [os.path.join(CSRC, "lm_driver.hip")], hdrs, ["-ldl"]),
+        (SOLVER_LIB, [os.path.join(CSRC, "lm_driver.hip"), os.path.join(CSRC, "fit_spline.cpp")], hdrs, ["-ldl"]),
         (WORKLOADS_LIB, [os.path.join(CSRC, "workloads.hip")], [], []),
     ]
     for target, srcs, deps, extra in jobs:
