@@ -523,4 +523,214 @@ __global__ __launch_bounds__(kJtj2Threads, 2) void k_jtj2(JtjArgs<double> a)
     else jtj2_body<NCB, BROYDEN, 3>(a, smem2, lane, s0, S);
 }
 
+// =========================================================================================
+// v3 (Broyden passes, fp64, n % 16 == 0, n <= 128, m even): the ring of v2 with the rank-one update done ONCE per
+// row instead of once per wave.
+//
+// In k_jtj2<NCB, true> each of the four waves recomputes the update of every row it multiplies (dot with dx, DPP
+// reduction, axpy: ~30 fp64 VALU instructions per 4-row group and wave). On gfx950 fp64 VALU work does not overlap
+// f64 MFMA -- both run on the same fp64 units (measured: the plain variant runs 9 MFMA per group and wave in
+// 0.37 ms, the Broyden variant adds exactly its VALU time, 0.45 ms) -- so that redundancy is ~15 % of the kernel.
+// Here the two storer waves (2, 3) update stage s + 1 in place in LDS (each a share of its row groups) and write
+// the rows back to HBM, while every wave runs the MFMA chains of stage s, which was updated one iteration earlier;
+// one barrier per stage still. The DMA of stage s + L (L = NS - 1) is issued right AFTER barrier s, when the slot
+// of stage s - 1 is free: the same two stages stay in flight as in v2 although a stage has to land one iteration
+// earlier. Arithmetic and summation order are those of v2: the results are bit-identical.
+// Outcome (MI355X, m = 1e6, n = 128): 0.444 ms against 0.451 ms -- the Broyden pass is limited by its mixed
+// read + write HBM stream (2.1 GB at ~4.7 TB/s; a pure copy kernel reaches ~5.2 TB/s), not by the VALU redundancy.
+// Kept as an opt-in (MIR_LSQ_JTJ_SPLIT=1) and as the bit-exact cross-check of v2 in the tests.
+// =========================================================================================
+template <int NCB, int ROLE>
+__device__ __forceinline__ void jtj3_body(const JtjArgs<double>& a, unsigned char* smem, int lane, size_t s0, size_t S)
+{
+    using T = double;
+    using Acc = typename Mma<T>::Acc;
+    using C = Jtj2Cfg<NCB, true>;
+    constexpr int NACC = jtj_nacc<NCB>();
+    constexpr int n = 16 * NCB;
+    constexpr bool LOADER = ROLE < 2;
+    constexpr int MYI = LOADER ? (C::IPS + 1 - ROLE) / 2 : 0;
+    constexpr int OPS = MYI;
+    constexpr int L = C::NS - 1;                             // stages issued ahead of the MFMA stage
+    const int q = lane >> 4, p = lane & 15;
+    const size_t m = a.m;
+
+    const unsigned char* Jb = reinterpret_cast<const unsigned char*>(a.J);
+    const size_t total = m * (size_t)n * sizeof(T);
+    auto issue = [&](size_t s) {
+        const size_t base = (s0 + s) * (size_t)C::RS * n * sizeof(T);
+        unsigned char* slot = smem + (s % C::NS) * C::SLOT_BYTES;
+#pragma unroll
+        for (int k = 0; k < MYI; ++k) {
+            const int ins = ROLE + 2 * k;
+            size_t off = base + (size_t)(ins * 64 + lane) * 16;
+            if (off + 16 > total) off = base;            // rows past m: any valid bytes (zeroed by the update phase)
+            __builtin_amdgcn_global_load_lds((jtj_gbl_ptr)(Jb + off), (jtj_lds_ptr)(slot + ins * 1024), 16, 0, 0);
+        }
+    };
+    const unsigned char* yb = reinterpret_cast<const unsigned char*>(a.y);
+    const unsigned char* yob = reinterpret_cast<const unsigned char*>(a.y_old);
+    const size_t ytotal = m * sizeof(T);
+    const size_t nchunks = (S * C::RS + 127) / 128;
+    size_t next_chunk = 0;
+    auto issue_y = [&](size_t c) {
+        size_t off = ((s0 * C::RS) + c * 128) * sizeof(T) + (size_t)lane * 16;
+        if (off + 16 > ytotal) off = 0;
+        __builtin_amdgcn_global_load_lds((jtj_gbl_ptr)(yb + off), (jtj_lds_ptr)(smem + C::Y_OFF + (c % C::YNS) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((jtj_gbl_ptr)(yob + off), (jtj_lds_ptr)(smem + C::YO_OFF + (c % C::YNS) * 1024), 16, 0, 0);
+    };
+
+    Acc acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = Acc{0, 0, 0, 0};
+    T jy[NCB], dxr[NCB];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+        jy[c] = 0;
+        dxr[c] = 0;
+        if constexpr (!LOADER) dxr[c] = a.dx[16 * c + p];
+    }
+    T neg_d = 0;
+    if constexpr (!LOADER) neg_d = -(T(1) / *a.dx_dot);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the loads above retire before the counted waits
+
+    T* const yring = reinterpret_cast<T*>(smem + C::Y_OFF);
+    T* const yoring = reinterpret_cast<T*>(smem + C::YO_OFF);
+    auto yindex = [&](size_t lr) { return (int)((lr >> 7) % C::YNS) * 128 + (int)(lr & 127); };
+
+    // LS:1003-1006 for the row groups of stage st this wave owns, in place in the LDS slot + write-back
+    auto update = [&](size_t st) {
+        T* slot = reinterpret_cast<T*>(smem + (st % C::NS) * C::SLOT_BYTES);
+        const size_t row0 = (s0 + st) * C::RS;
+#pragma unroll
+        for (int gi = ROLE - 2; gi < C::GPS; gi += 2) {
+            T v[NCB];
+            T* rp = slot + (4 * gi + q) * n + p;
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) v[c] = rp[16 * c];
+            const int yi = yindex(st * C::RS + 4 * gi + q);
+            const T y = yring[yi], yo = yoring[yi];
+            const size_t row = row0 + 4 * gi + q;
+            const bool rok = row < m;
+            T part = 0;
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) part += v[c] * dxr[c];
+            part = sum16(part);
+            const T t = (yo - y) + part;                  // LS:1003-1004
+            const T u = neg_d * t;                        // LS:1005
+            T* wp = a.Jout + (rok ? row : m - 1) * (size_t)n + p;
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) {
+                const T w = v[c] + u * dxr[c];            // LS:1006
+                rp[16 * c] = rok ? w : T(0);              // rows past m contribute nothing to the products
+                if (rok) wp[16 * c] = w;
+            }
+        }
+    };
+
+    auto mfma_phase = [&](size_t s, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const T* slot = reinterpret_cast<const T*>(smem + (s % C::NS) * C::SLOT_BYTES);
+        const size_t row0 = (s0 + s) * C::RS;
+        struct Grp { T v[NCB]; T y; };
+        auto read = [&](int gi, Grp& g) {
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) g.v[c] = slot[(4 * gi + q) * n + 16 * c + p];
+            g.y = 0;
+            if constexpr (ROLE == 0) {
+                g.y = yring[yindex(s * C::RS + 4 * gi + q)];
+                if constexpr (!FULL) g.y = (row0 + 4 * gi + q < m) ? g.y : T(0);
+            }
+        };
+        auto work = [&](const Grp& g) {
+            if constexpr (ROLE == 0) {
+#pragma unroll
+                for (int c = 0; c < NCB; ++c) jy[c] += g.v[c] * g.y;     // LS:1052
+            }
+#pragma unroll
+            for (int I = 0; I < NCB; ++I)
+#pragma unroll
+                for (int Jb2 = 0; Jb2 <= I; ++Jb2)
+                    if (jtj_owns<NCB, 4, ROLE>(I * (I + 1) / 2 + Jb2))
+                        acc[I * (I + 1) / 2 + Jb2] = Mma<T>::mma(g.v[I], g.v[Jb2], acc[I * (I + 1) / 2 + Jb2]);   // LS:1065
+        };
+        Grp ga, gb;
+        read(0, ga);
+#pragma unroll
+        for (int gi = 0; gi < C::GPS; gi += 2) {
+            if (gi + 1 < C::GPS) read(gi + 1, gb);
+            work(ga);
+            if (gi + 1 < C::GPS) {
+                if (gi + 2 < C::GPS) read(gi + 2, ga);
+                work(gb);
+            }
+        }
+    };
+
+    // ---- prologue: L stages in flight, stage 0 landed and updated
+    if constexpr (ROLE == 1) {
+        while (next_chunk < 3 && next_chunk < nchunks) issue_y(next_chunk++);
+    }
+    const size_t pre = S < (size_t)L ? S : (size_t)L;
+    if constexpr (LOADER) {
+        for (size_t s = 0; s < pre; ++s) issue(s);
+        if (pre == (size_t)L) { if constexpr (OPS > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((L - 1) * OPS) : "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                            // stage 0 (and the first y chunks) are in LDS
+    if constexpr (!LOADER) { if (S > 0) update(0); }
+
+    for (size_t s = 0; s < S; ++s) {
+        if constexpr (ROLE == 1) {
+            // the update phase of this iteration reads the chunk of stage s + 1: keep it plus two more in flight / resident
+            while (next_chunk <= ((s + 1) * C::RS) / 128 + 2 && next_chunk < nchunks) issue_y(next_chunk++);
+        }
+        if constexpr (LOADER) {
+            // outstanding here: stages s + 1 .. s + L - 1; stage s + 1 has landed once at most L - 2 stages remain
+            if (s + L - 1 < S) { if constexpr (OPS > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((L - 2) * OPS) : "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my LDS writes of update(s) are done
+        }
+        __builtin_amdgcn_s_barrier();                        // stage s is updated, stage s + 1 has landed, slot of s - 1 is free
+        if constexpr (LOADER) { if (s + L < S) issue(s + L); }
+        if constexpr (!LOADER) { if (s + 1 < S) update(s + 1); }
+        if ((s0 + s) * C::RS + C::RS <= m) mfma_phase(s, std::true_type{}); else mfma_phase(s, std::false_type{});
+    }
+
+    T* dst = a.slabs + (size_t)blockIdx.x * jtj_slab_len<NCB>();
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+        if (jtj_owns<NCB, 4, ROLE>(i)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(i * 4 + r) * kWave + lane] = acc[i][r];
+        }
+    if constexpr (ROLE == 0) {
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            jy[c] += wave_shfl_xor(jy[c], 16);
+            jy[c] += wave_shfl_xor(jy[c], 32);
+            dst[(NACC * 4 + c) * kWave + lane] = jy[c];
+        }
+    }
+}
+
+template <int NCB>
+__global__ __launch_bounds__(kJtj2Threads, 2) void k_jtj3(JtjArgs<double> a)
+{
+    using C = Jtj2Cfg<NCB, true>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t Stot = (a.m + C::RS - 1) / C::RS;
+    const size_t per = (Stot + gridDim.x - 1) / gridDim.x;
+    const size_t s0 = (size_t)blockIdx.x * per < Stot ? (size_t)blockIdx.x * per : Stot;
+    const size_t s1 = s0 + per < Stot ? s0 + per : Stot;
+    const size_t S = s1 - s0;
+    if (wave == 0) jtj3_body<NCB, 0>(a, smem3, lane, s0, S);
+    else if (wave == 1) jtj3_body<NCB, 1>(a, smem3, lane, s0, S);
+    else if (wave == 2) jtj3_body<NCB, 2>(a, smem3, lane, s0, S);
+    else jtj3_body<NCB, 3>(a, smem3, lane, s0, S);
+}
+
 }  // namespace mirlsq

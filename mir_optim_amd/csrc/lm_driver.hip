@@ -189,6 +189,25 @@ hipError_t jtj_launch_one(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
 template <int NCB, bool BR>
 hipError_t jtj2_launch_one(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t s)
 {
+    // MIR_LSQ_JTJ_SPLIT=1: Broyden passes on k_jtj3 (row update once per row, bit-identical results). Measured
+    // 0.444 vs 0.451 ms in the solve at m = 1e6, n = 128: the pass is bound by its mixed read + write HBM stream,
+    // not by the redundant VALU work, so the simpler v2 kernel stays the default.
+    static const bool split = std::getenv("MIR_LSQ_JTJ_SPLIT") != nullptr;
+    if constexpr (BR) {
+        if (split) {
+            auto k3 = k_jtj3<NCB>;
+            constexpr size_t lds3 = Jtj2Cfg<NCB, true>::LDS_BYTES;
+            static bool attr3_done = false;
+            if (!attr3_done) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k3),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+                if (e != hipSuccess) return e;
+                attr3_done = true;
+            }
+            hipLaunchKernelGGL(k3, dim3(p.nblk), dim3(kJtj2Threads), lds3, s, a);
+            return hipGetLastError();
+        }
+    }
     auto kern = k_jtj2<NCB, BR>;
     constexpr size_t lds = Jtj2Cfg<NCB, BR>::LDS_BYTES;
     static bool attr_done = false;
