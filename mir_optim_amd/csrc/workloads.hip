@@ -276,14 +276,18 @@ __device__ __forceinline__ constexpr int tlb_sigma(int i) { return (i + 12) & 15
 template <int NK> struct TlbCfg {
     static constexpr int N = 4 * NK;
     static constexpr int PPR = N / 2;                       // 16-byte pieces per row
-    static constexpr int RPI = 64 / PPR;                    // rows per 1 KB DMA instruction
-    static constexpr int ROWS = 32;                         // rows per stage (two MFMA row tiles)
-    static constexpr int IPS = ROWS / RPI;                  // A instructions per stage
+    // n <= 128: 8 compute waves x 16 points, two 16-row tiles per stage (two MFMA chains per wave), 168 VGPRs;
+    // n = 256: the X fragments alone are 128 VGPRs -> 6 compute waves (8 waves per workgroup: 256 VGPRs each), one
+    // tile per stage with the K range split over two accumulator chains
+    static constexpr int TILES = NK <= 32 ? 2 : 1;
+    static constexpr int COMPUTE_WAVES = NK <= 32 ? 8 : 6, LOADER_WAVES = 2;
+    static constexpr int CHUNK = 16 * COMPUTE_WAVES;        // points per sweep over A
+    static constexpr int ROWS = 16 * TILES;                 // rows per stage
     static constexpr int STAGE_BYTES = ROWS * N * 8;
+    static constexpr int IPS = STAGE_BYTES / 1024;          // 1 KB DMA instructions per stage
     static constexpr int NS = 4, D = 2, NSB = 8;
     static constexpr int B_OFF = NS * STAGE_BYTES;
     static constexpr int LDS_BYTES = B_OFF + NSB * 256;
-    static constexpr int COMPUTE_WAVES = 8, LOADER_WAVES = 2;
     static constexpr int THREADS = 64 * (COMPUTE_WAVES + LOADER_WAVES);
 };
 
@@ -296,7 +300,6 @@ __device__ __forceinline__ void tlb_loader(const double* __restrict__ A, const d
     constexpr int OPS = MYI + (LOADER == 1 ? 1 : 0);
     const unsigned char* Ab = reinterpret_cast<const unsigned char*>(A);
     const unsigned char* bb = reinterpret_cast<const unsigned char*>(b);
-    const int rin = lane / C::PPR, sp = lane % C::PPR;
     auto issue = [&](size_t f) {
         const size_t stage = blockIdx.x + (f % S) * (size_t)gridDim.x;
         const size_t row0 = stage * C::ROWS;
@@ -304,7 +307,8 @@ __device__ __forceinline__ void tlb_loader(const double* __restrict__ A, const d
 #pragma unroll
         for (int k = 0; k < MYI; ++k) {
             const int ins = LOADER + 2 * k;
-            const int R = ins * C::RPI + rin;                   // LDS row within the stage = 16 tile + MFMA row
+            const int g = ins * 64 + lane;                      // 16-byte piece of the stage image this lane fills
+            const int R = g / C::PPR, sp = g % C::PPR;          // LDS row within the stage = 16 tile + MFMA row
             size_t row = row0 + (R & 16) + tlb_rho(R & 15);     // the memory row that feeds it
             row = row < m ? row : m - 1;                        // rows past m: valid bytes, never stored
             const int piece = sp ^ tlb_sigma(R & 15);
@@ -347,7 +351,7 @@ __device__ __forceinline__ void tlb_compute(const double* __restrict__ X, double
 
     size_t f = 0;
     for (int ch = 0; ch < nchunks; ++ch) {
-        const bool wave_active = ch * 128 + wave * 16 < P;      // wave-uniform
+        const bool wave_active = ch * C::CHUNK + wave * 16 < P; // wave-uniform
         if (!wave_active) {                                     // nothing to compute: keep the barrier count
             for (size_t s = 0; s < S; ++s) __builtin_amdgcn_s_barrier();
             f += S;
@@ -355,26 +359,41 @@ __device__ __forceinline__ void tlb_compute(const double* __restrict__ X, double
         }
         // lanes past P duplicate point P - 1 (same inputs, same outputs, same addresses): the stores of the sweep
         // need no per-lane predicate and the MFMA + epilogue body stays one basic block
-        int pl = ch * 128 + wave * 16 + fr;
+        int pl = ch * C::CHUNK + wave * 16 + fr;
         pl = pl < P ? pl : P - 1;
         double xf[NK];
 #pragma unroll
         for (int s = 0; s < NK; ++s) xf[s] = X[(size_t)pl * C::N + 8 * (s >> 1) + 2 * fq + (s & 1)];
         double* yp = Y + (size_t)pl * m;
 
+        // TILES == 2: acc0 / acc1 are the two row tiles of the stage; TILES == 1: the even / odd column pairs of the
+        // one tile (two independent chains either way), summed into acc0 at the end
         auto mfma_stage = [&](size_t ff, Acc& acc0, Acc& acc1) {
             const unsigned char* slot = smem + (ff % C::NS) * C::STAGE_BYTES;
             acc0 = Acc{0, 0, 0, 0};
             acc1 = Acc{0, 0, 0, 0};
+            if constexpr (C::TILES == 2) {
 #pragma unroll
-            for (int j = 0; j < NK / 2; ++j) {
-                const int off = laddr[j & 3] + (j >> 2) * 256;  // (4 j & ~15) * 16 bytes
-                const double2 a0 = *reinterpret_cast<const double2*>(slot + off);
-                const double2 a1 = *reinterpret_cast<const double2*>(slot + off + 16 * C::N * 8);
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, xf[2 * j], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, xf[2 * j], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, xf[2 * j + 1], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, xf[2 * j + 1], acc1, 0, 0, 0);
+                for (int j = 0; j < NK / 2; ++j) {
+                    const int off = laddr[j & 3] + (j >> 2) * 256;  // (4 j & ~15) * 16 bytes
+                    const double2 a0 = *reinterpret_cast<const double2*>(slot + off);
+                    const double2 a1 = *reinterpret_cast<const double2*>(slot + off + 16 * C::N * 8);
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, xf[2 * j], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, xf[2 * j], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, xf[2 * j + 1], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, xf[2 * j + 1], acc1, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NK / 2; j += 2) {
+                    const double2 a0 = *reinterpret_cast<const double2*>(slot + laddr[j & 3] + (j >> 2) * 256);
+                    const double2 a1 = *reinterpret_cast<const double2*>(slot + laddr[(j + 1) & 3] + ((j + 1) >> 2) * 256);
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, xf[2 * j], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, xf[2 * j + 2], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, xf[2 * j + 1], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, xf[2 * j + 3], acc1, 0, 0, 0);
+                }
+                acc0 += acc1;
             }
         };
         // rows row0 + 2 fq + {0, 1} and row0 + 8 + 2 fq + {0, 1} of one 16-row tile
@@ -405,8 +424,10 @@ __device__ __forceinline__ void tlb_compute(const double* __restrict__ X, double
             const unsigned char* bs = smem + C::B_OFF + (ff % C::NSB) * 256;
             epilogue_tile(e0, row0, bs, full_tag);
             __builtin_amdgcn_sched_barrier(0);                  // one tile at a time: bounds the live tanh temporaries
-            epilogue_tile(e1, row0 + 16, bs + 128, full_tag);
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (C::TILES == 2) {
+                epilogue_tile(e1, row0 + 16, bs + 128, full_tag);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         };
         // The two compute waves of a SIMD (w and w + 4) run out of phase: waves 0..3 do MFMA(s) then epilogue(s),
         // waves 4..7 do epilogue(s - 1) then MFMA(s), so one wave's tanh / store VALU work overlaps the other's
@@ -449,7 +470,7 @@ __global__ __launch_bounds__(TlbCfg<NK>::THREADS) void k_tanh_linear_batched_dma
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t Stot = (m + C::ROWS - 1) / C::ROWS;
     const size_t S = blockIdx.x < Stot ? (Stot - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;   // stages blockIdx.x + k grid
-    const int nchunks = (P + 127) / 128;
+    const int nchunks = (P + C::CHUNK - 1) / C::CHUNK;
     const size_t F = S * (size_t)nchunks;                       // flat (chunk, stage) sequence: the ring never drains
     if (S == 0) return;
     if (wave == C::COMPUTE_WAVES) tlb_loader<NK, 0>(A, b, m, tlb_smem, lane, S, F);
@@ -484,6 +505,7 @@ bool launch_tlb_dma(const double* A, const double* b, const double* X, double* Y
 bool launch_tanh_linear_batched(const double* A, const double* b, const double* X, double* Y, size_t m, int n, int P,
                                 hipStream_t s)
 {
+    if (n == 256 && m >= 32 && launch_tlb_dma<64>(A, b, X, Y, m, P, s)) return true;
     if (n % 2 != 0 || n > 128 || n < 4) return false;
     static const bool v1_only = std::getenv("WL_BATCHED_V1") != nullptr;
     if (!v1_only && m >= 32) {

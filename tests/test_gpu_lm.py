@@ -294,7 +294,7 @@ def test_gauss_sum_cfg2_family(oracle):
 
 
 @pytest.mark.parametrize("m,n", [(1000, 4), (5000, 16), (3001, 30), (20000, 64), (40000, 128), (777, 100),
-                                 (4000, 32), (40001, 128), (50, 64), (300001, 128), (70000, 32)])
+                                 (4000, 32), (40001, 128), (50, 64), (300001, 128), (70000, 32), (20000, 256), (4099, 256)])
 def test_batched_residual_callback_matches_pointwise(m, n):
     """workloads.hip: the batched MFMA residual kernel == the per-point kernel (user-code side)."""
     import ctypes as C
