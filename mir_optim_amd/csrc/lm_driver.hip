@@ -24,6 +24,7 @@
 #include "common.h"
 #include "jtj_kernel.h"
 #include "jtj_wide.h"
+#include "jtj_ring8.h"
 #include "batched_kernel.h"
 #include "misc_kernels.h"
 #include "solve_kernel.h"
@@ -98,6 +99,7 @@ struct JtjPlan {
     size_t lds = 0;
     bool v2 = false;      // LDS-DMA ring kernel (f64, n = 16 ncb)
     bool wide = false;    // 128 < n <= 256: tiled jobs (jtj_wide.h)
+    bool ring8 = false;   // 128 < n <= 256, f64, n % 16 == 0, m even: eight-wave LDS-DMA ring (jtj_ring8.h)
     int njobs = 1;
 };
 
@@ -125,6 +127,16 @@ inline int jtj2_rs_rt(int ncb)
     return 4;
 }
 
+inline size_t jtj8_lds_rt(int ncb)
+{
+    switch (ncb) {
+    case 9: return Jtj8Cfg<9>::LDS_BYTES; case 10: return Jtj8Cfg<10>::LDS_BYTES; case 11: return Jtj8Cfg<11>::LDS_BYTES;
+    case 12: return Jtj8Cfg<12>::LDS_BYTES; case 13: return Jtj8Cfg<13>::LDS_BYTES; case 14: return Jtj8Cfg<14>::LDS_BYTES;
+    case 15: return Jtj8Cfg<15>::LDS_BYTES; case 16: return Jtj8Cfg<16>::LDS_BYTES;
+    }
+    return 0;
+}
+
 template <typename T>
 JtjPlan jtj_plan(size_t m, int n, int num_cu)
 {
@@ -132,6 +144,15 @@ JtjPlan jtj_plan(size_t m, int n, int num_cu)
     p.ncb = (n + 15) / 16;
     const int nacc = p.ncb * (p.ncb + 1) / 2;
     p.slab_len = (nacc * 4 + p.ncb) * kWave;
+    static const bool no_ring8 = std::getenv("MIR_LSQ_JTJ_WIDE_V1") != nullptr;
+    if (sizeof(T) == 8 && n > 128 && n <= 256 && n % 16 == 0 && m % 2 == 0 && !no_ring8) {
+        p.ring8 = true;
+        p.lds = jtj8_lds_rt(p.ncb);
+        const size_t stot = (m + 15) / 16;
+        size_t want = (stot + 7) / 8;                          // at least ~8 stages per workgroup
+        p.nblk = (int)(want < (size_t)num_cu ? (want ? want : 1) : (size_t)num_cu);   // one workgroup per CU
+        return p;
+    }
     if (n > 128) {
         p.wide = true;
         const int nt = (p.ncb + kWideTile - 1) / kWideTile;
@@ -285,9 +306,48 @@ hipError_t jtj_run_wide(const JtjPlan& p, const JtjArgs<T>& a, bool broyden, T* 
     return hipGetLastError();
 }
 
+template <int NCB>
+hipError_t jtj8_launch_one(const JtjPlan& p, const JtjArgs<double>& a, bool broyden, hipStream_t s)
+{
+    auto kern = k_jtj8<NCB>;
+    constexpr size_t lds = Jtj8Cfg<NCB>::LDS_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(kJtj8Threads), lds, s, a, broyden ? 1 : 0);
+    return hipGetLastError();
+}
+template <typename T>
+hipError_t jtj8_launch(const JtjPlan& p, const JtjArgs<T>& a, bool broyden, hipStream_t s)
+{
+    if constexpr (sizeof(T) == 8) {
+        switch (p.ncb) {
+        case 9: return jtj8_launch_one<9>(p, a, broyden, s);
+        case 10: return jtj8_launch_one<10>(p, a, broyden, s);
+        case 11: return jtj8_launch_one<11>(p, a, broyden, s);
+        case 12: return jtj8_launch_one<12>(p, a, broyden, s);
+        case 13: return jtj8_launch_one<13>(p, a, broyden, s);
+        case 14: return jtj8_launch_one<14>(p, a, broyden, s);
+        case 15: return jtj8_launch_one<15>(p, a, broyden, s);
+        case 16: return jtj8_launch_one<16>(p, a, broyden, s);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
 template <typename T>
 hipError_t jtj_run(const JtjPlan& p, const JtjArgs<T>& a, bool broyden, T* packed, hipStream_t s)
 {
+    if (p.ring8) {
+        hipError_t e = jtj8_launch<T>(p, a, broyden, s);
+        if (e != hipSuccess) return e;
+        const int rb = (p.slab_len + 31) / 32;
+        hipLaunchKernelGGL(k_jtj_slab_reduce<T>, dim3(rb), dim3(256), 0, s, a.slabs, p.nblk, p.slab_len, p.ncb, a.n, packed);
+        return hipGetLastError();
+    }
     if (p.wide) return jtj_run_wide<T>(p, a, broyden, packed, s);
     hipError_t e = broyden ? jtj_launch_br<T, true>(p, a, s) : jtj_launch_br<T, false>(p, a, s);
     if (e != hipSuccess) return e;

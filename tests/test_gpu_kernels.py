@@ -31,9 +31,11 @@ def test_jtj_and_jty_match_numpy(m, n):
     assert np.max(np.abs(Jy - Jyr)) < 1e-13 * np.sqrt(m) * np.linalg.norm(J, axis=0).max() * np.abs(y).max()
 
 
-@pytest.mark.parametrize("m,n", [(1000, 129), (5000, 160), (3001, 200), (20000, 256), (777, 255)])
+@pytest.mark.parametrize("m,n", [(1000, 129), (5000, 160), (3001, 200), (20000, 256), (777, 255), (30, 256), (4098, 144),
+                                 (2, 160), (10000, 176), (6006, 192), (5000, 208), (3000, 224), (2048, 240), (30002, 256)])
 def test_jtj_wide_n_matches_numpy(m, n):
-    """128 < n <= 256 (cfg 4's n = 256): tiled jobs + separate Broyden pass (jtj_wide.h)."""
+    """128 < n <= 256 (cfg 4's n = 256). n % 16 == 0 with even m runs the eight-wave LDS-DMA ring (jtj_ring8.h), the
+    rest the tiled jobs + separate Broyden pass (jtj_wide.h)."""
     rng = np.random.default_rng(m + n)
     J = rng.standard_normal((m, n))
     J[:, 1] = np.arange(m) % 5 - 2.0
