@@ -430,7 +430,7 @@ __device__ __forceinline__ void invert_diag_blocks(int n, const T* F, int ldf, T
 template <typename T, int NB>
 __device__ __forceinline__ void potrs_blocked(int n, const T* F, int ldf, const T* Dinv, T* xv)
 {
-    constexpr int K = NB > 4 ? 2 : 1;
+    constexpr int K = (16 * NB + kWave - 1) / kWave;      // rows per lane: l, l + 64, ...
     __syncthreads();
     if (threadIdx.x < kWave) {
         const int lane = threadIdx.x, r = lane & 15;
@@ -504,6 +504,111 @@ __device__ __forceinline__ void potrs_blocked(int n, const T* F, int ldf, const 
     __syncthreads();
 }
 
+// ---------------------------------------------------------------- generic path (factor in global memory), 128 < n <= 256
+// potrf_panel: left-looking Cholesky by 16-column panels with ONE ROW PER THREAD (n <= kSolveThreads). Thread i keeps
+// row i of the current panel in 16 registers:
+//   1. subtract the contribution of every earlier panel j: p[c] -= sum_t L[i][16 j + t] L[16 k + c][16 j + t]. The row
+//      L[i][.] is 16 coalesced loads from the factor (global, L2-resident); the 16 x 16 block L[16 k + ., 16 j + .] is
+//      the same for every thread: each lane loads four of its entries and they are broadcast with v_readlane;
+//   2. the wave that holds the 16 diagonal rows factors them in registers (16 pivots, wave-synchronous, no barrier)
+//      and publishes L_kk and 1 / pivots through LDS; the same loop finishes the other rows of that wave;
+//   3. every other row solves its 16 entries against L_kk (row-wise forward substitution), and the panel is stored.
+// Two barriers per panel instead of two per column with global-memory traffic in between (the first version of this
+// path: 3.4 ms per n = 256 solve). Same pivot arithmetic as potrf_tiled2 (rsqrt + multiply).
+// (the three generic-path routines are NOT inlined: each is large, unrolled code that box_qp_device would otherwise
+// instantiate four times per kernel; as out-of-line functions their pointer arguments are generic -- flat loads --
+// which this path can afford)
+template <typename T>
+__device__ __noinline__ int potrf_panel(int n, const T* A, int lda, T* F, int ldf, T* blk, T* rd, int* info_s)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = tid;
+    const int nblk = (n + 15) / 16;
+    if (tid == 0) *info_s = 0;
+    __syncthreads();
+    for (int k = 0; k < nblk; ++k) {
+        const int c0 = 16 * k;
+        const bool active = i < n && i >= c0;
+        const int ic = i < n ? i : n - 1;
+        T p[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int col = c0 + c < n ? c0 + c : n - 1;
+            const T v = A[ic + (size_t)col * lda];
+            p[c] = (active && c0 + c < n) ? v : ((i == c0 + c) ? T(1) : T(0));   // identity padding past n
+        }
+        if (64 * wave + 63 >= c0) {                             // waves entirely above the panel have nothing to update
+            for (int j = 0; j < k; ++j) {
+                T a[16], bv[4];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) a[t] = F[ic + (size_t)(16 * j + t) * ldf];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {                   // entry e = lane + 64 u of the block: (c, t) = (e >> 4, e & 15)
+                    const int e = lane + 64 * u;
+                    const int r = c0 + (e >> 4) < n ? c0 + (e >> 4) : n - 1;
+                    bv[u] = F[r + (size_t)(16 * j + (e & 15)) * ldf];
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const int e = 16 * c + t;
+                        p[c] -= a[t] * lane_bcast(bv[e >> 6], e & 63);
+                    }
+            }
+        }
+        // the diagonal rows c0 .. c0 + 15 are lanes l0 .. l0 + 15 of wave wd
+        const int wd = c0 >> 6, l0 = c0 & 63;
+        if (wave == wd) {
+            int bad = 0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const T piv = lane_bcast(p[c], l0 + c);
+                if (!(piv > 0)) { if (c0 + c < n && bad == 0) bad = c0 + c + 1; }
+                T rinv, d;
+                rsqrt_sqrt(piv > 0 ? piv : T(1), rinv, d);
+                if (i > c0 + c) p[c] *= rinv; else if (i == c0 + c) p[c] = d;
+                if (lane == l0 + c) rd[c] = rinv;
+#pragma unroll
+                for (int c2 = c + 1; c2 < 16; ++c2) {
+                    const T lc = lane_bcast(p[c], l0 + c2);      // L[c0 + c2][c0 + c]
+                    if (i > c0 + c) p[c2] -= p[c] * lc;
+                }
+            }
+            if (lane >= l0 && lane < l0 + 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) blk[(lane - l0) * 17 + c] = p[c];
+            }
+            if (bad != 0 && lane == 0) *info_s = bad;
+        }
+        __syncthreads();
+        const int info = *info_s;
+        if (info != 0) return info;                             // uniform
+        if (wave != wd && active) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                T v = p[c];
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    if (t < c) v -= p[t] * blk[c * 17 + t];
+                p[c] = v * rd[c];
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (c0 + c < n && i >= c0 + c) F[i + (size_t)(c0 + c) * ldf] = p[c];
+        }
+        __syncthreads();                                        // the panel is visible to the later ones; blk / rd reusable
+    }
+    return 0;
+}
+
+template <typename T>
+__device__ __noinline__ void invert_diag_blocks_generic(int n, const T* F, int ldf, T* Dinv) { invert_diag_blocks<T, 16>(n, F, ldf, Dinv); }
+template <typename T>
+__device__ __noinline__ void potrs_blocked_generic(int n, const T* F, int ldf, const T* Dinv, T* xv) { potrs_blocked<T, 16>(n, F, ldf, Dinv, xv); }
+
 // ---------------------------------------------------------------- ?posvx('E','L'), nrhs = 1
 // A: n x n full symmetric, leading dimension lda (overwritten by its equilibrated form).
 // b: right-hand side (overwritten by the scaled rhs). x: solution. s,r,w: n-vectors.
@@ -518,6 +623,12 @@ __device__ __forceinline__ int posvx_device(int n, T* A, int lda, T* F, int ldf,
     T* rdiag = colbuf + 32 * (NB > 0 ? NB : 1);
     T* Dinv = rdiag + 16 * (NB > 0 ? NB : 1);
     (void)colbuf; (void)rdiag; (void)Dinv;
+    // generic path (NB == 0): inverse diagonal blocks, the current diagonal block and its reciprocal pivots
+    __shared__ T gDinv[NB == 0 ? 16 * 272 : 1];
+    __shared__ T gblk[NB == 0 ? 16 * 17 : 1];
+    __shared__ T grd[NB == 0 ? 16 : 1];
+    __shared__ int ginfo[1];
+    (void)gDinv; (void)gblk; (void)grd; (void)ginfo;
     const int tid = threadIdx.x;
     const T eps = Lim<T>::eps / 2;              // dlamch('Epsilon')
     const T safmin = Lim<T>::min_normal;        // dlamch('Safe minimum')
@@ -553,34 +664,17 @@ __device__ __forceinline__ int posvx_device(int n, T* A, int lda, T* F, int ldf,
         if (info != 0) return info;
         invert_diag_blocks<T, NB>(n, F, ldf, Dinv);
     } else {
-        // generic path (factor in global memory): right-looking, two barriers per column
-        for (int idx = tid; idx < n * n; idx += kSolveThreads) {
-            const int i = idx % n, j = idx / n;
-            if (i >= j) F[i + (size_t)j * ldf] = A[i + (size_t)j * lda];
-        }
-        __syncthreads();
-        const int tx = tid & 63, ty = tid >> 6;
-        for (int j = 0; j < n; ++j) {
-            const T ajj = F[j + (size_t)j * ldf];
-            if (!(ajj > 0)) return j + 1;           // uniform: every thread reads the same value
-            const T d = dsqrt(ajj);
-            for (int i = j + 1 + tid; i < n; i += kSolveThreads) F[i + (size_t)j * ldf] /= d;
-            __syncthreads();
-            // F(j,j) is not read by the trailing update, so it can be overwritten in this phase
-            if (tid == 0) F[j + (size_t)j * ldf] = d;
-            for (int k = j + 1 + ty; k < n; k += kSolveThreads / kWave) {
-                const T fkj = F[k + (size_t)j * ldf];
-                for (int i = k + tx; i < n; i += kWave) F[i + (size_t)k * ldf] -= F[i + (size_t)j * ldf] * fkj;
-            }
-            __syncthreads();
-        }
+        // generic path: factor in global memory, left-looking panels (potrf_panel) + the blocked triangular solves
+        const int info = potrf_panel<T>(n, A, lda, F, ldf, gblk, grd, ginfo);
+        if (info != 0) return info;
+        invert_diag_blocks_generic<T>(n, F, ldf, gDinv);
     }
 
     MIRLSQ_STAMP(dbg, 4);
     // ?potrs
     if (tid < n) x[tid] = b[tid];
     if constexpr (NB > 0) potrs_blocked<T, NB>(n, F, ldf, Dinv, x);
-    else potrs_wave(n, F, ldf, x);
+    else potrs_blocked_generic<T>(n, F, ldf, gDinv, x);
 
     MIRLSQ_STAMP(dbg, 5);
     // ?porfs: iterative refinement, ITMAX = 5
@@ -619,7 +713,7 @@ __device__ __forceinline__ int posvx_device(int n, T* A, int lda, T* F, int ldf,
         if (count == 1) MIRLSQ_STAMP(dbg, 12);
         if (berr > eps && 2 * berr <= lstres && count <= 5) {
             if constexpr (NB > 0) potrs_blocked<T, NB>(n, F, ldf, Dinv, r);
-            else potrs_wave(n, F, ldf, r);
+            else potrs_blocked_generic<T>(n, F, ldf, gDinv, r);
             if (tid < n) x[tid] += r[tid];
             lstres = berr;
             __syncthreads();
