@@ -101,209 +101,9 @@ __device__ inline int block_or(int v, int* red)
     return *red;
 }
 
-// ---------------------------------------------------------------- ?potrs 'L' on one wave
-// F column-major (F(i,k) at F[i + k*ldf]), lower. xv: the right-hand side / solution in memory
-// visible to the workgroup. Must be called by all threads; wave 0 works, then a barrier.
-template <typename T>
-__device__ __forceinline__ void potrs_wave(int n, const T* F, int ldf, T* xv)
-{
-    constexpr int K = kSolveMaxN / kWave;   // elements per lane
-    __syncthreads();
-    if (threadIdx.x < kWave) {
-        const int lane = threadIdx.x;
-        T xr[K];
-#pragma unroll
-        for (int t = 0; t < K; ++t) { const int k = lane + kWave * t; xr[t] = k < n ? xv[k] : T(0); }
-        // forward: L z = b
-        for (int i = 0; i < n; ++i) {
-            T col[K];
-#pragma unroll
-            for (int t = 0; t < K; ++t) { const int k = lane + kWave * t; col[t] = (k > i && k < n) ? F[k + (size_t)i * ldf] : T(0); }
-            const T dii = F[i + (size_t)i * ldf];
-            T xi = 0;
-#pragma unroll
-            for (int t = 0; t < K; ++t) if ((i >> 6) == t) xi = __shfl(xr[t], i & 63, kWave);
-            xi = xi / dii;
-#pragma unroll
-            for (int t = 0; t < K; ++t) {
-                const int k = lane + kWave * t;
-                if (k == i) xr[t] = xi;
-                xr[t] -= col[t] * xi;
-            }
-        }
-        // backward: L^T x = z   (row i of L^T = column i of L read along k > i ... walk rows of L)
-        for (int i = n - 1; i >= 0; --i) {
-            T row[K];
-#pragma unroll
-            for (int t = 0; t < K; ++t) { const int k = lane + kWave * t; row[t] = (k < i) ? F[i + (size_t)k * ldf] : T(0); }
-            const T dii = F[i + (size_t)i * ldf];
-            T xi = 0;
-#pragma unroll
-            for (int t = 0; t < K; ++t) if ((i >> 6) == t) xi = __shfl(xr[t], i & 63, kWave);
-            xi = xi / dii;
-#pragma unroll
-            for (int t = 0; t < K; ++t) {
-                const int k = lane + kWave * t;
-                if (k == i) xr[t] = xi;
-                xr[t] -= row[t] * xi;
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < K; ++t) { const int k = lane + kWave * t; if (k < n) xv[k] = xr[t]; }
-    }
-    __syncthreads();
-}
-
-// ---------------------------------------------------------------- fast path: factor resident in LDS
-// Register-tiled right-looking Cholesky for n <= 16 NB on the 16 x 16 thread grid (tr = tid & 15,
-// tc = tid >> 4): thread (tr, tc) keeps F(16 a + tr, 16 b + tc), a, b < NB, in registers for the
-// whole factorisation; per column only the finished column (n values) crosses LDS. Two barriers per
-// column, no memory round trip for the trailing matrix. On exit F (column-major, ldf odd) holds L
-// and rdiag[i] = 1 / L(i,i). colbuf, rdiag: n values each; sh: 1 value. All three in LDS.
-template <typename T, int NB>
-__device__ __forceinline__ int potrf_tiled(int n, const T* A, int lda, T* F, int ldf, T* colbuf, T* rdiag, T* sh)
-{
-    const int tid = threadIdx.x;
-    const int tr = tid & 15, tc = tid >> 4;
-    T f[NB][NB];
-#pragma unroll
-    for (int a = 0; a < NB; ++a)
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int i = 16 * a + tr, k = 16 * b + tc;
-            if (b <= a) {   // compile-time after unrolling; addresses clamped so the loads need no branch
-                const T v = A[(i < n ? i : n - 1) + (size_t)(k < n ? k : n - 1) * lda];
-                f[a][b] = (i < n && k < n) ? v : T(0);
-            } else {
-                f[a][b] = T(0);
-            }
-        }
-    int info = 0;
-#pragma unroll
-    for (int JB = 0; JB < NB; ++JB) {
-        if (info != 0 || 16 * JB >= n) break;
-        for (int jc = 0; jc < 16; ++jc) {
-            const int j = 16 * JB + jc;
-            if (j >= n) break;
-            if (tr == jc && tc == jc) *sh = f[JB][JB];
-            __syncthreads();
-            const T ajj = *sh;
-            if (!(ajj > 0)) { info = j + 1; break; }      // uniform
-            const T d = dsqrt(ajj);
-            const T rinv = T(1) / d;                      // ?potf2 scales the column by ONE / AJJ
-            // (sqrt and the reciprocal are independent of each other's result only through d; both
-            //  sit on the per-column critical path -- see DESIGN.md "solve kernel")
-            if (tc == jc) {
-#pragma unroll
-                for (int a = JB; a < NB; ++a) {
-                    const int i = 16 * a + tr;
-                    if (i > j && i < n) { f[a][JB] = f[a][JB] * rinv; colbuf[i] = f[a][JB]; }
-                    else if (i == j) { f[a][JB] = d; rdiag[j] = rinv; }
-                }
-            }
-            __syncthreads();
-            T ci[NB], ck[NB];
-#pragma unroll
-            for (int a = JB; a < NB; ++a) {
-                const int i = 16 * a + tr, k = 16 * a + tc;
-                const T vi = colbuf[i < n ? i : n - 1], vk = colbuf[k < n ? k : n - 1];
-                ci[a] = (i > j && i < n) ? vi : T(0);
-                ck[a] = (k > j && k < n) ? vk : T(0);
-            }
-#pragma unroll
-            for (int a = JB; a < NB; ++a)
-#pragma unroll
-                for (int b = JB; b <= a; ++b) f[a][b] -= ci[a] * ck[b];
-        }
-    }
-    if (info != 0) return info;
-    __syncthreads();
-#pragma unroll
-    for (int a = 0; a < NB; ++a)
-#pragma unroll
-        for (int b = 0; b <= a; ++b) {
-            const int i = 16 * a + tr, k = 16 * b + tc;
-            if (i < n && k < n && i >= k) F[i + (size_t)k * ldf] = f[a][b];
-        }
-    __syncthreads();
-    return 0;
-}
-
-// ?potrs 'L' on one wave, factor in LDS, vector in registers (K = ceil(n / 64) values per lane),
-// columns/rows of L prefetched 8 steps ahead, reciprocal diagonal instead of a division on the
-// loop-carried path. Collective: all threads call; wave 0 works.
-template <typename T, int K>
-__device__ __forceinline__ void potrs_fast(int n, const T* F, int ldf, const T* rdiag, T* xv)
-{
-    __syncthreads();
-    if (threadIdx.x < kWave) {
-        const int lane = threadIdx.x;
-        T xr[K], rd[K];
-#pragma unroll
-        for (int t = 0; t < K; ++t) {
-            const int k = lane + kWave * t;
-            xr[t] = k < n ? xv[k] : T(0);
-            rd[t] = k < n ? rdiag[k] : T(0);
-        }
-        for (int i0 = 0; i0 < n; i0 += 8) {             // forward: L z = b
-            T col[8][K];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-#pragma unroll
-                for (int t = 0; t < K; ++t) {
-                    const int i = i0 + u, k = lane + kWave * t;
-                    const T v = F[(k < n ? k : n - 1) + (size_t)(i < n ? i : n - 1) * ldf];
-                    col[u][t] = (i < n && k > i && k < n) ? v : T(0);
-                }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0 + u;
-                if (i < n) {
-                    T xi = 0;
-#pragma unroll
-                    for (int t = 0; t < K; ++t) if ((i >> 6) == t) xi = lane_bcast(xr[t] * rd[t], i & 63);
-#pragma unroll
-                    for (int t = 0; t < K; ++t) {
-                        if (lane + kWave * t == i) xr[t] = xi;
-                        xr[t] -= col[u][t] * xi;
-                    }
-                }
-            }
-        }
-        for (int i0 = ((n - 1) | 7); i0 >= 0; i0 -= 8) { // backward: L^T x = z, i = i0, i0-1, ..., i0-7
-            T row[8][K];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-#pragma unroll
-                for (int t = 0; t < K; ++t) {
-                    const int i = i0 - u, k = lane + kWave * t;
-                    const int ic = i < 0 ? 0 : (i < n ? i : n - 1);
-                    const T v = F[ic + (size_t)(k < n ? k : n - 1) * ldf];
-                    row[u][t] = (i >= 0 && i < n && k < i) ? v : T(0);
-                }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0 - u;
-                if (i >= 0 && i < n) {
-                    T xi = 0;
-#pragma unroll
-                    for (int t = 0; t < K; ++t) if ((i >> 6) == t) xi = lane_bcast(xr[t] * rd[t], i & 63);
-#pragma unroll
-                    for (int t = 0; t < K; ++t) {
-                        if (lane + kWave * t == i) xr[t] = xi;
-                        xr[t] -= row[u][t] * xi;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < K; ++t) { const int k = lane + kWave * t; if (k < n) xv[k] = xr[t]; }
-    }
-    __syncthreads();
-}
-
-// ---------------------------------------------------------------- v2 of the LDS fast path
-// potrf_tiled2: same register tiling as potrf_tiled but ONE barrier per column. The 16 threads that
+// ---------------------------------------------------------------- LDS fast path (n <= 128)
+// potrf_tiled2: register-tiled Cholesky on a 16 x 16 thread grid (thread (tr, tc) holds the entries (16 a + tr,
+// 16 b + tc) of the lower triangle) with ONE barrier per column. The 16 threads that
 // hold column j (already updated by columns < j) publish it UNSCALED, pivot included, into one of two
 // column buffers; after the barrier every thread reads the pivot and the entries it needs, computes
 // 1/sqrt(pivot) itself (no second exchange) and applies the scaled rank-1 update; the holders of

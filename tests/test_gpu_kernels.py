@@ -169,7 +169,8 @@ def test_TQ_reference_unittest():
 
 @pytest.mark.parametrize("n,cond,badscale", [(1, 1, False), (2, 10, False), (3, 1e3, True), (16, 1e6, False),
                                              (33, 1e8, True), (64, 1e3, False), (128, 1e10, False), (128, 1e4, True),
-                                             (129, 1e3, False), (200, 1e5, True), (256, 1e6, False)])
+                                             (129, 1e3, False), (200, 1e5, True), (256, 1e6, False), (145, 1e9, True),
+                                             (250, 1e10, False), (256, 1e3, True)])
 def test_unconstrained_solve_matches_oracle_posvx(oracle, n, cond, badscale):
     A = spd(n, cond, n, np.logspace(-3, 3, n) if badscale else None)
     q = np.random.default_rng(7).standard_normal(n)
@@ -184,7 +185,7 @@ def test_unconstrained_solve_matches_oracle_posvx(oracle, n, cond, badscale):
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 4 * max(err, erro) + 1e-15
 
 
-@pytest.mark.parametrize("n,seed", [(3, 0), (8, 1), (16, 2), (40, 3), (64, 4), (128, 5), (150, 6)])
+@pytest.mark.parametrize("n,seed", [(3, 0), (8, 1), (16, 2), (40, 3), (64, 4), (128, 5), (150, 6), (208, 7), (256, 8)])
 def test_boxcqp_matches_oracle(oracle, n, seed):
     rng = np.random.default_rng(seed)
     Pm = spd(n, 100.0, seed + 10)
@@ -214,3 +215,25 @@ def test_boxcqp_float(oracle):
     p = P.tq()
     st, x, _ = M.solveBoxQP(p["P"], p["q"], p["l"], p["u"], dtype=np.float32)
     assert st == M.BoxQPStatus.solved and np.allclose(x, p["expect"], rtol=1e-5)
+    for n in (96, 200):                                            # LDS fast path / panel path (factor in global memory)
+        A = spd(n, 50.0, n)
+        q = np.random.default_rng(n).standard_normal(n)
+        l, u = np.full(n, -0.05), np.full(n, 0.05)
+        st, x, it = M.solveBoxQP(np.tril(A), q, l, u, dtype=np.float32)
+        so, xo, io = oracle.solve_box_qp(np.tril(A), q, l, u)       # double oracle: float result within float accuracy
+        assert st == M.BoxQPStatus.solved and so == 0 and np.allclose(x, xo, atol=2e-4)
+        l32, u32 = l.astype(np.float32), u.astype(np.float32)
+        assert np.mean((x == l32) == (xo == l)) > 0.97 and np.mean((x == u32) == (xo == u)) > 0.97
+
+
+def test_singular_matrix_reports_numeric_error_on_both_paths(oracle):
+    """info > 0 from the Cholesky (QP:212): rank-deficient P, n on the LDS path and on the panel path."""
+    for n in (64, 200):
+        B = np.random.default_rng(n).standard_normal((n, n // 2))
+        A = B @ B.T
+        A[n - 1, n - 1] = -1.0                                      # a negative pivot at the very end
+        q = np.ones(n)
+        inf = np.full(n, np.inf)
+        st, _, _ = M.solveBoxQP(np.tril(A), q, -inf, inf)
+        so = oracle.solve_box_qp(np.tril(A), q, -inf, inf)[0]
+        assert st == M.BoxQPStatus.numericError and so == int(M.BoxQPStatus.numericError)
