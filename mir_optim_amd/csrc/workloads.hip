@@ -69,25 +69,33 @@ __device__ inline float dtanh(float v) { return tanhf(v); }
 __device__ inline double dexp(double v) { return exp(v); }
 __device__ inline float dexp(float v) { return expf(v); }
 
-// ---- tanh-linear: y_i = tanh(a_i . x) - b_i.  A wave handles 4 rows per step; lane (q, p) reads
-//      A[4g + q][16 c + p], i.e. every 16-lane group streams one full 128-byte line per load.
+// ---- tanh-linear: y_i = tanh(a_i . x) - b_i.  A wave handles 4 rows per step; lane (q, p) reads the PAIRS
+//      A[4g + q][32 c + 2p, + 1] with one 16-byte load (8 bytes for f32): every 16-lane group streams 256
+//      contiguous bytes per load. n even: vector loads; n odd: the scalar layout (pair split into two loads).
 //      MODE 0: residual; MODE 1: analytic Jacobian row (1 - tanh^2) a_i.
-template <typename T, int NCB, int MODE>
+template <typename T> struct Pair;
+template <> struct Pair<double> { using type = double2; };
+template <> struct Pair<float> { using type = float2; };
+
+template <typename T, int NCP, int MODE, bool VEC>
 __global__ __launch_bounds__(256) void k_tanh_linear(const T* __restrict__ A, const T* __restrict__ b,
                                                      const T* __restrict__ x, T* __restrict__ out, size_t m, int n)
 {
+    using P2 = typename Pair<T>::type;
     const int lane = threadIdx.x & 63;
     const int q = lane >> 4, p = lane & 15;
-    T xr[NCB];
-    int coff[NCB];
-    bool cok[NCB];
+    T x0[NCP], x1[NCP];
+    int coff[NCP];
+    bool ok0[NCP], ok1[NCP];
 #pragma unroll
-    for (int c = 0; c < NCB; ++c) {
-        const int col = 16 * c + p;
-        cok[c] = col < n;
-        coff[c] = cok[c] ? col : n - 1;
-        const T t = x[coff[c]];
-        xr[c] = cok[c] ? t : T(0);
+    for (int c = 0; c < NCP; ++c) {
+        const int col = 32 * c + 2 * p;
+        ok0[c] = col < n;
+        ok1[c] = col + 1 < n;
+        coff[c] = ok0[c] ? col : 0;
+        const T t0 = x[ok0[c] ? col : 0], t1 = x[ok1[c] ? col + 1 : 0];
+        x0[c] = ok0[c] ? t0 : T(0);
+        x1[c] = ok1[c] ? t1 : T(0);
     }
     const size_t G = (m + 3) / 4;
     const size_t wave_id = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -96,12 +104,21 @@ __global__ __launch_bounds__(256) void k_tanh_linear(const T* __restrict__ A, co
         const size_t row = 4 * g + q;
         const bool rok = row < m;
         const T* rp = A + (rok ? row : m - 1) * (size_t)n;
-        T v[NCB];
+        T v0[NCP], v1[NCP];
 #pragma unroll
-        for (int c = 0; c < NCB; ++c) v[c] = rp[coff[c]];
+        for (int c = 0; c < NCP; ++c) {
+            if constexpr (VEC) {                           // n even: a pair never straddles the row end
+                const P2 t = *reinterpret_cast<const P2*>(rp + coff[c]);
+                v0[c] = t.x;
+                v1[c] = t.y;
+            } else {
+                v0[c] = rp[coff[c]];
+                v1[c] = rp[ok1[c] ? coff[c] + 1 : 0];
+            }
+        }
         T s = 0;
 #pragma unroll
-        for (int c = 0; c < NCB; ++c) s += v[c] * xr[c];
+        for (int c = 0; c < NCP; ++c) s += v0[c] * x0[c] + v1[c] * x1[c];
         s = sum16(s);
         const T t = dtanh(s);
         if constexpr (MODE == 0) {
@@ -110,9 +127,20 @@ __global__ __launch_bounds__(256) void k_tanh_linear(const T* __restrict__ A, co
             const T d = 1 - t * t;
             T* op = out + (rok ? row : m - 1) * (size_t)n;
 #pragma unroll
-            for (int c = 0; c < NCB; ++c) if (rok && cok[c]) op[coff[c]] = d * v[c];
+            for (int c = 0; c < NCP; ++c) {
+                if (rok && ok0[c]) op[coff[c]] = d * v0[c];
+                if (rok && ok1[c]) op[coff[c] + 1] = d * v1[c];
+            }
         }
     }
+}
+
+template <typename T, int NCP, int MODE>
+void launch_tanh_linear_ncp(const T* A, const T* b, const T* x, T* out, size_t m, int n, dim3 grid, hipStream_t s)
+{
+    const bool vec = (n % 2 == 0) && (reinterpret_cast<uintptr_t>(A) % (2 * sizeof(T)) == 0);
+    if (vec) hipLaunchKernelGGL((k_tanh_linear<T, NCP, MODE, true>), grid, dim3(256), 0, s, A, b, x, out, m, n);
+    else hipLaunchKernelGGL((k_tanh_linear<T, NCP, MODE, false>), grid, dim3(256), 0, s, A, b, x, out, m, n);
 }
 
 template <typename T, int MODE>
@@ -122,13 +150,12 @@ void launch_tanh_linear(const T* A, const T* b, const T* x, T* out, size_t m, in
     size_t blocks = (G + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
-    const int ncb = (n + 15) / 16;
-    dim3 grid((unsigned)blocks), blk(256);
-    if (ncb <= 1) hipLaunchKernelGGL((k_tanh_linear<T, 1, MODE>), grid, blk, 0, s, A, b, x, out, m, n);
-    else if (ncb <= 2) hipLaunchKernelGGL((k_tanh_linear<T, 2, MODE>), grid, blk, 0, s, A, b, x, out, m, n);
-    else if (ncb <= 4) hipLaunchKernelGGL((k_tanh_linear<T, 4, MODE>), grid, blk, 0, s, A, b, x, out, m, n);
-    else if (ncb <= 8) hipLaunchKernelGGL((k_tanh_linear<T, 8, MODE>), grid, blk, 0, s, A, b, x, out, m, n);
-    else hipLaunchKernelGGL((k_tanh_linear<T, 16, MODE>), grid, blk, 0, s, A, b, x, out, m, n);
+    const int ncp = (n + 31) / 32;                         // column pairs per lane
+    dim3 grid((unsigned)blocks);
+    if (ncp <= 1) launch_tanh_linear_ncp<T, 1, MODE>(A, b, x, out, m, n, grid, s);
+    else if (ncp <= 2) launch_tanh_linear_ncp<T, 2, MODE>(A, b, x, out, m, n, grid, s);
+    else if (ncp <= 4) launch_tanh_linear_ncp<T, 4, MODE>(A, b, x, out, m, n, grid, s);
+    else launch_tanh_linear_ncp<T, 8, MODE>(A, b, x, out, m, n, grid, s);
 }
 
 // ---- Gaussian-sum: n = 3K+1, x = [a | c | w | b]; y_i = sum_k a_k exp(-(t_i-c_k)^2/(2 w_k^2)) + b - data_i
@@ -524,24 +551,25 @@ bool launch_tanh_linear_batched(const double* A, const double* b, const double* 
 
 // ---- a handful of points (p <= 8) in one sweep over A: the lambda-ladder trials of the solver. HBM-bound like the
 //      single-point kernel (A is read once), one 16-lane DPP reduction and one tanh per (row, point).
-template <int NCB, int NP>
+template <int NCP, int NP>
 __global__ __launch_bounds__(256) void k_tanh_linear_multi(const double* __restrict__ A, const double* __restrict__ b,
                                                            const double* __restrict__ X, double* __restrict__ Y,
                                                            size_t m, int n, int P)
 {
     const int lane = threadIdx.x & 63;
     const int q = lane >> 4, p = lane & 15;
-    double xr[NP][NCB];
-    int coff[NCB];
+    double x0[NP][NCP], x1[NP][NCP];                       // column pairs 32 c + 2 p, + 1 (n even)
+    int coff[NCP];
 #pragma unroll
-    for (int c = 0; c < NCB; ++c) {
-        const int col = 16 * c + p;
+    for (int c = 0; c < NCP; ++c) {
+        const int col = 32 * c + 2 * p;
         const bool ok = col < n;
-        coff[c] = ok ? col : n - 1;
+        coff[c] = ok ? col : 0;
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            const double t = X[(size_t)(k < P ? k : 0) * n + coff[c]];
-            xr[k][c] = (ok && k < P) ? t : 0.0;
+            const double2 t = *reinterpret_cast<const double2*>(X + (size_t)(k < P ? k : 0) * n + coff[c]);
+            x0[k][c] = (ok && k < P) ? t.x : 0.0;
+            x1[k][c] = (ok && k < P) ? t.y : 0.0;
         }
     }
     const size_t G = (m + 3) / 4;
@@ -551,16 +579,16 @@ __global__ __launch_bounds__(256) void k_tanh_linear_multi(const double* __restr
         const size_t row = 4 * g + q;
         const bool rok = row < m;
         const double* rp = A + (rok ? row : m - 1) * (size_t)n;
-        double v[NCB];
+        double2 v[NCP];
 #pragma unroll
-        for (int c = 0; c < NCB; ++c) v[c] = rp[coff[c]];
+        for (int c = 0; c < NCP; ++c) v[c] = *reinterpret_cast<const double2*>(rp + coff[c]);
         const double bv = b[rok ? row : m - 1];
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             if (k < P) {
                 double s = 0;
 #pragma unroll
-                for (int c = 0; c < NCB; ++c) s += v[c] * xr[k][c];
+                for (int c = 0; c < NCP; ++c) s += v[c].x * x0[k][c] + v[c].y * x1[k][c];
                 s = sum16(s);
                 if (rok && p == 0) Y[(size_t)k * m + row] = dtanh(s) - bv;
             }
@@ -570,17 +598,17 @@ __global__ __launch_bounds__(256) void k_tanh_linear_multi(const double* __restr
 
 bool launch_tanh_linear_multi(const double* A, const double* b, const double* X, double* Y, size_t m, int n, int P, hipStream_t s)
 {
-    if (P > 8 || n > 128) return false;
+    if (P > 8 || n > 128 || n % 2 != 0) return false;
+    if (reinterpret_cast<uintptr_t>(A) % 16 != 0 || reinterpret_cast<uintptr_t>(X) % 16 != 0) return false;
     const size_t G = (m + 3) / 4;
     size_t blocks = (G + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
-    const int ncb = (n + 15) / 16;
+    const int ncp = (n + 31) / 32;
     dim3 grid((unsigned)blocks), blk(256);
-    if (ncb <= 1) hipLaunchKernelGGL((k_tanh_linear_multi<1, 8>), grid, blk, 0, s, A, b, X, Y, m, n, P);
-    else if (ncb <= 2) hipLaunchKernelGGL((k_tanh_linear_multi<2, 8>), grid, blk, 0, s, A, b, X, Y, m, n, P);
-    else if (ncb <= 4) hipLaunchKernelGGL((k_tanh_linear_multi<4, 8>), grid, blk, 0, s, A, b, X, Y, m, n, P);
-    else hipLaunchKernelGGL((k_tanh_linear_multi<8, 8>), grid, blk, 0, s, A, b, X, Y, m, n, P);
+    if (ncp <= 1) hipLaunchKernelGGL((k_tanh_linear_multi<1, 8>), grid, blk, 0, s, A, b, X, Y, m, n, P);
+    else if (ncp <= 2) hipLaunchKernelGGL((k_tanh_linear_multi<2, 8>), grid, blk, 0, s, A, b, X, Y, m, n, P);
+    else hipLaunchKernelGGL((k_tanh_linear_multi<4, 8>), grid, blk, 0, s, A, b, X, Y, m, n, P);
     return true;
 }
 
