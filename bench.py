@@ -171,12 +171,18 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data, m, n, args.cpu_iterations)
-        print(json.dumps(out), flush=True)
     if comm:
         api.lib().mir_lsq_comm_destroy(comm)
     api.lib().mir_lsq_workspace_destroy(ws)
     if distributed:
         dist.destroy_process_group()
+    if out is not None:
+        # RCCL writes a version banner through C stdio (fully buffered on a pipe): flush it first so that the JSON
+        # line is the LAST line of stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 def cpu_baseline(data, m, n, iterations):
