@@ -66,6 +66,12 @@ def parse():
     return ap.parse_args()
 
 
+def flush_c_stdio():
+    """RCCL prints its banner through C stdio, which is fully buffered on a pipe."""
+    C.CDLL(None).fflush(None)
+    sys.stdout.flush()
+
+
 def main():
     args = parse()
     os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 64)))   # CPU baseline leg (oracle, OpenMP)
@@ -121,6 +127,7 @@ def main():
 
     for _ in range(args.warmup):
         res, x = solve()
+    flush_c_stdio()     # every rank: RCCL's init banner leaves the C stdio buffer now, not at process exit
     stats = M.Stats()
     iters = 0
     barrier()
@@ -176,12 +183,12 @@ def main():
     api.lib().mir_lsq_workspace_destroy(ws)
     if distributed:
         dist.destroy_process_group()
+    flush_c_stdio()
     if out is not None:
-        # RCCL writes a version banner through C stdio (fully buffered on a pipe): flush it first so that the JSON
-        # line is the LAST line of stdout
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-        sys.stdout.flush()
+        # the JSON line is the LAST line of the job's stdout: everything is torn down and flushed, and with several
+        # ranks the others get a moment to exit first
+        if world > 1:
+            time.sleep(1.0)
         print(json.dumps(out), flush=True)
 
 
