@@ -868,7 +868,7 @@ struct Solver {
         bool fConverged = ret.residual <= S->maxGoodResidual;                // LS:956
         bool needJacobian = true;                                            // LS:959
         bool last_rejected = false;
-        const bool speculate = device_cb && fb != nullptr && !no_speculation;
+        const bool speculate = device_cb && !no_speculation;        // ladder trials: one fb call, or ks calls of f
         uint32_t age = maxAge;
         ret.lambda = 0;
         T mu = 1;
@@ -923,8 +923,8 @@ struct Solver {
             //
             // Speculation: after a rejection the reference re-solves with lambda * lambdaIncrease * mu, mu * 2
             // (LS:1103, 1127) and J^T J, J^T y unchanged -- the whole ladder lambda_0 .. lambda_{ks-1} is known in
-            // advance. When a batched residual callback exists, workgroup k solves with lambda_k, all trial points
-            // are evaluated in one sweep and k_decide_chain walks them in the reference's order; entries after the
+            // advance. Workgroup k solves with lambda_k, all trial points are evaluated (one sweep of the batched
+            // residual callback, or one call of f per point) and k_decide_chain walks them in the reference's order; entries after the
             // first accepted one are discarded, so results, counters and callback-visible semantics of accepted
             // points are unchanged. The ladder stops where the reference's top-of-loop checks would intervene
             // (lambda > maxLambda LS:979, forced refresh LS:984).
@@ -971,8 +971,8 @@ struct Solver {
             if (device_cb) {
                 // no host round trip before the residual: it is evaluated speculatively even when the record will
                 // forbid it (gradient converged, QP failure, step guard) -- the decision kernel then ignores it
-                if (ks > 1) fb(fbctx, m, n, (size_t)ks, B.trial, ytr);
-                else f(fctx, m, n, B.trial, ytr);
+                if (ks > 1 && fb) fb(fbctx, m, n, (size_t)ks, B.trial, ytr);
+                else for (int k = 0; k < ks; ++k) f(fctx, m, n, B.trial + (size_t)k * n, ytr + (size_t)k * m);
             } else {
                 // reference contract: the callback needs the trial point on the host
                 ChainRec<T> r0;
