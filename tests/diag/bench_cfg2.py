@@ -1,7 +1,7 @@
 """cfg 2 (Gaussian-sum fit, m = 1e5, n = 16, bounded, FD Jacobian) timing: GPU solve vs oracle (run on the GPU box)."""
 import ctypes as C, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 import mir_optim_amd as M
 from mir_optim_amd import workloads as W

@@ -1,7 +1,7 @@
 """Diagnostic: time GPU solve vs oracle solve on tanh-linear problems (run on the GPU box)."""
 import ctypes as C, sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 import mir_optim_amd as M
 from mir_optim_amd import workloads as W

@@ -1,7 +1,7 @@
 """Diagnostic: GPU (host-callback entry) vs oracle traces on the reference unittest problems."""
 import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 import mir_optim_amd as M
 from oracle import oracle as O
