@@ -36,7 +36,7 @@ def build(force=False, verbose=False):
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "mir_optim_amd.h"))
     jobs = [
         (SOLVER_LIB, [os.path.join(CSRC, "lm_driver.hip"), os.path.join(CSRC, "fit_spline.cpp")], hdrs, ["-ldl"]),
-        (WORKLOADS_LIB, [os.path.join(CSRC, "workloads.hip")], [], []),
+        (WORKLOADS_LIB, [os.path.join(CSRC, "workloads.hip")], [], ["-fopenmp"]),   # host-side data generation / host residual
     ]
     for target, srcs, deps, extra in jobs:
         if force or _stale(target, srcs + deps):

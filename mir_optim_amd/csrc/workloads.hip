@@ -666,6 +666,21 @@ void wl_tanh_linear_g_s(void* vctx, size_t m, size_t n, const float* x, float* J
     launch_tanh_linear<float, 1>((const float*)c->A, (const float*)c->b, x, J, m, (int)n, (hipStream_t)c->stream);
 }
 
+// HOST version of the tanh-linear residual (reference contract: x, y are host pointers, LS:78): what a caller of
+// the unmodified `mir_optimize_least_squares_d` would pass. ctx: host copies of A and b.
+struct wl_tanh_linear_host_ctx { const double* A; const double* b; };
+void wl_tanh_linear_f_host_d(void* vctx, size_t m, size_t n, const double* x, double* y)
+{
+    auto* c = static_cast<wl_tanh_linear_host_ctx*>(vctx);
+#pragma omp parallel for schedule(static)
+    for (ptrdiff_t i = 0; i < (ptrdiff_t)m; ++i) {
+        const double* a = c->A + (size_t)i * n;
+        double s = 0;
+        for (size_t j = 0; j < n; ++j) s += a[j] * x[j];
+        y[i] = std::tanh(s) - c->b[i];
+    }
+}
+
 void wl_gauss_sum_f_d(void* vctx, size_t m, size_t n, const double* x, double* y)
 {
     auto* c = static_cast<wl_curve_ctx*>(vctx);
