@@ -334,11 +334,13 @@ def test_cfg2_gauss_sum_full_size(oracle):
     assert np.allclose(x, g["truth"], rtol=5e-3, atol=1e-3)
 
 
-def test_repeated_solve_is_bit_reproducible():
+@pytest.mark.parametrize("m,n", [(60000, 128), (40000, 256), (50000, 64), (30000, 208)])
+def test_repeated_solve_is_bit_reproducible(m, n):
     """The whole path is deterministic (fixed-order reductions, no float atomics): repeated solves are
-    bitwise equal. m even and n = 128 select the LDS-DMA ring kernel; an earlier version of it mixed
+    bitwise equal. m even and n % 16 == 0 select the LDS-DMA ring kernels (k_jtj2 for n <= 128, the eight-wave
+    k_jtj8 above; the batched residual callback is a DMA ring kernel too); an earlier version of k_jtj2 mixed
     stores into a counted vmcnt wait and was caught by exactly this check."""
-    w = P.tanh_linear(60000, 128)
+    w = P.tanh_linear(m, n)
     prob = W.TanhLinear(w["A"], w["b"])
     s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
     ref = None
