@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_decide_chain(DecideArgs<T> a)
     }
     __syncthreads();
     const int acc = acc_s;
-    if (acc >= 0 && threadIdx.x < a.n) {
+    if (acc >= 0 && (int)threadIdx.x < a.n) {
         a.x[threadIdx.x] = a.trial[(size_t)acc * a.n + threadIdx.x];          // LS:1135
         a.dx_acc[threadIdx.x] = a.dx_chain[(size_t)acc * a.n + threadIdx.x];
     }

@@ -16,7 +16,6 @@
 
 namespace {
 
-constexpr int kWave = 64;
 
 template <int N> __device__ inline int dpp_row_ror(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x120 + N, 0xF, 0xF, false); }
 template <int N> __device__ inline double dpp_row_ror(double v)
