@@ -305,29 +305,74 @@ __device__ __forceinline__ void potrs_blocked(int n, const T* F, int ldf, const 
 }
 
 // ---------------------------------------------------------------- generic path (factor in global memory), 128 < n <= 256
-// potrf_panel: left-looking Cholesky by 16-column panels with ONE ROW PER THREAD (n <= kSolveThreads). Thread i keeps
-// row i of the current panel in 16 registers:
-//   1. subtract the contribution of every earlier panel j: p[c] -= sum_t L[i][16 j + t] L[16 k + c][16 j + t]. The row
-//      L[i][.] is 16 coalesced loads from the factor (global, L2-resident); the 16 x 16 block L[16 k + ., 16 j + .] is
-//      the same for every thread: each lane loads four of its entries and they are broadcast with v_readlane;
-//   2. the wave that holds the 16 diagonal rows factors them in registers (16 pivots, wave-synchronous, no barrier)
-//      and publishes L_kk and 1 / pivots through LDS; the same loop finishes the other rows of that wave;
-//   3. every other row solves its 16 entries against L_kk (row-wise forward substitution), and the panel is stored.
-// Two barriers per panel instead of two per column with global-memory traffic in between (the first version of this
-// path: 3.4 ms per n = 256 solve). Same pivot arithmetic as potrf_tiled2 (rsqrt + multiply).
-// (the three generic-path routines are NOT inlined: each is large, unrolled code that box_qp_device would otherwise
-// instantiate four times per kernel; as out-of-line functions their pointer arguments are generic -- flat loads --
-// which this path can afford)
+// potrf_panel: left-looking Cholesky by 16-column panels (n <= kSolveThreads = 256), three barriers per panel:
+//   1. S = L[:, :16k] L[16k:16k+16, :16k]^T, the contribution of every earlier panel to panel k, on MFMA 16x16x4:
+//      wave w owns the four 16-row blocks of rows 64 w .. 64 w + 63; per earlier panel j and k-step it loads one
+//      B fragment (the 16 panel rows) and one A fragment per row block straight from the factor (global,
+//      L2-resident; the loads of panel j + 1 are issued before the MFMAs of panel j) and S goes through LDS;
+//   2. ONE ROW PER THREAD from here on: thread i takes p[c] = A[i][16k + c] - S[i][c] into 16 registers; the wave
+//      that holds the 16 diagonal rows factors them wave-synchronously (16 pivots, v_readlane broadcasts, no barrier)
+//      and publishes L_kk and the reciprocal pivots through LDS; the same loop finishes the other rows of that wave;
+//   3. every other row solves its 16 entries against L_kk (row-wise forward substitution); the panel is stored.
+// History at n = 256: column-by-column through global memory 3.4 ms per solve kernel; row-per-thread with the update as
+// FMAs + v_readlane broadcasts 0.37 ms for the factorisation alone; this version moves that update to the matrix cores.
+// Same pivot arithmetic as potrf_tiled2 (rsqrt + multiply). The generic-path routines are NOT inlined: each is large
+// unrolled code that box_qp_device would otherwise instantiate four times per kernel; as out-of-line functions their
+// pointer arguments are generic (flat loads), which this path can afford.
 template <typename T>
-__device__ __noinline__ int potrf_panel(int n, const T* A, int lda, T* F, int ldf, T* blk, T* rd, int* info_s)
+__device__ __noinline__ int potrf_panel(int n, const T* A, int lda, T* F, int ldf, T* blk, T* rd, int* info_s, T* spanel)
 {
+    using Acc = typename Mma<T>::Acc;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = tid;
     const int nblk = (n + 15) / 16;
+    const int lr = lane & 15, lk = lane >> 4;
     if (tid == 0) *info_s = 0;
     __syncthreads();
     for (int k = 0; k < nblk; ++k) {
         const int c0 = 16 * k;
+        // ---- 1. S for this wave's row blocks rb = 4 wave + u that reach into the panel (rb >= k)
+        if (k > 0 && 4 * wave + 3 >= k) {
+            Acc acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = Acc{0, 0, 0, 0};
+            int rowa[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int r = 64 * wave + 16 * u + lr; rowa[u] = r < n ? r : n - 1; }
+            const int rowb = c0 + lr < n ? c0 + lr : n - 1;
+            T fa[2][4][4], fb[2][4];                            // [buffer][k-step][row block]
+            auto load = [&](int j, int buf) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const size_t col = (size_t)(16 * j + 4 * s4 + lk) * ldf;
+                    fb[buf][s4] = F[rowb + col];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) fa[buf][s4][u] = F[rowa[u] + col];
+                }
+            };
+            load(0, 0);
+            for (int j = 0; j < k; j += 2) {
+                if (j + 1 < k) load(j + 1, 1);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[u] = Mma<T>::mma(fa[0][s4][u], fb[0][s4], acc[u]);
+                if (j + 1 < k) {
+                    if (j + 2 < k) load(j + 2, 0);
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc[u] = Mma<T>::mma(fa[1][s4][u], fb[1][s4], acc[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    spanel[(64 * wave + 16 * u + Mma<T>::row(lane, r)) * 17 + lr] = acc[u][r];   // D: row, col = lane & 15
+        }
+        __syncthreads();
+        // ---- 2. row per thread
         const bool active = i < n && i >= c0;
         const int ic = i < n ? i : n - 1;
         T p[16];
@@ -335,27 +380,8 @@ __device__ __noinline__ int potrf_panel(int n, const T* A, int lda, T* F, int ld
         for (int c = 0; c < 16; ++c) {
             const int col = c0 + c < n ? c0 + c : n - 1;
             const T v = A[ic + (size_t)col * lda];
-            p[c] = (active && c0 + c < n) ? v : ((i == c0 + c) ? T(1) : T(0));   // identity padding past n
-        }
-        if (64 * wave + 63 >= c0) {                             // waves entirely above the panel have nothing to update
-            for (int j = 0; j < k; ++j) {
-                T a[16], bv[4];
-#pragma unroll
-                for (int t = 0; t < 16; ++t) a[t] = F[ic + (size_t)(16 * j + t) * ldf];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {                   // entry e = lane + 64 u of the block: (c, t) = (e >> 4, e & 15)
-                    const int e = lane + 64 * u;
-                    const int r = c0 + (e >> 4) < n ? c0 + (e >> 4) : n - 1;
-                    bv[u] = F[r + (size_t)(16 * j + (e & 15)) * ldf];
-                }
-#pragma unroll
-                for (int c = 0; c < 16; ++c)
-#pragma unroll
-                    for (int t = 0; t < 16; ++t) {
-                        const int e = 16 * c + t;
-                        p[c] -= a[t] * lane_bcast(bv[e >> 6], e & 63);
-                    }
-            }
+            const T sv = k > 0 ? spanel[i * 17 + c] : T(0);
+            p[c] = (active && c0 + c < n) ? v - sv : ((i == c0 + c) ? T(1) : T(0));   // identity padding past n
         }
         // the diagonal rows c0 .. c0 + 15 are lanes l0 .. l0 + 15 of wave wd
         const int wd = c0 >> 6, l0 = c0 & 63;
@@ -384,6 +410,7 @@ __device__ __noinline__ int potrf_panel(int n, const T* A, int lda, T* F, int ld
         __syncthreads();
         const int info = *info_s;
         if (info != 0) return info;                             // uniform
+        // ---- 3. the other rows against L_kk, store
         if (wave != wd && active) {
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
@@ -399,15 +426,71 @@ __device__ __noinline__ int potrf_panel(int n, const T* A, int lda, T* F, int ld
             for (int c = 0; c < 16; ++c)
                 if (c0 + c < n && i >= c0 + c) F[i + (size_t)(c0 + c) * ldf] = p[c];
         }
-        __syncthreads();                                        // the panel is visible to the later ones; blk / rd reusable
+        __syncthreads();                                        // the panel is visible to the later ones; blk / rd / spanel reusable
     }
     return 0;
 }
 
 template <typename T>
 __device__ __noinline__ void invert_diag_blocks_generic(int n, const T* F, int ldf, T* Dinv) { invert_diag_blocks<T, 16>(n, F, ldf, Dinv); }
+// ?potrs for the generic path, ONE ROW PER THREAD (n <= kSolveThreads): block step kb = the 16 owners of rows
+// 16 kb .. 16 kb + 15 (16 lanes of one wave) form x_kb = inv(L_kk) z_kb with v_readlane broadcasts and publish it;
+// after ONE barrier every remaining row subtracts its 16 products. The factor entries a row needs do not depend on
+// the solution, so their loads (global, L2) are issued before the barrier. Replaces the one-wave blocked solve here
+// (105 us per call at n = 256: 32 dependent block steps, each a round trip to L2).
 template <typename T>
-__device__ __noinline__ void potrs_blocked_generic(int n, const T* F, int ldf, const T* Dinv, T* xv) { potrs_blocked<T, 16>(n, F, ldf, Dinv, xv); }
+__device__ __noinline__ void potrs_rows(int n, const T* F, int ldf, const T* Dinv, T* xv, T* xk)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = tid, ic = i < n ? i : n - 1;
+    const int nb = (n + 15) / 16;
+    __syncthreads();
+    T z = i < n ? xv[i] : T(0);
+    // ---- forward: L z = b
+    for (int kb = 0; kb < nb; ++kb) {
+        const int c0 = 16 * kb;
+        T lrow[16];                                             // L[i][c0 .. c0 + 15], needed when i >= c0 + 16
+#pragma unroll
+        for (int c = 0; c < 16; ++c) lrow[c] = F[ic + (size_t)(c0 + c < n ? c0 + c : n - 1) * ldf];
+        if (wave == (c0 >> 6)) {
+            const int l0 = c0 & 63, r = (lane - l0) & 15;
+            T xn = 0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) xn += Dinv[kb * 272 + r + 17 * c] * lane_bcast(z, l0 + c);   // entries above the diagonal are 0
+            if (lane >= l0 && lane < l0 + 16) { z = xn; xk[(kb & 1) * 16 + r] = xn; }
+        }
+        __syncthreads();
+        if (i >= c0 + 16 && i < n) {
+            T acc = 0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc += lrow[c] * ((c0 + c < n) ? xk[(kb & 1) * 16 + c] : T(0));
+            z -= acc;
+        }
+    }
+    // ---- backward: L^T x = z
+    for (int kb = nb - 1; kb >= 0; --kb) {
+        const int c0 = 16 * kb;
+        T lcol[16];                                             // L[c0 .. c0 + 15][i], needed when i < c0
+#pragma unroll
+        for (int c = 0; c < 16; ++c) lcol[c] = F[(c0 + c < n ? c0 + c : n - 1) + (size_t)ic * ldf];
+        if (wave == (c0 >> 6)) {
+            const int l0 = c0 & 63, r = (lane - l0) & 15;
+            T xn = 0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) xn += Dinv[kb * 272 + c + 17 * r] * lane_bcast(z, l0 + c);   // (inv L_kk)^T (r, c) = inv(c, r)
+            if (lane >= l0 && lane < l0 + 16) { z = xn; xk[(kb & 1) * 16 + r] = xn; }
+        }
+        __syncthreads();
+        if (i < c0) {
+            T acc = 0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc += lcol[c] * ((c0 + c < n) ? xk[(kb & 1) * 16 + c] : T(0));
+            z -= acc;
+        }
+    }
+    if (i < n) xv[i] = z;
+    __syncthreads();
+}
 
 // ---------------------------------------------------------------- ?posvx('E','L'), nrhs = 1
 // A: n x n full symmetric, leading dimension lda (overwritten by its equilibrated form).
@@ -426,9 +509,10 @@ __device__ __forceinline__ int posvx_device(int n, T* A, int lda, T* F, int ldf,
     // generic path (NB == 0): inverse diagonal blocks, the current diagonal block and its reciprocal pivots
     __shared__ T gDinv[NB == 0 ? 16 * 272 : 1];
     __shared__ T gblk[NB == 0 ? 16 * 17 : 1];
+    __shared__ T gpanel[NB == 0 ? kSolveThreads * 17 : 1];
     __shared__ T grd[NB == 0 ? 16 : 1];
     __shared__ int ginfo[1];
-    (void)gDinv; (void)gblk; (void)grd; (void)ginfo;
+    (void)gDinv; (void)gblk; (void)grd; (void)ginfo; (void)gpanel;
     const int tid = threadIdx.x;
     const T eps = Lim<T>::eps / 2;              // dlamch('Epsilon')
     const T safmin = Lim<T>::min_normal;        // dlamch('Safe minimum')
@@ -465,7 +549,7 @@ __device__ __forceinline__ int posvx_device(int n, T* A, int lda, T* F, int ldf,
         invert_diag_blocks<T, NB>(n, F, ldf, Dinv);
     } else {
         // generic path: factor in global memory, left-looking panels (potrf_panel) + the blocked triangular solves
-        const int info = potrf_panel<T>(n, A, lda, F, ldf, gblk, grd, ginfo);
+        const int info = potrf_panel<T>(n, A, lda, F, ldf, gblk, grd, ginfo, gpanel);
         if (info != 0) return info;
         invert_diag_blocks_generic<T>(n, F, ldf, gDinv);
     }
@@ -474,7 +558,7 @@ __device__ __forceinline__ int posvx_device(int n, T* A, int lda, T* F, int ldf,
     // ?potrs
     if (tid < n) x[tid] = b[tid];
     if constexpr (NB > 0) potrs_blocked<T, NB>(n, F, ldf, Dinv, x);
-    else potrs_blocked_generic<T>(n, F, ldf, gDinv, x);
+    else potrs_rows<T>(n, F, ldf, gDinv, x, gblk);
 
     MIRLSQ_STAMP(dbg, 5);
     // ?porfs: iterative refinement, ITMAX = 5
@@ -513,7 +597,7 @@ __device__ __forceinline__ int posvx_device(int n, T* A, int lda, T* F, int ldf,
         if (count == 1) MIRLSQ_STAMP(dbg, 12);
         if (berr > eps && 2 * berr <= lstres && count <= 5) {
             if constexpr (NB > 0) potrs_blocked<T, NB>(n, F, ldf, Dinv, r);
-            else potrs_blocked_generic<T>(n, F, ldf, gDinv, r);
+            else potrs_rows<T>(n, F, ldf, gDinv, r, gblk);
             if (tid < n) x[tid] += r[tid];
             lstres = berr;
             __syncthreads();
