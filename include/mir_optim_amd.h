@@ -187,6 +187,7 @@ typedef struct mir_lsq_stats {
     double fd_ms;                    /* finite-difference refresh incl. callbacks */
     double total_ms;                 /* whole call, host wall clock */
     uint64_t qp_active_set_passes;   /* passes in which BOXCQP's active-set loop ran */
+    uint64_t broyden_lr_columns;     /* sum over the Broyden sweeps of the pending columns each one read (broyden_lr.h) */
 } mir_lsq_stats;
 
 /* Optional per-pass trace (not in the reference; a parity-pinning aid: tests compare it event by event with the

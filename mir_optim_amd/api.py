@@ -116,7 +116,8 @@ class Stats(C.Structure):
                 ("step_guard_rejects", C.c_uint64), ("jacobian_full", C.c_uint64), ("jacobian_broyden", C.c_uint64),
                 ("jtj_launches", C.c_uint64), ("jtj_broyden_launches", C.c_uint64), ("jtj_ms", C.c_double),
                 ("jtj_broyden_ms", C.c_double), ("solve_ms", C.c_double), ("solve_launches", C.c_uint64),
-                ("fd_ms", C.c_double), ("total_ms", C.c_double), ("qp_active_set_passes", C.c_uint64)]
+                ("fd_ms", C.c_double), ("total_ms", C.c_double), ("qp_active_set_passes", C.c_uint64),
+                ("broyden_lr_columns", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -1,0 +1,350 @@
+// broyden_lr.h -- Broyden passes that do not rewrite J (gfx950).
+//
+// The reference's Broyden pass (least_squares.d:1002-1006, then 1052 and 1065) is
+//     u = (y_new - y_old - J dx) / (dx.dx);  J += u dx^T;  Jy = J^T y_new;  JJ = J^T J
+// i.e. three BLAS-2 sweeps plus a syrk over the updated m x n matrix. Here J stays what the last full
+// refresh made it (J0) and the accepted updates are kept as k <= kLrMax pending rank-one terms,
+//     J_k = J0 + U D^T          U: m x k (columns u_l),  D: n x k (columns dx_l),
+// so that one READ-ONLY sweep over J0 (+ the k columns of U) yields everything a pass needs:
+//     s_i   = J0[i,:].dx + sum_l U[i,l] (D_l.dx)                    (= (J_{k-1} dx)_i)
+//     u_i   = -(1/dx.dx) ((y_old_i - y_new_i) + s_i)                (the reference's operation order)
+//     v0    = J0^T u,  w_l = U_l.u,  uu = u.u                       -> v = J_{k-1}^T u = v0 + D w
+//     g0    = J0^T y,  h_l = U_l.y,  uy = u.y                       -> J_k^T y = g0 + D h + dx uy
+//     J_k^T J_k = J_{k-1}^T J_{k-1} + v dx^T + dx v^T + uu dx dx^T  (n x n, k_lr_finish)
+// HBM traffic per pass: T (m n + (k + 3) m) instead of T (2 m n + 3 m); no n^2 work per row at all.
+// When k reaches the cap the pending terms are folded into J (k_lr_flush: J += sum_l u_l dx_l^T, applied in
+// update order like the reference's successive `ger`s).
+//
+// Lane map of the sweep (same as the residual kernels): a wave takes 4 rows per step, lane (q = lane >> 4,
+// p = lane & 15) reads the column pairs [32 c + 2 p, + 1] of row 4 g + q, so every 16-lane group streams 256
+// contiguous bytes per load. Lane p of a group also owns pending column l = p: it carries U[i, p] into the
+// row dot product and accumulates w_p and h_p (hence kLrMax = 16). Each wave walks a contiguous range of
+// rows, per-block partials are summed in a fixed order by k_lr_reduce: results are bitwise reproducible.
+#pragma once
+
+#include "common.h"
+#include "solve_kernel.h"
+
+namespace mirlsq {
+
+constexpr int kLrMax = 16;
+// [ v0 (n) | g0 (n) | w (kLrMax) | h (kLrMax) | uu | uy ]
+__host__ __device__ constexpr int lr_len(int n) { return 2 * n + 2 * kLrMax + 2; }
+constexpr int kLrMaxN = 256;
+
+template <typename T> struct LrPair;
+template <> struct LrPair<double> { using type = double2; };
+template <> struct LrPair<float> { using type = float2; };
+
+template <typename T>
+struct LrArgs {
+    const T* J;        // m x n row-major, read only (J0)
+    T* U;              // kLrMax columns of length m (column l at U + l m); column k is written
+    const T* D;        // kLrMax x n, rows 0..k-1 valid
+    const T* dx;       // the accepted step of this update (length n)
+    const T* dx_dot;   // device scalar dx.dx (LS:1002: d = 1 / deltaX_dot)
+    const T* y;        // residual at the new point
+    const T* y_old;    // residual at the previous point (the reference's mBuffer after the swap LS:1136)
+    T* partials;       // gridDim.x x lr_len(n)
+    size_t m;
+    int n;
+    int k;
+};
+
+template <typename T, int NCP, bool VEC>
+__global__ __launch_bounds__(256) void k_broyden_lr(const LrArgs<T> a)
+{
+    using P2 = typename LrPair<T>::type;
+    __shared__ T red[4][lr_len(kLrMaxN)];
+    __shared__ T coef[kLrMax];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, p = lane & 15;
+    const int n = a.n, k = a.k;
+    const size_t m = a.m;
+
+    // coef[l] = D_l . dx for the pending columns (wave w takes l = w, w + 4, ...)
+    for (int l = wave; l < k; l += 4) {
+        T s = 0;
+        for (int j = lane; j < n; j += kWave) s += a.D[(size_t)l * n + j] * a.dx[j];
+        s = wave_sum(s);
+        if (lane == 0) coef[l] = s;
+    }
+    T d0[NCP], d1[NCP];
+    int coff[NCP];
+    bool ok0[NCP], ok1[NCP];
+#pragma unroll
+    for (int c = 0; c < NCP; ++c) {
+        const int col = 32 * c + 2 * p;
+        ok0[c] = col < n;
+        ok1[c] = col + 1 < n;
+        coff[c] = ok0[c] ? col : 0;
+        const T t0 = a.dx[ok0[c] ? col : 0], t1 = a.dx[ok1[c] ? col + 1 : 0];
+        d0[c] = ok0[c] ? t0 : T(0);
+        d1[c] = ok1[c] ? t1 : T(0);
+    }
+    __syncthreads();
+    const bool own = p < k;
+    const T cp = own ? coef[p] : T(0);
+    const T* __restrict__ Up = a.U + (size_t)(own ? p : 0) * m;
+    T* __restrict__ Uk = a.U + (size_t)k * m;
+    const T nd = -(T(1) / *a.dx_dot);
+
+    T va0[NCP], va1[NCP], ga0[NCP], ga1[NCP];
+#pragma unroll
+    for (int c = 0; c < NCP; ++c) { va0[c] = 0; va1[c] = 0; ga0[c] = 0; ga1[c] = 0; }
+    T wl = 0, hl = 0, uu = 0, uy = 0;
+
+    const size_t G = (m + 3) / 4;
+    const size_t nw = (size_t)gridDim.x * 4, wid = (size_t)blockIdx.x * 4 + wave;
+    const size_t per = (G + nw - 1) / nw;
+    const size_t gb = wid * per;
+    const size_t ge = gb + per < G ? gb + per : G;
+    for (size_t g = gb; g < ge; ++g) {
+        const size_t row = 4 * g + q;
+        const bool rok = row < m;
+        const size_t rr = rok ? row : m - 1;
+        const T* __restrict__ rp = a.J + rr * (size_t)n;
+        T v0[NCP], v1[NCP];
+#pragma unroll
+        for (int c = 0; c < NCP; ++c) {
+            if constexpr (VEC) {
+                const P2 t = *reinterpret_cast<const P2*>(rp + coff[c]);
+                v0[c] = t.x;
+                v1[c] = t.y;
+            } else {
+                v0[c] = rp[coff[c]];
+                v1[c] = rp[ok1[c] ? coff[c] + 1 : 0];
+            }
+        }
+        T yn = a.y[rr];
+        const T yo = a.y_old[rr];
+        const T ul = own ? Up[rr] : T(0);
+        T s = ul * cp;
+#pragma unroll
+        for (int c = 0; c < NCP; ++c) s += v0[c] * d0[c] + v1[c] * d1[c];
+        s = sum16(s);
+        T u = nd * ((yo - yn) + s);                        // LS:1003-1005: axpy(-1, y, mBuffer); gemv; scal(-d)
+        if (!rok) { u = 0; yn = 0; }
+        if (rok && p == 0) Uk[row] = u;
+#pragma unroll
+        for (int c = 0; c < NCP; ++c) {
+            va0[c] += v0[c] * u;
+            va1[c] += v1[c] * u;
+            ga0[c] += v0[c] * yn;
+            ga1[c] += v1[c] * yn;
+        }
+        wl += ul * u;
+        hl += ul * yn;
+        uu += u * u;
+        uy += u * yn;
+    }
+
+    // the four row groups of the wave, then the four waves of the block, in a fixed order
+    auto qsum = [](T v) { v += wave_shfl_xor(v, 16); v += wave_shfl_xor(v, 32); return v; };
+#pragma unroll
+    for (int c = 0; c < NCP; ++c) { va0[c] = qsum(va0[c]); va1[c] = qsum(va1[c]); ga0[c] = qsum(ga0[c]); ga1[c] = qsum(ga1[c]); }
+    wl = qsum(wl); hl = qsum(hl); uu = qsum(uu); uy = qsum(uy);
+    if (q == 0) {
+#pragma unroll
+        for (int c = 0; c < NCP; ++c) {
+            if (ok0[c]) { red[wave][coff[c]] = va0[c]; red[wave][n + coff[c]] = ga0[c]; }
+            if (ok1[c]) { red[wave][coff[c] + 1] = va1[c]; red[wave][n + coff[c] + 1] = ga1[c]; }
+        }
+        red[wave][2 * n + p] = wl;
+        red[wave][2 * n + kLrMax + p] = hl;
+        if (p == 0) { red[wave][2 * n + 2 * kLrMax] = uu; red[wave][2 * n + 2 * kLrMax + 1] = uy; }
+    }
+    __syncthreads();
+    const int len = lr_len(n);
+    T* __restrict__ out = a.partials + (size_t)blockIdx.x * len;
+    for (int e = threadIdx.x; e < len; e += blockDim.x) out[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+}
+
+// sum the per-block partial vectors in a fixed order: blockDim = 256 = 32 entries x 8 block ranges
+template <typename T>
+__global__ __launch_bounds__(256) void k_lr_reduce(const T* __restrict__ partials, int nparts, int len, T* __restrict__ out)
+{
+    __shared__ T part[8][32];
+    const int es = threadIdx.x & 31, sp = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + es;
+    T s = 0;
+    if (e < len) {
+        const int per = (nparts + 7) / 8;
+        const int b0 = sp * per, b1 = (b0 + per < nparts) ? b0 + per : nparts;
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) s += partials[(size_t)b * len + e];
+    }
+    part[sp][es] = s;
+    __syncthreads();
+    if (sp == 0 && e < len) {
+        T tot = part[0][es];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) tot += part[r][es];
+        out[e] = tot;
+    }
+}
+
+// n x n side of a pass: JJ += v dx^T + dx v^T + uu dx dx^T (block i < n: row i), Jy and |Jy|_inf (LS:1052-1053),
+// D_k = dx (block n). `lr` is the (all-reduced) vector of k_lr_reduce.
+template <typename T>
+__global__ __launch_bounds__(256) void k_lr_finish(const T* __restrict__ lr, T* __restrict__ D, const T* __restrict__ dx,
+                                                   int k, int n, T* __restrict__ JJ, T* __restrict__ Jy, LmState<T>* st)
+{
+    __shared__ T v[kLrMaxN];
+    __shared__ T red[4];
+    const T* __restrict__ w = lr + 2 * n;
+    const T* __restrict__ h = w + kLrMax;
+    const T uu = lr[2 * n + 2 * kLrMax], uy = lr[2 * n + 2 * kLrMax + 1];
+    const int i = blockIdx.x;
+    if (i < n) {
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {
+            T s = lr[j];
+            for (int l = 0; l < k; ++l) s += D[(size_t)l * n + j] * w[l];
+            v[j] = s;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {
+            const int r = i >= j ? i : j, c = i >= j ? j : i;      // one expression for (i, j) and (j, i): exactly symmetric
+            JJ[(size_t)i * n + j] += (v[r] * dx[c] + dx[r] * v[c]) + uu * dx[r] * dx[c];
+        }
+        return;
+    }
+    T mx = 0;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        T s = lr[n + j];
+        for (int l = 0; l < k; ++l) s += D[(size_t)l * n + j] * h[l];
+        s += dx[j] * uy;
+        Jy[j] = s;
+        const T av = dabs(s);
+        if (av > mx) mx = av;
+        D[(size_t)k * n + j] = dx[j];
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T r = red[0];
+        for (int wv = 1; wv < (int)(blockDim.x >> 6); ++wv) r = red[wv] > r ? red[wv] : r;
+        st->jy_inf = r;
+    }
+}
+
+// fold the k pending terms into J: J[i,:] += u_0[i] dx_0 + ... + u_{k-1}[i] dx_{k-1}, in update order
+template <typename T, int NCP, bool VEC>
+__global__ __launch_bounds__(256) void k_lr_flush(T* __restrict__ J, const T* __restrict__ U, const T* __restrict__ D,
+                                                  int k, size_t m, int n)
+{
+    using P2 = typename LrPair<T>::type;
+    extern __shared__ unsigned char lr_smem[];
+    T* Ds = reinterpret_cast<T*>(lr_smem);                 // k x n
+    for (int e = threadIdx.x; e < k * n; e += blockDim.x) Ds[e] = D[e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int q = lane >> 4, p = lane & 15;
+    int coff[NCP];
+    bool ok0[NCP], ok1[NCP];
+#pragma unroll
+    for (int c = 0; c < NCP; ++c) {
+        const int col = 32 * c + 2 * p;
+        ok0[c] = col < n;
+        ok1[c] = col + 1 < n;
+        coff[c] = ok0[c] ? col : 0;
+    }
+    const size_t G = (m + 3) / 4;
+    const size_t wave_id = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t g = wave_id; g < G; g += nwaves) {
+        const size_t row = 4 * g + q;
+        const bool rok = row < m;
+        const size_t rr = rok ? row : m - 1;
+        T* __restrict__ rp = J + rr * (size_t)n;
+        T v0[NCP], v1[NCP];
+#pragma unroll
+        for (int c = 0; c < NCP; ++c) {
+            if constexpr (VEC) {
+                const P2 t = *reinterpret_cast<const P2*>(rp + coff[c]);
+                v0[c] = t.x;
+                v1[c] = t.y;
+            } else {
+                v0[c] = rp[coff[c]];
+                v1[c] = rp[ok1[c] ? coff[c] + 1 : 0];
+            }
+        }
+        for (int l = 0; l < k; ++l) {
+            const T ul = U[(size_t)l * m + rr];
+#pragma unroll
+            for (int c = 0; c < NCP; ++c) {
+                v0[c] += ul * Ds[l * n + coff[c]];
+                v1[c] += ul * Ds[l * n + (ok1[c] ? coff[c] + 1 : 0)];
+            }
+        }
+        if (rok) {
+#pragma unroll
+            for (int c = 0; c < NCP; ++c) {
+                if constexpr (VEC) {
+                    if (ok0[c]) { P2 t; t.x = v0[c]; t.y = v1[c]; *reinterpret_cast<P2*>(rp + coff[c]) = t; }
+                } else {
+                    if (ok0[c]) rp[coff[c]] = v0[c];
+                    if (ok1[c]) rp[coff[c] + 1] = v1[c];
+                }
+            }
+        }
+    }
+}
+
+// ---- host-side launchers
+template <typename T, int NCP>
+hipError_t lr_sweep_ncp(const LrArgs<T>& a, int nblk, bool vec, hipStream_t s)
+{
+    if (vec) hipLaunchKernelGGL((k_broyden_lr<T, NCP, true>), dim3(nblk), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_broyden_lr<T, NCP, false>), dim3(nblk), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+template <typename T>
+hipError_t lr_sweep(const LrArgs<T>& a, int nblk, hipStream_t s)
+{
+    if (a.n > kLrMaxN || a.k < 0 || a.k >= kLrMax) return hipErrorInvalidValue;
+    const bool vec = (a.n % 2 == 0) && (reinterpret_cast<uintptr_t>(a.J) % (2 * sizeof(T)) == 0);
+    const int ncp = (a.n + 31) / 32;
+    if (ncp <= 1) return lr_sweep_ncp<T, 1>(a, nblk, vec, s);
+    if (ncp <= 2) return lr_sweep_ncp<T, 2>(a, nblk, vec, s);
+    if (ncp <= 4) return lr_sweep_ncp<T, 4>(a, nblk, vec, s);
+    return lr_sweep_ncp<T, 8>(a, nblk, vec, s);
+}
+
+template <typename T, int NCP>
+hipError_t lr_flush_ncp(T* J, const T* U, const T* D, int k, size_t m, int n, int nblk, bool vec, hipStream_t s)
+{
+    const size_t lds = (size_t)k * n * sizeof(T);
+    if (vec) hipLaunchKernelGGL((k_lr_flush<T, NCP, true>), dim3(nblk), dim3(256), lds, s, J, U, D, k, m, n);
+    else hipLaunchKernelGGL((k_lr_flush<T, NCP, false>), dim3(nblk), dim3(256), lds, s, J, U, D, k, m, n);
+    return hipGetLastError();
+}
+template <typename T>
+hipError_t lr_flush(T* J, const T* U, const T* D, int k, size_t m, int n, int num_cu, hipStream_t s)
+{
+    if (k <= 0) return hipSuccess;
+    if (n > kLrMaxN || k > kLrMax) return hipErrorInvalidValue;
+    const size_t G = (m + 3) / 4;
+    size_t blocks = (G + 3) / 4;
+    if (blocks > (size_t)num_cu * 8) blocks = (size_t)num_cu * 8;
+    if (blocks < 1) blocks = 1;
+    const bool vec = (n % 2 == 0) && (reinterpret_cast<uintptr_t>(J) % (2 * sizeof(T)) == 0);
+    const int ncp = (n + 31) / 32;
+    if (ncp <= 1) return lr_flush_ncp<T, 1>(J, U, D, k, m, n, (int)blocks, vec, s);
+    if (ncp <= 2) return lr_flush_ncp<T, 2>(J, U, D, k, m, n, (int)blocks, vec, s);
+    if (ncp <= 4) return lr_flush_ncp<T, 4>(J, U, D, k, m, n, (int)blocks, vec, s);
+    return lr_flush_ncp<T, 8>(J, U, D, k, m, n, (int)blocks, vec, s);
+}
+
+// workgroups of the sweep: 4 per CU, at least ~8 row steps per wave
+inline int lr_blocks(size_t m, int num_cu)
+{
+    const size_t G = (m + 3) / 4;
+    size_t want = (G + 4 * 8 - 1) / (4 * 8);
+    const size_t cap = (size_t)num_cu * 4;
+    if (want > cap) want = cap;
+    return (int)(want ? want : 1);
+}
+
+}  // namespace mirlsq

@@ -26,6 +26,7 @@
 #include "jtj_wide.h"
 #include "jtj_ring8.h"
 #include "batched_kernel.h"
+#include "broyden_lr.h"
 #include "misc_kernels.h"
 #include "solve_kernel.h"
 
@@ -52,6 +53,7 @@ struct mir_lsq_workspace {
     void* ypanel = nullptr;    // lazily allocated FD panel (device mode)
     size_t ypanel_bytes = 0;
     void* ytrial = nullptr;    // lazily allocated kChainMax x m trial residuals (speculative lambda ladder)
+    void* ulr = nullptr;       // lazily allocated kLrMax x m pending Broyden columns (broyden_lr.h)
     void* pinned = nullptr;    // small pinned host block (state + trial readback)
     void* pinned_y = nullptr;  // m-vector staging (host-callback mode), lazily allocated
     void* pinned_J = nullptr;  // m*n staging for host analytic Jacobians, lazily allocated
@@ -367,6 +369,7 @@ struct Buffers {
     LmState<T>* st;
     ChainRec<T>* rec;
     T* slabs;
+    T *lrD, *lrvec, *lrpart;   // pending Broyden steps (kLrMax x n), reduced sweep vector, per-workgroup partials
     SolveScratch<T> sc[kChainMax];
     size_t bytes;
 };
@@ -374,7 +377,7 @@ struct Buffers {
 constexpr int kPartials = 1024;
 
 template <typename T>
-Buffers<T> carve(void* base, size_t m, size_t n, const JtjPlan& plan)
+Buffers<T> carve(void* base, size_t m, size_t n, const JtjPlan& plan, int num_cu)
 {
     Buffers<T> b{};
     long long* dbg_all = nullptr;
@@ -404,6 +407,9 @@ Buffers<T> carve(void* base, size_t m, size_t n, const JtjPlan& plan)
     b.st = (LmState<T>*)take(1, sizeof(LmState<T>));
     b.rec = (ChainRec<T>*)take(kChainMax, sizeof(ChainRec<T>));
     b.slabs = (T*)take((size_t)plan.nblk * plan.njobs * plan.slab_len, sizeof(T));
+    b.lrD = (T*)take((size_t)kLrMax * n, sizeof(T));
+    b.lrvec = (T*)take((size_t)lr_len((int)n) + 6, sizeof(T));
+    b.lrpart = (T*)take((size_t)lr_blocks(m, num_cu) * lr_len((int)n), sizeof(T));
     for (int k = 0; k < kChainMax; ++k) {
         b.sc[k].Pm = (T*)take(n * n, sizeof(T));
         b.sc[k].A = (T*)take(n * n, sizeof(T));
@@ -434,7 +440,7 @@ mir_lsq_workspace* workspace_create(size_t m, size_t n)
     ws->m = m; ws->n = n; ws->elem = sizeof(T);
     ws->num_cu = query_num_cu();
     const JtjPlan plan = jtj_plan<T>(m, (int)n, ws->num_cu);
-    const Buffers<T> sz = carve<T>(nullptr, m, n, plan);
+    const Buffers<T> sz = carve<T>(nullptr, m, n, plan, ws->num_cu);
     ws->dev_bytes = sz.bytes;
     if (hipMalloc(&ws->dev, ws->dev_bytes) != hipSuccess) {
         std::fprintf(stderr, "[mir_optim_amd] hipMalloc(%zu bytes) failed\n", ws->dev_bytes);
@@ -455,6 +461,7 @@ void workspace_destroy(mir_lsq_workspace* ws)
     if (ws->dev) (void)hipFree(ws->dev);
     if (ws->ypanel) (void)hipFree(ws->ypanel);
     if (ws->ytrial) (void)hipFree(ws->ytrial);
+    if (ws->ulr) (void)hipFree(ws->ulr);
     if (ws->pinned) (void)hipHostFree(ws->pinned);
     if (ws->pinned_y) (void)hipHostFree(ws->pinned_y);
     if (ws->pinned_J) (void)hipHostFree(ws->pinned_J);
@@ -499,6 +506,12 @@ struct Solver {
     LmSettingsDev<T> sd;
     bool dbg_solve = std::getenv("MIR_LSQ_DEBUG_SOLVE") != nullptr;
     bool no_speculation = std::getenv("MIR_LSQ_NO_SPECULATION") != nullptr;
+    // Broyden passes keep J and carry the updates as pending rank-one terms (broyden_lr.h); MIR_LSQ_BROYDEN=fused
+    // selects the kernels that rewrite J every pass (k_jtj2<., true> / k_jtj8 / k_broyden_wide), MIR_LSQ_LR_MAX
+    // (1..16) the number of pending terms after which they are folded into J
+    bool lowrank = !(std::getenv("MIR_LSQ_BROYDEN") && std::getenv("MIR_LSQ_BROYDEN")[0] == 'f');
+    int lr_cap = kLrMax;
+    int lr_k = 0;
     int f_in_lds = 0;
     int solve_nb_ = 0;
     size_t solve_lds = 0;
@@ -551,7 +564,7 @@ struct Solver {
             return false;
         }
         plan = jtj_plan<T>(m, (int)n, ws->num_cu);
-        B = carve<T>(ws->dev, m, n, plan);
+        B = carve<T>(ws->dev, m, n, plan, ws->num_cu);
         st_h = reinterpret_cast<LmState<T>*>(ws->pinned);
         trial_h = reinterpret_cast<T*>(static_cast<char*>(ws->pinned) + sizeof(LmState<T>));
         if (!stream) {
@@ -564,6 +577,10 @@ struct Solver {
         sd.goodStepQuality = S->goodStepQuality; sd.lambdaIncrease = S->lambdaIncrease; sd.lambdaDecrease = S->lambdaDecrease;
         sd.qpRelTolerance = S->qpSettings.relTolerance; sd.qpAbsTolerance = S->qpSettings.absTolerance;
         sd.qpMaxIterations = S->qpSettings.maxIterations; sd.pad = 0;
+        if (const char* e = std::getenv("MIR_LSQ_LR_MAX")) {
+            const int v = std::atoi(e);
+            if (v >= 1 && v <= kLrMax) lr_cap = v;
+        }
         solve_nb_ = solve_nb((int)n, (int)sizeof(T));
         f_in_lds = solve_nb_ > 0;
         solve_lds = solve_lds_bytes((int)n, (int)sizeof(T));
@@ -689,8 +706,33 @@ struct Solver {
     }
 
     // ---- fused [Broyden] + J^T J + J^T y, all-reduce, unpack (LS:1003-1006, 1052, 1065)
+    bool broyden_lowrank(const T* y_dev, const T* yold_dev)
+    {
+        if (!ws->ulr && !ok(hipMalloc(&ws->ulr, (size_t)kLrMax * m * sizeof(T)), "hipMalloc(pending Broyden columns)")) return false;
+        T* U = static_cast<T*>(ws->ulr);
+        if (lr_k >= lr_cap) {
+            if (!ok(lr_flush<T>(B.J, U, B.lrD, lr_k, m, (int)n, ws->num_cu, stream), "broyden flush")) return false;
+            lr_k = 0;
+        }
+        LrArgs<T> a{};
+        a.J = B.J; a.U = U; a.D = B.lrD; a.dx = B.dx_acc; a.dx_dot = &B.st->dx_dot; a.y = y_dev; a.y_old = yold_dev;
+        a.partials = B.lrpart; a.m = m; a.n = (int)n; a.k = lr_k;
+        const int nblk = lr_blocks(m, ws->num_cu), len = lr_len((int)n);
+        ev_begin(1);
+        if (!ok(lr_sweep<T>(a, nblk, stream), "broyden sweep")) return false;
+        ev_end();
+        hipLaunchKernelGGL(k_lr_reduce<T>, dim3((len + 31) / 32), dim3(256), 0, stream, B.lrpart, nblk, len, B.lrvec);
+        if (comm && comm_allreduce<T>(comm, B.lrvec, (size_t)len, stream) != 0) return false;
+        hipLaunchKernelGGL(k_lr_finish<T>, dim3(n + 1), dim3(256), 0, stream, B.lrvec, B.lrD, B.dx_acc, lr_k, (int)n, B.JJ, B.Jy, B.st);
+        if (stats) stats->broyden_lr_columns += (uint64_t)lr_k;
+        ++lr_k;
+        return ok(hipGetLastError(), "broyden finish");
+    }
+
     bool jacobian_products(bool broyden, const T* y_dev, const T* yold_dev)
     {
+        if (broyden && lowrank) return broyden_lowrank(y_dev, yold_dev);
+        if (!broyden) lr_k = 0;                  // J was refreshed in full: nothing is pending any more
         JtjArgs<T> a{};
         a.J = B.J; a.Jout = B.J; a.y = y_dev; a.y_old = yold_dev; a.dx = B.dx_acc; a.dx_dot = &B.st->dx_dot;
         a.slabs = B.slabs; a.m = m; a.n = (int)n;
@@ -724,7 +766,6 @@ struct Solver {
         const size_t need = 2 * pb * m * sizeof(T);
         if (ws->ypanel_bytes < need) {
             if (ws->ypanel) (void)hipFree(ws->ypanel);
-    if (ws->ytrial) (void)hipFree(ws->ytrial);
             ws->ypanel = nullptr; ws->ypanel_bytes = 0;
             if (!ok(hipMalloc(&ws->ypanel, need), "hipMalloc(FD panel)")) return false;
             ws->ypanel_bytes = need;
