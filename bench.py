@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def pmc_traffic(kernel, m, n):
+def pmc_field(kernel, m, n, field):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/rNN/pmc_traffic.json,
     made by scripts/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command).
     PMC counters cannot be read from inside the timed run, so this is the stored measurement; None if absent or
@@ -49,9 +49,13 @@ def pmc_traffic(kernel, m, n):
     if not files:
         return None
     try:
-        return json.load(open(files[-1]))["kernels"][kernel]["hbm_bytes_per_launch"]
+        return json.load(open(files[-1]))["kernels"][kernel][field]
     except (KeyError, ValueError):
         return None
+
+
+def pmc_traffic(kernel, m, n):
+    return pmc_field(kernel, m, n, "hbm_bytes_per_launch")
 
 
 def parse():
@@ -207,6 +211,9 @@ def main():
                 "unit": "TFLOP/s", "frac": plain_flops / (plain_ms * 1e-3) / 1e12 / 78.6 if plain_ms else 0.0,
                 "avg_launch_ms": plain_ms, "launches": st["jtj_launches"] - st["jtj_broyden_launches"],
                 "traffic": pmc_traffic("mirlsq::k_jtj2<8, false>", m, n), "algorithmic_bytes_per_launch": 8.0 * (m * n + m),
+                # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) from the committed PMC pass: pipe occupancy
+                # at the clock the kernel actually ran at (the TFLOP/s fraction above is against the 2.4 GHz peak)
+                "mfma_util_pmc": pmc_field("mirlsq::k_jtj2<8, false>", m, n, "mfma_util"),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -1,7 +1,10 @@
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, as MI355X_MICROARCH.md prescribes)
 into profiles/<round>/pmc_traffic.json.  FETCH_SIZE is doubled (gfx950 reports half the bytes of a wide
 coalesced streaming read; checked here against kernels with a known byte count: k_tanh_linear reads
-8(mn + m) = 1.032 GB and reports 504 047 KB).  usage: python scripts/pmc_summary.py gpurun_out profiles/r01"""
+8(mn + m) = 1.032 GB and reports 504 047 KB).  An optional third pass `pmc_MFMA` (--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE)
+adds the MFMA pipe utilisation per kernel: busy cycles (64 per v_mfma_f64_16x16x4_f64, summed over the 1024 SIMDs) over
+GRBM_GUI_ACTIVE (summed over the 8 XCDs by rocprofv3, hence / 8) x 1024 SIMDs.
+usage: python scripts/pmc_summary.py gpurun_out profiles/r01"""
 import collections, csv, glob, json, os, sys
 
 src, dst = sys.argv[1], sys.argv[2]
@@ -16,6 +19,21 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, (n, v) in agg.items():
         out.setdefault(k, {})[c + "_KB_per_launch"] = v / n
         out[k]["launches_" + c] = n
+mf = glob.glob(os.path.join(src, "pmc_MFMA", "*", "*counter_collection.csv"))
+if mf:
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(mf[0])):
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        agg[k]["_rows"] += 1
+    for k, d in agg.items():
+        n = d["_rows"] / 4.0                                   # four counters per dispatch
+        busy, gui = d["SQ_VALU_MFMA_BUSY_CYCLES"] / n, d["GRBM_GUI_ACTIVE"] / n
+        e = out.setdefault(k, {})
+        e["mfma_busy_cycles_per_launch"] = busy
+        e["gui_active_cycles_per_xcd"] = gui / 8.0
+        e["mfma_mops_f64_per_launch"] = d["SQ_INSTS_VALU_MFMA_MOPS_F64"] / n
+        e["mfma_util"] = busy / (gui / 8.0 * 1024.0) if gui else 0.0
 for k, d in out.items():
     f, w = d.get("FETCH_SIZE_KB_per_launch", 0.0), d.get("WRITE_SIZE_KB_per_launch", 0.0)
     d["hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0          # FETCH_SIZE doubled: gfx950 correction
@@ -24,4 +42,4 @@ json.dump({"note": "rocprofv3 --pmc, separate passes; hbm_bytes = (2*FETCH_SIZE 
                    "command: bench.py --steps 2 --warmup 1 --no-cpu-baseline (cfg3, m=1e6, n=128)",
            "kernels": out}, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 for k in sorted(out, key=lambda k: -out[k]["hbm_bytes_per_launch"])[:8]:
-    print(f"{k[:60]:60s} {out[k]['hbm_bytes_per_launch'] / 1e9:8.3f} GB/launch")
+    print(f"{k[:60]:60s} {out[k]['hbm_bytes_per_launch'] / 1e9:8.3f} GB/launch   MFMA util {out[k].get('mfma_util', 0.0):.3f}")
