@@ -188,6 +188,8 @@ typedef struct mir_lsq_stats {
     double total_ms;                 /* whole call, host wall clock */
     uint64_t qp_active_set_passes;   /* passes in which BOXCQP's active-set loop ran */
     uint64_t broyden_lr_columns;     /* sum over the Broyden sweeps of the pending columns each one read (broyden_lr.h) */
+    double jtj_fd_ms;                /* of jtj_ms: launches with the finite-difference fill fused in (fbRowMajor) */
+    uint64_t jtj_fd_launches;
 } mir_lsq_stats;
 
 /* Optional per-pass trace (not in the reference; a parity-pinning aid: tests compare it event by event with the
@@ -223,6 +225,12 @@ typedef struct mir_lsq_gpu_options {
     mir_lsq_stats* stats;            /* optional out */
     mir_lsq_trace* trace;            /* optional out; read only when struct_size covers it (costs one extra
                                         device-to-host copy per pass) */
+    void* fbRowMajor;                /* optional mir_lsq_batched_function_{d,s} that writes Y as m x p ROW-major
+                                        (point k's residual of row i at Y[i * p + k]), context fbContext. With it the
+                                        finite-difference refresh of f64 problems with n % 16 == 0, n <= 128, m even needs
+                                        no separate column-fill pass: the 2n points are evaluated in one call and the
+                                        J^T J kernel forms the Jacobian rows from the (+h, -h) pairs while it writes J.
+                                        Read only when struct_size covers it; `fb` is still used for lambda-ladder trials */
 } mir_lsq_gpu_options;
 
 /* Same algorithm and result contract as mir_optimize_least_squares_{d,s}; x/l/u stay host
@@ -272,6 +280,13 @@ int mir_lsq_jtj_d(size_t m, size_t n, double* J, const double* y, const double* 
                   int broyden, double* JJ, double* Jy, void* stream, float* kernel_ms);
 int mir_lsq_jtj_s(size_t m, size_t n, float* J, const float* y, const float* y_old, const float* dx,
                   int broyden, float* JJ, float* Jy, void* stream, float* kernel_ms);
+
+/* Finite-difference fill fused into the J^T J kernel (f64, n % 16 == 0, n <= 128, m even; else -6). Yrm: m x 2n
+ * row-major, Yrm[i][2j] = f(x + h e_j)_i, Yrm[i][2j+1] = f(x - h e_j)_i; twh[j] = (x_j + h) - (x_j - h) after clipping
+ * (0 = collapsed interval: zero column, LS:1046). Writes J (m x n row-major, (Y+ - Y-) * (1 / twh) as LS:1041-1047),
+ * JJ = J^T J (full symmetric) and Jy = J^T y. */
+int mir_lsq_fd_jtj_d(size_t m, size_t n, const double* Yrm, const double* twh, const double* y, double* J,
+                     double* JJ, double* Jy, void* stream, float* kernel_ms);
 
 /* Workspace: device buffers for one (m, n, element size) problem, reusable across calls. */
 mir_lsq_workspace* mir_lsq_workspace_create(size_t m, size_t n, size_t elem_size);

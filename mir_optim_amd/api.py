@@ -29,7 +29,7 @@ __all__ = [
     "LeastSquaresException", "optimize", "optimizeLeastSquares", "solveBoxQP", "leastSquaresStatusString",
     "mir_least_squares_work_length", "mir_least_squares_iwork_length", "mir_box_qp_work_length",
     "mir_box_qp_iwork_length", "GpuOptions", "Stats", "lib", "workloads_lib", "device_count",
-    "DeviceBuffer", "Stream", "jtj", "DEVICE_CALLBACKS", "TIME_KERNELS", "optimizeLeastSquaresBatched",
+    "DeviceBuffer", "Stream", "jtj", "fd_jtj", "DEVICE_CALLBACKS", "TIME_KERNELS", "optimizeLeastSquaresBatched",
     "MODEL_EXP_DECAY", "MODEL_EXP3_AFFINE", "Trace", "TraceRecord", "Spline", "FitSplineResult", "fitSpline",
     "fit_spline_residuals",
 ]
@@ -117,7 +117,8 @@ class Stats(C.Structure):
                 ("jtj_launches", C.c_uint64), ("jtj_broyden_launches", C.c_uint64), ("jtj_ms", C.c_double),
                 ("jtj_broyden_ms", C.c_double), ("solve_ms", C.c_double), ("solve_launches", C.c_uint64),
                 ("fd_ms", C.c_double), ("total_ms", C.c_double), ("qp_active_set_passes", C.c_uint64),
-                ("broyden_lr_columns", C.c_uint64)]
+                ("broyden_lr_columns", C.c_uint64),
+                ("jtj_fd_ms", C.c_double), ("jtj_fd_launches", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -153,7 +154,8 @@ class Trace:
 class GpuOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("flags", C.c_uint32), ("stream", C.c_void_p), ("comm", C.c_void_p),
                 ("workspace", C.c_void_p), ("fbContext", C.c_void_p), ("fb", C.c_void_p), ("fd_batch", C.c_uint32),
-                ("reserved", C.c_uint32), ("stats", C.POINTER(Stats)), ("trace", C.POINTER(_TraceHeader))]
+                ("reserved", C.c_uint32), ("stats", C.POINTER(Stats)), ("trace", C.POINTER(_TraceHeader)),
+                ("fbRowMajor", C.c_void_p)]
 
     def __init__(self, **kw):
         super().__init__(**kw)
@@ -214,6 +216,9 @@ def lib():
             fn.restype = C.c_int
             fn.argtypes = [sz, sz, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                            C.c_void_p, C.POINTER(C.c_float)]
+        L.mir_lsq_fd_jtj_d.restype = C.c_int
+        L.mir_lsq_fd_jtj_d.argtypes = [sz, sz, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]
         L.mir_optimize_least_squares_batched_s.restype = C.c_int
         L.mir_optimize_least_squares_batched_s.argtypes = [C.POINTER(_Ss), sz, sz, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                            C.c_void_p, sz, C.c_void_p, C.c_void_p]
@@ -535,6 +540,29 @@ def jtj(J, y, y_old=None, dx=None, dtype=np.float64):
         raise RuntimeError(f"mir_lsq_jtj failed: {rc}")
     out = dJJ.download(), dJy.download(), dJ.download(), ms.value
     for b in (dJ, dy, dyo, ddx, dJJ, dJy):
+        b.free()
+    return out
+
+
+def fd_jtj(Yrm, twh, y):
+    """Unit-level access to the J^T J kernel with the finite-difference fill fused in (mir_lsq_fd_jtj_d).
+    Yrm: m x 2n row-major (+h / -h residual pairs). Returns (J, JJ full symmetric, Jy, kernel_ms)."""
+    L = lib()
+    Yrm = np.ascontiguousarray(Yrm, dtype=np.float64)
+    m, n2 = Yrm.shape
+    n = n2 // 2
+    dY = DeviceBuffer(Yrm)
+    dt = DeviceBuffer(np.ascontiguousarray(twh, dtype=np.float64))
+    dy = DeviceBuffer(np.ascontiguousarray(y, dtype=np.float64))
+    dJ = DeviceBuffer(nbytes=m * n * 8, dtype=np.float64, shape=(m, n))
+    dJJ = DeviceBuffer(nbytes=n * n * 8, dtype=np.float64, shape=(n, n))
+    dJy = DeviceBuffer(nbytes=n * 8, dtype=np.float64, shape=(n,))
+    ms = C.c_float(0)
+    rc = L.mir_lsq_fd_jtj_d(m, n, dY.ptr, dt.ptr, dy.ptr, dJ.ptr, dJJ.ptr, dJy.ptr, None, C.byref(ms))
+    if rc != 0:
+        raise RuntimeError(f"mir_lsq_fd_jtj_d failed: {rc}")
+    out = dJ.download(), dJJ.download(), dJy.download(), ms.value
+    for b in (dY, dt, dy, dJ, dJJ, dJy):
         b.free()
     return out
 

@@ -43,6 +43,8 @@ struct JtjArgs {
     T* slabs;          // gridDim.x slabs of jtj_slab_len<NCB>() elements
     size_t m;
     int n;
+    const T* twh;      // FD (k_jtj2<., false, true>): interval widths xph - xmh (LS:1031); then J is the m x 2n row-major
+                       // panel of perturbed residuals [f(x + h e_j), f(x - h e_j)]_j and Jout receives the Jacobian
 };
 
 constexpr int kJtjWaves = 4;   // waves per workgroup
@@ -307,12 +309,23 @@ __global__ __launch_bounds__(256) void k_jtj_slab_reduce(const T* __restrict__ s
 typedef __attribute__((address_space(3))) void* jtj_lds_ptr;
 typedef const __attribute__((address_space(1))) void* jtj_gbl_ptr;
 
-template <int NCB, bool BROYDEN> struct Jtj2Cfg {
+template <int NCB, bool BROYDEN, bool FD = false> struct Jtj2Cfg {
     // rows per stage: ~16 KB stages so that one barrier is amortised over 4+ row groups (a probe on
-    // MI355X: 4 KB stages 0.33 ms, 16 KB stages 0.27 ms for the n = 128 MFMA work; scripts/probes)
-    static constexpr int RS = NCB <= 4 ? 32 : (NCB == 5 ? 24 : (NCB == 6 ? 20 : 16));
+    // MI355X: 4 KB stages 0.33 ms, 16 KB stages 0.27 ms for the n = 128 MFMA work; scripts/probes).
+    // FD: a source row is 2n doubles (the +h / -h residual pairs), so half the rows make the same stage bytes
+#ifndef MIRLSQ_FD_BIG_STAGES
+#define MIRLSQ_FD_BIG_STAGES 0          // measured: 2.78 ms at m = 1e6, n = 128 (one workgroup per CU cannot hide the MFMA latency)
+#endif
+#ifndef MIRLSQ_FD_RS8
+#define MIRLSQ_FD_RS8 8                 // rows per stage at NCB > 5; measured at m = 1e6, n = 128: 8 rows (D = 2) 0.755 ms,
+                                        // 4 rows (D = 6, three times the bytes in flight) 0.852 ms: barriers cost more than latency
+#endif
+    // FD, big stages: the plain kernel's rows per stage (twice its bytes) in a 128 KB ring, one workgroup per CU
+    static constexpr bool FDBIG = FD && MIRLSQ_FD_BIG_STAGES;
+    static constexpr int RS = (FD && !FDBIG) ? (NCB <= 4 ? 16 : (NCB == 5 ? 12 : MIRLSQ_FD_RS8))
+                                             : (NCB <= 4 ? 32 : (NCB == 5 ? 24 : (NCB == 6 ? 20 : 16)));
     static constexpr int GPS = RS / 4;                                                     // 4-row groups per stage
-    static constexpr int IPS = RS * NCB / 8;                                               // 1 KB DMA instructions per stage
+    static constexpr int IPS = RS * NCB * (FD ? 2 : 1) / 8;                                // 1 KB DMA instructions per stage
     static constexpr int SLOT_BYTES = IPS * 1024;
     // DMA instructions the busier of the two loading waves issues per stage (waves 0, 1 issue every
     // DMA and never store; waves 2, 3 do every Broyden write-back and issue no DMA: a counted vmcnt
@@ -320,7 +333,7 @@ template <int NCB, bool BROYDEN> struct Jtj2Cfg {
     // DMA wait pass early now and then, a run-to-run nondeterminism caught by scripts/diag_determinism.py)
     static constexpr int MAX_OPS = (IPS + 1) / 2;
     static constexpr int D0 = 60 / MAX_OPS;                                                // vmcnt is 6 bits
-    static constexpr int D1 = (64 * 1024) / SLOT_BYTES - 2;                                // 64 KB ring
+    static constexpr int D1 = ((FDBIG ? 128 : 64) * 1024) / SLOT_BYTES - 2;                // 64 KB ring (128 KB: FD big stages)
     static constexpr int D2 = D0 < D1 ? D0 : D1;
     static constexpr int D = D2 < 1 ? 1 : (D2 > 15 ? 15 : D2);                             // stages in flight
     static constexpr int NS = D + 2;                                                       // ring slots
@@ -333,14 +346,16 @@ template <int NCB, bool BROYDEN> struct Jtj2Cfg {
 };
 constexpr int kJtj2Threads = 4 * kWave;
 
-template <int NCB, bool BROYDEN, int ROLE>
+template <int NCB, bool BROYDEN, int ROLE, bool FD = false>
 __device__ __forceinline__ void jtj2_body(const JtjArgs<double>& a, unsigned char* smem, int lane, size_t s0, size_t S)
 {
     using T = double;
     using Acc = typename Mma<T>::Acc;
-    using C = Jtj2Cfg<NCB, BROYDEN>;
+    using C = Jtj2Cfg<NCB, BROYDEN, FD>;
+    static_assert(!(BROYDEN && FD), "a pass either refreshes J from finite differences or updates it");
     constexpr int NACC = jtj_nacc<NCB>();
     constexpr int n = 16 * NCB;
+    constexpr int RW = FD ? 2 * n : n;                       // doubles per source row
     // this wave's share of a stage: waves 0, 1 issue the DMA instructions (ROLE, ROLE + 2, ...) and never
     // store; waves 2, 3 write back the Broyden-updated column blocks c = ROLE (mod 2) and never load
     constexpr bool LOADER = ROLE < 2;
@@ -350,9 +365,9 @@ __device__ __forceinline__ void jtj2_body(const JtjArgs<double>& a, unsigned cha
     const size_t m = a.m;
 
     const unsigned char* Jb = reinterpret_cast<const unsigned char*>(a.J);
-    const size_t total = m * (size_t)n * sizeof(T);
+    const size_t total = m * (size_t)RW * sizeof(T);
     auto issue = [&](size_t s) {
-        const size_t base = (s0 + s) * (size_t)C::RS * n * sizeof(T);
+        const size_t base = (s0 + s) * (size_t)C::RS * RW * sizeof(T);
         unsigned char* slot = smem + (s % C::NS) * C::SLOT_BYTES;
 #pragma unroll
         for (int k = 0; k < MYI; ++k) {
@@ -388,6 +403,18 @@ __device__ __forceinline__ void jtj2_body(const JtjArgs<double>& a, unsigned cha
     }
     T neg_d = 0;
     if constexpr (BROYDEN) neg_d = -(T(1) / *a.dx_dot);
+    T inv[NCB];                                              // FD: 1 / twh of this lane's columns (LS:1047)
+    bool zc[NCB];                                            //     collapsed interval: zero column (LS:1046)
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+        inv[c] = 0;
+        zc[c] = false;
+        if constexpr (FD) {
+            const T t = a.twh[16 * c + p];
+            zc[c] = t == 0;
+            inv[c] = zc[c] ? T(0) : T(1) / t;
+        }
+    }
     // the loads above must have retired before the counted waits below start counting
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -421,7 +448,17 @@ __device__ __forceinline__ void jtj2_body(const JtjArgs<double>& a, unsigned cha
         struct Grp { T v[NCB]; T y, yo; };
         auto read = [&](int gi, Grp& g) {
 #pragma unroll
-            for (int c = 0; c < NCB; ++c) g.v[c] = slot[(4 * gi + q) * n + 16 * c + p];
+            for (int c = 0; c < NCB; ++c) {
+                if constexpr (FD) {
+                    // one ds_read_b128: [f(x + h e_j), f(x - h e_j)] of row 4 gi + q, j = 16 c + p
+                    const double2 t = *reinterpret_cast<const double2*>(slot + (4 * gi + q) * RW + 2 * (16 * c + p));
+                    T d = t.x;                           // copy(mBuffer, Jj)          LS:1041
+                    d += T(-1) * t.y;                    // axpy(-1, mBuffer, Jj)      LS:1045
+                    g.v[c] = zc[c] ? T(0) : d * inv[c];  // scal(1 / twh, Jj)          LS:1047
+                } else {
+                    g.v[c] = slot[(4 * gi + q) * n + 16 * c + p];
+                }
+            }
             const size_t lr = s * C::RS + 4 * gi + q;       // row index local to this workgroup
             const int yidx = (int)((lr >> 7) % C::YNS) * 128 + (int)(lr & 127);
             g.y = yring[yidx];
@@ -451,6 +488,14 @@ __device__ __forceinline__ void jtj2_body(const JtjArgs<double>& a, unsigned cha
                     g.v[c] = g.v[c] + u * dxr[c];         // LS:1006
                     if constexpr (!LOADER) { if (c % 2 == ROLE - 2) { if (rok) wp[16 * c + p] = g.v[c]; } }
                 }
+            }
+            if constexpr (FD && !LOADER) {
+                // the Jacobian rows leave through the two storer waves (column blocks c = ROLE (mod 2)), like the
+                // Broyden write-back: the loader waves' counted vmcnt waits stay over DMA operations only
+                T* wp = a.Jout + (rok ? row : m - 1) * (size_t)n;
+#pragma unroll
+                for (int c = 0; c < NCB; ++c)
+                    if (c % 2 == ROLE - 2) { if (rok) wp[16 * c + p] = g.v[c]; }
             }
             if constexpr (ROLE == 0) {
 #pragma unroll
@@ -502,10 +547,10 @@ __device__ __forceinline__ void jtj2_body(const JtjArgs<double>& a, unsigned cha
     }
 }
 
-template <int NCB, bool BROYDEN>
+template <int NCB, bool BROYDEN, bool FD = false>
 __global__ __launch_bounds__(kJtj2Threads, 2) void k_jtj2(JtjArgs<double> a)
 {
-    using C = Jtj2Cfg<NCB, BROYDEN>;
+    using C = Jtj2Cfg<NCB, BROYDEN, FD>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -517,10 +562,10 @@ __global__ __launch_bounds__(kJtj2Threads, 2) void k_jtj2(JtjArgs<double> a)
     const size_t s1 = s0 + per < Stot ? s0 + per : Stot;
     const size_t S = s1 - s0;
 
-    if (wave == 0) jtj2_body<NCB, BROYDEN, 0>(a, smem2, lane, s0, S);
-    else if (wave == 1) jtj2_body<NCB, BROYDEN, 1>(a, smem2, lane, s0, S);
-    else if (wave == 2) jtj2_body<NCB, BROYDEN, 2>(a, smem2, lane, s0, S);
-    else jtj2_body<NCB, BROYDEN, 3>(a, smem2, lane, s0, S);
+    if (wave == 0) jtj2_body<NCB, BROYDEN, 0, FD>(a, smem2, lane, s0, S);
+    else if (wave == 1) jtj2_body<NCB, BROYDEN, 1, FD>(a, smem2, lane, s0, S);
+    else if (wave == 2) jtj2_body<NCB, BROYDEN, 2, FD>(a, smem2, lane, s0, S);
+    else jtj2_body<NCB, BROYDEN, 3, FD>(a, smem2, lane, s0, S);
 }
 
 // =========================================================================================

@@ -258,6 +258,51 @@ hipError_t jtj2_launch(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t s
     }
     return hipErrorInvalidValue;
 }
+// finite-difference refresh fused in: J = a.J is the m x 2n row-major residual panel, a.Jout receives the Jacobian
+template <int NCB>
+hipError_t jtj2_fd_launch_one(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t s)
+{
+    auto kern = k_jtj2<NCB, false, true>;
+    constexpr size_t lds = Jtj2Cfg<NCB, false, true>::LDS_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(kJtj2Threads), lds, s, a);
+    return hipGetLastError();
+}
+template <typename T>
+hipError_t jtj2_fd_launch(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
+{
+    if constexpr (sizeof(T) == 8) {
+        if (!p.v2) return hipErrorInvalidValue;
+        switch (p.ncb) {
+        case 1: return jtj2_fd_launch_one<1>(p, a, s);
+        case 2: return jtj2_fd_launch_one<2>(p, a, s);
+        case 3: return jtj2_fd_launch_one<3>(p, a, s);
+        case 4: return jtj2_fd_launch_one<4>(p, a, s);
+        case 5: return jtj2_fd_launch_one<5>(p, a, s);
+        case 6: return jtj2_fd_launch_one<6>(p, a, s);
+        case 7: return jtj2_fd_launch_one<7>(p, a, s);
+        case 8: return jtj2_fd_launch_one<8>(p, a, s);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+// same, with the slab reduction: -> packed[ n(n+1)/2 + n ]
+template <typename T>
+hipError_t jtj_run_fd(const JtjPlan& p, const JtjArgs<T>& a, T* packed, hipStream_t s)
+{
+    hipError_t e = jtj2_fd_launch<T>(p, a, s);
+    if (e != hipSuccess) return e;
+    const int rb = (p.slab_len + 31) / 32;
+    hipLaunchKernelGGL(k_jtj_slab_reduce<T>, dim3(rb), dim3(256), 0, s, a.slabs, p.nblk, p.slab_len, p.ncb, a.n, packed);
+    return hipGetLastError();
+}
+
 template <typename T, bool BR>
 hipError_t jtj2_dispatch(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
 {
@@ -490,6 +535,8 @@ struct Solver {
     void* gctx; G g;
     void* tmctx; mir_least_squares_thread_manager tm;
     void* fbctx; FB fb;
+    FB fbr = nullptr;          // batched residual callback writing Y row-major (m x p): finite differences fused into k_jtj2
+    bool fd_fused = false;     // the FD panel of this refresh is row-major in ws->ypanel and J has not been filled yet
     uint32_t fd_batch;
     bool device_cb;
     bool time_kernels;
@@ -600,6 +647,7 @@ struct Solver {
                 if (e.kind == 0) { stats->jtj_ms += ms; stats->jtj_launches++; }
                 else if (e.kind == 1) { stats->jtj_ms += ms; stats->jtj_launches++; stats->jtj_broyden_ms += ms; stats->jtj_broyden_launches++; }
                 else if (e.kind == 2) { stats->solve_ms += ms; stats->solve_launches++; }
+                else if (e.kind == 3) { stats->jtj_ms += ms; stats->jtj_launches++; stats->jtj_fd_ms += ms; stats->jtj_fd_launches++; }
             }
         }
         for (auto& e : events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -736,9 +784,19 @@ struct Solver {
         JtjArgs<T> a{};
         a.J = B.J; a.Jout = B.J; a.y = y_dev; a.y_old = yold_dev; a.dx = B.dx_acc; a.dx_dot = &B.st->dx_dot;
         a.slabs = B.slabs; a.m = m; a.n = (int)n;
-        ev_begin(broyden ? 1 : 0);
-        if (!ok(jtj_run<T>(plan, a, broyden, B.packed, stream), "jtj kernel")) return false;
-        ev_end();
+        if (!broyden && fd_fused) {
+            // the row-major FD panel is still in ws->ypanel: one kernel forms the Jacobian rows (LS:1041-1047), writes
+            // them to J and accumulates J^T J / J^T y from the same registers
+            fd_fused = false;
+            a.J = static_cast<const T*>(ws->ypanel); a.twh = B.twh;
+            ev_begin(3);
+            if (!ok(jtj_run_fd<T>(plan, a, B.packed, stream), "fd + jtj kernel")) return false;
+            ev_end();
+        } else {
+            ev_begin(broyden ? 1 : 0);
+            if (!ok(jtj_run<T>(plan, a, broyden, B.packed, stream), "jtj kernel")) return false;
+            ev_end();
+        }
         if (comm && comm_allreduce<T>(comm, B.packed, (size_t)n * (n + 1) / 2 + n, stream) != 0) return false;
         hipLaunchKernelGGL(k_unpack_grad<T>, dim3(n + 1), dim3(128), 0, stream, B.packed, (int)n, B.JJ, B.Jy, B.st);
         return ok(hipGetLastError(), "unpack");
@@ -771,6 +829,15 @@ struct Solver {
             ws->ypanel_bytes = need;
         }
         T* Y = static_cast<T*>(ws->ypanel);
+        static const bool no_fuse = std::getenv("MIR_LSQ_FD_FUSE") && std::getenv("MIR_LSQ_FD_FUSE")[0] == '0';
+        if (fbr && plan.v2 && pb == n && sizeof(T) == 8 && !no_fuse) {
+            // all 2n points in one sweep, Y[i][2j], Y[i][2j+1] = f(x + h e_j)_i, f(x - h e_j)_i; k_jtj2<., false, true>
+            // (jacobian_products) turns the pairs into Jacobian rows on its way to J^T J -- no k_fd_fill pass
+            fbr(fbctx, m, n, 2 * (size_t)n, B.X, Y);
+            fd_fused = true;
+            ret.fCalls += n;
+            return ok(hipGetLastError(), "fd batched callback");
+        }
         for (size_t j0 = 0; j0 < n; j0 += pb) {
             const size_t pc = (j0 + pb <= n) ? pb : n - j0;
             if (fb) {
@@ -1099,6 +1166,8 @@ typename Abi<T>::Result solve_entry(const typename Abi<T>::Settings* settings, s
         s.fd_batch = opt->fd_batch;
         s.stats = opt->stats;
         if (opt->struct_size >= offsetof(mir_lsq_gpu_options, trace) + sizeof(void*)) s.trace = opt->trace;
+        if (opt->struct_size >= offsetof(mir_lsq_gpu_options, fbRowMajor) + sizeof(void*) && s.device_cb)
+            s.fbr = reinterpret_cast<typename Abi<T>::FB>(opt->fbRowMajor);
         if (s.trace) s.trace->count = 0;
     }
     return s.run();
@@ -1424,6 +1493,36 @@ int mir_lsq_jtj_d(size_t m, size_t n, double* J, const double* y, const double* 
                   double* JJ, double* Jy, void* stream, float* kernel_ms)
 {
     return jtj_entry<double>(m, n, J, y, y_old, dx, broyden, JJ, Jy, stream, kernel_ms);
+}
+int mir_lsq_fd_jtj_d(size_t m, size_t n, const double* Yrm, const double* twh, const double* y, double* J,
+                     double* JJ, double* Jy, void* stream_, float* kernel_ms)
+{
+    if (!device_available()) return -1;
+    if (n == 0 || n > (size_t)kSolveMaxN || m == 0) return -2;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const JtjPlan plan = jtj_plan<double>(m, (int)n, query_num_cu());
+    if (!plan.v2) return -6;                                    // shape not covered by the fused kernel
+    const size_t packed_len = n * (n + 1) / 2 + n + 8;
+    double *slabs = nullptr, *packed = nullptr;
+    LmState<double>* st = nullptr;
+    if (hipMalloc((void**)&slabs, sizeof(double) * (size_t)plan.nblk * plan.njobs * plan.slab_len) != hipSuccess) return -3;
+    if (hipMalloc((void**)&packed, sizeof(double) * packed_len) != hipSuccess) { (void)hipFree(slabs); return -3; }
+    if (hipMalloc((void**)&st, sizeof(LmState<double>)) != hipSuccess) { (void)hipFree(slabs); (void)hipFree(packed); return -3; }
+    int rc = 0;
+    JtjArgs<double> a{};
+    a.J = Yrm; a.Jout = J; a.y = y; a.y_old = y; a.dx = nullptr; a.dx_dot = nullptr; a.slabs = slabs; a.m = m; a.n = (int)n;
+    a.twh = twh;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, stream);
+    if (jtj_run_fd<double>(plan, a, packed, stream) != hipSuccess) rc = -4;
+    (void)hipEventRecord(e1, stream);
+    hipLaunchKernelGGL(k_unpack_grad<double>, dim3((unsigned)n + 1), dim3(128), 0, stream, packed, (int)n, JJ, Jy, st);
+    if (hipStreamSynchronize(stream) != hipSuccess) rc = -5;
+    if (kernel_ms) { float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); *kernel_ms = ms; }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(slabs); (void)hipFree(packed); (void)hipFree(st);
+    return rc;
 }
 int mir_lsq_jtj_s(size_t m, size_t n, float* J, const float* y, const float* y_old, const float* dx, int broyden,
                   float* JJ, float* Jy, void* stream, float* kernel_ms)

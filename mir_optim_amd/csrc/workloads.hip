@@ -361,7 +361,9 @@ __device__ __forceinline__ void tlb_loader(const double* __restrict__ A, const d
     }
 }
 
-template <int NK, bool ALIGNED, int GROUP>
+// RM: Y is m x P row-major (point k's residual of row i at Y[i P + k]; 16 lanes of a row = 128 contiguous bytes) --
+// the layout the solver's fused finite-difference J^T J kernel consumes (mir_lsq_gpu_options.fbRowMajor)
+template <int NK, bool ALIGNED, int GROUP, bool RM = false>
 __device__ __forceinline__ void tlb_compute(const double* __restrict__ X, double* __restrict__ Y, size_t m, int P,
                                             unsigned char* smem, int lane, int wave, size_t S, int nchunks)
 {
@@ -390,7 +392,8 @@ __device__ __forceinline__ void tlb_compute(const double* __restrict__ X, double
         double xf[NK];
 #pragma unroll
         for (int s = 0; s < NK; ++s) xf[s] = X[(size_t)pl * C::N + 8 * (s >> 1) + 2 * fq + (s & 1)];
-        double* yp = Y + (size_t)pl * m;
+        double* yp = RM ? Y + pl : Y + (size_t)pl * m;
+        const size_t ldr = RM ? (size_t)P : 1;                  // distance between consecutive rows of one point
 
         // TILES == 2: acc0 / acc1 are the two row tiles of the stage; TILES == 1: the even / odd column pairs of the
         // one tile (two independent chains either way), summed into acc0 at the end
@@ -430,7 +433,12 @@ __device__ __forceinline__ void tlb_compute(const double* __restrict__ X, double
             const double y0 = dtanh(acc[0]) - b0.x, y1 = dtanh(acc[1]) - b0.y;
             const double y2 = dtanh(acc[2]) - b1.x, y3 = dtanh(acc[3]) - b1.y;
             const size_t ra = row0 + 2 * fq, rb = row0 + 8 + 2 * fq;
-            if constexpr (FULL && ALIGNED) {
+            if constexpr (RM) {
+                if (FULL || ra < m) yp[ra * ldr] = y0;
+                if (FULL || ra + 1 < m) yp[(ra + 1) * ldr] = y1;
+                if (FULL || rb < m) yp[rb * ldr] = y2;
+                if (FULL || rb + 1 < m) yp[(rb + 1) * ldr] = y3;
+            } else if constexpr (FULL && ALIGNED) {
                 *reinterpret_cast<double2*>(yp + ra) = make_double2(y0, y1);
                 *reinterpret_cast<double2*>(yp + rb) = make_double2(y2, y3);
             } else if constexpr (FULL) {
@@ -484,7 +492,7 @@ __device__ __forceinline__ void tlb_compute(const double* __restrict__ X, double
     }
 }
 
-template <int NK>
+template <int NK, bool RM = false>
 __global__ __launch_bounds__(TlbCfg<NK>::THREADS) void k_tanh_linear_batched_dma(const double* __restrict__ A,
                                                                                   const double* __restrict__ b,
                                                                                   const double* __restrict__ X,
@@ -502,30 +510,66 @@ __global__ __launch_bounds__(TlbCfg<NK>::THREADS) void k_tanh_linear_batched_dma
     if (wave == C::COMPUTE_WAVES) tlb_loader<NK, 0>(A, b, m, tlb_smem, lane, S, F);
     else if (wave == C::COMPUTE_WAVES + 1) tlb_loader<NK, 1>(A, b, m, tlb_smem, lane, S, F);
     else {
-        const bool aligned = ((m & 1) == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
-        if (wave < 4) {
-            if (aligned) tlb_compute<NK, true, 0>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
-            else tlb_compute<NK, false, 0>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
+        if constexpr (RM) {
+            if (wave < 4) tlb_compute<NK, false, 0, true>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
+            else tlb_compute<NK, false, 1, true>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
         } else {
-            if (aligned) tlb_compute<NK, true, 1>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
-            else tlb_compute<NK, false, 1>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
+            const bool aligned = ((m & 1) == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
+            if (wave < 4) {
+                if (aligned) tlb_compute<NK, true, 0>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
+                else tlb_compute<NK, false, 0>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
+            } else {
+                if (aligned) tlb_compute<NK, true, 1>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
+                else tlb_compute<NK, false, 1>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
+            }
         }
     }
 }
 
-template <int NK>
+template <int NK, bool RM = false>
 bool launch_tlb_dma(const double* A, const double* b, const double* X, double* Y, size_t m, int P, hipStream_t s)
 {
     using C = TlbCfg<NK>;
     static bool attr_ok = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(k_tanh_linear_batched_dma<NK>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k_tanh_linear_batched_dma<NK, RM>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) == hipSuccess;
     }();
     if (!attr_ok) return false;
     const size_t Stot = (m + C::ROWS - 1) / C::ROWS;
     const unsigned grid = (unsigned)(Stot < 256 ? Stot : 256);
-    hipLaunchKernelGGL((k_tanh_linear_batched_dma<NK>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, s, A, b, X, Y, m, P);
+    hipLaunchKernelGGL((k_tanh_linear_batched_dma<NK, RM>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, s, A, b, X, Y, m, P);
     return true;
+}
+
+// row-major output for shapes the DMA kernel does not cover: one thread per (row, point), plain dot product
+__global__ __launch_bounds__(256) void k_tanh_linear_batched_rm_generic(const double* __restrict__ A, const double* __restrict__ b,
+                                                                        const double* __restrict__ X, double* __restrict__ Y,
+                                                                        size_t m, int n, int P)
+{
+    const size_t total = m * (size_t)P;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = e / P;
+        const int k = (int)(e % P);
+        const double* a = A + i * (size_t)n;
+        const double* x = X + (size_t)k * n;
+        double s0 = 0;
+        for (int j = 0; j < n; ++j) s0 += a[j] * x[j];
+        Y[e] = dtanh(s0) - b[i];
+    }
+}
+
+void launch_tanh_linear_batched_rm(const double* A, const double* b, const double* X, double* Y, size_t m, int n, int P,
+                                   hipStream_t s)
+{
+    if (m >= 32) {
+        if (n == 256 && launch_tlb_dma<64, true>(A, b, X, Y, m, P, s)) return;
+        if (n == 128 && launch_tlb_dma<32, true>(A, b, X, Y, m, P, s)) return;
+        if (n == 64 && launch_tlb_dma<16, true>(A, b, X, Y, m, P, s)) return;
+        if (n == 32 && launch_tlb_dma<8, true>(A, b, X, Y, m, P, s)) return;
+    }
+    size_t blocks = (m * (size_t)P + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_tanh_linear_batched_rm_generic, dim3((unsigned)(blocks ? blocks : 1)), dim3(256), 0, s, A, b, X, Y, m, n, P);
 }
 
 bool launch_tanh_linear_batched(const double* A, const double* b, const double* X, double* Y, size_t m, int n, int P,
@@ -653,6 +697,12 @@ void wl_tanh_linear_fb_d(void* vctx, size_t m, size_t n, size_t p, const double*
     if (launch_tanh_linear_batched((const double*)c->A, (const double*)c->b, X, Y, m, (int)n, (int)p, (hipStream_t)c->stream)) return;
     for (size_t k = 0; k < p; ++k)
         launch_tanh_linear<double, 0>((const double*)c->A, (const double*)c->b, X + k * n, Y + k * m, m, (int)n, (hipStream_t)c->stream);
+}
+// the same p points with Y written m x p row-major (mir_lsq_gpu_options.fbRowMajor)
+void wl_tanh_linear_fbr_d(void* vctx, size_t m, size_t n, size_t p, const double* X, double* Y)
+{
+    auto* c = static_cast<wl_tanh_linear_ctx*>(vctx);
+    launch_tanh_linear_batched_rm((const double*)c->A, (const double*)c->b, X, Y, m, (int)n, (int)p, (hipStream_t)c->stream);
 }
 void wl_tanh_linear_f_s(void* vctx, size_t m, size_t n, const float* x, float* y)
 {

@@ -53,6 +53,8 @@ class DeviceProblem:
             o.fbContext = C.addressof(self.ctx)
             o.fb = self.fb
             o.fd_batch = fd_batch
+            if getattr(self, "fbr", None) is not None and batched != "pointmajor":
+                o.fbRowMajor = self.fbr          # row-major FD panel: the fill is fused into the J^T J kernel
         if stats is not None:
             o.stats = C.pointer(stats)
         if trace is not None:
@@ -78,6 +80,7 @@ class TanhLinear(DeviceProblem):
         self.f = _addr("wl_tanh_linear_f_" + suf)
         self.g = _addr("wl_tanh_linear_g_" + suf)
         self.fb = _addr("wl_tanh_linear_fb_d") if dtype == np.float64 else None
+        self.fbr = _addr("wl_tanh_linear_fbr_d") if dtype == np.float64 else None
 
 
 class Curve(DeviceProblem):

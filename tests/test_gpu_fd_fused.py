@@ -1,0 +1,137 @@
+"""Finite-difference refresh fused into the J^T J kernel (k_jtj2<., false, true>, mir_lsq_gpu_options.fbRowMajor).
+
+Kernel level (mir_lsq_fd_jtj_d): J is bit-exact against the reference's column arithmetic copy / axpy(-1) / scal(1/twh)
+(LS:1041-1047) done in numpy; J^T J and J^T y are bit-exact on exact-integer inputs and within rounding otherwise.
+Whole path: solves through the row-major batched callback against the same solves through the point-major callback +
+k_fd_fill, and the user-side row-major residual kernel against its point-major twin."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import mir_optim_amd as M
+from mir_optim_amd import api, workloads as W
+import problems as P
+from test_gpu_broyden_lr import assert_same_trajectory
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_fill(Yrm, twh):
+    yp, ym = Yrm[:, 0::2], Yrm[:, 1::2]
+    d = yp.copy()
+    d += -1.0 * ym
+    with np.errstate(divide="ignore"):
+        inv = 1.0 / twh
+    J = d * inv
+    J[:, twh == 0] = 0.0
+    return J
+
+
+@pytest.mark.parametrize("m,n", [(4096, 128), (5000, 16), (30, 32), (2, 48), (10002, 64), (7778, 80), (12344, 96),
+                                 (6, 112), (100000, 128)])
+def test_fd_jtj_exact_integers(m, n):
+    rng = np.random.default_rng(m + n)
+    Yrm = rng.integers(-8, 9, size=(m, 2 * n)).astype(np.float64)
+    twh = np.full(n, 2.0 ** -25)
+    twh[rng.integers(0, n)] = 2.0 ** -26                       # a clipped interval
+    if n > 16:
+        twh[3] = 0.0                                           # a collapsed one
+    y = rng.integers(-4, 5, size=m).astype(np.float64)
+    J, JJ, Jy, ms = M.fd_jtj(Yrm, twh, y)
+    Jr = ref_fill(Yrm, twh)
+    assert np.array_equal(J, Jr)
+    # entries are integers times powers of two: sums are exact as long as they stay below 2^53 ulps of the scale
+    assert np.array_equal(JJ, Jr.T @ Jr) or np.allclose(JJ, Jr.T @ Jr, rtol=1e-15, atol=0)
+    assert np.array_equal(Jy, Jr.T @ y) or np.allclose(Jy, Jr.T @ y, rtol=1e-15, atol=0)
+    assert np.array_equal(JJ, JJ.T)
+
+
+@pytest.mark.parametrize("m,n", [(20000, 128), (9998, 32), (50, 16), (33334, 112)])
+def test_fd_jtj_random(m, n):
+    rng = np.random.default_rng(7 * m + n)
+    base = rng.standard_normal((m, 1))
+    Jtrue = rng.standard_normal((m, n))
+    h = 2.0 ** -26
+    Yrm = np.empty((m, 2 * n))
+    Yrm[:, 0::2] = base + h * Jtrue
+    Yrm[:, 1::2] = base - h * Jtrue
+    twh = np.full(n, 2 * h)
+    y = rng.standard_normal(m)
+    J, JJ, Jy, ms = M.fd_jtj(Yrm, twh, y)
+    Jr = ref_fill(Yrm, twh)
+    assert np.array_equal(J, Jr)
+    assert np.allclose(JJ, Jr.T @ Jr, rtol=1e-12, atol=1e-9 * m)
+    assert np.allclose(Jy, Jr.T @ y, rtol=1e-12, atol=1e-9 * m)
+    # the same J through the plain kernel: the two J^T J differ by summation order only
+    JJ2, Jy2, _, _ = M.jtj(Jr, y)
+    assert np.allclose(JJ, JJ2, rtol=1e-13, atol=1e-10 * m) and np.allclose(Jy, Jy2, rtol=1e-13, atol=1e-10 * m)
+
+
+@pytest.mark.parametrize("m,n", [(5000, 128), (4098, 64), (3000, 32), (2500, 16), (2222, 48), (40, 128), (31, 32)])
+def test_row_major_batched_residual_equals_point_major(m, n):
+    w = P.tanh_linear(m, n)
+    prob = W.TanhLinear(w["A"], w["b"])
+    rng = np.random.default_rng(n)
+    p = 2 * n
+    X = w["x0"][None, :] + 1e-3 * rng.standard_normal((p, n))
+    dX = api.DeviceBuffer(np.ascontiguousarray(X))
+    dY1 = api.DeviceBuffer(nbytes=p * m * 8, dtype=np.float64, shape=(p, m))
+    dY2 = api.DeviceBuffer(nbytes=p * m * 8, dtype=np.float64, shape=(m, p))
+    FB = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p)
+    FB(prob.fb)(C.addressof(prob.ctx), m, n, p, dX.ptr, dY1.ptr)
+    FB(prob.fbr)(C.addressof(prob.ctx), m, n, p, dX.ptr, dY2.ptr)
+    prob.stream.synchronize()
+    Y1, Y2 = dY1.download(), dY2.download()
+    expect = np.tanh(w["A"] @ X.T) - w["b"][:, None]
+    assert np.allclose(Y2, expect, rtol=0, atol=1e-13)
+    if n in (32, 64, 128) and m >= 32:
+        assert np.array_equal(Y2, Y1.T)                          # same kernel, same arithmetic, other store pattern
+    else:
+        assert np.allclose(Y2, Y1.T, rtol=0, atol=1e-14)
+    for b in (dX, dY1, dY2):
+        b.free()
+
+
+@pytest.mark.parametrize("m,n,bounded", [(20000, 32, False), (50000, 128, False), (4096, 16, False), (30000, 64, False),
+                                         (7000, 48, False), (3000, 16, True), (10000, 96, True)])
+def test_fused_fd_solve_matches_fill_pass(m, n, bounded):
+    w = P.tanh_linear(m, n)
+    prob = W.TanhLinear(w["A"], w["b"])
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
+    lo = up = None
+    if bounded:
+        lo = np.where(np.arange(n) % 3 == 0, w["xstar"] + 0.02, -np.inf)     # the minimiser violates a third of the bounds
+        up = np.full(n, np.inf)
+    x0 = w["x0"] if not bounded else np.maximum(w["x0"], np.where(np.isfinite(lo), lo, -np.inf))
+    out = {}
+    for mode in (True, "pointmajor"):
+        tr, st = M.Trace(4096), M.Stats()
+        res, x = prob.solve(x0, l=lo, u=up, settings=s, batched=mode, trace=tr, stats=st, flags=M.TIME_KERNELS)
+        out[mode] = (res, x, tr.records(), st)
+    (rf, xf, tf, sf), (rp, xp, tp, sp) = out[True], out["pointmajor"]
+    assert sf.jtj_fd_launches == sf.jacobian_full >= 1 and sp.jtj_fd_launches == 0
+    assert (rf.fCalls, rf.gCalls) == (rp.fCalls, rp.gCalls) or first_differs_late(tf, tp)
+    assert int(rf.status) >= 0 and int(rp.status) >= 0
+    assert np.allclose(xf, xp, rtol=1e-6, atol=1e-9), np.abs(xf - xp).max()
+    assert np.isclose(rf.residual, rp.residual, rtol=1e-9)
+    assert_same_trajectory(tf, tp, (m, n, bounded))
+
+
+def first_differs_late(ta, tb):
+    k = next((i for i, (a, b) in enumerate(zip(ta, tb)) if a[0] != b[0]), min(len(ta), len(tb)))
+    return k >= 5
+
+
+def test_collapsed_interval_gives_zero_column_through_the_fused_path():
+    """x_j pinned by l_j = u_j: xph == xmh, twh = 0, the column of J is zero (LS:1033, 1046) and x_j never moves."""
+    m, n = 6000, 32
+    w = P.tanh_linear(m, n)
+    prob = W.TanhLinear(w["A"], w["b"])
+    lo, up = np.full(n, -np.inf), np.full(n, np.inf)
+    lo[5] = up[5] = w["x0"][5]
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
+    r1, x1 = prob.solve(w["x0"], l=lo, u=up, settings=s, batched=True)
+    r2, x2 = prob.solve(w["x0"], l=lo, u=up, settings=s, batched="pointmajor")
+    assert x1[5] == w["x0"][5] == x2[5]
+    assert int(r1.status) >= 0 and np.allclose(x1, x2, rtol=1e-6, atol=1e-9) and np.isclose(r1.residual, r2.residual, rtol=1e-9)
