@@ -71,6 +71,11 @@ def parse():
                          "J^T J kernel), through the point-major batched callback + k_fd_fill, or one call per point")
     ap.add_argument("--abs-tolerance", type=float, default=1e-5,
                     help="LeastSquaresSettings.absTolerance of the workload (see DESIGN.md section 5 for why not 1e-9)")
+    ap.add_argument("--control-plane", choices=["gloo", "nccl"], default="gloo",
+                    help="torch.distributed backend for barriers / id exchange (the solve's collectives always use the "
+                         "solver's own RCCL communicator)")
+    ap.add_argument("--settle", type=float, default=8.0,
+                    help="N > 1: minimum seconds between RCCL communicator creation and the first warm-up solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iterations", type=int, default=6, help="accepted iterations of the CPU sample")
     return ap.parse_args()
@@ -109,13 +114,24 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # Control plane (unique-id exchange, the barriers around the timed region, the max over ranks): torch.distributed.
+        # Data plane (every collective of the solve): the solver's OWN RCCL communicator over xGMI, created below.
+        # The control plane defaults to gloo: a second, idle RCCL instance (torch's "nccl" process group with its
+        # watchdog / heartbeat threads and streams) next to the solver's communicator buys nothing and was seen to cost
+        # sporadic 20-60 ms host stalls inside timed solves on the one-GPU box; --control-plane nccl selects it anyway.
+        if args.control_plane == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+        ctl_dev = "cuda" if args.control_plane == "nccl" else "cpu"
 
         def bcast(buf):
-            t = torch.from_numpy(buf).cuda()
+            t = torch.from_numpy(buf).to(ctl_dev)
             dist.broadcast(t, 0)
             return t.cpu().numpy()
-        comm = PAR.rccl_comm(world, rank, bcast)     # the solver's own RCCL communicator (xGMI), id via torch.distributed
+        if os.environ.get("BENCH_DIAG_NO_RCCL") != "1":   # diagnostic: process group only
+            comm = PAR.rccl_comm(world, rank, bcast)  # the solver's own RCCL communicator (xGMI), id via torch.distributed
+        t_comm = time.perf_counter()
 
     m, n = args.m, args.n
     data = W.tanh_linear_data(m, n, row_offset=rank * m)
@@ -135,6 +151,15 @@ def main():
         return prob.solve(data["x0"], settings=settings, stats=stats, flags=flags, comm=comm, workspace=ws,
                           batched={"batched": True, "pointmajor": "pointmajor", "serial": False}[args.fd])
 
+    # RCCL finishes part of its initialisation asynchronously: a few seconds after ncclCommInitRank (of the solver's
+    # communicator; torch's process group alone does not show it) every HIP launch of the process stalls once or twice for
+    # 60-150 ms. Measured on the one-GPU box with MIR_LSQ_FORCE_COMM=1: 160-310 it/s when that lands in the timed region,
+    # 740-760 when it does not; warm collectives at creation and RCCL_MSCCL*/NCCL_* knobs do not move it, waiting does.
+    # So: keep `settle` seconds between communicator creation and the first warm-up solve (set-up time counts).
+    if comm is not None and args.settle > 0:
+        wait = args.settle - (time.perf_counter() - t_comm)
+        if wait > 0:
+            time.sleep(wait)
     for _ in range(args.warmup):
         res, x = solve()
     flush_c_stdio()     # every rank: RCCL's init banner leaves the C stdio buffer now, not at process exit
@@ -148,7 +173,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if distributed:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     if res.status < 0:

@@ -576,6 +576,20 @@ struct Solver {
     std::mutex fd_mutex;
     bool fd_failed = false;
 
+    // MIR_LSQ_HOST_PROFILE=1: host wall time per category of runtime call, printed at teardown (diagnostic)
+    bool host_profile = std::getenv("MIR_LSQ_HOST_PROFILE") != nullptr;
+    double hp_ms[6] = {0, 0, 0, 0, 0, 0};   // 0 events, 1 all-reduce calls, 2 callbacks, 3 sync/readback, 4 launches (solve), 5 max single
+    struct HpScope {
+        Solver* s; int cat; std::chrono::steady_clock::time_point t0;
+        HpScope(Solver* s_, int c) : s(s_), cat(c) { if (s->host_profile) t0 = std::chrono::steady_clock::now(); }
+        ~HpScope() {
+            if (!s->host_profile) return;
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            s->hp_ms[cat] += ms;
+            if (ms > s->hp_ms[5]) s->hp_ms[5] = ms;
+        }
+    };
+
     bool ok(hipError_t e, const char* what)
     {
         if (e == hipSuccess) return true;
@@ -586,6 +600,7 @@ struct Solver {
     void ev_begin(int kind)
     {
         if (!time_kernels) return;
+        HpScope hp(this, 0);
         EventPair p{};
         p.kind = kind;
         (void)hipEventCreate(&p.a);
@@ -596,6 +611,7 @@ struct Solver {
     void ev_end()
     {
         if (!time_kernels) return;
+        HpScope hp(this, 0);
         (void)hipEventRecord(events.back().b, stream);
     }
 
@@ -640,6 +656,9 @@ struct Solver {
     void teardown()
     {
         if (stream) (void)hipStreamSynchronize(stream);
+        if (host_profile)
+            std::fprintf(stderr, "[host profile] events %.3f ms  all-reduce calls %.3f  trial callbacks %.3f  readback+sync %.3f  solve launch %.3f  "
+                                 "longest single call %.3f\n", hp_ms[0], hp_ms[1], hp_ms[2], hp_ms[3], hp_ms[4], hp_ms[5]);
         if (stats) {
             for (auto& e : events) {
                 float ms = 0;
@@ -708,7 +727,10 @@ struct Solver {
         if (nb < 1) nb = 1;
         hipLaunchKernelGGL(k_sumsq_partial<T>, dim3(nb, count), dim3(256), 0, stream, v, m, B.partials, vstride, kPartials);
         hipLaunchKernelGGL(k_sumsq_final<T>, dim3(count), dim3(256), 0, stream, B.partials, nb, B.sum + slot, kPartials);
-        if (comm && comm_allreduce<T>(comm, B.sum + slot, (size_t)count, stream) != 0) return false;
+        if (comm) {
+            HpScope hp(this, 1);
+            if (comm_allreduce<T>(comm, B.sum + slot, (size_t)count, stream) != 0) return false;
+        }
         return ok(hipGetLastError(), "sumsq");
     }
 
@@ -748,6 +770,7 @@ struct Solver {
 
     bool read_state(const T* vec_dev)
     {
+        HpScope hp(this, 3);
         if (!ok(hipMemcpyAsync(st_h, B.st, sizeof(LmState<T>), hipMemcpyDeviceToHost, stream), "D2H state")) return false;
         if (vec_dev && !ok(hipMemcpyAsync(trial_h, vec_dev, n * sizeof(T), hipMemcpyDeviceToHost, stream), "D2H vec")) return false;
         return ok(hipStreamSynchronize(stream), "sync");
@@ -770,7 +793,10 @@ struct Solver {
         if (!ok(lr_sweep<T>(a, nblk, stream), "broyden sweep")) return false;
         ev_end();
         hipLaunchKernelGGL(k_lr_reduce<T>, dim3((len + 31) / 32), dim3(256), 0, stream, B.lrpart, nblk, len, B.lrvec);
-        if (comm && comm_allreduce<T>(comm, B.lrvec, (size_t)len, stream) != 0) return false;
+        if (comm) {
+            HpScope hp(this, 1);
+            if (comm_allreduce<T>(comm, B.lrvec, (size_t)len, stream) != 0) return false;
+        }
         hipLaunchKernelGGL(k_lr_finish<T>, dim3(n + 1), dim3(256), 0, stream, B.lrvec, B.lrD, B.dx_acc, lr_k, (int)n, B.JJ, B.Jy, B.st);
         if (stats) stats->broyden_lr_columns += (uint64_t)lr_k;
         ++lr_k;
@@ -797,7 +823,10 @@ struct Solver {
             if (!ok(jtj_run<T>(plan, a, broyden, B.packed, stream), "jtj kernel")) return false;
             ev_end();
         }
-        if (comm && comm_allreduce<T>(comm, B.packed, (size_t)n * (n + 1) / 2 + n, stream) != 0) return false;
+        if (comm) {
+            HpScope hp(this, 1);
+            if (comm_allreduce<T>(comm, B.packed, (size_t)n * (n + 1) / 2 + n, stream) != 0) return false;
+        }
         hipLaunchKernelGGL(k_unpack_grad<T>, dim3(n + 1), dim3(128), 0, stream, B.packed, (int)n, B.JJ, B.Jy, B.st);
         return ok(hipGetLastError(), "unpack");
     }
@@ -1060,7 +1089,10 @@ struct Solver {
                 a.lambda_from_state = lambda_from_state ? 1 : 0;
                 if (!dbg_solve) a.sc[0].dbg = nullptr;
                 ev_begin(2);
-                if (!ok(launch_solve(a, ks), "solve launch")) { fail = true; break; }
+                {
+                    HpScope hp(this, 4);
+                    if (!ok(launch_solve(a, ks), "solve launch")) { fail = true; break; }
+                }
                 ev_end();
             }
             if (dbg_solve) {
@@ -1079,6 +1111,7 @@ struct Solver {
             if (device_cb) {
                 // no host round trip before the residual: it is evaluated speculatively even when the record will
                 // forbid it (gradient converged, QP failure, step guard) -- the decision kernel then ignores it
+                HpScope hp(this, 2);
                 if (ks > 1 && fb) fb(fbctx, m, n, (size_t)ks, B.trial, ytr);
                 else for (int k = 0; k < ks; ++k) f(fctx, m, n, B.trial + (size_t)k * n, ytr + (size_t)k * m);
             } else {
@@ -1530,9 +1563,16 @@ int mir_lsq_jtj_s(size_t m, size_t n, float* J, const float* y, const float* y_o
     return jtj_entry<float>(m, n, J, y, y_old, dx, broyden, JJ, Jy, stream, kernel_ms);
 }
 
+namespace {
+__global__ void k_preload() {}
+}
 mir_lsq_workspace* mir_lsq_workspace_create(size_t m, size_t n, size_t elem_size)
 {
     if (!device_available() || n == 0 || m == 0) return nullptr;
+    // HIP loads a library's device code at its first kernel launch (tens of ms for this one): do it here, where the
+    // caller sets things up, rather than in the first solve
+    hipLaunchKernelGGL(k_preload, dim3(1), dim3(1), 0, nullptr);
+    (void)hipStreamSynchronize(nullptr);
     if (elem_size == 8) return workspace_create<double>(m, n);
     if (elem_size == 4) return workspace_create<float>(m, n);
     return nullptr;
@@ -1565,6 +1605,20 @@ mir_lsq_comm* mir_lsq_comm_create_rccl(int nranks, int rank, const void* unique_
     auto* comm = new mir_lsq_comm();
     comm->nranks = nranks; comm->rank = rank; comm->kind = 1; comm->lib = h; comm->nccl_comm = c;
     comm->allreduce_fn = ar; comm->destroy_fn = destroy;
+    if (nranks > 1 || std::getenv("MIR_LSQ_RCCL_WARM_ALWAYS")) {
+        // RCCL loads its kernels and connects its channels at the first collective of each size class: do that here
+        // (creation is collective anyway), with the three payload sizes of a solve -- one scalar, the Broyden sweep
+        // vector, the packed [J^T J | J^T y] -- so that the caller's first solve does not pay for it
+        double* w = nullptr;
+        const size_t sizes[3] = {1, 1024, 40000};
+        if (hipMalloc((void**)&w, sizes[2] * sizeof(double)) == hipSuccess) {
+            (void)hipMemset(w, 0, sizes[2] * sizeof(double));
+            for (size_t sz : sizes)
+                if (ar(w, w, sz, 8 /*ncclDouble*/, 0 /*ncclSum*/, c, nullptr) != 0) break;
+            (void)hipStreamSynchronize(nullptr);
+            (void)hipFree(w);
+        }
+    }
     return comm;
 }
 
