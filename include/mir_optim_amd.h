@@ -190,6 +190,9 @@ typedef struct mir_lsq_stats {
     uint64_t broyden_lr_columns;     /* sum over the Broyden sweeps of the pending columns each one read (broyden_lr.h) */
     double jtj_fd_ms;                /* of jtj_ms: launches with the finite-difference fill fused in (fbRowMajor) */
     uint64_t jtj_fd_launches;
+    uint64_t elided_evaluations;     /* trial evaluations not made because trial == x bit for bit (null steps at the end of
+                                        a noisy solve; the callbacks are `pure`, LS:73-80, so f(trial) is already known);
+                                        fCalls counts them like the reference does */
 } mir_lsq_stats;
 
 /* Optional per-pass trace (not in the reference; a parity-pinning aid: tests compare it event by event with the

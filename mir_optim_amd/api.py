@@ -118,7 +118,8 @@ class Stats(C.Structure):
                 ("jtj_broyden_ms", C.c_double), ("solve_ms", C.c_double), ("solve_launches", C.c_uint64),
                 ("fd_ms", C.c_double), ("total_ms", C.c_double), ("qp_active_set_passes", C.c_uint64),
                 ("broyden_lr_columns", C.c_uint64),
-                ("jtj_fd_ms", C.c_double), ("jtj_fd_launches", C.c_uint64)]
+                ("jtj_fd_ms", C.c_double), ("jtj_fd_launches", C.c_uint64),
+                ("elided_evaluations", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -559,6 +559,10 @@ struct Solver {
     bool lowrank = !(std::getenv("MIR_LSQ_BROYDEN") && std::getenv("MIR_LSQ_BROYDEN")[0] == 'f');
     int lr_cap = kLrMax;
     int lr_k = 0;
+    // null steps (trial == x bit for bit; kFlagNullStep): once a round ended on one, the next round's solves are looked
+    // at before the callbacks are launched, and when every entry is a null step nothing is evaluated
+    bool no_null_skip = std::getenv("MIR_LSQ_NO_NULL_SKIP") != nullptr;
+    bool tail_null = false;
     int f_in_lds = 0;
     int solve_nb_ = 0;
     size_t solve_lds = 0;
@@ -1102,13 +1106,27 @@ struct Solver {
                                  h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[8] - h[7], h[8] - h[0], (double)(h[10] - h[9]) / (double)(h[8] - h[0]) * 100.0, h[11] - h[5], h[12] - h[11]);
             }
 
+            // null-step probe: one small read-back instead of ks residual evaluations, only while the tail is running
+            bool skip_eval = false;
+            if (device_cb && tail_null && last_rejected && !newJacobian && !no_null_skip) {
+                HpScope hp(this, 3);
+                ChainRec<T> rr[kChainMax];
+                if (!ok(hipMemcpyAsync(rr, B.rec, (size_t)ks * sizeof(ChainRec<T>), hipMemcpyDeviceToHost, stream), "D2H rec")
+                    || !ok(hipStreamSynchronize(stream), "sync")) { fail = true; break; }
+                skip_eval = true;
+                for (int k = 0; k < ks; ++k) if (!(rr[k].flags & kFlagNullStep)) skip_eval = false;
+                if (skip_eval && stats) stats->elided_evaluations += (uint64_t)ks;
+            }
+
             // trial residuals -> ytr (k-th vector at ytr + k * m); with one trial they go straight into mB
             T* ytr = mB;
             if (ks > 1) {
                 if (!ws->ytrial && !ok(hipMalloc(&ws->ytrial, (size_t)kChainMax * m * sizeof(T)), "hipMalloc(trial residuals)")) { fail = true; break; }
                 ytr = static_cast<T*>(ws->ytrial);
             }
-            if (device_cb) {
+            if (skip_eval) {
+                // every trial of the round equals x: the decision kernel substitutes the residual it already has
+            } else if (device_cb) {
                 // no host round trip before the residual: it is evaluated speculatively even when the record will
                 // forbid it (gradient converged, QP failure, step guard) -- the decision kernel then ignores it
                 HpScope hp(this, 2);
@@ -1118,11 +1136,13 @@ struct Solver {
                 // reference contract: the callback needs the trial point on the host
                 ChainRec<T> r0;
                 if (!ok(hipMemcpyAsync(&r0, B.rec, sizeof r0, hipMemcpyDeviceToHost, stream), "D2H rec") || !read_state(B.trial)) { fail = true; break; }
+                const bool null_step = (r0.flags & kFlagNullStep) && !no_null_skip;     // trial_h == xh bit for bit
+                if (null_step && stats) stats->elided_evaluations++;
                 const bool no_f = (newJacobian && (r0.flags & kFlagGradSmall)) || r0.qp_status != 0
-                    || (r0.flags & (kFlagDxNaN | kFlagStepTooLong));
+                    || (r0.flags & (kFlagDxNaN | kFlagStepTooLong)) || null_step;
                 if (!no_f && !eval_f(B.trial, trial_h, ytr)) { fail = true; break; }
             }
-            if (!sumsq(ytr, 1, ks, m)) { fail = true; break; }
+            if (!skip_eval && !sumsq(ytr, 1, ks, m)) { fail = true; break; }
             {
                 DecideArgs<T> d{};
                 d.sums = B.sum + 1; d.rec = B.rec; d.st = B.st; d.set = sd; d.x = B.x; d.trial = B.trial; d.dx_chain = B.dx;
@@ -1134,6 +1154,7 @@ struct Solver {
 
             if (trace && !trace_round(ks, ret.residual, ret.iterations)) { fail = true; break; }
             const int dec = st_h->decision;
+            tail_null = st_h->null_tail != 0;
             ret.fCalls += st_h->fcalls;                                      // LS:1112
             if (stats) {
                 if (st_h->consumed > 1) stats->passes += st_h->consumed - 1;

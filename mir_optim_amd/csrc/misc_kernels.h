@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void k_fd_fill_col(const T* __restrict__ yp, c
 //      have computed them. One block of kSolveThreads.
 template <typename T>
 struct DecideArgs {
-    const T* sums;
+    T* sums;            // ks trial sums of squares; entries of null steps are filled in here (= the current residual)
     const ChainRec<T>* rec;
     LmState<T>* st;
     LmSettingsDev<T> set;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_decide_chain(DecideArgs<T> a)
     if (threadIdx.x == 0) {
         LmState<T> s = *a.st;
         int dec = kDecideReject, acc = -1;
-        uint32_t consumed = 0, fcalls = 0, rejects = 0, guards = 0, qpact = 0;
+        uint32_t consumed = 0, fcalls = 0, rejects = 0, guards = 0, qpact = 0, null_tail = 0;
         for (int k = 0; k < a.ks; ++k) {
             const ChainRec<T> r = a.rec[k];
             if (k == 0 && a.check_grad && (r.flags & kFlagGradSmall)) { dec = kDecideGradSmall; break; }   // LS:1053
@@ -200,6 +200,10 @@ __global__ __launch_bounds__(kSolveThreads) void k_decide_chain(DecideArgs<T> a)
                 continue;
             }
             ++fcalls;                                                         // LS:1112
+            // null step: trial == x, the pure callback would return the residual vector already held (kFlagNullStep)
+            const bool null_step = (r.flags & kFlagNullStep) != 0;
+            if (null_step) a.sums[k] = s.residual;
+            null_tail = null_step ? 1u : 0u;
             const T tr = a.sums[k];
             s.trial_residual = tr;
             if (!(tr <= Lim<T>::inf())) { dec = kDecideNumericError; s.flags |= kFlagTrialNotFinite; break; }   // LS:1117
@@ -233,6 +237,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_decide_chain(DecideArgs<T> a)
         }
         s.decision = dec; s.accepted_k = acc; s.consumed = consumed; s.fcalls = fcalls;
         s.rejects = rejects; s.guards = guards; s.qp_active = qpact;
+        s.null_tail = (dec == kDecideReject) ? null_tail : 0u;
         *a.st = s;
         acc_s = acc;
     }

@@ -38,7 +38,8 @@ struct LmState {
     int32_t accepted_k;        // chain index of the accepted trial (-1: none)
     uint32_t consumed;         // chain steps the reference would have executed this round
     uint32_t fcalls;           // residual evaluations among them (LS:1112)
-    uint32_t rejects, guards, qp_active, pad1;
+    uint32_t rejects, guards, qp_active;
+    uint32_t null_tail;        // the last consumed trial of the round was a null step (trial == x): the next ones probably are too
 };
 
 // One solve of the lambda ladder (chain step k): everything the acceptance logic needs about it.
@@ -48,7 +49,11 @@ struct ChainRec {
     T lambda, new_dx_dot, predicted, trial_xnorm;
     int32_t qp_status, qp_iterations, flags, pad;
 };
-enum : int32_t { kFlagDxNaN = 1, kFlagXNaN = 2, kFlagStepTooLong = 4, kFlagTrialNotFinite = 8, kFlagGradSmall = 16 };
+// kFlagNullStep: the rounded step (LS:1096-1097) is exactly zero in every component, so trial == x bit for bit. The
+// callbacks are `pure` (LS:73-80): f(trial) is the residual vector the solver already holds, ||f(trial)||^2 == residual,
+// improvement == 0 and the pass is rejected (LS:1125) -- the evaluation can be elided without changing any result.
+enum : int32_t { kFlagDxNaN = 1, kFlagXNaN = 2, kFlagStepTooLong = 4, kFlagTrialNotFinite = 8, kFlagGradSmall = 16,
+                 kFlagNullStep = 32 };
 enum : int32_t {
     kDecideNone = 0, kDecideReject = 1, kDecideAccept = 2, kDecideAcceptNoPrediction = 3,
     kDecideNumericError = 4, kDecideGradSmall = 5
@@ -856,6 +861,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
     T ndd = 0, pred = 0, xn = 0;
     if (qp == 0) {
         T d = 0, tr = 0;
+        int moved = 0;
         if (tid < n) {
             d = xq[tid];
             if (!(d <= d)) flags = kFlagDxNaN;                       // LS:1087
@@ -866,8 +872,10 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
             tr = dfmax(dfmin(d + xi, a.upper[tid]), a.lower[tid]);   // LS:1108-1110
             trial_out[tid] = tr;
             if (!(tr <= tr)) flags |= kFlagXNaN;
+            moved = !(tr == xi);                                     // NaN counts as moved
         }
         flags = block_or(flags, ired);
+        if (!block_or(moved, ired)) flags |= kFlagNullStep;
         ndd = block_sum(d * d, red);                                 // LS:1099
         // predicted reduction with the UNDAMPED JJ, LS:1141-1142: t = JJ dx + 2 Jy ; pred = -(t . dx)
         T ti = 0;

@@ -386,3 +386,45 @@ def test_stats_and_reentrancy(oracle):
     assert np.array_equal(x1, x1b) and r1.iterations == r1b.iterations
     assert st.accepted == r1.iterations and st.jtj_launches == st.jacobian_full + st.jacobian_broyden
     assert st.jtj_ms > 0 and st.passes >= st.accepted + st.rejected
+
+
+@pytest.mark.parametrize("m,n", [(3000, 17), (9000, 32), (20000, 64)])
+def test_null_step_elision_is_bitwise_equivalent(m, n, monkeypatch):
+    """At the end of a noisy solve lambda grows until the rounded step is exactly zero (trial == x bit for bit) long before
+    lambda > maxLambda ends the loop (quirk Q3). The callbacks are pure (LS:73-80), so those evaluations are elided: same
+    x, residual, lambda, counters (fCalls counts them like the reference) and the same trace, with fewer callback launches."""
+    w = P.tanh_linear(m, n)
+    prob = W.TanhLinear(w["A"], w["b"])
+    s = M.LeastSquaresSettings(); s.absTolerance = 0.0            # an accepted step has dx != 0: never x-converged, always the tail
+    out = []
+    for skip in (True, False):
+        if not skip:
+            monkeypatch.setenv("MIR_LSQ_NO_NULL_SKIP", "1")
+        st, tr = M.Stats(), M.Trace(4096)
+        r, x = prob.solve(w["x0"], settings=s, batched=True, stats=st, trace=tr)
+        out.append((r, x, st, tr.records()))
+        if not skip:
+            monkeypatch.delenv("MIR_LSQ_NO_NULL_SKIP")
+    (r1, x1, st1, t1), (r0, x0, st0, t0) = out
+    assert r1.status == M.LeastSquaresStatus.furtherImprovement == r0.status      # lambda > maxLambda, LS:979
+    assert st1.elided_evaluations >= 8 and st0.elided_evaluations == 0
+    assert np.array_equal(x1, x0) and r1.residual == r0.residual and r1.lambda_ == r0.lambda_
+    assert (r1.iterations, r1.fCalls) == (r0.iterations, r0.fCalls)
+    assert (st1.passes, st1.accepted, st1.rejected) == (st0.passes, st0.accepted, st0.rejected)
+    assert t1 == t0
+
+
+def test_null_step_elision_host_callbacks(oracle):
+    """Reference ABI (host callbacks): the trial point reaches the host anyway, f is simply not called when it equals x.
+    T3b ends with 51 rejections at the bound; the counters still match the oracle's."""
+    p = P.t3b()
+    calls = [0]
+
+    def f(x, y):
+        calls[0] += 1
+        p["f"](x, y)
+    res, x = M.optimize(f, p["m"], p["x0"], p["lower"], p["upper"], g=p["g"])
+    ro, xo = run_oracle(oracle, p)
+    assert (res.iterations, res.fCalls, res.gCalls) == (ro.iterations, ro.fCalls, ro.gCalls)
+    assert np.array_equal(x, xo) or np.allclose(x, xo, rtol=1e-12)
+    assert calls[0] < res.fCalls                                                  # some evaluations were elided
