@@ -421,7 +421,16 @@ __device__ __forceinline__ void jtj2_body(const JtjArgs<double>& a, unsigned cha
     if constexpr (ROLE == 1) {
         while (next_chunk < 3 && next_chunk < nchunks) issue_y(next_chunk++);
     }
-    const size_t pre = S < (size_t)C::D ? S : (size_t)C::D;
+    // LATE (FD variant, experiment kept behind a macro): the DMA of stage s + L, L = NS - 1, issued right AFTER barrier s,
+    // into the slot stage s - 1 has just left -- one more stage in flight (48 KB per workgroup instead of 32) with the same
+    // ring and barriers. Measured at m = 1e6, n = 128: 0.805 ms against 0.733 ms for the default order (issue before the
+    // wait, D = 2): like the 4-row-stage experiment, more bytes in flight make this read + write stream slower, not faster.
+#ifndef MIRLSQ_FD_LATE_ISSUE
+#define MIRLSQ_FD_LATE_ISSUE 0
+#endif
+    constexpr bool LATE = FD && MIRLSQ_FD_LATE_ISSUE;
+    constexpr int L = LATE ? C::NS - 1 : C::D;
+    const size_t pre = S < (size_t)L ? S : (size_t)L;
     for (size_t s = 0; s < pre; ++s) issue(s);
 
     for (size_t s = 0; s < S; ++s) {
@@ -429,7 +438,14 @@ __device__ __forceinline__ void jtj2_body(const JtjArgs<double>& a, unsigned cha
             // keep the chunk holding this stage's first row plus two more in flight / resident
             while (next_chunk <= (s * C::RS) / 128 + 2 && next_chunk < nchunks) issue_y(next_chunk++);
         }
-        if (s + C::D < S) {
+        if constexpr (LATE) {
+            // stages s + 1 .. s + L - 1 were issued after barriers s - L + 1 .. s - 1 and may still be in flight
+            if (s + L - 1 < S) {
+                if constexpr (OPS > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((L - 1) * OPS) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else if (s + C::D < S) {
             issue(s + C::D);
             // my DMA of stage s (and everything older) has landed once at most D * OPS younger ops remain
             if constexpr (OPS > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::D * OPS) : "memory");
@@ -437,6 +453,9 @@ __device__ __forceinline__ void jtj2_body(const JtjArgs<double>& a, unsigned cha
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();                       // stage s is complete in LDS for every wave
+        if constexpr (LATE) {
+            if (s + L < S) issue(s + L);                    // slot of stage s - 1: every wave is past it
+        }
         const T* slot = reinterpret_cast<const T*>(smem + (s % C::NS) * C::SLOT_BYTES);
         const T* yring = reinterpret_cast<const T*>(smem + C::Y_OFF);
         const T* yoring = reinterpret_cast<const T*>(smem + C::YO_OFF);
