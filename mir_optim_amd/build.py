@@ -13,7 +13,7 @@ LIBDIR = os.path.join(HERE, "lib")
 SOLVER_LIB = os.path.join(LIBDIR, "libmir_optim_amd.so")
 WORKLOADS_LIB = os.path.join(LIBDIR, "libmir_optim_amd_workloads.so")
 
-_COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+_COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + os.environ.get("MIR_OPTIM_AMD_CXXFLAGS", "").split()
 
 
 def _hipcc():

@@ -313,6 +313,9 @@ template <int NCB, bool BROYDEN, bool FD = false> struct Jtj2Cfg {
     // rows per stage: ~16 KB stages so that one barrier is amortised over 4+ row groups (a probe on
     // MI355X: 4 KB stages 0.33 ms, 16 KB stages 0.27 ms for the n = 128 MFMA work; scripts/probes).
     // FD: a source row is 2n doubles (the +h / -h residual pairs), so half the rows make the same stage bytes
+#ifndef MIRLSQ_FD_EXPERIMENT_NOWRITE
+#define MIRLSQ_FD_EXPERIMENT_NOWRITE 0
+#endif
 #ifndef MIRLSQ_FD_BIG_STAGES
 #define MIRLSQ_FD_BIG_STAGES 0          // measured: 2.78 ms at m = 1e6, n = 128 (one workgroup per CU cannot hide the MFMA latency)
 #endif
@@ -514,7 +517,7 @@ __device__ __forceinline__ void jtj2_body(const JtjArgs<double>& a, unsigned cha
                 T* wp = a.Jout + (rok ? row : m - 1) * (size_t)n;
 #pragma unroll
                 for (int c = 0; c < NCB; ++c)
-                    if (c % 2 == ROLE - 2) { if (rok) wp[16 * c + p] = g.v[c]; }
+                    if (c % 2 == ROLE - 2) { if (rok && !MIRLSQ_FD_EXPERIMENT_NOWRITE) wp[16 * c + p] = g.v[c]; }
             }
             if constexpr (ROLE == 0) {
 #pragma unroll
