@@ -19,7 +19,7 @@ K timed solves) x N / time: LM iterations per second per 1e6 x 128 row block, ag
 
 The JSON line also carries
   roofline     -- the library kernel with the most time in the timed region, HIP-event timed on the solver's stream:
-                  k_jtj2<., false, true> (finite-difference rows -> J, J^T J + J^T y on f64 MFMA; HBM-bound, algorithmic
+                  k_jtj_fdp (finite-difference rows -> J, J^T J + J^T y on f64 MFMA; HBM-bound, algorithmic
                   bytes 8 (3 m n + m)) or the Broyden sweep k_broyden_lr (HBM-bound, 8 (m n + (k + 3) m))
   broyden_kernel / jtj_kernel -- the other one of the two
   cpu_baseline -- the oracle (CPU port of the reference algorithm, OpenBLAS for syrk/gemv/ger/posvx)
@@ -220,12 +220,13 @@ def main():
         jtj_flops = m * n * (n + 1.0) + 2.0 * m * n
         if nfd:
             fd_ms = st["jtj_fd_ms"] / nfd
-            fd_name = f"mirlsq::k_jtj2<{ncb}, false, true>"
+            ring = os.environ.get("MIR_LSQ_FD_KERNEL", "")[:1] == "r"
+            fd_name = f"mirlsq::k_jtj2<{ncb}, false, true>" if ring else f"mirlsq::k_jtj_fdp<{ncb}>"
             fd_bytes = 8.0 * (3.0 * m * n + m)                # read the m x 2n panel and y, write J
             fd_rate = fd_bytes / (fd_ms * 1e-3) / 1e9
             fresh = {
                 "kernel": fd_name + " (finite-difference rows from the (+h, -h) panel -> J, J^T J + J^T y on f64 MFMA 16x16x4, "
-                                    "LDS-DMA ring)",
+                                    + ("LDS-DMA ring)" if ring else "register-staged producer waves + MFMA consumer waves)"),
                 "bound": "hbm", "achieved": fd_rate, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fd_rate / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(fd_name, m, n), "algorithmic_bytes_per_launch": fd_bytes, "avg_launch_ms": fd_ms,
                 "launches": nfd, "mfma_tflops": (jtj_flops + 2.0 * m * n) / (fd_ms * 1e-3) / 1e12,

@@ -1,0 +1,226 @@
+// jtj_fdp.h -- finite-difference rows -> J, J^T J, J^T y with register-staged producer waves (gfx950, f64).
+//
+// Same job as k_jtj2<NCB, false, true> (jtj_kernel.h): the m x 2n row-major panel of perturbed residuals
+// Y[i][2j] = f(x + h e_j)_i, Y[i][2j+1] = f(x - h e_j)_i becomes the Jacobian (LS:1041-1047), which is written to J and
+// contracted to J^T J (LS:1065) and J^T y (LS:1052) in the same pass. The LDS-DMA ring of k_jtj2 keeps the bytes in
+// flight in LDS (64 KB per CU) and its read side tops out near 2.9 TB/s; here the bytes in flight live in REGISTERS:
+//
+//   * a workgroup has 8 waves: 4 PRODUCERS and 4 CONSUMERS (the MFMA roles of k_jtj2, 9 accumulator blocks each at
+//     n = 128);
+//   * a stage is 32 rows; producer w owns rows 8w .. 8w+7 of every stage, i.e. 16n contiguous doubles of the panel,
+//     which it reads with 2 NCB coalesced 16-byte loads per lane (the flat pair index 64 i + lane: row = f / n,
+//     column = f % n): 64 VGPRs = 16 KB per wave, 64 KB per workgroup, 128 KB per CU in flight at n = 128 -- twice the
+//     ring's. It forms J = (Y+ - Y-) (1 / twh) ONCE per element and writes the stage, in the plain row-major layout the
+//     MFMA fragments are read from, into one of two LDS slots (ds_write_b64, lane-consecutive), then issues the loads of
+//     the next stage, which fly while it waits at the barrier;
+//     (a deeper register pipeline -- loads of stage t + 2 issued before stage t + 1 is consumed -- needs waits counted
+//     across the loop back edge: the compiler's are maximally conservative there, and untracked inline-asm loads are
+//     unsafe because the register allocator copies "defined" destination registers around while the data is in flight);
+//   * one workgroup barrier per stage: after barrier t the consumers read stage t (ds_read_b64 fragments, MFMAs, J^T y)
+//     while the producers convert stage t + 1 into the other slot; consumer roles 2 and 3 also write the J rows to
+//     HBM from their fragments (128-byte segments), so the producers' vmcnt stream contains loads only.
+//
+// Slabs are laid out exactly like k_jtj2's, so k_jtj_slab_reduce finishes the job. Rows past m are clamped on the
+// load side and written as zeros to LDS.
+#pragma once
+
+#include "jtj_kernel.h"
+
+namespace mirlsq {
+
+template <int NCB> struct JtjFdpCfg {
+    static constexpr int N = 16 * NCB;
+    static constexpr int RP = (N % 64 == 0) ? 8 : 4;       // rows per producer wave and stage (per-lane column tables cost
+                                                           // registers when n is not a multiple of 64)
+    static constexpr int RS = 4 * RP;                      // rows per stage
+    static constexpr int GPS = RS / 4;
+    static constexpr int NI = RP * NCB / 4;                // 16-byte loads per lane and stage (RP n pairs / 64 lanes)
+    static constexpr int SLOT_DOUBLES = RS * N + RS;       // the J stage, then its y values
+    static constexpr int LDS_BYTES = 2 * SLOT_DOUBLES * 8;
+    static constexpr int THREADS = 8 * kWave;
+};
+
+typedef double fdp_v2d __attribute__((ext_vector_type(2)));
+
+// Producer wave w owns rows RP w .. RP w + RP - 1 of every stage: RP * 2n contiguous doubles of the panel, read with NI
+// coalesced 16-byte loads per lane (flat pair index f = 64 i + lane: row = f / n, column = f % n). The loads of stage
+// t + 1 are issued right after stage t has been converted and are in flight while the wave waits at the barrier for the
+// consumers (64 VGPRs = 16 KB per wave, 128 KB per CU at n = 128); one buffer, so every wait the compiler inserts is a
+// plain "everything I issued has landed" -- no counted waits across the loop back edge are needed.
+template <int NCB>
+__device__ __forceinline__ void fdp_producer(const JtjArgs<double>& a, double* smem, int lane, int w, size_t s0, size_t S)
+{
+    using C = JtjFdpCfg<NCB>;
+    constexpr int n = C::N;
+    constexpr int NI = C::NI;
+    const size_t m = a.m;
+    const fdp_v2d* __restrict__ Y = reinterpret_cast<const fdp_v2d*>(a.J);
+
+    // n % 64 == 0: instruction i covers row (64 i) / n, columns (64 i) % n + lane -- the row is a compile-time constant and
+    // only n / 64 distinct column sets exist; otherwise both are per-lane values
+    constexpr bool ALIGNED = n % 64 == 0;
+    constexpr int KD = ALIGNED ? n / 64 : NI;              // distinct (column, 1 / twh) registers per lane
+    int jrow_v[ALIGNED ? 1 : NI], jcol_v[KD];
+    double inv[KD];
+    bool zc[KD];
+#pragma unroll
+    for (int k = 0; k < KD; ++k) {
+        const int f = 64 * k + lane;
+        jcol_v[k] = ALIGNED ? f : f % n;
+        const double t = a.twh[jcol_v[k]];
+        zc[k] = t == 0;                                    // collapsed interval: zero column (LS:1046)
+        inv[k] = zc[k] ? 0.0 : 1.0 / t;                    // LS:1047
+    }
+    if constexpr (!ALIGNED) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) jrow_v[i] = (64 * i + lane) / n;
+    }
+    auto jrow = [&](int i) { if constexpr (ALIGNED) return (64 * i) / n; else return jrow_v[i]; };
+    auto kd = [&](int i) { if constexpr (ALIGNED) return i % KD; else return i; };
+
+    fdp_v2d b[NI];
+    double yb = 0;
+    auto issue = [&](size_t s) {
+        const size_t row0 = (s0 + s) * C::RS + C::RP * (size_t)w;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            size_t row = row0 + jrow(i);
+            row = row < m ? row : m - 1;
+            b[i] = Y[row * (size_t)n + jcol_v[kd(i)]];
+        }
+        size_t yr = row0 + (lane & (C::RP - 1));
+        yr = yr < m ? yr : m - 1;
+        yb = a.y[yr];
+    };
+    auto convert = [&](size_t s) {
+        double* slot = smem + (s & 1) * C::SLOT_DOUBLES;
+        const size_t row0 = (s0 + s) * C::RS + C::RP * (size_t)w;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            double d = b[i].x;                             // copy(mBuffer, Jj)       LS:1041
+            d += -1.0 * b[i].y;                            // axpy(-1, mBuffer, Jj)   LS:1045
+            double v = zc[kd(i)] ? 0.0 : d * inv[kd(i)];   // scal(1 / twh, Jj)       LS:1047
+            v = (row0 + jrow(i) < m) ? v : 0.0;            // rows past m contribute nothing
+            slot[w * C::RP * n + 64 * i + lane] = v;
+        }
+        if (lane < C::RP) slot[C::RS * n + C::RP * w + lane] = (row0 + lane < m) ? yb : 0.0;
+    };
+
+    if (S > 0) issue(0);
+    for (size_t t = 0; t < S; ++t) {
+        convert(t);
+        if (t + 1 < S) issue(t + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my LDS writes of stage t are done
+        __builtin_amdgcn_s_barrier();                       // barrier t: stage t is complete for the consumers
+    }
+}
+
+template <int NCB, int ROLE>
+__device__ __forceinline__ void fdp_consumer(const JtjArgs<double>& a, const double* smem, int lane, size_t s0, size_t S)
+{
+    using T = double;
+    using Acc = typename Mma<T>::Acc;
+    using C = JtjFdpCfg<NCB>;
+    constexpr int NACC = jtj_nacc<NCB>();
+    constexpr int n = C::N;
+    const int q = lane >> 4, p = lane & 15;
+    const size_t m = a.m;
+
+    Acc acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = Acc{0, 0, 0, 0};
+    T jy[NCB];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) jy[c] = 0;
+
+    for (size_t s = 0; s < S; ++s) {
+        __builtin_amdgcn_s_barrier();                       // barrier s: the producers have written stage s
+        const T* slot = smem + (s & 1) * C::SLOT_DOUBLES;
+        const size_t row0 = (s0 + s) * C::RS;
+        struct Grp { T v[NCB]; T y; };
+        auto read = [&](int gi, Grp& g) {
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) g.v[c] = slot[(4 * gi + q) * n + 16 * c + p];
+            g.y = 0;
+            if constexpr (ROLE == 0) g.y = slot[C::RS * n + 4 * gi + q];
+        };
+        auto side = [&](int gi, const Grp& g) {
+            if constexpr (ROLE >= 2) {
+                // the Jacobian rows leave through roles 2 and 3 (column blocks c = ROLE (mod 2))
+                const size_t row = row0 + 4 * gi + q;
+                if (row < m) {
+                    T* wp = a.Jout + row * (size_t)n;
+#pragma unroll
+                    for (int c = 0; c < NCB; ++c)
+                        if (c % 2 == ROLE - 2) wp[16 * c + p] = g.v[c];
+                }
+            }
+            if constexpr (ROLE == 0) {
+#pragma unroll
+                for (int c = 0; c < NCB; ++c) jy[c] += g.v[c] * g.y;     // LS:1052
+            }
+        };
+        auto mfmas = [&](const Grp& g) {
+#pragma unroll
+            for (int I = 0; I < NCB; ++I)
+#pragma unroll
+                for (int Jb2 = 0; Jb2 <= I; ++Jb2)
+                    if (jtj_owns<NCB, 4, ROLE>(I * (I + 1) / 2 + Jb2))
+                        acc[I * (I + 1) / 2 + Jb2] = Mma<T>::mma(g.v[I], g.v[Jb2], acc[I * (I + 1) / 2 + Jb2]);   // LS:1065
+        };
+        Grp ga, gb;
+        read(0, ga);
+        side(0, ga);
+#pragma unroll
+        for (int gi = 0; gi < C::GPS; gi += 2) {
+            if (gi + 1 < C::GPS) read(gi + 1, gb);
+            mfmas(ga);
+            if (gi + 1 < C::GPS) {
+                side(gi + 1, gb);
+                if (gi + 2 < C::GPS) read(gi + 2, ga);
+                mfmas(gb);
+                if (gi + 2 < C::GPS) side(gi + 2, ga);
+            }
+        }
+    }
+
+    T* dst = a.slabs + (size_t)blockIdx.x * jtj_slab_len<NCB>();
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+        if (jtj_owns<NCB, 4, ROLE>(i)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(i * 4 + r) * kWave + lane] = acc[i][r];
+        }
+    if constexpr (ROLE == 0) {
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            jy[c] += wave_shfl_xor(jy[c], 16);
+            jy[c] += wave_shfl_xor(jy[c], 32);
+            dst[(NACC * 4 + c) * kWave + lane] = jy[c];
+        }
+    }
+}
+
+template <int NCB>
+__global__ __launch_bounds__(JtjFdpCfg<NCB>::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_jtj_fdp(JtjArgs<double> a)
+{
+    using C = JtjFdpCfg<NCB>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fdp_smem[];
+    double* smem = reinterpret_cast<double*>(fdp_smem);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    const size_t Stot = (a.m + C::RS - 1) / C::RS;
+    const size_t per = (Stot + gridDim.x - 1) / gridDim.x;
+    const size_t s0 = (size_t)blockIdx.x * per < Stot ? (size_t)blockIdx.x * per : Stot;
+    const size_t s1 = s0 + per < Stot ? s0 + per : Stot;
+    const size_t S = s1 - s0;
+
+    if (wave == 0) fdp_consumer<NCB, 0>(a, smem, lane, s0, S);
+    else if (wave == 1) fdp_consumer<NCB, 1>(a, smem, lane, s0, S);
+    else if (wave == 2) fdp_consumer<NCB, 2>(a, smem, lane, s0, S);
+    else if (wave == 3) fdp_consumer<NCB, 3>(a, smem, lane, s0, S);
+    else fdp_producer<NCB>(a, smem, lane, wave - 4, s0, S);
+}
+
+}  // namespace mirlsq

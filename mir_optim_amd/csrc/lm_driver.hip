@@ -25,6 +25,7 @@
 #include "jtj_kernel.h"
 #include "jtj_wide.h"
 #include "jtj_ring8.h"
+#include "jtj_fdp.h"
 #include "batched_kernel.h"
 #include "broyden_lr.h"
 #include "misc_kernels.h"
@@ -262,6 +263,19 @@ hipError_t jtj2_launch(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t s
 template <int NCB>
 hipError_t jtj2_fd_launch_one(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t s)
 {
+    // default: register-staged producer waves (jtj_fdp.h); MIR_LSQ_FD_KERNEL=ring selects the LDS-DMA ring variant
+    static const bool ring = std::getenv("MIR_LSQ_FD_KERNEL") && std::getenv("MIR_LSQ_FD_KERNEL")[0] == 'r';
+    if (!ring) {
+        static bool fdp_attr_done = false;
+        if (!fdp_attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_jtj_fdp<NCB>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, JtjFdpCfg<NCB>::LDS_BYTES);
+            if (e != hipSuccess) return e;
+            fdp_attr_done = true;
+        }
+        hipLaunchKernelGGL(k_jtj_fdp<NCB>, dim3(p.nblk), dim3(JtjFdpCfg<NCB>::THREADS), JtjFdpCfg<NCB>::LDS_BYTES, s, a);
+        return hipGetLastError();
+    }
     auto kern = k_jtj2<NCB, false, true>;
     constexpr size_t lds = Jtj2Cfg<NCB, false, true>::LDS_BYTES;
     static bool attr_done = false;
