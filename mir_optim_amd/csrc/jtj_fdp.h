@@ -28,13 +28,15 @@
 
 namespace mirlsq {
 
-template <int NCB> struct JtjFdpCfg {
+constexpr int kJtjFdpThreads = 8 * kWave;
+
+template <int NCB, bool FD = true> struct JtjFdpCfg {
     static constexpr int N = 16 * NCB;
-    static constexpr int RP = (N % 64 == 0) ? 8 : 4;       // rows per producer wave and stage (per-lane column tables cost
-                                                           // registers when n is not a multiple of 64)
+    static constexpr int RP = !FD ? 8 : ((N % 64 == 0) ? 8 : 4);   // rows per producer wave and stage (FD: per-lane column
+                                                                   // tables cost registers when n is not a multiple of 64)
     static constexpr int RS = 4 * RP;                      // rows per stage
     static constexpr int GPS = RS / 4;
-    static constexpr int NI = RP * NCB / 4;                // 16-byte loads per lane and stage (RP n pairs / 64 lanes)
+    static constexpr int NI = FD ? RP * NCB / 4 : RP * NCB / 8;   // 16-byte loads per lane and stage
     static constexpr int SLOT_DOUBLES = RS * N + RS;       // the J stage, then its y values
     static constexpr int LDS_BYTES = 2 * SLOT_DOUBLES * 8;
     static constexpr int THREADS = 8 * kWave;
@@ -115,12 +117,64 @@ __device__ __forceinline__ void fdp_producer(const JtjArgs<double>& a, double* s
     }
 }
 
-template <int NCB, int ROLE>
+// Plain variant (FD = false): the source is J itself (m x n row-major); a producer copies its RP rows of every stage --
+// RP n contiguous doubles, NI = NCB 16-byte loads per lane -- into the LDS slot unchanged. Nothing is written back.
+template <int NCB>
+__device__ __forceinline__ void fdp_producer_plain(const JtjArgs<double>& a, double* smem, int lane, int w, size_t s0, size_t S)
+{
+    using C = JtjFdpCfg<NCB, false>;
+    constexpr int n = C::N;
+    constexpr int NI = C::NI;
+    const size_t m = a.m;
+    const fdp_v2d* __restrict__ Jp = reinterpret_cast<const fdp_v2d*>(a.J);
+    const size_t last_pair = m * (size_t)n / 2 - 1;
+
+    fdp_v2d b[NI];
+    double yb = 0;
+    auto issue = [&](size_t s) {
+        const size_t row0 = (s0 + s) * C::RS + C::RP * (size_t)w;
+        const size_t base = row0 * (size_t)(n / 2);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            size_t g = base + 64 * i + lane;
+            g = g < last_pair ? g : last_pair;             // rows past m: any valid bytes, zeroed in convert
+            b[i] = Jp[g];
+        }
+        size_t yr = row0 + (lane & (C::RP - 1));
+        yr = yr < m ? yr : m - 1;
+        yb = a.y[yr];
+    };
+    auto convert = [&](size_t s) {
+        double* slot = smem + (s & 1) * C::SLOT_DOUBLES;
+        const size_t row0 = (s0 + s) * C::RS + C::RP * (size_t)w;
+        const bool full = row0 + C::RP <= m;               // wave-uniform
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            fdp_v2d v = b[i];
+            if (!full) {
+                const size_t row = row0 + (size_t)(2 * (64 * i + lane)) / n;
+                if (row >= m) v = fdp_v2d{0.0, 0.0};
+            }
+            *reinterpret_cast<fdp_v2d*>(slot + w * C::RP * n + 2 * (64 * i + lane)) = v;
+        }
+        if (lane < C::RP) slot[C::RS * n + C::RP * w + lane] = (row0 + lane < m) ? yb : 0.0;
+    };
+
+    if (S > 0) issue(0);
+    for (size_t t = 0; t < S; ++t) {
+        convert(t);
+        if (t + 1 < S) issue(t + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+template <int NCB, int ROLE, bool FD = true>
 __device__ __forceinline__ void fdp_consumer(const JtjArgs<double>& a, const double* smem, int lane, size_t s0, size_t S)
 {
     using T = double;
     using Acc = typename Mma<T>::Acc;
-    using C = JtjFdpCfg<NCB>;
+    using C = JtjFdpCfg<NCB, FD>;
     constexpr int NACC = jtj_nacc<NCB>();
     constexpr int n = C::N;
     const int q = lane >> 4, p = lane & 15;
@@ -145,7 +199,7 @@ __device__ __forceinline__ void fdp_consumer(const JtjArgs<double>& a, const dou
             if constexpr (ROLE == 0) g.y = slot[C::RS * n + 4 * gi + q];
         };
         auto side = [&](int gi, const Grp& g) {
-            if constexpr (ROLE >= 2) {
+            if constexpr (FD && ROLE >= 2) {
                 // the Jacobian rows leave through roles 2 and 3 (column blocks c = ROLE (mod 2))
                 const size_t row = row0 + 4 * gi + q;
                 if (row < m) {
@@ -201,10 +255,10 @@ __device__ __forceinline__ void fdp_consumer(const JtjArgs<double>& a, const dou
     }
 }
 
-template <int NCB>
-__global__ __launch_bounds__(JtjFdpCfg<NCB>::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_jtj_fdp(JtjArgs<double> a)
+template <int NCB, bool FD = true>
+__global__ __launch_bounds__(kJtjFdpThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_jtj_fdp(JtjArgs<double> a)
 {
-    using C = JtjFdpCfg<NCB>;
+    using C = JtjFdpCfg<NCB, FD>;
     extern __shared__ __attribute__((aligned(16))) unsigned char fdp_smem[];
     double* smem = reinterpret_cast<double*>(fdp_smem);
     const int lane = threadIdx.x & 63;
@@ -216,11 +270,12 @@ __global__ __launch_bounds__(JtjFdpCfg<NCB>::THREADS) __attribute__((amdgpu_wave
     const size_t s1 = s0 + per < Stot ? s0 + per : Stot;
     const size_t S = s1 - s0;
 
-    if (wave == 0) fdp_consumer<NCB, 0>(a, smem, lane, s0, S);
-    else if (wave == 1) fdp_consumer<NCB, 1>(a, smem, lane, s0, S);
-    else if (wave == 2) fdp_consumer<NCB, 2>(a, smem, lane, s0, S);
-    else if (wave == 3) fdp_consumer<NCB, 3>(a, smem, lane, s0, S);
-    else fdp_producer<NCB>(a, smem, lane, wave - 4, s0, S);
+    if (wave == 0) fdp_consumer<NCB, 0, FD>(a, smem, lane, s0, S);
+    else if (wave == 1) fdp_consumer<NCB, 1, FD>(a, smem, lane, s0, S);
+    else if (wave == 2) fdp_consumer<NCB, 2, FD>(a, smem, lane, s0, S);
+    else if (wave == 3) fdp_consumer<NCB, 3, FD>(a, smem, lane, s0, S);
+    else if constexpr (FD) fdp_producer<NCB>(a, smem, lane, wave - 4, s0, S);
+    else fdp_producer_plain<NCB>(a, smem, lane, wave - 4, s0, S);
 }
 
 }  // namespace mirlsq

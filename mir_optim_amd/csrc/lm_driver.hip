@@ -232,6 +232,22 @@ hipError_t jtj2_launch_one(const JtjPlan& p, const JtjArgs<double>& a, hipStream
             return hipGetLastError();
         }
     }
+    if constexpr (!BR) {
+        // plain J^T J + J^T y: producer / consumer waves (jtj_fdp.h, FD = false); MIR_LSQ_JTJ_KERNEL=ring: the LDS-DMA ring
+        static const bool ring = std::getenv("MIR_LSQ_JTJ_KERNEL") && std::getenv("MIR_LSQ_JTJ_KERNEL")[0] == 'r';
+        if (!ring) {
+            using FC = JtjFdpCfg<NCB, false>;
+            static bool fdp_attr_done = false;
+            if (!fdp_attr_done) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_jtj_fdp<NCB, false>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, FC::LDS_BYTES);
+                if (e != hipSuccess) return e;
+                fdp_attr_done = true;
+            }
+            hipLaunchKernelGGL((k_jtj_fdp<NCB, false>), dim3(p.nblk), dim3(FC::THREADS), FC::LDS_BYTES, s, a);
+            return hipGetLastError();
+        }
+    }
     auto kern = k_jtj2<NCB, BR>;
     constexpr size_t lds = Jtj2Cfg<NCB, BR>::LDS_BYTES;
     static bool attr_done = false;
@@ -268,12 +284,12 @@ hipError_t jtj2_fd_launch_one(const JtjPlan& p, const JtjArgs<double>& a, hipStr
     if (!ring) {
         static bool fdp_attr_done = false;
         if (!fdp_attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_jtj_fdp<NCB>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_jtj_fdp<NCB, true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, JtjFdpCfg<NCB>::LDS_BYTES);
             if (e != hipSuccess) return e;
             fdp_attr_done = true;
         }
-        hipLaunchKernelGGL(k_jtj_fdp<NCB>, dim3(p.nblk), dim3(JtjFdpCfg<NCB>::THREADS), JtjFdpCfg<NCB>::LDS_BYTES, s, a);
+        hipLaunchKernelGGL((k_jtj_fdp<NCB, true>), dim3(p.nblk), dim3(JtjFdpCfg<NCB>::THREADS), JtjFdpCfg<NCB>::LDS_BYTES, s, a);
         return hipGetLastError();
     }
     auto kern = k_jtj2<NCB, false, true>;
