@@ -62,8 +62,8 @@ def pmc_traffic(kernel, m, n):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--m", type=int, default=1_000_000, help="rows per GPU")
     ap.add_argument("--n", type=int, default=128)
     ap.add_argument("--fd", choices=["batched", "pointmajor", "serial"], default="batched",
