@@ -591,6 +591,7 @@ struct Solver {
     int lr_k = 0;
     // null steps (trial == x bit for bit; kFlagNullStep): once a round ended on one, the next round's solves are looked
     // at before the callbacks are launched, and when every entry is a null step nothing is evaluated
+    bool has_bounds = true;    // some lower / upper entry is finite (set in run()); MIR_LSQ_SOLVE_BOUNDED=1 forces the full kernel
     bool no_null_skip = std::getenv("MIR_LSQ_NO_NULL_SKIP") != nullptr;
     bool tail_null = false;
     int f_in_lds = 0;
@@ -729,10 +730,10 @@ struct Solver {
             && ok(hipStreamSynchronize(stream), "sync");
     }
 
-    template <int NB>
-    hipError_t launch_solve_nb(const LmSolveArgs<T>& a, int ks)
+    template <int NB, bool BOUNDED>
+    hipError_t launch_solve_nbb(const LmSolveArgs<T>& a, int ks)
     {
-        auto kern = k_lm_solve<T, NB>;
+        auto kern = k_lm_solve<T, NB, BOUNDED>;
         static bool attr_done = false;
         if (!attr_done && solve_lds > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
@@ -741,6 +742,12 @@ struct Solver {
         }
         hipLaunchKernelGGL(kern, dim3(ks), dim3(kSolveThreads), solve_lds, stream, a);
         return hipGetLastError();
+    }
+    template <int NB>
+    hipError_t launch_solve_nb(const LmSolveArgs<T>& a, int ks)
+    {
+        // all bounds infinite: the variant without the BOXCQP active-set loop (solve_kernel.h, BOUNDED = false)
+        return has_bounds ? launch_solve_nbb<NB, true>(a, ks) : launch_solve_nbb<NB, false>(a, ks);
     }
     hipError_t launch_solve(const LmSolveArgs<T>& a, int ks)
     {
@@ -1019,6 +1026,9 @@ struct Solver {
         }
         if (!device_available()) return ret;
         if (!setup()) { teardown(); return ret; }
+        has_bounds = std::getenv("MIR_LSQ_SOLVE_BOUNDED") != nullptr;
+        for (uint32_t i = 0; i < n; ++i)
+            if (lh[i] > -Lim<T>::inf() || uh[i] < Lim<T>::inf()) has_bounds = true;
 
         const uint32_t maxAge = S->maxAge ? S->maxAge : (g ? 3 : 2 * n);     // LS:945 (quirk Q4)
 

@@ -619,7 +619,12 @@ __device__ __forceinline__ int posvx_device(int n, T* A, int lda, T* F, int ldf,
 // ---------------------------------------------------------------- solveBoxQP, boxcqp.d:122-379
 // Pm: n x n full symmetric (unscaled). q, l, u: n-vectors. x: in/out (holds the unconstrained
 // solution on entry when skip_unconstrained). Returns BoxQPStatus; *iters = active-set passes.
-template <typename T, int NB>
+// BOUNDED = false (k_lm_solve for problems whose lower / upper are all infinite, so qpl = -inf, qpu = +inf): the
+// active-set loop is compiled out. It could only be entered with a NaN in the unconstrained solution (QP:216-219), where
+// the reference's loop classifies every variable as free and leaves with `s == n` (QP:265, quirk Q8) and a status other
+// than `solved` -- which is all the LM loop looks at (LS:1080): this variant returns numericError there. One inlined copy
+// of posvx instead of two roughly halves the kernel and relieves its register allocation (512 VGPRs, 786 spilled SGPRs).
+template <typename T, int NB, bool BOUNDED = true>
 __device__ __forceinline__ int box_qp_device(int n, const T* Pm, const T* q, const T* l, const T* u, T* x,
                              bool unconstrainedSolution, T relTol, T absTol, uint32_t maxIterations,
                              SolveScratch<T>& sc, T* F, int ldf, T* red, int* ired, int* iters, bool a_prefilled = false)
@@ -661,6 +666,7 @@ __device__ __forceinline__ int box_qp_device(int n, const T* Pm, const T* q, con
         if (tid < n) bad = !(l[tid] <= x[tid] && x[tid] <= u[tid]);
         if (!block_or(bad, ired)) return 0;
     }
+    if constexpr (!BOUNDED) return 1;
 
     if (!maxIterations) maxIterations = (uint32_t)n * 10 + 100;     // QP:224-226
     if (tid < n) { la[tid] = 0; mu[tid] = 0; }                      // QP:228-232
@@ -782,7 +788,7 @@ struct LmSolveArgs {
     int lambda_from_state; // step 0 takes st->lambda and applies the lambda_0 rule LS:1067-1072
 };
 
-template <typename T, int NB>
+template <typename T, int NB, bool BOUNDED = true>
 __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -853,8 +859,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
 
     MIRLSQ_STAMP(sc.dbg, 1);
     int qp_iters = 0;
-    const int qp = box_qp_device<T, NB>(n, sc.Pm, a.Jy, qpl, qpu, xq, false, a.set.qpRelTolerance, a.set.qpAbsTolerance,
-                                 a.set.qpMaxIterations, sc, F, ldf, red, ired, &qp_iters, true);   // LS:1080
+    const int qp = box_qp_device<T, NB, BOUNDED>(n, sc.Pm, a.Jy, qpl, qpu, xq, false, a.set.qpRelTolerance, a.set.qpAbsTolerance,
+                                          a.set.qpMaxIterations, sc, F, ldf, red, ired, &qp_iters, true);   // LS:1080
 
     MIRLSQ_STAMP(sc.dbg, 7);
     int flags = 0;
