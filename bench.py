@@ -257,6 +257,9 @@ def main():
                 "workload": f"cfg3 tanh-linear NLS m={m}/GPU x n={n} fp64, FD Jacobian ({args.fd} residual callback), "
                             f"absTolerance={args.abs_tolerance:g}, whole solves x0 -> termination",
                 "m_per_gpu": m, "m_total": m * world, "n": n, "parallelism": f"rows sharded x{world}, RCCL all-reduce",
+                "abs_tolerance": args.abs_tolerance,
+                "abs_tolerance_note": "1e-5: every accept/reject decision of the solve has margin; at 1e-9 the last acceptance "
+                                      "compares rounding noise (12 it / 16 passes or 11 it / 56 passes), DESIGN.md section 5",
                 "iterations_per_solve": iters / args.steps, "status": res.status.name,
                 "passes_per_solve": st["passes"] / args.steps, "fcalls_per_solve": res.fCalls,
                 "jacobian_full_per_solve": st["jacobian_full"] / args.steps,
