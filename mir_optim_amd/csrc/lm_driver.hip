@@ -103,6 +103,8 @@ struct JtjPlan {
     bool v2 = false;      // LDS-DMA ring kernel (f64, n = 16 ncb)
     bool wide = false;    // 128 < n <= 256: tiled jobs (jtj_wide.h)
     bool ring8 = false;   // 128 < n <= 256, f64, n % 16 == 0, m even: eight-wave LDS-DMA ring (jtj_ring8.h)
+    bool fdp = false;     // f64, n % 16 == 0, n <= 128, any m: producer / consumer kernels (jtj_fdp.h) for the plain and
+                          // the finite-difference J^T J; v2 (the LDS-DMA ring kernels) additionally needs m even
     int njobs = 1;
 };
 
@@ -170,6 +172,7 @@ JtjPlan jtj_plan(size_t m, int n, int num_cu)
         return p;
     }
     static const bool no_v2 = std::getenv("MIR_LSQ_JTJ_V1") != nullptr;
+    p.fdp = sizeof(T) == 8 && n % 16 == 0 && n <= 128 && !no_v2;
     if (sizeof(T) == 8 && n % 16 == 0 && n <= 128 && m % 2 == 0 && !no_v2) {
         p.v2 = true;
         p.lds = jtj2_lds_rt(p.ncb, false);
@@ -210,6 +213,39 @@ hipError_t jtj_launch_one(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
     return hipGetLastError();
 }
 
+// plain J^T J + J^T y with producer / consumer waves (jtj_fdp.h, FD = false)
+template <int NCB>
+hipError_t jtj_fdp_plain_one(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t s)
+{
+    using FC = JtjFdpCfg<NCB, false>;
+    static bool fdp_attr_done = false;
+    if (!fdp_attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_jtj_fdp<NCB, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, FC::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        fdp_attr_done = true;
+    }
+    hipLaunchKernelGGL((k_jtj_fdp<NCB, false>), dim3(p.nblk), dim3(FC::THREADS), FC::LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+template <typename T>
+hipError_t jtj_fdp_plain(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
+{
+    if constexpr (sizeof(T) == 8) {
+        switch (p.ncb) {
+        case 1: return jtj_fdp_plain_one<1>(p, a, s);
+        case 2: return jtj_fdp_plain_one<2>(p, a, s);
+        case 3: return jtj_fdp_plain_one<3>(p, a, s);
+        case 4: return jtj_fdp_plain_one<4>(p, a, s);
+        case 5: return jtj_fdp_plain_one<5>(p, a, s);
+        case 6: return jtj_fdp_plain_one<6>(p, a, s);
+        case 7: return jtj_fdp_plain_one<7>(p, a, s);
+        case 8: return jtj_fdp_plain_one<8>(p, a, s);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
 template <int NCB, bool BR>
 hipError_t jtj2_launch_one(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t s)
 {
@@ -229,22 +265,6 @@ hipError_t jtj2_launch_one(const JtjPlan& p, const JtjArgs<double>& a, hipStream
                 attr3_done = true;
             }
             hipLaunchKernelGGL(k3, dim3(p.nblk), dim3(kJtj2Threads), lds3, s, a);
-            return hipGetLastError();
-        }
-    }
-    if constexpr (!BR) {
-        // plain J^T J + J^T y: producer / consumer waves (jtj_fdp.h, FD = false); MIR_LSQ_JTJ_KERNEL=ring: the LDS-DMA ring
-        static const bool ring = std::getenv("MIR_LSQ_JTJ_KERNEL") && std::getenv("MIR_LSQ_JTJ_KERNEL")[0] == 'r';
-        if (!ring) {
-            using FC = JtjFdpCfg<NCB, false>;
-            static bool fdp_attr_done = false;
-            if (!fdp_attr_done) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_jtj_fdp<NCB, false>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, FC::LDS_BYTES);
-                if (e != hipSuccess) return e;
-                fdp_attr_done = true;
-            }
-            hipLaunchKernelGGL((k_jtj_fdp<NCB, false>), dim3(p.nblk), dim3(FC::THREADS), FC::LDS_BYTES, s, a);
             return hipGetLastError();
         }
     }
@@ -281,7 +301,7 @@ hipError_t jtj2_fd_launch_one(const JtjPlan& p, const JtjArgs<double>& a, hipStr
 {
     // default: register-staged producer waves (jtj_fdp.h); MIR_LSQ_FD_KERNEL=ring selects the LDS-DMA ring variant
     static const bool ring = std::getenv("MIR_LSQ_FD_KERNEL") && std::getenv("MIR_LSQ_FD_KERNEL")[0] == 'r';
-    if (!ring) {
+    if (!ring || !p.v2) {
         static bool fdp_attr_done = false;
         if (!fdp_attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_jtj_fdp<NCB, true>),
@@ -308,7 +328,7 @@ template <typename T>
 hipError_t jtj2_fd_launch(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
 {
     if constexpr (sizeof(T) == 8) {
-        if (!p.v2) return hipErrorInvalidValue;
+        if (!p.fdp) return hipErrorInvalidValue;
         switch (p.ncb) {
         case 1: return jtj2_fd_launch_one<1>(p, a, s);
         case 2: return jtj2_fd_launch_one<2>(p, a, s);
@@ -345,6 +365,11 @@ hipError_t jtj_launch_br(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
 {
     static const char* v1sel = std::getenv("MIR_LSQ_JTJ_V1_ONLY");   // diagnostics: "br" / "nobr" use v1 for that variant
     const bool force_v1 = v1sel && ((BR && v1sel[0] == 'b') || (!BR && v1sel[0] == 'n'));
+    if constexpr (!BR) {
+        // MIR_LSQ_JTJ_KERNEL=ring: the LDS-DMA ring (needs m even) instead of the producer / consumer kernel
+        static const bool ring = std::getenv("MIR_LSQ_JTJ_KERNEL") && std::getenv("MIR_LSQ_JTJ_KERNEL")[0] == 'r';
+        if (p.fdp && !force_v1 && !(ring && p.v2)) return jtj_fdp_plain<T>(p, a, s);
+    }
     if (p.v2 && !force_v1) return jtj2_dispatch<T, BR>(p, a, s);
     switch (p.ncb) {
     case 1: return jtj_launch_one<T, 1, BR>(p, a, s);
@@ -900,7 +925,7 @@ struct Solver {
         }
         T* Y = static_cast<T*>(ws->ypanel);
         static const bool no_fuse = std::getenv("MIR_LSQ_FD_FUSE") && std::getenv("MIR_LSQ_FD_FUSE")[0] == '0';
-        if (fbr && plan.v2 && pb == n && sizeof(T) == 8 && !no_fuse) {
+        if (fbr && plan.fdp && pb == n && sizeof(T) == 8 && !no_fuse) {
             // all 2n points in one sweep, Y[i][2j], Y[i][2j+1] = f(x + h e_j)_i, f(x - h e_j)_i; k_jtj2<., false, true>
             // (jacobian_products) turns the pairs into Jacobian rows on its way to J^T J -- no k_fd_fill pass
             fbr(fbctx, m, n, 2 * (size_t)n, B.X, Y);
@@ -1595,7 +1620,7 @@ int mir_lsq_fd_jtj_d(size_t m, size_t n, const double* Yrm, const double* twh, c
     if (n == 0 || n > (size_t)kSolveMaxN || m == 0) return -2;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const JtjPlan plan = jtj_plan<double>(m, (int)n, query_num_cu());
-    if (!plan.v2) return -6;                                    // shape not covered by the fused kernel
+    if (!plan.fdp) return -6;                                   // shape not covered by the fused kernel
     const size_t packed_len = n * (n + 1) / 2 + n + 8;
     double *slabs = nullptr, *packed = nullptr;
     LmState<double>* st = nullptr;

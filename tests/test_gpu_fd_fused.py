@@ -29,7 +29,7 @@ def ref_fill(Yrm, twh):
 
 
 @pytest.mark.parametrize("m,n", [(4096, 128), (5000, 16), (30, 32), (2, 48), (10002, 64), (7778, 80), (12344, 96),
-                                 (6, 112), (100000, 128)])
+                                 (6, 112), (100000, 128), (4097, 128), (10001, 64), (1, 16), (33, 32), (7777, 112)])
 def test_fd_jtj_exact_integers(m, n):
     rng = np.random.default_rng(m + n)
     Yrm = rng.integers(-8, 9, size=(m, 2 * n)).astype(np.float64)
@@ -94,7 +94,8 @@ def test_row_major_batched_residual_equals_point_major(m, n):
 
 
 @pytest.mark.parametrize("m,n,bounded", [(20000, 32, False), (50000, 128, False), (4096, 16, False), (30000, 64, False),
-                                         (7000, 48, False), (3000, 16, True), (10000, 96, True)])
+                                         (7000, 48, False), (3000, 16, True), (10000, 96, True), (20001, 32, False),
+                                         (9999, 128, False), (5001, 80, True)])
 def test_fused_fd_solve_matches_fill_pass(m, n, bounded):
     w = P.tanh_linear(m, n)
     prob = W.TanhLinear(w["A"], w["b"])
