@@ -303,8 +303,9 @@ def cpu_baseline(data, m, n, iterations, abs_tolerance):
                         use_openblas=ob)
     dt = time.perf_counter() - t0
     return {"value": ro.iterations / dt, "unit": "iterations/s", "cores": threads, "kind": "port",
-            "sample": f"first {ro.iterations} accepted LM iterations of the same m={m} x n={n} solve "
-                      f"(1 FD Jacobian = {2 * n} residual calls + Broyden passes), {dt:.1f} s, "
+            "sample": f"the first {ro.iterations} accepted LM iterations of the same m={m} x n={n} solve (bounded by "
+                      f"maxIterations={iterations}; status {O.status_name(ro.status) if hasattr(O, 'status_name') else ro.status}, "
+                      f"fCalls {ro.fCalls}: FD Jacobians of {2 * n} residual calls each + Broyden passes), {dt:.1f} s, "
                       f"OpenBLAS={'yes' if ob else 'no (plain loops)'}, residual calls OpenMP x{threads}",
             "seconds": dt, "fcalls": ro.fCalls}
 
