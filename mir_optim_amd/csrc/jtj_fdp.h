@@ -53,13 +53,15 @@ template <int NCB>
 __device__ __forceinline__ void fdp_producer(const JtjArgs<double>& a, double* smem, int lane, int w, size_t s0, size_t S)
 {
     using C = JtjFdpCfg<NCB>;
-    constexpr int n = C::N;
+    constexpr int n = C::N;                                // PADDED column count 16 NCB: the LDS stage layout
     constexpr int NI = C::NI;
     const size_t m = a.m;
+    const int nr = a.n;                                    // the problem's n <= 16 NCB: row stride of Y (in pairs) and of J
     const fdp_v2d* __restrict__ Y = reinterpret_cast<const fdp_v2d*>(a.J);
 
     // n % 64 == 0: instruction i covers row (64 i) / n, columns (64 i) % n + lane -- the row is a compile-time constant and
-    // only n / 64 distinct column sets exist; otherwise both are per-lane values
+    // only n / 64 distinct column sets exist; otherwise both are per-lane values. Padding columns (>= nr) behave like
+    // collapsed intervals: they read a valid address and produce zeros.
     constexpr bool ALIGNED = n % 64 == 0;
     constexpr int KD = ALIGNED ? n / 64 : NI;              // distinct (column, 1 / twh) registers per lane
     int jrow_v[ALIGNED ? 1 : NI], jcol_v[KD];
@@ -68,8 +70,10 @@ __device__ __forceinline__ void fdp_producer(const JtjArgs<double>& a, double* s
 #pragma unroll
     for (int k = 0; k < KD; ++k) {
         const int f = 64 * k + lane;
-        jcol_v[k] = ALIGNED ? f : f % n;
-        const double t = a.twh[jcol_v[k]];
+        const int jc = ALIGNED ? f : f % n;
+        const bool pad = jc >= nr;
+        jcol_v[k] = pad ? 0 : jc;
+        const double t = pad ? 0.0 : a.twh[jcol_v[k]];
         zc[k] = t == 0;                                    // collapsed interval: zero column (LS:1046)
         inv[k] = zc[k] ? 0.0 : 1.0 / t;                    // LS:1047
     }
@@ -88,7 +92,7 @@ __device__ __forceinline__ void fdp_producer(const JtjArgs<double>& a, double* s
         for (int i = 0; i < NI; ++i) {
             size_t row = row0 + jrow(i);
             row = row < m ? row : m - 1;
-            b[i] = Y[row * (size_t)n + jcol_v[kd(i)]];
+            b[i] = Y[row * (size_t)nr + jcol_v[kd(i)]];
         }
         size_t yr = row0 + (lane & (C::RP - 1));
         yr = yr < m ? yr : m - 1;
@@ -117,28 +121,41 @@ __device__ __forceinline__ void fdp_producer(const JtjArgs<double>& a, double* s
     }
 }
 
-// Plain variant (FD = false): the source is J itself (m x n row-major); a producer copies its RP rows of every stage --
-// RP n contiguous doubles, NI = NCB 16-byte loads per lane -- into the LDS slot unchanged. Nothing is written back.
+// Plain variant (FD = false): the source is J itself (m x n row-major, n even so that a row starts on a 16-byte
+// boundary); a producer copies its RP rows of every stage into the LDS slot -- NI = NCB 16-byte loads per lane over the
+// padded row (pairs past n read a valid address and are stored as zeros). Nothing is written back.
 template <int NCB>
 __device__ __forceinline__ void fdp_producer_plain(const JtjArgs<double>& a, double* smem, int lane, int w, size_t s0, size_t S)
 {
     using C = JtjFdpCfg<NCB, false>;
-    constexpr int n = C::N;
+    constexpr int n = C::N;                                // padded
     constexpr int NI = C::NI;
+    constexpr int HP = n / 2;                              // pairs per padded row
     const size_t m = a.m;
+    const int nr = a.n;
+    const size_t hr = (size_t)(nr / 2);                    // pairs per source row
     const fdp_v2d* __restrict__ Jp = reinterpret_cast<const fdp_v2d*>(a.J);
-    const size_t last_pair = m * (size_t)n / 2 - 1;
+
+    int prow[NI], pcol[NI];                                // row inside the wave's RP rows, pair column (0 for padding)
+    bool pad[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int f = 64 * i + lane;
+        prow[i] = f / HP;
+        const int jp = f % HP;
+        pad[i] = 2 * jp >= nr;
+        pcol[i] = pad[i] ? 0 : jp;
+    }
 
     fdp_v2d b[NI];
     double yb = 0;
     auto issue = [&](size_t s) {
         const size_t row0 = (s0 + s) * C::RS + C::RP * (size_t)w;
-        const size_t base = row0 * (size_t)(n / 2);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            size_t g = base + 64 * i + lane;
-            g = g < last_pair ? g : last_pair;             // rows past m: any valid bytes, zeroed in convert
-            b[i] = Jp[g];
+            size_t row = row0 + prow[i];
+            row = row < m ? row : m - 1;
+            b[i] = Jp[row * hr + pcol[i]];
         }
         size_t yr = row0 + (lane & (C::RP - 1));
         yr = yr < m ? yr : m - 1;
@@ -147,14 +164,10 @@ __device__ __forceinline__ void fdp_producer_plain(const JtjArgs<double>& a, dou
     auto convert = [&](size_t s) {
         double* slot = smem + (s & 1) * C::SLOT_DOUBLES;
         const size_t row0 = (s0 + s) * C::RS + C::RP * (size_t)w;
-        const bool full = row0 + C::RP <= m;               // wave-uniform
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             fdp_v2d v = b[i];
-            if (!full) {
-                const size_t row = row0 + (size_t)(2 * (64 * i + lane)) / n;
-                if (row >= m) v = fdp_v2d{0.0, 0.0};
-            }
+            if (pad[i] || row0 + prow[i] >= m) v = fdp_v2d{0.0, 0.0};
             *reinterpret_cast<fdp_v2d*>(slot + w * C::RP * n + 2 * (64 * i + lane)) = v;
         }
         if (lane < C::RP) slot[C::RS * n + C::RP * w + lane] = (row0 + lane < m) ? yb : 0.0;
@@ -203,10 +216,10 @@ __device__ __forceinline__ void fdp_consumer(const JtjArgs<double>& a, const dou
                 // the Jacobian rows leave through roles 2 and 3 (column blocks c = ROLE (mod 2))
                 const size_t row = row0 + 4 * gi + q;
                 if (row < m) {
-                    T* wp = a.Jout + row * (size_t)n;
+                    T* wp = a.Jout + row * (size_t)a.n;    // the problem's n: row stride of J; padding columns stay in LDS
 #pragma unroll
                     for (int c = 0; c < NCB; ++c)
-                        if (c % 2 == ROLE - 2) wp[16 * c + p] = g.v[c];
+                        if (c % 2 == ROLE - 2) { if (16 * c + p < a.n) wp[16 * c + p] = g.v[c]; }
                 }
             }
             if constexpr (ROLE == 0) {

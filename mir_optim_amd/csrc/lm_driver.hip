@@ -103,8 +103,8 @@ struct JtjPlan {
     bool v2 = false;      // LDS-DMA ring kernel (f64, n = 16 ncb)
     bool wide = false;    // 128 < n <= 256: tiled jobs (jtj_wide.h)
     bool ring8 = false;   // 128 < n <= 256, f64, n % 16 == 0, m even: eight-wave LDS-DMA ring (jtj_ring8.h)
-    bool fdp = false;     // f64, n % 16 == 0, n <= 128, any m: producer / consumer kernels (jtj_fdp.h) for the plain and
-                          // the finite-difference J^T J; v2 (the LDS-DMA ring kernels) additionally needs m even
+    bool fdp = false;     // f64, n <= 128, any m: producer / consumer kernel (jtj_fdp.h) for the finite-difference J^T J
+    bool fdp_plain = false;   // ... and, n even, for the plain J^T J; v2 (the LDS-DMA ring kernels) needs n % 16 == 0 and m even
     int njobs = 1;
 };
 
@@ -172,7 +172,8 @@ JtjPlan jtj_plan(size_t m, int n, int num_cu)
         return p;
     }
     static const bool no_v2 = std::getenv("MIR_LSQ_JTJ_V1") != nullptr;
-    p.fdp = sizeof(T) == 8 && n % 16 == 0 && n <= 128 && !no_v2;
+    p.fdp = sizeof(T) == 8 && n <= 128 && !no_v2;
+    p.fdp_plain = p.fdp && n % 2 == 0;
     if (sizeof(T) == 8 && n % 16 == 0 && n <= 128 && m % 2 == 0 && !no_v2) {
         p.v2 = true;
         p.lds = jtj2_lds_rt(p.ncb, false);
@@ -368,7 +369,7 @@ hipError_t jtj_launch_br(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
     if constexpr (!BR) {
         // MIR_LSQ_JTJ_KERNEL=ring: the LDS-DMA ring (needs m even) instead of the producer / consumer kernel
         static const bool ring = std::getenv("MIR_LSQ_JTJ_KERNEL") && std::getenv("MIR_LSQ_JTJ_KERNEL")[0] == 'r';
-        if (p.fdp && !force_v1 && !(ring && p.v2)) return jtj_fdp_plain<T>(p, a, s);
+        if (p.fdp_plain && !force_v1 && !(ring && p.v2)) return jtj_fdp_plain<T>(p, a, s);
     }
     if (p.v2 && !force_v1) return jtj2_dispatch<T, BR>(p, a, s);
     switch (p.ncb) {

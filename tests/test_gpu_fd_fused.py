@@ -29,13 +29,14 @@ def ref_fill(Yrm, twh):
 
 
 @pytest.mark.parametrize("m,n", [(4096, 128), (5000, 16), (30, 32), (2, 48), (10002, 64), (7778, 80), (12344, 96),
-                                 (6, 112), (100000, 128), (4097, 128), (10001, 64), (1, 16), (33, 32), (7777, 112)])
+                                 (6, 112), (100000, 128), (4097, 128), (10001, 64), (1, 16), (33, 32), (7777, 112),
+                                 (5000, 100), (3001, 7), (2048, 17), (999, 33), (6000, 127), (40, 1), (12345, 90)])
 def test_fd_jtj_exact_integers(m, n):
     rng = np.random.default_rng(m + n)
     Yrm = rng.integers(-8, 9, size=(m, 2 * n)).astype(np.float64)
     twh = np.full(n, 2.0 ** -25)
     twh[rng.integers(0, n)] = 2.0 ** -26                       # a clipped interval
-    if n > 16:
+    if n > 3:
         twh[3] = 0.0                                           # a collapsed one
     y = rng.integers(-4, 5, size=m).astype(np.float64)
     J, JJ, Jy, ms = M.fd_jtj(Yrm, twh, y)
@@ -47,7 +48,7 @@ def test_fd_jtj_exact_integers(m, n):
     assert np.array_equal(JJ, JJ.T)
 
 
-@pytest.mark.parametrize("m,n", [(20000, 128), (9998, 32), (50, 16), (33334, 112)])
+@pytest.mark.parametrize("m,n", [(20000, 128), (9998, 32), (50, 16), (33334, 112), (5000, 100), (7001, 9), (3000, 126)])
 def test_fd_jtj_random(m, n):
     rng = np.random.default_rng(7 * m + n)
     base = rng.standard_normal((m, 1))
@@ -95,7 +96,8 @@ def test_row_major_batched_residual_equals_point_major(m, n):
 
 @pytest.mark.parametrize("m,n,bounded", [(20000, 32, False), (50000, 128, False), (4096, 16, False), (30000, 64, False),
                                          (7000, 48, False), (3000, 16, True), (10000, 96, True), (20001, 32, False),
-                                         (9999, 128, False), (5001, 80, True)])
+                                         (9999, 128, False), (5001, 80, True), (9973, 100, False), (6000, 7, False),
+                                         (8000, 33, True), (12000, 90, False)])
 def test_fused_fd_solve_matches_fill_pass(m, n, bounded):
     w = P.tanh_linear(m, n)
     prob = W.TanhLinear(w["A"], w["b"])
