@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--control-plane", choices=["gloo", "nccl"], default="gloo",
                     help="torch.distributed backend for barriers / id exchange (the solve's collectives always use the "
                          "solver's own RCCL communicator)")
+    ap.add_argument("--comm", choices=["rccl", "gloo-callback"], default="rccl",
+                    help="data-plane communicator: the solver's RCCL communicator (production) or, to rehearse N > 1 on a box "
+                         "with fewer GPUs, its callback communicator over gloo (ranks then share GPUs)")
     ap.add_argument("--settle", type=float, default=8.0,
                     help="N > 1: minimum seconds between RCCL communicator creation and the first warm-up solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -105,8 +108,9 @@ def main():
 
     if not torch.cuda.is_available() or M.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: mir_optim_amd has no CPU path")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count() if args.comm == "gloo-callback" else local_rank)
     comm = None
+    comm_obj = None
     distributed = world > 1 or os.environ.get("MIR_LSQ_FORCE_COMM") == "1"   # the env knob exercises the N > 1 code path on one GPU
     if distributed:
         from mir_optim_amd import parallel as PAR
@@ -117,8 +121,8 @@ def main():
         # Control plane (unique-id exchange, the barriers around the timed region, the max over ranks): torch.distributed.
         # Data plane (every collective of the solve): the solver's OWN RCCL communicator over xGMI, created below.
         # The control plane defaults to gloo: a second, idle RCCL instance (torch's "nccl" process group with its
-        # watchdog / heartbeat threads and streams) next to the solver's communicator buys nothing and was seen to cost
-        # sporadic 20-60 ms host stalls inside timed solves on the one-GPU box; --control-plane nccl selects it anyway.
+        # watchdog / heartbeat threads and streams) next to the solver's communicator buys nothing;
+        # --control-plane nccl selects it anyway.
         if args.control_plane == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -129,7 +133,12 @@ def main():
             t = torch.from_numpy(buf).to(ctl_dev)
             dist.broadcast(t, 0)
             return t.cpu().numpy()
-        if os.environ.get("BENCH_DIAG_NO_RCCL") != "1":   # diagnostic: process group only
+        if args.comm == "gloo-callback":
+            # rehearsal of the N > 1 code path on a box with fewer GPUs than ranks: the solver's callback communicator, its
+            # all-reduce done by torch.distributed over gloo (device -> host -> gloo -> device); ranks may share a GPU
+            comm_obj = PAR.HostAllreduceComm(world, rank, PAR.torch_allreduce_numpy(dist))
+            comm = comm_obj.handle
+        elif os.environ.get("BENCH_DIAG_NO_RCCL") != "1":   # diagnostic: process group only
             comm = PAR.rccl_comm(world, rank, bcast)  # the solver's own RCCL communicator (xGMI), id via torch.distributed
         t_comm = time.perf_counter()
 
@@ -156,7 +165,7 @@ def main():
     # 60-150 ms. Measured on the one-GPU box with MIR_LSQ_FORCE_COMM=1: 160-310 it/s when that lands in the timed region,
     # 740-760 when it does not; warm collectives at creation and RCCL_MSCCL*/NCCL_* knobs do not move it, waiting does.
     # So: keep `settle` seconds between communicator creation and the first warm-up solve (set-up time counts).
-    if comm is not None and args.settle > 0:
+    if comm is not None and args.comm == "rccl" and args.settle > 0:
         wait = args.settle - (time.perf_counter() - t_comm)
         if wait > 0:
             time.sleep(wait)
@@ -256,7 +265,7 @@ def main():
             "config": {
                 "workload": f"cfg3 tanh-linear NLS m={m}/GPU x n={n} fp64, FD Jacobian ({args.fd} residual callback), "
                             f"absTolerance={args.abs_tolerance:g}, whole solves x0 -> termination",
-                "m_per_gpu": m, "m_total": m * world, "n": n, "parallelism": f"rows sharded x{world}, RCCL all-reduce",
+                "m_per_gpu": m, "m_total": m * world, "n": n, "parallelism": f"rows sharded x{world}, " + ("RCCL all-reduce" if args.comm == "rccl" else "gloo callback all-reduce (rehearsal)"),
                 "abs_tolerance": args.abs_tolerance,
                 "abs_tolerance_note": "1e-5: every accept/reject decision of the solve has margin; at 1e-9 the last acceptance "
                                       "compares rounding noise (12 it / 16 passes or 11 it / 56 passes), DESIGN.md section 5",
@@ -273,7 +282,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data, m, n, args.cpu_iterations, args.abs_tolerance)
-    if comm:
+    if comm_obj is not None:
+        comm_obj.close()
+    elif comm:
         api.lib().mir_lsq_comm_destroy(comm)
     api.lib().mir_lsq_workspace_destroy(ws)
     if distributed:
