@@ -301,7 +301,8 @@ template <int NCB>
 hipError_t jtj2_fd_launch_one(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t s)
 {
     // default: register-staged producer waves (jtj_fdp.h); MIR_LSQ_FD_KERNEL=ring selects the LDS-DMA ring variant
-    static const bool ring = std::getenv("MIR_LSQ_FD_KERNEL") && std::getenv("MIR_LSQ_FD_KERNEL")[0] == 'r';
+    const char* sel = std::getenv("MIR_LSQ_FD_KERNEL");       // read per call: the tests switch it within one process
+    const bool ring = sel && sel[0] == 'r';
     if (!ring || !p.v2) {
         static bool fdp_attr_done = false;
         if (!fdp_attr_done) {
@@ -368,7 +369,8 @@ hipError_t jtj_launch_br(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
     const bool force_v1 = v1sel && ((BR && v1sel[0] == 'b') || (!BR && v1sel[0] == 'n'));
     if constexpr (!BR) {
         // MIR_LSQ_JTJ_KERNEL=ring: the LDS-DMA ring (needs m even) instead of the producer / consumer kernel
-        static const bool ring = std::getenv("MIR_LSQ_JTJ_KERNEL") && std::getenv("MIR_LSQ_JTJ_KERNEL")[0] == 'r';
+        const char* sel = std::getenv("MIR_LSQ_JTJ_KERNEL");  // read per call: the tests switch it within one process
+        const bool ring = sel && sel[0] == 'r';
         if (p.fdp_plain && !force_v1 && !(ring && p.v2)) return jtj_fdp_plain<T>(p, a, s);
     }
     if (p.v2 && !force_v1) return jtj2_dispatch<T, BR>(p, a, s);
