@@ -64,8 +64,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--m", type=int, default=1_000_000, help="rows per GPU")
-    ap.add_argument("--n", type=int, default=128)
+    # (under torch.distributed.run, abbreviations such as --m collide with the launcher's own options: BENCH_M / BENCH_N)
+    ap.add_argument("--m", type=int, default=int(os.environ.get("BENCH_M", 1_000_000)), help="rows per GPU")
+    ap.add_argument("--n", type=int, default=int(os.environ.get("BENCH_N", 128)))
     ap.add_argument("--fd", choices=["batched", "pointmajor", "serial"], default="batched",
                     help="finite differences through the batched residual callbacks (row-major panel, fill fused into the "
                          "J^T J kernel), through the point-major batched callback + k_fd_fill, or one call per point")

@@ -97,3 +97,23 @@ def test_rccl_communicator_world_size_1(oracle):
     r0, x0 = prob.solve(w["x0"], settings=s)
     M.api.lib().mir_lsq_comm_destroy(comm)
     assert r1.status >= 0 and np.array_equal(x1, x0) and r1.iterations == r0.iterations   # sum over one rank = identity
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """bench.py through torch.distributed.run with two ranks sharing the GPU (callback communicator over gloo): rank 0
+    prints one JSON line, last; both shards contribute; the control flow of the N > 1 path (barriers, max over ranks,
+    teardown) completes."""
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, BENCH_M="200000", BENCH_N="64", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--comm", "gloo-callback"]
+    p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    d = json.loads(lines[-1])
+    assert sum(1 for l in lines if l.startswith('{"metric"')) == 1
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["m_total"] == 400000 and d["config"]["status"] in ("xConverged", "furtherImprovement", "fConverged", "gConverged")
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
