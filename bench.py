@@ -282,7 +282,7 @@ def main():
             other_key: other,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(data, m, n, args.cpu_iterations, args.abs_tolerance)
+            out["cpu_baseline"] = cpu_baseline(data, m, n, args.cpu_iterations, args.abs_tolerance, x, res)
     if comm_obj is not None:
         comm_obj.close()
     elif comm:
@@ -299,7 +299,7 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def cpu_baseline(data, m, n, iterations, abs_tolerance):
+def cpu_baseline(data, m, n, iterations, abs_tolerance, x_gpu=None, res_gpu=None):
     """The oracle (port of the reference algorithm; OpenBLAS from scipy for syrk/gemv/ger/posvx -- the
     library class the reference links) on the same inputs, bounded to `iterations` accepted steps."""
     from oracle import oracle as O
@@ -314,7 +314,15 @@ def cpu_baseline(data, m, n, iterations, abs_tolerance):
     ro, xo = O.optimize(O.native_fn("wlc_tanh_linear_f"), m, data["x0"], settings=so, fctx=C.addressof(ctx),
                         use_openblas=ob)
     dt = time.perf_counter() - t0
-    return {"value": ro.iterations / dt, "unit": "iterations/s", "cores": threads, "kind": "port",
+    parity = {}
+    if x_gpu is not None and ro.iterations == res_gpu.iterations:
+        # the CPU sample ran the same number of accepted iterations as the GPU solve: the full-size parity datum
+        import numpy as np
+        parity = {"parity_x_max_abs_diff": float(np.abs(np.asarray(x_gpu) - np.asarray(xo)).max()),
+                  "parity_x_max_abs": float(np.abs(np.asarray(xo)).max()),
+                  "parity_residual_rel_diff": abs(res_gpu.residual - ro.residual) / abs(ro.residual),
+                  "parity_status": [int(res_gpu.status), int(ro.status)]}
+    return {**parity, "value": ro.iterations / dt, "unit": "iterations/s", "cores": threads, "kind": "port",
             "sample": f"the first {ro.iterations} accepted LM iterations of the same m={m} x n={n} solve (bounded by "
                       f"maxIterations={iterations}; status {O.status_name(ro.status) if hasattr(O, 'status_name') else ro.status}, "
                       f"fCalls {ro.fCalls}: FD Jacobians of {2 * n} residual calls each + Broyden passes), {dt:.1f} s, "
