@@ -244,10 +244,11 @@ def main():
             }
         else:
             plain_ms = (st["jtj_ms"] - st["jtj_broyden_ms"]) / max(1, npl)
-            pl_name = f"mirlsq::k_jtj2<{ncb}, false>"
+            pl_name = (f"mirlsq::k_jtj8<{ncb}>" if n > 128 else f"mirlsq::k_jtj_fdp<{ncb}, false>" if n % 2 == 0
+                       else f"mirlsq::k_jtj<double, {ncb}, false>")
             tf = jtj_flops / (plain_ms * 1e-3) / 1e12 if plain_ms else 0.0
             fresh = {
-                "kernel": pl_name + " (J^T J + J^T y of a fresh Jacobian, f64 MFMA 16x16x4, LDS-DMA ring)",
+                "kernel": pl_name + " (J^T J + J^T y of a fresh Jacobian, f64 MFMA 16x16x4)",
                 "bound": "mfma", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
                 "avg_launch_ms": plain_ms, "launches": npl,
                 "traffic": pmc_traffic(pl_name, m, n), "algorithmic_bytes_per_launch": 8.0 * (m * n + m),
