@@ -916,7 +916,10 @@ struct Solver {
         // panel width bounded by an 8 GiB scratch
         size_t pb = n;
         const size_t cap = (size_t)8 << 30;
-        if (2 * pb * m * sizeof(T) > cap) pb = cap / (2 * m * sizeof(T));
+        if (2 * pb * m * sizeof(T) > cap) {
+            pb = cap / (2 * m * sizeof(T));
+            if (pb >= 64) pb -= pb % 64;         // whole multiples of 128 points per call: batched callbacks work in such chunks
+        }
         if (pb < 1) pb = 1;
         if (fb && fd_batch && fd_batch / 2 < pb) pb = fd_batch / 2 ? fd_batch / 2 : 1;
         const size_t need = 2 * pb * m * sizeof(T);
