@@ -913,9 +913,18 @@ struct Solver {
             xph = std::fmin(xph, uh[j]);
             twh_h[j] = xph - xmh;
         }
-        // panel width bounded by an 8 GiB scratch
+        // panel width bounded by the scratch the device can spare: half of the free HBM, at most 64 GiB (288 GB per GPU: the
+        // whole 2n-point panel of cfg 4's 8e6 x 256 problem, 33 GB, stays in one piece), at least 1 GiB
         size_t pb = n;
-        const size_t cap = (size_t)8 << 30;
+        size_t cap = (size_t)64 << 30;
+        {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const size_t have = ws->ypanel_bytes + free_b;         // what the panel already holds counts as available
+                if (have / 2 < cap) cap = have / 2;
+            }
+            if (cap < ((size_t)1 << 30)) cap = (size_t)1 << 30;
+        }
         if (2 * pb * m * sizeof(T) > cap) {
             pb = cap / (2 * m * sizeof(T));
             if (pb >= 64) pb -= pb % 64;         // whole multiples of 128 points per call: batched callbacks work in such chunks
