@@ -575,8 +575,10 @@ __device__ __forceinline__ int posvx_device(int n, T* A, int lda, T* F, int ldf,
             const int i = base + (tid >> 1), h = tid & 1;
             const int ic = i < n ? i : n - 1;
             const int k0 = h ? n / 2 : 0, k1 = h ? n : n / 2;
-            const T* __restrict__ Ap = A;
-            const T* __restrict__ xp = x;
+            // plain pointers: A was written and x is rewritten between sweeps by other threads of this workgroup, so the
+            // compiler must not treat these loads as invariant (no scalar-cache loads, no hoisting across the barriers)
+            const T* Ap = A;
+            const T* xp = x;
             T ri = 0, wi = 0;
             for (int kb = k0; kb < k1; kb += 16) {
                 T av[16], xv[16];
