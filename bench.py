@@ -231,7 +231,7 @@ def main():
         if nfd:
             fd_ms = st["jtj_fd_ms"] / nfd
             ring = os.environ.get("MIR_LSQ_FD_KERNEL", "")[:1] == "r"
-            fd_name = f"mirlsq::k_jtj2<{ncb}, false, true>" if ring else f"mirlsq::k_jtj_fdp<{ncb}>"
+            fd_name = f"mirlsq::k_jtj2<{ncb}, false, true>" if ring else f"mirlsq::k_jtj_fdp<{ncb}, true>"
             fd_bytes = 8.0 * (3.0 * m * n + m)                # read the m x 2n panel and y, write J
             fd_rate = fd_bytes / (fd_ms * 1e-3) / 1e9
             fresh = {
