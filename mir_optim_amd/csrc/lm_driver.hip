@@ -917,7 +917,7 @@ struct Solver {
         // whole 2n-point panel of cfg 4's 8e6 x 256 problem, 33 GB, stays in one piece), at least 1 GiB
         size_t pb = n;
         size_t cap = (size_t)64 << 30;
-        {
+        if (ws->ypanel_bytes < 2 * pb * m * sizeof(T)) {              // the whole panel is not there yet: ask the device
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
                 const size_t have = ws->ypanel_bytes + free_b;         // what the panel already holds counts as available
