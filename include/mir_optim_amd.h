@@ -175,6 +175,27 @@ enum {
     MIR_LSQ_TIME_KERNELS = 2u        /* bracket the hot kernels with HIP events and fill `stats` */
 };
 
+/* `variant` bits of mir_lsq_gpu_options: A/B switches for tests and diagnostics. 0 = the product path. Every variant
+ * computes the same quantities (results agree to rounding, several bit for bit); they exist so that the tests can compare
+ * the product kernels with literal restatements of the reference's operation order. Read per call, never latched. */
+enum {
+    MIR_LSQ_VARIANT_BROYDEN_REWRITE = 1u << 0,   /* Broyden passes rewrite J every pass (LS:1003-1006 literally) instead of
+                                                    the read-only sweep with pending rank-one terms (broyden_lr.h) */
+    MIR_LSQ_VARIANT_FD_SEPARATE_FILL = 1u << 1,  /* ignore fbRowMajor: point-major panel + column-fill pass + plain J^T J */
+    MIR_LSQ_VARIANT_JTJ_RING = 1u << 2,          /* plain J^T J on the LDS-DMA ring kernel (n % 16 == 0, m even) */
+    MIR_LSQ_VARIANT_JTJ_STREAM = 1u << 3,        /* register-streaming J^T J kernels (tile-pair jobs above n = 128) */
+    MIR_LSQ_VARIANT_NO_SPECULATION = 1u << 4,    /* one trial per pass instead of the lambda ladder */
+    MIR_LSQ_VARIANT_NO_NULL_SKIP = 1u << 5,      /* evaluate f also for trials equal to x bit for bit */
+    MIR_LSQ_VARIANT_SOLVE_BOUNDED = 1u << 6,     /* always the solve kernel with the BOXCQP loop compiled in */
+    MIR_LSQ_VARIANT_DEBUG_SOLVE = 1u << 7,       /* print phase stamps of the solve kernel (stderr) */
+    MIR_LSQ_VARIANT_HOST_PROFILE = 1u << 8,      /* print host wall time per category of runtime call (stderr) */
+    MIR_LSQ_VARIANT_NO_RESYNC = 1u << 9,         /* do not recompute J^T J / J^T y from J when the pending Broyden terms are
+                                                    folded into it (the recurrence then runs until the next full refresh) */
+    MIR_LSQ_VARIANT_SOLVE_GENERIC = 1u << 10,    /* the any-n solve path (biglinalg.h) also for n <= 256 */
+    MIR_LSQ_VARIANT_LR_CAP_SHIFT = 16            /* bits 16..20: fold the pending Broyden terms into J after this many
+                                                    updates (1..16; 0 = 16) */
+};
+
 typedef struct mir_lsq_stats {
     uint64_t passes, accepted, rejected, step_guard_rejects;
     uint64_t jacobian_full, jacobian_broyden;
@@ -193,6 +214,13 @@ typedef struct mir_lsq_stats {
     uint64_t elided_evaluations;     /* trial evaluations not made because trial == x bit for bit (null steps at the end of
                                         a noisy solve; the callbacks are `pure`, LS:73-80, so f(trial) is already known);
                                         fCalls counts them like the reference does */
+    /* row-shard exchanges of this call (counted whenever a communicator is attached, also with one rank):
+     * [0] packed [J^T J lower | J^T y] after a full refresh or a resynchronisation: n(n+1)/2 + n elements each
+     * [1] sweep vector of a Broyden pass: 2n + 34 elements each     [2] sums of squares of residual vectors */
+    uint64_t allreduce_calls[3];
+    uint64_t allreduce_elems[3];
+    uint64_t broyden_flushes;        /* times the pending rank-one terms were folded into J */
+    uint64_t jtj_resyncs;            /* of those, followed by a recomputation of J^T J / J^T y from the flushed J */
 } mir_lsq_stats;
 
 /* Optional per-pass trace (not in the reference; a parity-pinning aid: tests compare it event by event with the
@@ -224,7 +252,7 @@ typedef struct mir_lsq_gpu_options {
     void* fbContext;
     void* fb;                        /* mir_lsq_batched_function_{d,s} or NULL */
     uint32_t fd_batch;               /* max points per fb call (0 = 2n) */
-    uint32_t reserved;
+    uint32_t variant;                /* MIR_LSQ_VARIANT_* bits; 0 = product path */
     mir_lsq_stats* stats;            /* optional out */
     mir_lsq_trace* trace;            /* optional out; read only when struct_size covers it (costs one extra
                                         device-to-host copy per pass) */
@@ -283,6 +311,9 @@ int mir_lsq_jtj_d(size_t m, size_t n, double* J, const double* y, const double* 
                   int broyden, double* JJ, double* Jy, void* stream, float* kernel_ms);
 int mir_lsq_jtj_s(size_t m, size_t n, float* J, const float* y, const float* y_old, const float* dx,
                   int broyden, float* JJ, float* Jy, void* stream, float* kernel_ms);
+/* same with MIR_LSQ_VARIANT_* kernel selection (JTJ_RING, JTJ_STREAM) */
+int mir_lsq_jtj_variant_d(size_t m, size_t n, double* J, const double* y, const double* y_old, const double* dx,
+                          int broyden, double* JJ, double* Jy, void* stream, float* kernel_ms, uint32_t variant);
 
 /* Finite-difference fill fused into the J^T J kernel (f64, n <= 128; else -6). Yrm: m x 2n
  * row-major, Yrm[i][2j] = f(x + h e_j)_i, Yrm[i][2j+1] = f(x - h e_j)_i; twh[j] = (x_j + h) - (x_j - h) after clipping
@@ -303,6 +334,13 @@ mir_lsq_comm* mir_lsq_comm_create_rccl(int nranks, int rank, const void* unique_
  * ranks in place, ordered after prior work on `stream` (used with gloo in the tests). */
 typedef void (*mir_lsq_allreduce_fn)(void* ctx, double* device_buf, size_t count, void* stream);
 mir_lsq_comm* mir_lsq_comm_create_callback(int nranks, int rank, mir_lsq_allreduce_fn fn, void* ctx);
+/* In-process group: `nranks` solver instances inside ONE process -- one host thread each, on the same device (R logical
+ * shards on one GPU: the single-device emulation of SURVEY.md section 7 step 7) or on different devices (one process
+ * driving several GPUs without RCCL). An all-reduce copies each rank's buffer to pinned host memory, the ranks meet at a
+ * barrier, every rank sums the nranks contributions in rank order (bitwise identical totals on all ranks) and copies the
+ * total back. out_comms receives nranks handles (rank r at out_comms[r]); destroy each with mir_lsq_comm_destroy.
+ * A rank that waits longer than 120 s at the barrier gives up (the solve then returns numericError). Returns 0. */
+int mir_lsq_comm_create_local_group(int nranks, mir_lsq_comm** out_comms);
 void mir_lsq_comm_destroy(mir_lsq_comm* comm);
 
 /* Small device utilities for language bindings that have no HIP runtime of their own. */

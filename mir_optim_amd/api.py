@@ -31,7 +31,10 @@ __all__ = [
     "mir_box_qp_iwork_length", "GpuOptions", "Stats", "lib", "workloads_lib", "device_count",
     "DeviceBuffer", "Stream", "jtj", "fd_jtj", "DEVICE_CALLBACKS", "TIME_KERNELS", "optimizeLeastSquaresBatched",
     "MODEL_EXP_DECAY", "MODEL_EXP3_AFFINE", "Trace", "TraceRecord", "Spline", "FitSplineResult", "fitSpline",
-    "fit_spline_residuals",
+    "fit_spline_residuals", "variant_lr_cap",
+    "VARIANT_BROYDEN_REWRITE", "VARIANT_FD_SEPARATE_FILL", "VARIANT_JTJ_RING", "VARIANT_JTJ_STREAM",
+    "VARIANT_NO_SPECULATION", "VARIANT_NO_NULL_SKIP", "VARIANT_SOLVE_BOUNDED", "VARIANT_DEBUG_SOLVE",
+    "VARIANT_HOST_PROFILE", "VARIANT_NO_RESYNC", "VARIANT_SOLVE_GENERIC",
 ]
 
 MODEL_EXP_DECAY = 0      # n = 3: p0 exp(-t p1) + p2
@@ -39,6 +42,24 @@ MODEL_EXP3_AFFINE = 1    # n = 8: p0 exp(-t p1) + p2 exp(-t p3) + p4 exp(-t p5) 
 
 DEVICE_CALLBACKS = 1
 TIME_KERNELS = 2
+
+# MIR_LSQ_VARIANT_* (include/mir_optim_amd.h): A/B switches for tests and diagnostics; 0 = the product path
+VARIANT_BROYDEN_REWRITE = 1 << 0
+VARIANT_FD_SEPARATE_FILL = 1 << 1
+VARIANT_JTJ_RING = 1 << 2
+VARIANT_JTJ_STREAM = 1 << 3
+VARIANT_NO_SPECULATION = 1 << 4
+VARIANT_NO_NULL_SKIP = 1 << 5
+VARIANT_SOLVE_BOUNDED = 1 << 6
+VARIANT_DEBUG_SOLVE = 1 << 7
+VARIANT_HOST_PROFILE = 1 << 8
+VARIANT_NO_RESYNC = 1 << 9
+VARIANT_SOLVE_GENERIC = 1 << 10
+
+
+def variant_lr_cap(k):
+    """Fold the pending Broyden terms into J after k (1..16) updates."""
+    return (int(k) & 31) << 16
 
 
 class LeastSquaresStatus(enum.IntEnum):  # LS:20-46
@@ -119,10 +140,12 @@ class Stats(C.Structure):
                 ("fd_ms", C.c_double), ("total_ms", C.c_double), ("qp_active_set_passes", C.c_uint64),
                 ("broyden_lr_columns", C.c_uint64),
                 ("jtj_fd_ms", C.c_double), ("jtj_fd_launches", C.c_uint64),
-                ("elided_evaluations", C.c_uint64)]
+                ("elided_evaluations", C.c_uint64),
+                ("allreduce_calls", C.c_uint64 * 3), ("allreduce_elems", C.c_uint64 * 3),
+                ("broyden_flushes", C.c_uint64), ("jtj_resyncs", C.c_uint64)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        return {k: (list(getattr(self, k)) if k.startswith("allreduce_") else getattr(self, k)) for k, _ in self._fields_}
 
 
 class TraceRecord(C.Structure):
@@ -155,7 +178,7 @@ class Trace:
 class GpuOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("flags", C.c_uint32), ("stream", C.c_void_p), ("comm", C.c_void_p),
                 ("workspace", C.c_void_p), ("fbContext", C.c_void_p), ("fb", C.c_void_p), ("fd_batch", C.c_uint32),
-                ("reserved", C.c_uint32), ("stats", C.POINTER(Stats)), ("trace", C.POINTER(_TraceHeader)),
+                ("variant", C.c_uint32), ("stats", C.POINTER(Stats)), ("trace", C.POINTER(_TraceHeader)),
                 ("fbRowMajor", C.c_void_p)]
 
     def __init__(self, **kw):
@@ -217,6 +240,11 @@ def lib():
             fn.restype = C.c_int
             fn.argtypes = [sz, sz, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                            C.c_void_p, C.POINTER(C.c_float)]
+        L.mir_lsq_jtj_variant_d.restype = C.c_int
+        L.mir_lsq_jtj_variant_d.argtypes = [sz, sz, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.POINTER(C.c_float), C.c_uint32]
+        L.mir_lsq_comm_create_local_group.restype = C.c_int
+        L.mir_lsq_comm_create_local_group.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.mir_lsq_fd_jtj_d.restype = C.c_int
         L.mir_lsq_fd_jtj_d.argtypes = [sz, sz, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]
@@ -521,9 +549,9 @@ def solveBoxQP(P, q, l, u, x=None, settings=None, dtype=np.float64, unconstraine
     return BoxQPStatus(st), xo, it.value
 
 
-def jtj(J, y, y_old=None, dx=None, dtype=np.float64):
-    """Unit-level access to the fused [Broyden +] J^T J + J^T y kernel (mir_lsq_jtj_*).
-    Returns (JJ full symmetric, Jy, J_after, kernel_ms)."""
+def jtj(J, y, y_old=None, dx=None, dtype=np.float64, variant=0):
+    """Unit-level access to the fused [Broyden +] J^T J + J^T y kernel (mir_lsq_jtj_*; `variant`: VARIANT_JTJ_RING /
+    VARIANT_JTJ_STREAM select the A/B kernels, f64 only). Returns (JJ full symmetric, Jy, J_after, kernel_ms)."""
     L = lib()
     J = np.ascontiguousarray(J, dtype=dtype)
     m, n = J.shape
@@ -535,8 +563,13 @@ def jtj(J, y, y_old=None, dx=None, dtype=np.float64):
     dJJ = DeviceBuffer(nbytes=n * n * J.itemsize, dtype=dtype, shape=(n, n))
     dJy = DeviceBuffer(nbytes=n * J.itemsize, dtype=dtype, shape=(n,))
     ms = C.c_float(0)
-    fn = L.mir_lsq_jtj_d if dtype == np.float64 else L.mir_lsq_jtj_s
-    rc = fn(m, n, dJ.ptr, dy.ptr, dyo.ptr, ddx.ptr, 1 if broyden else 0, dJJ.ptr, dJy.ptr, None, C.byref(ms))
+    if variant:
+        assert dtype == np.float64
+        rc = L.mir_lsq_jtj_variant_d(m, n, dJ.ptr, dy.ptr, dyo.ptr, ddx.ptr, 1 if broyden else 0, dJJ.ptr, dJy.ptr, None,
+                                     C.byref(ms), variant)
+    else:
+        fn = L.mir_lsq_jtj_d if dtype == np.float64 else L.mir_lsq_jtj_s
+        rc = fn(m, n, dJ.ptr, dy.ptr, dyo.ptr, ddx.ptr, 1 if broyden else 0, dJJ.ptr, dJy.ptr, None, C.byref(ms))
     if rc != 0:
         raise RuntimeError(f"mir_lsq_jtj failed: {rc}")
     out = dJJ.download(), dJy.download(), dJ.download(), ms.value

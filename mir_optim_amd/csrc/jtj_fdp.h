@@ -219,7 +219,7 @@ __device__ __forceinline__ void fdp_consumer(const JtjArgs<double>& a, const dou
                     T* wp = a.Jout + row * (size_t)a.n;    // the problem's n: row stride of J; padding columns stay in LDS
 #pragma unroll
                     for (int c = 0; c < NCB; ++c)
-                        if (c % 2 == ROLE - 2) { if (16 * c + p < a.n && !MIRLSQ_FD_EXPERIMENT_NOWRITE) wp[16 * c + p] = g.v[c]; }
+                        if (c % 2 == ROLE - 2) { if (16 * c + p < a.n) wp[16 * c + p] = g.v[c]; }
                 }
             }
             if constexpr (ROLE == 0) {

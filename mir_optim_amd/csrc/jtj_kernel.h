@@ -43,8 +43,8 @@ struct JtjArgs {
     T* slabs;          // gridDim.x slabs of jtj_slab_len<NCB>() elements
     size_t m;
     int n;
-    const T* twh;      // FD (k_jtj2<., false, true>): interval widths xph - xmh (LS:1031); then J is the m x 2n row-major
-                       // panel of perturbed residuals [f(x + h e_j), f(x - h e_j)]_j and Jout receives the Jacobian
+    const T* twh;      // finite-difference kernels (jtj_fdp.h, jtj_fdp8.h): interval widths xph - xmh (LS:1031); then J is the
+                       // m x 2n row-major panel of perturbed residuals [f(x + h e_j), f(x - h e_j)]_j and Jout receives the Jacobian
 };
 
 constexpr int kJtjWaves = 4;   // waves per workgroup
@@ -309,26 +309,12 @@ __global__ __launch_bounds__(256) void k_jtj_slab_reduce(const T* __restrict__ s
 typedef __attribute__((address_space(3))) void* jtj_lds_ptr;
 typedef const __attribute__((address_space(1))) void* jtj_gbl_ptr;
 
-template <int NCB, bool BROYDEN, bool FD = false> struct Jtj2Cfg {
+template <int NCB, bool BROYDEN> struct Jtj2Cfg {
     // rows per stage: ~16 KB stages so that one barrier is amortised over 4+ row groups (a probe on
     // MI355X: 4 KB stages 0.33 ms, 16 KB stages 0.27 ms for the n = 128 MFMA work; scripts/probes).
-    // FD: a source row is 2n doubles (the +h / -h residual pairs), so half the rows make the same stage bytes
-#ifndef MIRLSQ_FD_EXPERIMENT_NOWRITE
-#define MIRLSQ_FD_EXPERIMENT_NOWRITE 0
-#endif
-#ifndef MIRLSQ_FD_BIG_STAGES
-#define MIRLSQ_FD_BIG_STAGES 0          // measured: 2.78 ms at m = 1e6, n = 128 (one workgroup per CU cannot hide the MFMA latency)
-#endif
-#ifndef MIRLSQ_FD_RS8
-#define MIRLSQ_FD_RS8 8                 // rows per stage at NCB > 5; measured at m = 1e6, n = 128: 8 rows (D = 2) 0.755 ms,
-                                        // 4 rows (D = 6, three times the bytes in flight) 0.852 ms: barriers cost more than latency
-#endif
-    // FD, big stages: the plain kernel's rows per stage (twice its bytes) in a 128 KB ring, one workgroup per CU
-    static constexpr bool FDBIG = FD && MIRLSQ_FD_BIG_STAGES;
-    static constexpr int RS = (FD && !FDBIG) ? (NCB <= 4 ? 16 : (NCB == 5 ? 12 : MIRLSQ_FD_RS8))
-                                             : (NCB <= 4 ? 32 : (NCB == 5 ? 24 : (NCB == 6 ? 20 : 16)));
+    static constexpr int RS = NCB <= 4 ? 32 : (NCB == 5 ? 24 : (NCB == 6 ? 20 : 16));
     static constexpr int GPS = RS / 4;                                                     // 4-row groups per stage
-    static constexpr int IPS = RS * NCB * (FD ? 2 : 1) / 8;                                // 1 KB DMA instructions per stage
+    static constexpr int IPS = RS * NCB / 8;                                               // 1 KB DMA instructions per stage
     static constexpr int SLOT_BYTES = IPS * 1024;
     // DMA instructions the busier of the two loading waves issues per stage (waves 0, 1 issue every
     // DMA and never store; waves 2, 3 do every Broyden write-back and issue no DMA: a counted vmcnt
@@ -336,7 +322,7 @@ template <int NCB, bool BROYDEN, bool FD = false> struct Jtj2Cfg {
     // DMA wait pass early now and then, a run-to-run nondeterminism caught by scripts/diag_determinism.py)
     static constexpr int MAX_OPS = (IPS + 1) / 2;
     static constexpr int D0 = 60 / MAX_OPS;                                                // vmcnt is 6 bits
-    static constexpr int D1 = ((FDBIG ? 128 : 64) * 1024) / SLOT_BYTES - 2;                // 64 KB ring (128 KB: FD big stages)
+    static constexpr int D1 = (64 * 1024) / SLOT_BYTES - 2;                                // 64 KB ring
     static constexpr int D2 = D0 < D1 ? D0 : D1;
     static constexpr int D = D2 < 1 ? 1 : (D2 > 15 ? 15 : D2);                             // stages in flight
     static constexpr int NS = D + 2;                                                       // ring slots
@@ -349,16 +335,15 @@ template <int NCB, bool BROYDEN, bool FD = false> struct Jtj2Cfg {
 };
 constexpr int kJtj2Threads = 4 * kWave;
 
-template <int NCB, bool BROYDEN, int ROLE, bool FD = false>
+template <int NCB, bool BROYDEN, int ROLE>
 __device__ __forceinline__ void jtj2_body(const JtjArgs<double>& a, unsigned char* smem, int lane, size_t s0, size_t S)
 {
     using T = double;
     using Acc = typename Mma<T>::Acc;
-    using C = Jtj2Cfg<NCB, BROYDEN, FD>;
-    static_assert(!(BROYDEN && FD), "a pass either refreshes J from finite differences or updates it");
+    using C = Jtj2Cfg<NCB, BROYDEN>;
     constexpr int NACC = jtj_nacc<NCB>();
     constexpr int n = 16 * NCB;
-    constexpr int RW = FD ? 2 * n : n;                       // doubles per source row
+    constexpr int RW = n;                                    // doubles per source row
     // this wave's share of a stage: waves 0, 1 issue the DMA instructions (ROLE, ROLE + 2, ...) and never
     // store; waves 2, 3 write back the Broyden-updated column blocks c = ROLE (mod 2) and never load
     constexpr bool LOADER = ROLE < 2;
@@ -406,33 +391,13 @@ __device__ __forceinline__ void jtj2_body(const JtjArgs<double>& a, unsigned cha
     }
     T neg_d = 0;
     if constexpr (BROYDEN) neg_d = -(T(1) / *a.dx_dot);
-    T inv[NCB];                                              // FD: 1 / twh of this lane's columns (LS:1047)
-    bool zc[NCB];                                            //     collapsed interval: zero column (LS:1046)
-#pragma unroll
-    for (int c = 0; c < NCB; ++c) {
-        inv[c] = 0;
-        zc[c] = false;
-        if constexpr (FD) {
-            const T t = a.twh[16 * c + p];
-            zc[c] = t == 0;
-            inv[c] = zc[c] ? T(0) : T(1) / t;
-        }
-    }
     // the loads above must have retired before the counted waits below start counting
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     if constexpr (ROLE == 1) {
         while (next_chunk < 3 && next_chunk < nchunks) issue_y(next_chunk++);
     }
-    // LATE (FD variant, experiment kept behind a macro): the DMA of stage s + L, L = NS - 1, issued right AFTER barrier s,
-    // into the slot stage s - 1 has just left -- one more stage in flight (48 KB per workgroup instead of 32) with the same
-    // ring and barriers. Measured at m = 1e6, n = 128: 0.805 ms against 0.733 ms for the default order (issue before the
-    // wait, D = 2): like the 4-row-stage experiment, more bytes in flight make this read + write stream slower, not faster.
-#ifndef MIRLSQ_FD_LATE_ISSUE
-#define MIRLSQ_FD_LATE_ISSUE 0
-#endif
-    constexpr bool LATE = FD && MIRLSQ_FD_LATE_ISSUE;
-    constexpr int L = LATE ? C::NS - 1 : C::D;
+    constexpr int L = C::D;
     const size_t pre = S < (size_t)L ? S : (size_t)L;
     for (size_t s = 0; s < pre; ++s) issue(s);
 
@@ -441,14 +406,7 @@ __device__ __forceinline__ void jtj2_body(const JtjArgs<double>& a, unsigned cha
             // keep the chunk holding this stage's first row plus two more in flight / resident
             while (next_chunk <= (s * C::RS) / 128 + 2 && next_chunk < nchunks) issue_y(next_chunk++);
         }
-        if constexpr (LATE) {
-            // stages s + 1 .. s + L - 1 were issued after barriers s - L + 1 .. s - 1 and may still be in flight
-            if (s + L - 1 < S) {
-                if constexpr (OPS > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((L - 1) * OPS) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-        } else if (s + C::D < S) {
+        if (s + C::D < S) {
             issue(s + C::D);
             // my DMA of stage s (and everything older) has landed once at most D * OPS younger ops remain
             if constexpr (OPS > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::D * OPS) : "memory");
@@ -456,9 +414,6 @@ __device__ __forceinline__ void jtj2_body(const JtjArgs<double>& a, unsigned cha
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();                       // stage s is complete in LDS for every wave
-        if constexpr (LATE) {
-            if (s + L < S) issue(s + L);                    // slot of stage s - 1: every wave is past it
-        }
         const T* slot = reinterpret_cast<const T*>(smem + (s % C::NS) * C::SLOT_BYTES);
         const T* yring = reinterpret_cast<const T*>(smem + C::Y_OFF);
         const T* yoring = reinterpret_cast<const T*>(smem + C::YO_OFF);
@@ -471,15 +426,7 @@ __device__ __forceinline__ void jtj2_body(const JtjArgs<double>& a, unsigned cha
         auto read = [&](int gi, Grp& g) {
 #pragma unroll
             for (int c = 0; c < NCB; ++c) {
-                if constexpr (FD) {
-                    // one ds_read_b128: [f(x + h e_j), f(x - h e_j)] of row 4 gi + q, j = 16 c + p
-                    const double2 t = *reinterpret_cast<const double2*>(slot + (4 * gi + q) * RW + 2 * (16 * c + p));
-                    T d = t.x;                           // copy(mBuffer, Jj)          LS:1041
-                    d += T(-1) * t.y;                    // axpy(-1, mBuffer, Jj)      LS:1045
-                    g.v[c] = zc[c] ? T(0) : d * inv[c];  // scal(1 / twh, Jj)          LS:1047
-                } else {
-                    g.v[c] = slot[(4 * gi + q) * n + 16 * c + p];
-                }
+                g.v[c] = slot[(4 * gi + q) * n + 16 * c + p];
             }
             const size_t lr = s * C::RS + 4 * gi + q;       // row index local to this workgroup
             const int yidx = (int)((lr >> 7) % C::YNS) * 128 + (int)(lr & 127);
@@ -510,14 +457,6 @@ __device__ __forceinline__ void jtj2_body(const JtjArgs<double>& a, unsigned cha
                     g.v[c] = g.v[c] + u * dxr[c];         // LS:1006
                     if constexpr (!LOADER) { if (c % 2 == ROLE - 2) { if (rok) wp[16 * c + p] = g.v[c]; } }
                 }
-            }
-            if constexpr (FD && !LOADER) {
-                // the Jacobian rows leave through the two storer waves (column blocks c = ROLE (mod 2)), like the
-                // Broyden write-back: the loader waves' counted vmcnt waits stay over DMA operations only
-                T* wp = a.Jout + (rok ? row : m - 1) * (size_t)n;
-#pragma unroll
-                for (int c = 0; c < NCB; ++c)
-                    if (c % 2 == ROLE - 2) { if (rok && !MIRLSQ_FD_EXPERIMENT_NOWRITE) wp[16 * c + p] = g.v[c]; }
             }
             if constexpr (ROLE == 0) {
 #pragma unroll
@@ -569,10 +508,10 @@ __device__ __forceinline__ void jtj2_body(const JtjArgs<double>& a, unsigned cha
     }
 }
 
-template <int NCB, bool BROYDEN, bool FD = false>
+template <int NCB, bool BROYDEN>
 __global__ __launch_bounds__(kJtj2Threads, 2) void k_jtj2(JtjArgs<double> a)
 {
-    using C = Jtj2Cfg<NCB, BROYDEN, FD>;
+    using C = Jtj2Cfg<NCB, BROYDEN>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -584,220 +523,10 @@ __global__ __launch_bounds__(kJtj2Threads, 2) void k_jtj2(JtjArgs<double> a)
     const size_t s1 = s0 + per < Stot ? s0 + per : Stot;
     const size_t S = s1 - s0;
 
-    if (wave == 0) jtj2_body<NCB, BROYDEN, 0, FD>(a, smem2, lane, s0, S);
-    else if (wave == 1) jtj2_body<NCB, BROYDEN, 1, FD>(a, smem2, lane, s0, S);
-    else if (wave == 2) jtj2_body<NCB, BROYDEN, 2, FD>(a, smem2, lane, s0, S);
-    else jtj2_body<NCB, BROYDEN, 3, FD>(a, smem2, lane, s0, S);
-}
-
-// =========================================================================================
-// v3 (Broyden passes, fp64, n % 16 == 0, n <= 128, m even): the ring of v2 with the rank-one update done ONCE per
-// row instead of once per wave.
-//
-// In k_jtj2<NCB, true> each of the four waves recomputes the update of every row it multiplies (dot with dx, DPP
-// reduction, axpy: ~30 fp64 VALU instructions per 4-row group and wave). On gfx950 fp64 VALU work does not overlap
-// f64 MFMA -- both run on the same fp64 units (measured: the plain variant runs 9 MFMA per group and wave in
-// 0.37 ms, the Broyden variant adds exactly its VALU time, 0.45 ms) -- so that redundancy is ~15 % of the kernel.
-// Here the two storer waves (2, 3) update stage s + 1 in place in LDS (each a share of its row groups) and write
-// the rows back to HBM, while every wave runs the MFMA chains of stage s, which was updated one iteration earlier;
-// one barrier per stage still. The DMA of stage s + L (L = NS - 1) is issued right AFTER barrier s, when the slot
-// of stage s - 1 is free: the same two stages stay in flight as in v2 although a stage has to land one iteration
-// earlier. Arithmetic and summation order are those of v2: the results are bit-identical.
-// Outcome (MI355X, m = 1e6, n = 128): 0.444 ms against 0.451 ms -- the Broyden pass is limited by its mixed
-// read + write HBM stream (2.1 GB at ~4.7 TB/s; a pure copy kernel reaches ~5.2 TB/s), not by the VALU redundancy.
-// Kept as an opt-in (MIR_LSQ_JTJ_SPLIT=1) and as the bit-exact cross-check of v2 in the tests.
-// =========================================================================================
-template <int NCB, int ROLE>
-__device__ __forceinline__ void jtj3_body(const JtjArgs<double>& a, unsigned char* smem, int lane, size_t s0, size_t S)
-{
-    using T = double;
-    using Acc = typename Mma<T>::Acc;
-    using C = Jtj2Cfg<NCB, true>;
-    constexpr int NACC = jtj_nacc<NCB>();
-    constexpr int n = 16 * NCB;
-    constexpr bool LOADER = ROLE < 2;
-    constexpr int MYI = LOADER ? (C::IPS + 1 - ROLE) / 2 : 0;
-    constexpr int OPS = MYI;
-    constexpr int L = C::NS - 1;                             // stages issued ahead of the MFMA stage
-    const int q = lane >> 4, p = lane & 15;
-    const size_t m = a.m;
-
-    const unsigned char* Jb = reinterpret_cast<const unsigned char*>(a.J);
-    const size_t total = m * (size_t)n * sizeof(T);
-    auto issue = [&](size_t s) {
-        const size_t base = (s0 + s) * (size_t)C::RS * n * sizeof(T);
-        unsigned char* slot = smem + (s % C::NS) * C::SLOT_BYTES;
-#pragma unroll
-        for (int k = 0; k < MYI; ++k) {
-            const int ins = ROLE + 2 * k;
-            size_t off = base + (size_t)(ins * 64 + lane) * 16;
-            if (off + 16 > total) off = base;            // rows past m: any valid bytes (zeroed by the update phase)
-            __builtin_amdgcn_global_load_lds((jtj_gbl_ptr)(Jb + off), (jtj_lds_ptr)(slot + ins * 1024), 16, 0, 0);
-        }
-    };
-    const unsigned char* yb = reinterpret_cast<const unsigned char*>(a.y);
-    const unsigned char* yob = reinterpret_cast<const unsigned char*>(a.y_old);
-    const size_t ytotal = m * sizeof(T);
-    const size_t nchunks = (S * C::RS + 127) / 128;
-    size_t next_chunk = 0;
-    auto issue_y = [&](size_t c) {
-        size_t off = ((s0 * C::RS) + c * 128) * sizeof(T) + (size_t)lane * 16;
-        if (off + 16 > ytotal) off = 0;
-        __builtin_amdgcn_global_load_lds((jtj_gbl_ptr)(yb + off), (jtj_lds_ptr)(smem + C::Y_OFF + (c % C::YNS) * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((jtj_gbl_ptr)(yob + off), (jtj_lds_ptr)(smem + C::YO_OFF + (c % C::YNS) * 1024), 16, 0, 0);
-    };
-
-    Acc acc[NACC];
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] = Acc{0, 0, 0, 0};
-    T jy[NCB], dxr[NCB];
-#pragma unroll
-    for (int c = 0; c < NCB; ++c) {
-        jy[c] = 0;
-        dxr[c] = 0;
-        if constexpr (!LOADER) dxr[c] = a.dx[16 * c + p];
-    }
-    T neg_d = 0;
-    if constexpr (!LOADER) neg_d = -(T(1) / *a.dx_dot);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the loads above retire before the counted waits
-
-    T* const yring = reinterpret_cast<T*>(smem + C::Y_OFF);
-    T* const yoring = reinterpret_cast<T*>(smem + C::YO_OFF);
-    auto yindex = [&](size_t lr) { return (int)((lr >> 7) % C::YNS) * 128 + (int)(lr & 127); };
-
-    // LS:1003-1006 for the row groups of stage st this wave owns, in place in the LDS slot + write-back
-    auto update = [&](size_t st) {
-        T* slot = reinterpret_cast<T*>(smem + (st % C::NS) * C::SLOT_BYTES);
-        const size_t row0 = (s0 + st) * C::RS;
-#pragma unroll
-        for (int gi = ROLE - 2; gi < C::GPS; gi += 2) {
-            T v[NCB];
-            T* rp = slot + (4 * gi + q) * n + p;
-#pragma unroll
-            for (int c = 0; c < NCB; ++c) v[c] = rp[16 * c];
-            const int yi = yindex(st * C::RS + 4 * gi + q);
-            const T y = yring[yi], yo = yoring[yi];
-            const size_t row = row0 + 4 * gi + q;
-            const bool rok = row < m;
-            T part = 0;
-#pragma unroll
-            for (int c = 0; c < NCB; ++c) part += v[c] * dxr[c];
-            part = sum16(part);
-            const T t = (yo - y) + part;                  // LS:1003-1004
-            const T u = neg_d * t;                        // LS:1005
-            T* wp = a.Jout + (rok ? row : m - 1) * (size_t)n + p;
-#pragma unroll
-            for (int c = 0; c < NCB; ++c) {
-                const T w = v[c] + u * dxr[c];            // LS:1006
-                rp[16 * c] = rok ? w : T(0);              // rows past m contribute nothing to the products
-                if (rok) wp[16 * c] = w;
-            }
-        }
-    };
-
-    auto mfma_phase = [&](size_t s, auto full_tag) {
-        constexpr bool FULL = decltype(full_tag)::value;
-        const T* slot = reinterpret_cast<const T*>(smem + (s % C::NS) * C::SLOT_BYTES);
-        const size_t row0 = (s0 + s) * C::RS;
-        struct Grp { T v[NCB]; T y; };
-        auto read = [&](int gi, Grp& g) {
-#pragma unroll
-            for (int c = 0; c < NCB; ++c) g.v[c] = slot[(4 * gi + q) * n + 16 * c + p];
-            g.y = 0;
-            if constexpr (ROLE == 0) {
-                g.y = yring[yindex(s * C::RS + 4 * gi + q)];
-                if constexpr (!FULL) g.y = (row0 + 4 * gi + q < m) ? g.y : T(0);
-            }
-        };
-        auto work = [&](const Grp& g) {
-            if constexpr (ROLE == 0) {
-#pragma unroll
-                for (int c = 0; c < NCB; ++c) jy[c] += g.v[c] * g.y;     // LS:1052
-            }
-#pragma unroll
-            for (int I = 0; I < NCB; ++I)
-#pragma unroll
-                for (int Jb2 = 0; Jb2 <= I; ++Jb2)
-                    if (jtj_owns<NCB, 4, ROLE>(I * (I + 1) / 2 + Jb2))
-                        acc[I * (I + 1) / 2 + Jb2] = Mma<T>::mma(g.v[I], g.v[Jb2], acc[I * (I + 1) / 2 + Jb2]);   // LS:1065
-        };
-        Grp ga, gb;
-        read(0, ga);
-#pragma unroll
-        for (int gi = 0; gi < C::GPS; gi += 2) {
-            if (gi + 1 < C::GPS) read(gi + 1, gb);
-            work(ga);
-            if (gi + 1 < C::GPS) {
-                if (gi + 2 < C::GPS) read(gi + 2, ga);
-                work(gb);
-            }
-        }
-    };
-
-    // ---- prologue: L stages in flight, stage 0 landed and updated
-    if constexpr (ROLE == 1) {
-        while (next_chunk < 3 && next_chunk < nchunks) issue_y(next_chunk++);
-    }
-    const size_t pre = S < (size_t)L ? S : (size_t)L;
-    if constexpr (LOADER) {
-        for (size_t s = 0; s < pre; ++s) issue(s);
-        if (pre == (size_t)L) { if constexpr (OPS > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((L - 1) * OPS) : "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();                            // stage 0 (and the first y chunks) are in LDS
-    if constexpr (!LOADER) { if (S > 0) update(0); }
-
-    for (size_t s = 0; s < S; ++s) {
-        if constexpr (ROLE == 1) {
-            // the update phase of this iteration reads the chunk of stage s + 1: keep it plus two more in flight / resident
-            while (next_chunk <= ((s + 1) * C::RS) / 128 + 2 && next_chunk < nchunks) issue_y(next_chunk++);
-        }
-        if constexpr (LOADER) {
-            // outstanding here: stages s + 1 .. s + L - 1; stage s + 1 has landed once at most L - 2 stages remain
-            if (s + L - 1 < S) { if constexpr (OPS > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((L - 2) * OPS) : "memory"); }
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my LDS writes of update(s) are done
-        }
-        __builtin_amdgcn_s_barrier();                        // stage s is updated, stage s + 1 has landed, slot of s - 1 is free
-        if constexpr (LOADER) { if (s + L < S) issue(s + L); }
-        if constexpr (!LOADER) { if (s + 1 < S) update(s + 1); }
-        if ((s0 + s) * C::RS + C::RS <= m) mfma_phase(s, std::true_type{}); else mfma_phase(s, std::false_type{});
-    }
-
-    T* dst = a.slabs + (size_t)blockIdx.x * jtj_slab_len<NCB>();
-#pragma unroll
-    for (int i = 0; i < NACC; ++i)
-        if (jtj_owns<NCB, 4, ROLE>(i)) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dst[(i * 4 + r) * kWave + lane] = acc[i][r];
-        }
-    if constexpr (ROLE == 0) {
-#pragma unroll
-        for (int c = 0; c < NCB; ++c) {
-            jy[c] += wave_shfl_xor(jy[c], 16);
-            jy[c] += wave_shfl_xor(jy[c], 32);
-            dst[(NACC * 4 + c) * kWave + lane] = jy[c];
-        }
-    }
-}
-
-template <int NCB>
-__global__ __launch_bounds__(kJtj2Threads, 2) void k_jtj3(JtjArgs<double> a)
-{
-    using C = Jtj2Cfg<NCB, true>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const size_t Stot = (a.m + C::RS - 1) / C::RS;
-    const size_t per = (Stot + gridDim.x - 1) / gridDim.x;
-    const size_t s0 = (size_t)blockIdx.x * per < Stot ? (size_t)blockIdx.x * per : Stot;
-    const size_t s1 = s0 + per < Stot ? s0 + per : Stot;
-    const size_t S = s1 - s0;
-    if (wave == 0) jtj3_body<NCB, 0>(a, smem3, lane, s0, S);
-    else if (wave == 1) jtj3_body<NCB, 1>(a, smem3, lane, s0, S);
-    else if (wave == 2) jtj3_body<NCB, 2>(a, smem3, lane, s0, S);
-    else jtj3_body<NCB, 3>(a, smem3, lane, s0, S);
+    if (wave == 0) jtj2_body<NCB, BROYDEN, 0>(a, smem2, lane, s0, S);
+    else if (wave == 1) jtj2_body<NCB, BROYDEN, 1>(a, smem2, lane, s0, S);
+    else if (wave == 2) jtj2_body<NCB, BROYDEN, 2>(a, smem2, lane, s0, S);
+    else jtj2_body<NCB, BROYDEN, 3>(a, smem2, lane, s0, S);
 }
 
 }  // namespace mirlsq

@@ -12,6 +12,7 @@
 // diagnostic and return status = numericError.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -22,10 +23,7 @@
 #include "../../include/mir_optim_amd.h"
 #include "comm.h"
 #include "common.h"
-#include "jtj_kernel.h"
-#include "jtj_wide.h"
-#include "jtj_ring8.h"
-#include "jtj_fdp.h"
+#include "jtj_launch.h"
 #include "batched_kernel.h"
 #include "broyden_lr.h"
 #include "misc_kernels.h"
@@ -53,8 +51,9 @@ struct mir_lsq_workspace {
     size_t dev_bytes = 0;
     void* ypanel = nullptr;    // lazily allocated FD panel (device mode)
     size_t ypanel_bytes = 0;
-    void* ytrial = nullptr;    // lazily allocated kChainMax x m trial residuals (speculative lambda ladder)
-    void* ulr = nullptr;       // lazily allocated kLrMax x m pending Broyden columns (broyden_lr.h)
+    void* ytrial = nullptr;    // kChainMax x m trial residuals (speculative lambda ladder)
+    void* ulr = nullptr;       // kLrMax x m pending Broyden columns (broyden_lr.h)
+    int device = 0;            // the device the workspace lives on (callbacks' worker threads select it)
     void* pinned = nullptr;    // small pinned host block (state + trial readback)
     void* pinned_y = nullptr;  // m-vector staging (host-callback mode), lazily allocated
     void* pinned_J = nullptr;  // m*n staging for host analytic Jacobians, lazily allocated
@@ -93,375 +92,6 @@ bool device_available()
 }
 
 // ------------------------------------------------------------------------------------------
-// J^T J launch plan
-// ------------------------------------------------------------------------------------------
-struct JtjPlan {
-    int ncb = 0;
-    int nblk = 0;
-    int slab_len = 0;
-    size_t lds = 0;
-    bool v2 = false;      // LDS-DMA ring kernel (f64, n = 16 ncb)
-    bool wide = false;    // 128 < n <= 256: tiled jobs (jtj_wide.h)
-    bool ring8 = false;   // 128 < n <= 256, f64, n % 16 == 0, m even: eight-wave LDS-DMA ring (jtj_ring8.h)
-    bool fdp = false;     // f64, n <= 128, any m: producer / consumer kernel (jtj_fdp.h) for the finite-difference J^T J
-    bool fdp_plain = false;   // ... and, n even, for the plain J^T J; v2 (the LDS-DMA ring kernels) needs n % 16 == 0 and m even
-    int njobs = 1;
-};
-
-inline size_t jtj2_lds_rt(int ncb, bool br)
-{
-    switch (ncb) {
-    case 1: return br ? Jtj2Cfg<1, true>::LDS_BYTES : Jtj2Cfg<1, false>::LDS_BYTES;
-    case 2: return br ? Jtj2Cfg<2, true>::LDS_BYTES : Jtj2Cfg<2, false>::LDS_BYTES;
-    case 3: return br ? Jtj2Cfg<3, true>::LDS_BYTES : Jtj2Cfg<3, false>::LDS_BYTES;
-    case 4: return br ? Jtj2Cfg<4, true>::LDS_BYTES : Jtj2Cfg<4, false>::LDS_BYTES;
-    case 5: return br ? Jtj2Cfg<5, true>::LDS_BYTES : Jtj2Cfg<5, false>::LDS_BYTES;
-    case 6: return br ? Jtj2Cfg<6, true>::LDS_BYTES : Jtj2Cfg<6, false>::LDS_BYTES;
-    case 7: return br ? Jtj2Cfg<7, true>::LDS_BYTES : Jtj2Cfg<7, false>::LDS_BYTES;
-    case 8: return br ? Jtj2Cfg<8, true>::LDS_BYTES : Jtj2Cfg<8, false>::LDS_BYTES;
-    }
-    return 0;
-}
-inline int jtj2_rs_rt(int ncb)
-{
-    switch (ncb) {
-    case 1: return Jtj2Cfg<1, false>::RS; case 2: return Jtj2Cfg<2, false>::RS; case 3: return Jtj2Cfg<3, false>::RS;
-    case 4: return Jtj2Cfg<4, false>::RS; case 5: return Jtj2Cfg<5, false>::RS; case 6: return Jtj2Cfg<6, false>::RS;
-    case 7: return Jtj2Cfg<7, false>::RS; case 8: return Jtj2Cfg<8, false>::RS;
-    }
-    return 4;
-}
-
-inline size_t jtj8_lds_rt(int ncb)
-{
-    switch (ncb) {
-    case 9: return Jtj8Cfg<9>::LDS_BYTES; case 10: return Jtj8Cfg<10>::LDS_BYTES; case 11: return Jtj8Cfg<11>::LDS_BYTES;
-    case 12: return Jtj8Cfg<12>::LDS_BYTES; case 13: return Jtj8Cfg<13>::LDS_BYTES; case 14: return Jtj8Cfg<14>::LDS_BYTES;
-    case 15: return Jtj8Cfg<15>::LDS_BYTES; case 16: return Jtj8Cfg<16>::LDS_BYTES;
-    }
-    return 0;
-}
-
-template <typename T>
-JtjPlan jtj_plan(size_t m, int n, int num_cu)
-{
-    JtjPlan p;
-    p.ncb = (n + 15) / 16;
-    const int nacc = p.ncb * (p.ncb + 1) / 2;
-    p.slab_len = (nacc * 4 + p.ncb) * kWave;
-    static const bool no_ring8 = std::getenv("MIR_LSQ_JTJ_WIDE_V1") != nullptr;
-    if (sizeof(T) == 8 && n > 128 && n <= 256 && n % 16 == 0 && m % 2 == 0 && !no_ring8) {
-        p.ring8 = true;
-        p.lds = jtj8_lds_rt(p.ncb);
-        const size_t stot = (m + 15) / 16;
-        size_t want = (stot + 7) / 8;                          // at least ~8 stages per workgroup
-        p.nblk = (int)(want < (size_t)num_cu ? (want ? want : 1) : (size_t)num_cu);   // one workgroup per CU
-        return p;
-    }
-    if (n > 128) {
-        p.wide = true;
-        const int nt = (p.ncb + kWideTile - 1) / kWideTile;
-        p.njobs = nt * (nt + 1) / 2;
-        p.slab_len = kWideSlabLen;
-        p.lds = (size_t)2 * kWideSlabLen * sizeof(T);
-        const size_t G = (m + 3) / 4;
-        size_t want = (G + 4 * 8 - 1) / (4 * 8);
-        size_t cap = (size_t)num_cu * 4 / p.njobs;
-        if (cap < 1) cap = 1;
-        p.nblk = (int)(want < cap ? (want ? want : 1) : cap);
-        return p;
-    }
-    static const bool no_v2 = std::getenv("MIR_LSQ_JTJ_V1") != nullptr;
-    p.fdp = sizeof(T) == 8 && n <= 128 && !no_v2;
-    p.fdp_plain = p.fdp && n % 2 == 0;
-    if (sizeof(T) == 8 && n % 16 == 0 && n <= 128 && m % 2 == 0 && !no_v2) {
-        p.v2 = true;
-        p.lds = jtj2_lds_rt(p.ncb, false);
-        const size_t stot = (m + jtj2_rs_rt(p.ncb) - 1) / jtj2_rs_rt(p.ncb);
-        size_t want = (stot + 7) / 8;                          // at least ~8 stages per workgroup
-        const size_t cap = (size_t)num_cu * 2;
-        p.nblk = (int)(want < cap ? (want ? want : 1) : cap);
-        return p;
-    }
-    const int rpb = 4 * (int)(sizeof(T) / 4);
-    const int roles = jtj_roles_rt(p.ncb, rpb);
-    p.lds = (size_t)(roles == 4 ? 0 : (roles == 2 ? 1 : 2)) * p.slab_len * sizeof(T);
-    // workgroups per CU: LDS- and register-limited (one workgroup = one wave per SIMD)
-    int per_cu = p.lds ? (int)((160 * 1024) / p.lds) : 8;
-    const int reg_waves = (nacc * rpb / roles > 40) ? 2 : 4;   // matches jtj_min_waves
-    if (per_cu > reg_waves) per_cu = reg_waves;
-    if (per_cu < 1) per_cu = 1;
-    const size_t G = (m + 3) / 4;
-    const size_t slots_per_blk = kJtjWaves / roles;
-    size_t want = (G + slots_per_blk * 8 - 1) / (slots_per_blk * 8);     // at least ~8 row groups per wave
-    size_t cap = (size_t)num_cu * per_cu;
-    p.nblk = (int)(want < cap ? (want ? want : 1) : cap);
-    return p;
-}
-
-template <typename T, int NCB, bool BR>
-hipError_t jtj_launch_one(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
-{
-    auto kern = k_jtj<T, NCB, BR>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(256), p.lds, s, a);
-    return hipGetLastError();
-}
-
-// plain J^T J + J^T y with producer / consumer waves (jtj_fdp.h, FD = false)
-template <int NCB>
-hipError_t jtj_fdp_plain_one(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t s)
-{
-    using FC = JtjFdpCfg<NCB, false>;
-    static bool fdp_attr_done = false;
-    if (!fdp_attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_jtj_fdp<NCB, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, FC::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        fdp_attr_done = true;
-    }
-    hipLaunchKernelGGL((k_jtj_fdp<NCB, false>), dim3(p.nblk), dim3(FC::THREADS), FC::LDS_BYTES, s, a);
-    return hipGetLastError();
-}
-template <typename T>
-hipError_t jtj_fdp_plain(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
-{
-    if constexpr (sizeof(T) == 8) {
-        switch (p.ncb) {
-        case 1: return jtj_fdp_plain_one<1>(p, a, s);
-        case 2: return jtj_fdp_plain_one<2>(p, a, s);
-        case 3: return jtj_fdp_plain_one<3>(p, a, s);
-        case 4: return jtj_fdp_plain_one<4>(p, a, s);
-        case 5: return jtj_fdp_plain_one<5>(p, a, s);
-        case 6: return jtj_fdp_plain_one<6>(p, a, s);
-        case 7: return jtj_fdp_plain_one<7>(p, a, s);
-        case 8: return jtj_fdp_plain_one<8>(p, a, s);
-        }
-    }
-    return hipErrorInvalidValue;
-}
-
-template <int NCB, bool BR>
-hipError_t jtj2_launch_one(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t s)
-{
-    // MIR_LSQ_JTJ_SPLIT=1: Broyden passes on k_jtj3 (row update once per row, bit-identical results). Measured
-    // 0.444 vs 0.451 ms in the solve at m = 1e6, n = 128: the pass is bound by its mixed read + write HBM stream,
-    // not by the redundant VALU work, so the simpler v2 kernel stays the default.
-    static const bool split = std::getenv("MIR_LSQ_JTJ_SPLIT") != nullptr;
-    if constexpr (BR) {
-        if (split) {
-            auto k3 = k_jtj3<NCB>;
-            constexpr size_t lds3 = Jtj2Cfg<NCB, true>::LDS_BYTES;
-            static bool attr3_done = false;
-            if (!attr3_done) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k3),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-                if (e != hipSuccess) return e;
-                attr3_done = true;
-            }
-            hipLaunchKernelGGL(k3, dim3(p.nblk), dim3(kJtj2Threads), lds3, s, a);
-            return hipGetLastError();
-        }
-    }
-    auto kern = k_jtj2<NCB, BR>;
-    constexpr size_t lds = Jtj2Cfg<NCB, BR>::LDS_BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(kJtj2Threads), lds, s, a);
-    return hipGetLastError();
-}
-template <bool BR>
-hipError_t jtj2_launch(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t s)
-{
-    switch (p.ncb) {
-    case 1: return jtj2_launch_one<1, BR>(p, a, s);
-    case 2: return jtj2_launch_one<2, BR>(p, a, s);
-    case 3: return jtj2_launch_one<3, BR>(p, a, s);
-    case 4: return jtj2_launch_one<4, BR>(p, a, s);
-    case 5: return jtj2_launch_one<5, BR>(p, a, s);
-    case 6: return jtj2_launch_one<6, BR>(p, a, s);
-    case 7: return jtj2_launch_one<7, BR>(p, a, s);
-    case 8: return jtj2_launch_one<8, BR>(p, a, s);
-    }
-    return hipErrorInvalidValue;
-}
-// finite-difference refresh fused in: J = a.J is the m x 2n row-major residual panel, a.Jout receives the Jacobian
-template <int NCB>
-hipError_t jtj2_fd_launch_one(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t s)
-{
-    // default: register-staged producer waves (jtj_fdp.h); MIR_LSQ_FD_KERNEL=ring selects the LDS-DMA ring variant
-    const char* sel = std::getenv("MIR_LSQ_FD_KERNEL");       // read per call: the tests switch it within one process
-    const bool ring = sel && sel[0] == 'r';
-    if (!ring || !p.v2) {
-        static bool fdp_attr_done = false;
-        if (!fdp_attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_jtj_fdp<NCB, true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, JtjFdpCfg<NCB>::LDS_BYTES);
-            if (e != hipSuccess) return e;
-            fdp_attr_done = true;
-        }
-        hipLaunchKernelGGL((k_jtj_fdp<NCB, true>), dim3(p.nblk), dim3(JtjFdpCfg<NCB>::THREADS), JtjFdpCfg<NCB>::LDS_BYTES, s, a);
-        return hipGetLastError();
-    }
-    auto kern = k_jtj2<NCB, false, true>;
-    constexpr size_t lds = Jtj2Cfg<NCB, false, true>::LDS_BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(kJtj2Threads), lds, s, a);
-    return hipGetLastError();
-}
-template <typename T>
-hipError_t jtj2_fd_launch(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
-{
-    if constexpr (sizeof(T) == 8) {
-        if (!p.fdp) return hipErrorInvalidValue;
-        switch (p.ncb) {
-        case 1: return jtj2_fd_launch_one<1>(p, a, s);
-        case 2: return jtj2_fd_launch_one<2>(p, a, s);
-        case 3: return jtj2_fd_launch_one<3>(p, a, s);
-        case 4: return jtj2_fd_launch_one<4>(p, a, s);
-        case 5: return jtj2_fd_launch_one<5>(p, a, s);
-        case 6: return jtj2_fd_launch_one<6>(p, a, s);
-        case 7: return jtj2_fd_launch_one<7>(p, a, s);
-        case 8: return jtj2_fd_launch_one<8>(p, a, s);
-        }
-    }
-    return hipErrorInvalidValue;
-}
-// same, with the slab reduction: -> packed[ n(n+1)/2 + n ]
-template <typename T>
-hipError_t jtj_run_fd(const JtjPlan& p, const JtjArgs<T>& a, T* packed, hipStream_t s)
-{
-    hipError_t e = jtj2_fd_launch<T>(p, a, s);
-    if (e != hipSuccess) return e;
-    const int rb = (p.slab_len + 31) / 32;
-    hipLaunchKernelGGL(k_jtj_slab_reduce<T>, dim3(rb), dim3(256), 0, s, a.slabs, p.nblk, p.slab_len, p.ncb, a.n, packed);
-    return hipGetLastError();
-}
-
-template <typename T, bool BR>
-hipError_t jtj2_dispatch(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
-{
-    if constexpr (sizeof(T) == 8) return jtj2_launch<BR>(p, a, s);
-    else return hipErrorInvalidValue;
-}
-
-template <typename T, bool BR>
-hipError_t jtj_launch_br(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
-{
-    static const char* v1sel = std::getenv("MIR_LSQ_JTJ_V1_ONLY");   // diagnostics: "br" / "nobr" use v1 for that variant
-    const bool force_v1 = v1sel && ((BR && v1sel[0] == 'b') || (!BR && v1sel[0] == 'n'));
-    if constexpr (!BR) {
-        // MIR_LSQ_JTJ_KERNEL=ring: the LDS-DMA ring (needs m even) instead of the producer / consumer kernel
-        const char* sel = std::getenv("MIR_LSQ_JTJ_KERNEL");  // read per call: the tests switch it within one process
-        const bool ring = sel && sel[0] == 'r';
-        if (p.fdp_plain && !force_v1 && !(ring && p.v2)) return jtj_fdp_plain<T>(p, a, s);
-    }
-    if (p.v2 && !force_v1) return jtj2_dispatch<T, BR>(p, a, s);
-    switch (p.ncb) {
-    case 1: return jtj_launch_one<T, 1, BR>(p, a, s);
-    case 2: return jtj_launch_one<T, 2, BR>(p, a, s);
-    case 3: return jtj_launch_one<T, 3, BR>(p, a, s);
-    case 4: return jtj_launch_one<T, 4, BR>(p, a, s);
-    case 5: return jtj_launch_one<T, 5, BR>(p, a, s);
-    case 6: return jtj_launch_one<T, 6, BR>(p, a, s);
-    case 7: return jtj_launch_one<T, 7, BR>(p, a, s);
-    case 8: return jtj_launch_one<T, 8, BR>(p, a, s);
-    }
-    return hipErrorInvalidValue;
-}
-
-// fused [Broyden] + JtJ + Jty -> packed[ n(n+1)/2 + n ]
-template <typename T>
-hipError_t jtj_run_wide(const JtjPlan& p, const JtjArgs<T>& a, bool broyden, T* packed, hipStream_t s)
-{
-    if (broyden) {
-        const size_t G = (a.m + 3) / 4;
-        size_t blocks = (G + 3) / 4;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(k_broyden_wide<T>, dim3((unsigned)blocks), dim3(256), 0, s, a.Jout, a.y, a.y_old, a.dx, a.dx_dot, a.m, a.n);
-    }
-    JtjWideArgs<T> w{};
-    w.J = a.J; w.y = a.y; w.slabs = a.slabs; w.m = a.m; w.n = a.n;
-    w.nt = ((a.n + 15) / 16 + kWideTile - 1) / kWideTile;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_jtj_wide<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(k_jtj_wide<T>, dim3(p.nblk, p.njobs), dim3(256), p.lds, s, w);
-    hipLaunchKernelGGL(k_jtj_wide_reduce<T>, dim3((kWideSlabLen + 31) / 32, p.njobs), dim3(256), 0, s, a.slabs, p.nblk, a.n, packed);
-    return hipGetLastError();
-}
-
-template <int NCB>
-hipError_t jtj8_launch_one(const JtjPlan& p, const JtjArgs<double>& a, bool broyden, hipStream_t s)
-{
-    auto kern = k_jtj8<NCB>;
-    constexpr size_t lds = Jtj8Cfg<NCB>::LDS_BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(kJtj8Threads), lds, s, a, broyden ? 1 : 0);
-    return hipGetLastError();
-}
-template <typename T>
-hipError_t jtj8_launch(const JtjPlan& p, const JtjArgs<T>& a, bool broyden, hipStream_t s)
-{
-    if constexpr (sizeof(T) == 8) {
-        switch (p.ncb) {
-        case 9: return jtj8_launch_one<9>(p, a, broyden, s);
-        case 10: return jtj8_launch_one<10>(p, a, broyden, s);
-        case 11: return jtj8_launch_one<11>(p, a, broyden, s);
-        case 12: return jtj8_launch_one<12>(p, a, broyden, s);
-        case 13: return jtj8_launch_one<13>(p, a, broyden, s);
-        case 14: return jtj8_launch_one<14>(p, a, broyden, s);
-        case 15: return jtj8_launch_one<15>(p, a, broyden, s);
-        case 16: return jtj8_launch_one<16>(p, a, broyden, s);
-        }
-    }
-    return hipErrorInvalidValue;
-}
-
-template <typename T>
-hipError_t jtj_run(const JtjPlan& p, const JtjArgs<T>& a, bool broyden, T* packed, hipStream_t s)
-{
-    if (p.ring8) {
-        hipError_t e = jtj8_launch<T>(p, a, broyden, s);
-        if (e != hipSuccess) return e;
-        const int rb = (p.slab_len + 31) / 32;
-        hipLaunchKernelGGL(k_jtj_slab_reduce<T>, dim3(rb), dim3(256), 0, s, a.slabs, p.nblk, p.slab_len, p.ncb, a.n, packed);
-        return hipGetLastError();
-    }
-    if (p.wide) return jtj_run_wide<T>(p, a, broyden, packed, s);
-    hipError_t e = broyden ? jtj_launch_br<T, true>(p, a, s) : jtj_launch_br<T, false>(p, a, s);
-    if (e != hipSuccess) return e;
-    const int rb = (p.slab_len + 31) / 32;
-    hipLaunchKernelGGL(k_jtj_slab_reduce<T>, dim3(rb), dim3(256), 0, s, a.slabs, p.nblk, p.slab_len, p.ncb, a.n, packed);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------
 // device buffers carved from one allocation
 // ------------------------------------------------------------------------------------------
 template <typename T>
@@ -479,8 +109,17 @@ struct Buffers {
 
 constexpr int kPartials = 1024;
 
+// slab elements the J^T J kernels may need for this shape: the larger of the product plan and the streaming variant's
 template <typename T>
-Buffers<T> carve(void* base, size_t m, size_t n, const JtjPlan& plan, int num_cu)
+size_t slab_elems(size_t m, size_t n, int num_cu)
+{
+    const JtjPlan a = jtj_plan<T>(m, (int)n, num_cu, 0), b = jtj_plan<T>(m, (int)n, num_cu, MIR_LSQ_VARIANT_JTJ_STREAM);
+    const size_t ea = (size_t)a.nblk * a.njobs * a.slab_len, eb = (size_t)b.nblk * b.njobs * b.slab_len;
+    return ea > eb ? ea : eb;
+}
+
+template <typename T>
+Buffers<T> carve(void* base, size_t m, size_t n, int num_cu)
 {
     Buffers<T> b{};
     long long* dbg_all = nullptr;
@@ -509,7 +148,7 @@ Buffers<T> carve(void* base, size_t m, size_t n, const JtjPlan& plan, int num_cu
     b.sum = (T*)take(8 + kChainMax, sizeof(T));
     b.st = (LmState<T>*)take(1, sizeof(LmState<T>));
     b.rec = (ChainRec<T>*)take(kChainMax, sizeof(ChainRec<T>));
-    b.slabs = (T*)take((size_t)plan.nblk * plan.njobs * plan.slab_len, sizeof(T));
+    b.slabs = (T*)take(slab_elems<T>(m, n, num_cu), sizeof(T));
     b.lrD = (T*)take((size_t)kLrMax * n, sizeof(T));
     b.lrvec = (T*)take((size_t)lr_len((int)n) + 6, sizeof(T));
     b.lrpart = (T*)take((size_t)lr_blocks(m, num_cu) * lr_len((int)n), sizeof(T));
@@ -536,23 +175,29 @@ int query_num_cu()
     return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 }
 
+void workspace_destroy(mir_lsq_workspace* ws);
+
 template <typename T>
 mir_lsq_workspace* workspace_create(size_t m, size_t n)
 {
     auto* ws = new mir_lsq_workspace();
     ws->m = m; ws->n = n; ws->elem = sizeof(T);
     ws->num_cu = query_num_cu();
-    const JtjPlan plan = jtj_plan<T>(m, (int)n, ws->num_cu);
-    const Buffers<T> sz = carve<T>(nullptr, m, n, plan, ws->num_cu);
+    const Buffers<T> sz = carve<T>(nullptr, m, n, ws->num_cu);
     ws->dev_bytes = sz.bytes;
     if (hipMalloc(&ws->dev, ws->dev_bytes) != hipSuccess) {
         std::fprintf(stderr, "[mir_optim_amd] hipMalloc(%zu bytes) failed\n", ws->dev_bytes);
         delete ws;
         return nullptr;
     }
-    if (hipHostMalloc(&ws->pinned, sizeof(LmState<T>) + (2 * n + 8) * sizeof(T), hipHostMallocDefault) != hipSuccess) {
-        (void)hipFree(ws->dev);
-        delete ws;
+    // the m-sized side buffers of the solve loop are part of the workspace (no allocation inside a solve): the pending
+    // Broyden columns (kLrMax x m) and the trial residuals of the lambda ladder (kChainMax x m)
+    if (hipGetDevice(&ws->device) != hipSuccess) ws->device = 0;
+    if (hipMalloc(&ws->ulr, (size_t)kLrMax * m * sizeof(T)) != hipSuccess
+        || hipMalloc(&ws->ytrial, (size_t)kChainMax * m * sizeof(T)) != hipSuccess
+        || hipHostMalloc(&ws->pinned, sizeof(LmState<T>) + (2 * n + 8) * sizeof(T), hipHostMallocDefault) != hipSuccess) {
+        std::fprintf(stderr, "[mir_optim_amd] workspace side buffers: allocation failed\n");
+        workspace_destroy(ws);
         return nullptr;
     }
     return ws;
@@ -609,18 +254,21 @@ struct Solver {
     Buffers<T> B;
     JtjPlan plan;
     LmSettingsDev<T> sd;
-    bool dbg_solve = std::getenv("MIR_LSQ_DEBUG_SOLVE") != nullptr;
-    bool no_speculation = std::getenv("MIR_LSQ_NO_SPECULATION") != nullptr;
-    // Broyden passes keep J and carry the updates as pending rank-one terms (broyden_lr.h); MIR_LSQ_BROYDEN=fused
-    // selects the kernels that rewrite J every pass (k_jtj2<., true> / k_jtj8 / k_broyden_wide), MIR_LSQ_LR_MAX
-    // (1..16) the number of pending terms after which they are folded into J
-    bool lowrank = !(std::getenv("MIR_LSQ_BROYDEN") && std::getenv("MIR_LSQ_BROYDEN")[0] == 'f');
+    // A/B switches (mir_lsq_gpu_options.variant, MIR_LSQ_VARIANT_*): 0 = product path. Broyden passes keep J and carry the
+    // updates as pending rank-one terms (broyden_lr.h); BROYDEN_REWRITE selects the kernels that rewrite J every pass
+    // (k_jtj2<., true> / k_jtj8 / k_broyden_wide); bits 16..20 the number of pending terms after which they are folded into J
+    uint32_t variant = 0;
+    bool dbg_solve = false, no_speculation = false, lowrank = true, no_null_skip = false, host_profile = false;
     int lr_cap = kLrMax;
     int lr_k = 0;
+    int device = 0, caller_device = -1;
+    // the reference swaps the contents of y and mBuffer on acceptance (LS:1136); here the two device buffers swap roles.
+    // Everything that touches them goes through these members (never through B.y / B.mB directly).
+    T* y = nullptr;
+    T* mB = nullptr;
     // null steps (trial == x bit for bit; kFlagNullStep): once a round ended on one, the next round's solves are looked
     // at before the callbacks are launched, and when every entry is a null step nothing is evaluated
     bool has_bounds = true;    // some lower / upper entry is finite (set in run()); MIR_LSQ_SOLVE_BOUNDED=1 forces the full kernel
-    bool no_null_skip = std::getenv("MIR_LSQ_NO_NULL_SKIP") != nullptr;
     bool tail_null = false;
     int f_in_lds = 0;
     int solve_nb_ = 0;
@@ -637,10 +285,9 @@ struct Solver {
     std::vector<Slot> slots;
     std::vector<int> slot_count;
     std::mutex fd_mutex;
-    bool fd_failed = false;
+    std::atomic<bool> fd_failed{false};
 
     // MIR_LSQ_HOST_PROFILE=1: host wall time per category of runtime call, printed at teardown (diagnostic)
-    bool host_profile = std::getenv("MIR_LSQ_HOST_PROFILE") != nullptr;
     double hp_ms[6] = {0, 0, 0, 0, 0, 0};   // 0 events, 1 all-reduce calls, 2 callbacks, 3 sync/readback, 4 launches (solve), 5 max single
     struct HpScope {
         Solver* s; int cat; std::chrono::steady_clock::time_point t0;
@@ -689,8 +336,13 @@ struct Solver {
             ws = nullptr;
             return false;
         }
-        plan = jtj_plan<T>(m, (int)n, ws->num_cu);
-        B = carve<T>(ws->dev, m, n, plan, ws->num_cu);
+        // the workspace's device becomes current for the call (restored at teardown): kernels, streams and the dynamic-LDS
+        // attributes are per device, and a caller may drive several devices from one process
+        if (hipGetDevice(&caller_device) != hipSuccess) caller_device = ws->device;
+        if (caller_device != ws->device && !ok(hipSetDevice(ws->device), "hipSetDevice")) return false;
+        plan = jtj_plan<T>(m, (int)n, ws->num_cu, variant);
+        B = carve<T>(ws->dev, m, n, ws->num_cu);
+        device = ws->device;
         st_h = reinterpret_cast<LmState<T>*>(ws->pinned);
         trial_h = reinterpret_cast<T*>(static_cast<char*>(ws->pinned) + sizeof(LmState<T>));
         if (!stream) {
@@ -703,10 +355,17 @@ struct Solver {
         sd.goodStepQuality = S->goodStepQuality; sd.lambdaIncrease = S->lambdaIncrease; sd.lambdaDecrease = S->lambdaDecrease;
         sd.qpRelTolerance = S->qpSettings.relTolerance; sd.qpAbsTolerance = S->qpSettings.absTolerance;
         sd.qpMaxIterations = S->qpSettings.maxIterations; sd.pad = 0;
-        if (const char* e = std::getenv("MIR_LSQ_LR_MAX")) {
-            const int v = std::atoi(e);
+        dbg_solve = (variant & MIR_LSQ_VARIANT_DEBUG_SOLVE) != 0;
+        no_speculation = (variant & MIR_LSQ_VARIANT_NO_SPECULATION) != 0;
+        lowrank = (variant & MIR_LSQ_VARIANT_BROYDEN_REWRITE) == 0;
+        no_null_skip = (variant & MIR_LSQ_VARIANT_NO_NULL_SKIP) != 0;
+        host_profile = (variant & MIR_LSQ_VARIANT_HOST_PROFILE) != 0;
+        {
+            const int v = (int)((variant >> MIR_LSQ_VARIANT_LR_CAP_SHIFT) & 31u);
             if (v >= 1 && v <= kLrMax) lr_cap = v;
         }
+        y = B.y;
+        mB = B.mB;
         solve_nb_ = solve_nb((int)n, (int)sizeof(T));
         f_in_lds = solve_nb_ > 0;
         solve_lds = solve_lds_bytes((int)n, (int)sizeof(T));
@@ -741,6 +400,7 @@ struct Solver {
         }
         slots.clear();
         if (own_stream && stream) (void)hipStreamDestroy(stream);
+        if (ws && caller_device >= 0 && caller_device != ws->device) (void)hipSetDevice(caller_device);
         if (own_ws && ws) workspace_destroy(ws);
     }
 
@@ -762,12 +422,7 @@ struct Solver {
     hipError_t launch_solve_nbb(const LmSolveArgs<T>& a, int ks)
     {
         auto kern = k_lm_solve<T, NB, BOUNDED>;
-        static bool attr_done = false;
-        if (!attr_done && solve_lds > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-            if (e != hipSuccess) return e;
-            attr_done = true;
-        }
+        if (solve_lds > 48 * 1024) MIRLSQ_ENSURE_LDS(kern, (size_t)(160 * 1024 - 256));
         hipLaunchKernelGGL(kern, dim3(ks), dim3(kSolveThreads), solve_lds, stream, a);
         return hipGetLastError();
     }
@@ -796,14 +451,19 @@ struct Solver {
         if (nb < 1) nb = 1;
         hipLaunchKernelGGL(k_sumsq_partial<T>, dim3(nb, count), dim3(256), 0, stream, v, m, B.partials, vstride, kPartials);
         hipLaunchKernelGGL(k_sumsq_final<T>, dim3(count), dim3(256), 0, stream, B.partials, nb, B.sum + slot, kPartials);
-        if (comm) {
-            HpScope hp(this, 1);
-            if (comm_allreduce<T>(comm, B.sum + slot, (size_t)count, stream) != 0) return false;
-        }
+        if (comm && !allreduce(B.sum + slot, (size_t)count, 2)) return false;
         return ok(hipGetLastError(), "sumsq");
     }
 
-    // mirror the device state (and optionally n values: the current x after a decision, or trial 0 before a host callback)
+    // ---- row-shard exchange: sum `count` elements over the ranks, in place, ordered on the stream. kind: 0 packed
+    //      [J^T J | J^T y], 1 Broyden sweep vector, 2 residual sums (mir_lsq_stats.allreduce_*)
+    bool allreduce(T* buf, size_t count, int kind)
+    {
+        HpScope hp(this, 1);
+        if (stats) { stats->allreduce_calls[kind]++; stats->allreduce_elems[kind] += count; }
+        return comm_allreduce<T>(comm, buf, count, stream) == 0;
+    }
+
     // ---- optional per-pass trace (mir_lsq_trace)
     void trace_emit(int event, uint32_t iterations, T lambda, T residual, T trial_residual, T dx_dot)
     {
@@ -848,11 +508,21 @@ struct Solver {
     // ---- fused [Broyden] + J^T J + J^T y, all-reduce, unpack (LS:1003-1006, 1052, 1065)
     bool broyden_lowrank(const T* y_dev, const T* yold_dev)
     {
-        if (!ws->ulr && !ok(hipMalloc(&ws->ulr, (size_t)kLrMax * m * sizeof(T)), "hipMalloc(pending Broyden columns)")) return false;
         T* U = static_cast<T*>(ws->ulr);
         if (lr_k >= lr_cap) {
+            // fold the pending rank-one terms into J (the reference's successive `ger`s, LS:1006) ...
             if (!ok(lr_flush<T>(B.J, U, B.lrD, lr_k, m, (int)n, ws->num_cu, stream), "broyden flush")) return false;
             lr_k = 0;
+            if (stats) stats->broyden_flushes++;
+            // ... and resynchronise: J^T J and J^T y_old recomputed from the flushed J, as the reference's syrk / gemv do
+            // every pass (LS:1052, 1065). The recurrence J^T J += v dx^T + dx v^T + uu dx dx^T below then never runs for more
+            // than lr_cap passes on its own rounding errors (ill-conditioned problems: cancellation could otherwise
+            // accumulate over up to maxAge = 2n passes). y_old: the sweep expects J_{k-1}^T J_{k-1} in JJ; Jy is
+            // rebuilt by every sweep anyway.
+            if (!(variant & MIR_LSQ_VARIANT_NO_RESYNC)) {
+                if (!plain_products(yold_dev)) return false;
+                if (stats) stats->jtj_resyncs++;
+            }
         }
         LrArgs<T> a{};
         a.J = B.J; a.U = U; a.D = B.lrD; a.dx = B.dx_acc; a.dx_dot = &B.st->dx_dot; a.y = y_dev; a.y_old = yold_dev;
@@ -862,14 +532,25 @@ struct Solver {
         if (!ok(lr_sweep<T>(a, nblk, stream), "broyden sweep")) return false;
         ev_end();
         hipLaunchKernelGGL(k_lr_reduce<T>, dim3((len + 31) / 32), dim3(256), 0, stream, B.lrpart, nblk, len, B.lrvec);
-        if (comm) {
-            HpScope hp(this, 1);
-            if (comm_allreduce<T>(comm, B.lrvec, (size_t)len, stream) != 0) return false;
-        }
+        if (comm && !allreduce(B.lrvec, (size_t)len, 1)) return false;
         hipLaunchKernelGGL(k_lr_finish<T>, dim3(n + 1), dim3(256), 0, stream, B.lrvec, B.lrD, B.dx_acc, lr_k, (int)n, B.JJ, B.Jy, B.st);
         if (stats) stats->broyden_lr_columns += (uint64_t)lr_k;
         ++lr_k;
         return ok(hipGetLastError(), "broyden finish");
+    }
+
+    // J^T J, J^T y_vec of the J in memory -> JJ, Jy (all-reduced, unpacked)
+    bool plain_products(const T* y_vec)
+    {
+        JtjArgs<T> a{};
+        a.J = B.J; a.Jout = B.J; a.y = y_vec; a.y_old = y_vec; a.dx = B.dx_acc; a.dx_dot = &B.st->dx_dot;
+        a.slabs = B.slabs; a.m = m; a.n = (int)n;
+        ev_begin(0);
+        if (!ok(jtj_run<T>(plan, a, false, B.packed, stream, variant), "jtj kernel")) return false;
+        ev_end();
+        if (comm && !allreduce(B.packed, (size_t)n * (n + 1) / 2 + n, 0)) return false;
+        hipLaunchKernelGGL(k_unpack_grad<T>, dim3(n + 1), dim3(128), 0, stream, B.packed, (int)n, B.JJ, B.Jy, B.st);
+        return ok(hipGetLastError(), "unpack");
     }
 
     bool jacobian_products(bool broyden, const T* y_dev, const T* yold_dev)
@@ -889,13 +570,10 @@ struct Solver {
             ev_end();
         } else {
             ev_begin(broyden ? 1 : 0);
-            if (!ok(jtj_run<T>(plan, a, broyden, B.packed, stream), "jtj kernel")) return false;
+            if (!ok(jtj_run<T>(plan, a, broyden, B.packed, stream, variant), "jtj kernel")) return false;
             ev_end();
         }
-        if (comm) {
-            HpScope hp(this, 1);
-            if (comm_allreduce<T>(comm, B.packed, (size_t)n * (n + 1) / 2 + n, stream) != 0) return false;
-        }
+        if (comm && !allreduce(B.packed, (size_t)n * (n + 1) / 2 + n, 0)) return false;
         hipLaunchKernelGGL(k_unpack_grad<T>, dim3(n + 1), dim3(128), 0, stream, B.packed, (int)n, B.JJ, B.Jy, B.st);
         return ok(hipGetLastError(), "unpack");
     }
@@ -939,7 +617,7 @@ struct Solver {
             ws->ypanel_bytes = need;
         }
         T* Y = static_cast<T*>(ws->ypanel);
-        static const bool no_fuse = std::getenv("MIR_LSQ_FD_FUSE") && std::getenv("MIR_LSQ_FD_FUSE")[0] == '0';
+        const bool no_fuse = (variant & MIR_LSQ_VARIANT_FD_SEPARATE_FILL) != 0;
         if (fbr && plan.fdp && pb == n && sizeof(T) == 8 && !no_fuse) {
             // all 2n points in one sweep, Y[i][2j], Y[i][2j+1] = f(x + h e_j)_i, f(x - h e_j)_i; k_jtj2<., false, true>
             // (jacobian_products) turns the pairs into Jacobian rows on its way to J^T J -- no k_fd_fill pass
@@ -975,6 +653,8 @@ struct Solver {
     {
         const uint32_t idx = totalThreads >= n ? j : threadId;       // LS:1022
         if (idx >= n || j >= n) { fd_failed = true; return; }
+        // the manager's worker threads start on device 0: select the solver's device before any runtime call
+        if (hipSetDevice(device) != hipSuccess) { fd_failed = true; return; }
         Slot* s;
         {
             std::lock_guard<std::mutex> lk(fd_mutex);
@@ -1002,16 +682,19 @@ struct Solver {
             f(fctx, m, n, p, s->ym);
             p[j] = save;
         }
+        // Staging: the CURRENT mBuffer (it holds y_old, which is dead while the Jacobian is refreshed in full: the next
+        // Broyden update only comes after another accepted step has rewritten it) and the spare m-vector -- never the live
+        // residual `y`, whichever of the two physical buffers it is in after the role swaps of the accepted steps.
         std::lock_guard<std::mutex> lk(fd_mutex);
         if (twh != 0) {
-            if (hipMemcpyAsync(B.mB, s->yp, m * sizeof(T), hipMemcpyHostToDevice, stream) != hipSuccess
+            if (hipMemcpyAsync(mB, s->yp, m * sizeof(T), hipMemcpyHostToDevice, stream) != hipSuccess
                 || hipMemcpyAsync(B.ytmp, s->ym, m * sizeof(T), hipMemcpyHostToDevice, stream) != hipSuccess) {
                 fd_failed = true;
                 return;
             }
         }
         hipLaunchKernelGGL(k_fd_fill_col<T>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream,
-                           B.mB, B.ytmp, twh, B.J, m, (int)n, (int)j);
+                           mB, B.ytmp, twh, B.J, m, (int)n, (int)j);
         if (hipStreamSynchronize(stream) != hipSuccess) fd_failed = true;
     }
     bool fd_host()
@@ -1066,14 +749,11 @@ struct Solver {
         }
         if (!device_available()) return ret;
         if (!setup()) { teardown(); return ret; }
-        has_bounds = std::getenv("MIR_LSQ_SOLVE_BOUNDED") != nullptr;
+        has_bounds = (variant & MIR_LSQ_VARIANT_SOLVE_BOUNDED) != 0;
         for (uint32_t i = 0; i < n; ++i)
             if (lh[i] > -Lim<T>::inf() || uh[i] < Lim<T>::inf()) has_bounds = true;
 
         const uint32_t maxAge = S->maxAge ? S->maxAge : (g ? 3 : 2 * n);     // LS:945 (quirk Q4)
-
-        T* y = B.y;          // the reference swaps the contents of y and mBuffer (LS:1136); here the
-        T* mB = B.mB;        // two device buffers swap roles
 
         bool fail = false;
         do {   // single-exit block for device errors
@@ -1201,8 +881,7 @@ struct Solver {
             // trial residuals -> ytr (k-th vector at ytr + k * m); with one trial they go straight into mB
             T* ytr = mB;
             if (ks > 1) {
-                if (!ws->ytrial && !ok(hipMalloc(&ws->ytrial, (size_t)kChainMax * m * sizeof(T)), "hipMalloc(trial residuals)")) { fail = true; break; }
-                ytr = static_cast<T*>(ws->ytrial);
+                    ytr = static_cast<T*>(ws->ytrial);
             }
             if (skip_eval) {
                 // every trial of the round equals x: the decision kernel substitutes the residual it already has
@@ -1298,6 +977,7 @@ typename Abi<T>::Result solve_entry(const typename Abi<T>::Settings* settings, s
         s.fbctx = opt->fbContext;
         s.fb = s.device_cb ? reinterpret_cast<typename Abi<T>::FB>(opt->fb) : nullptr;
         s.fd_batch = opt->fd_batch;
+        s.variant = opt->variant;
         s.stats = opt->stats;
         if (opt->struct_size >= offsetof(mir_lsq_gpu_options, trace) + sizeof(void*)) s.trace = opt->trace;
         if (opt->struct_size >= offsetof(mir_lsq_gpu_options, fbRowMajor) + sizeof(void*) && s.device_cb)
@@ -1472,12 +1152,12 @@ int box_qp_entry(const QS* settings, size_t n_, const T* P, const T* q, const T*
 
 template <typename T>
 int jtj_entry(size_t m, size_t n, T* J, const T* y, const T* y_old, const T* dx, int broyden, T* JJ, T* Jy,
-              void* stream_, float* kernel_ms)
+              void* stream_, float* kernel_ms, uint32_t variant = 0)
 {
     if (!device_available()) return -1;
     if (n == 0 || n > (size_t)kSolveMaxN || m == 0) return -2;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const JtjPlan plan = jtj_plan<T>(m, (int)n, query_num_cu());
+    const JtjPlan plan = jtj_plan<T>(m, (int)n, query_num_cu(), variant);
     const size_t packed_len = n * (n + 1) / 2 + n + 8;
     T *slabs = nullptr, *packed = nullptr, *dxdot = nullptr;
     LmState<T>* st = nullptr;
@@ -1496,7 +1176,7 @@ int jtj_entry(size_t m, size_t n, T* J, const T* y, const T* y_old, const T* dx,
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, stream);
-    if (jtj_run<T>(plan, a, broyden != 0, packed, stream) != hipSuccess) rc = -4;
+    if (jtj_run<T>(plan, a, broyden != 0, packed, stream, variant) != hipSuccess) rc = -4;
     (void)hipEventRecord(e1, stream);
     hipLaunchKernelGGL(k_unpack_grad<T>, dim3((unsigned)n + 1), dim3(128), 0, stream, packed, (int)n, JJ, Jy, st);
     if (hipStreamSynchronize(stream) != hipSuccess) rc = -5;
@@ -1628,6 +1308,11 @@ int mir_lsq_jtj_d(size_t m, size_t n, double* J, const double* y, const double* 
 {
     return jtj_entry<double>(m, n, J, y, y_old, dx, broyden, JJ, Jy, stream, kernel_ms);
 }
+int mir_lsq_jtj_variant_d(size_t m, size_t n, double* J, const double* y, const double* y_old, const double* dx, int broyden,
+                          double* JJ, double* Jy, void* stream, float* kernel_ms, uint32_t variant)
+{
+    return jtj_entry<double>(m, n, J, y, y_old, dx, broyden, JJ, Jy, stream, kernel_ms, variant);
+}
 int mir_lsq_fd_jtj_d(size_t m, size_t n, const double* Yrm, const double* twh, const double* y, double* J,
                      double* JJ, double* Jy, void* stream_, float* kernel_ms)
 {
@@ -1706,7 +1391,7 @@ mir_lsq_comm* mir_lsq_comm_create_rccl(int nranks, int rank, const void* unique_
     auto* comm = new mir_lsq_comm();
     comm->nranks = nranks; comm->rank = rank; comm->kind = 1; comm->lib = h; comm->nccl_comm = c;
     comm->allreduce_fn = ar; comm->destroy_fn = destroy;
-    if (nranks > 1 || std::getenv("MIR_LSQ_RCCL_WARM_ALWAYS")) {
+    {
         // RCCL loads its kernels and connects its channels at the first collective of each size class: do that here
         // (creation is collective anyway), with the three payload sizes of a solve -- one scalar, the Broyden sweep
         // vector, the packed [J^T J | J^T y] -- so that the caller's first solve does not pay for it
@@ -1731,10 +1416,41 @@ mir_lsq_comm* mir_lsq_comm_create_callback(int nranks, int rank, mir_lsq_allredu
     return comm;
 }
 
+int mir_lsq_comm_create_local_group(int nranks, mir_lsq_comm** out_comms)
+{
+    if (nranks < 1 || !out_comms) return -1;
+    auto* g = new LocalGroup();
+    g->nranks = nranks; g->refs = nranks;
+    g->slots[0].resize(nranks); g->slots[1].resize(nranks); g->total.resize(nranks);
+    for (int r = 0; r < nranks; ++r) {
+        auto* c = new mir_lsq_comm();
+        c->nranks = nranks; c->rank = r; c->kind = 3; c->group = g;
+        out_comms[r] = c;
+    }
+    return 0;
+}
+
 void mir_lsq_comm_destroy(mir_lsq_comm* comm)
 {
     if (!comm) return;
     if (comm->kind == 1 && comm->destroy_fn && comm->nccl_comm) comm->destroy_fn(comm->nccl_comm);
+    if (comm->kind == 3 && comm->group) {
+        LocalGroup* g = comm->group;
+        bool last;
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            for (int par = 0; par < 2; ++par) {
+                auto& sl = g->slots[par][comm->rank];
+                if (sl.host) (void)hipHostFree(sl.host);
+                sl.host = nullptr; sl.bytes = 0;
+            }
+            auto& t = g->total[comm->rank];
+            if (t.host) (void)hipHostFree(t.host);
+            t.host = nullptr; t.bytes = 0;
+            last = --g->refs == 0;
+        }
+        if (last) delete g;
+    }
     delete comm;
 }
 

@@ -75,3 +75,18 @@ def torch_allreduce_numpy(dist):
         t = torch.from_numpy(buf)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return f
+
+
+def local_group(world):
+    """In-process group (mir_lsq_comm_create_local_group): `world` communicator handles for `world` solver instances
+    in THIS process, one host thread each. Returns (handles, close)."""
+    L = api.lib()
+    arr = (C.c_void_p * world)()
+    if L.mir_lsq_comm_create_local_group(world, arr) != 0:
+        raise RuntimeError("mir_lsq_comm_create_local_group failed")
+    handles = [arr[r] for r in range(world)]
+
+    def close():
+        for h in handles:
+            L.mir_lsq_comm_destroy(h)
+    return handles, close

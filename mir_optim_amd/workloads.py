@@ -43,9 +43,10 @@ class DeviceProblem:
 
     suffix = "d"
 
-    def options(self, flags=0, stats=None, comm=None, workspace=None, batched=False, fd_batch=0, trace=None):
+    def options(self, flags=0, stats=None, comm=None, workspace=None, batched=False, fd_batch=0, trace=None, variant=0):
         o = api.GpuOptions()
         o.flags = api.DEVICE_CALLBACKS | flags
+        o.variant = variant
         o.stream = self.stream.handle
         o.comm = comm
         o.workspace = workspace

@@ -49,22 +49,20 @@ def test_fd_jtj_exact_integers(m, n):
 
 
 @pytest.mark.parametrize("m,n", [(4096, 128), (5000, 16), (30, 32), (10002, 64), (7778, 80), (12344, 96), (6, 112), (50000, 128)])
-def test_ring_variants_agree_with_producer_consumer_kernels(m, n, monkeypatch):
-    """MIR_LSQ_FD_KERNEL=ring / MIR_LSQ_JTJ_KERNEL=ring select the LDS-DMA ring kernels (n % 16 == 0, m even): same J bit for
-    bit, J^T J and J^T y bit-exact on exact-integer inputs."""
+def test_ring_and_streaming_variants_agree_with_producer_consumer_kernels(m, n):
+    """VARIANT_JTJ_RING / VARIANT_JTJ_STREAM select the LDS-DMA ring kernel (n % 16 == 0, m even) and the register-streaming
+    kernel for the plain J^T J: bit-exact on exact-integer inputs, like the producer / consumer kernels."""
     rng = np.random.default_rng(3 * m + n)
     Yrm = rng.integers(-8, 9, size=(m, 2 * n)).astype(np.float64)
     twh = np.full(n, 2.0 ** -25)
     y = rng.integers(-4, 5, size=m).astype(np.float64)
     J0, JJ0, Jy0, _ = M.fd_jtj(Yrm, twh, y)
     P0 = M.jtj(J0, y)
-    monkeypatch.setenv("MIR_LSQ_FD_KERNEL", "ring")
-    monkeypatch.setenv("MIR_LSQ_JTJ_KERNEL", "ring")
-    J1, JJ1, Jy1, _ = M.fd_jtj(Yrm, twh, y)
-    P1 = M.jtj(J0, y)
-    assert np.array_equal(J1, J0)
+    P1 = M.jtj(J0, y, variant=M.VARIANT_JTJ_RING)
+    P2 = M.jtj(J0, y, variant=M.VARIANT_JTJ_STREAM)
     Jr = ref_fill(Yrm, twh)
-    for JJ, Jy in ((JJ0, Jy0), (JJ1, Jy1), (P0[0], P0[1]), (P1[0], P1[1])):
+    assert np.array_equal(J0, Jr)
+    for JJ, Jy in ((JJ0, Jy0), (P0[0], P0[1]), (P1[0], P1[1]), (P2[0], P2[1])):
         assert np.array_equal(JJ, Jr.T @ Jr) or np.allclose(JJ, Jr.T @ Jr, rtol=1e-15, atol=0)
         assert np.array_equal(Jy, Jr.T @ y) or np.allclose(Jy, Jr.T @ y, rtol=1e-15, atol=0)
 

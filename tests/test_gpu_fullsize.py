@@ -1,0 +1,69 @@
+"""BASELINE cfg 3 at FULL size in the GPU test tier: tanh-linear NLS, m = 1e6 x n = 128, fp64, finite-difference
+Jacobian through the batched device callbacks -- the bench.py workload -- against the oracle (the CPU restatement of
+least_squares.d:877-1176 with OpenBLAS for syrk / gemv / ger / posvx) on the same inputs.
+
+The oracle needs ~3 s per accepted iteration on a 16..64-core host (syrk dominates), so it is bounded:
+  * absTolerance = 1e-5 (bench.py's setting): the whole solve is 6 accepted iterations; x, residual, status, fCalls compared;
+  * absTolerance = 1e-9 (SURVEY 8d's setting): the last acceptance compares rounding noise, so the
+    status is xConverged OR furtherImprovement on either side; the minimiser is the same to 1e-6 relative regardless.
+Tolerances (north star): |x_gpu - x_oracle| <= 1e-6 |x|_inf, residual rtol 1e-9."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import mir_optim_amd as M
+from mir_optim_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+M_ROWS, N = 1_000_000, 128
+
+
+@pytest.fixture(scope="module")
+def cfg3():
+    data = W.tanh_linear_data(M_ROWS, N)
+    prob = W.TanhLinear(data["A"], data["b"])
+    yield data, prob
+    prob.dA.free(); prob.db.free()
+
+
+def oracle_run(oracle, data, abs_tolerance, max_iterations):
+    threads = min(os.cpu_count() or 1, 64)
+    ob = oracle.load_openblas(threads=threads)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    so = oracle.default_settings()
+    so.absTolerance = abs_tolerance
+    so.maxIterations = max_iterations
+    ctx = oracle.TanhLinearCtx(data["A"].ctypes.data, data["b"].ctypes.data)
+    return oracle.optimize(oracle.native_fn("wlc_tanh_linear_f"), M_ROWS, data["x0"], settings=so, fctx=C.addressof(ctx),
+                           use_openblas=ob)
+
+
+def test_cfg3_full_size_bench_setting_matches_oracle(oracle, cfg3):
+    data, prob = cfg3
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-5
+    st = M.Stats()
+    res, x = prob.solve(data["x0"], settings=s, batched=True, stats=st)
+    ro, xo = oracle_run(oracle, data, 1e-5, 1000)
+    assert int(res.status) == ro.status == M.LeastSquaresStatus.xConverged
+    assert (res.iterations, res.fCalls) == (ro.iterations, ro.fCalls)
+    assert np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max(), np.abs(x - xo).max()
+    assert np.isclose(res.residual, ro.residual, rtol=1e-9, atol=0)
+    assert st.jacobian_full == 2 and st.accepted == res.iterations
+    # the minimiser really is one: the gradient of the data's generating point is O(noise), x is within 1e-2 of it
+    assert np.abs(x - data["xstar"]).max() < 5e-2
+
+
+def test_cfg3_full_size_survey_setting_matches_oracle(oracle, cfg3):
+    data, prob = cfg3
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
+    res, x = prob.solve(data["x0"], settings=s, batched=True)
+    ro, xo = oracle_run(oracle, data, 1e-9, 14)
+    ok = (M.LeastSquaresStatus.xConverged, M.LeastSquaresStatus.furtherImprovement)
+    assert res.status in ok, res
+    assert ro.status in (0, 1, -1)               # -1: the bounded oracle sample stopped at maxIterations = 14
+    assert np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max(), np.abs(x - xo).max()
+    assert np.isclose(res.residual, ro.residual, rtol=1e-9, atol=0)
+    assert 10 <= res.iterations <= 14

@@ -93,27 +93,6 @@ def test_broyden_fused_update(m, n):
     assert np.allclose(J_after @ dx, y - y_old, rtol=1e-9, atol=1e-12)
 
 
-@pytest.mark.parametrize("m,n", [(40000, 128), (30002, 64), (10000, 96), (50, 128), (4098, 16), (100000, 80)])
-def test_broyden_split_row_kernel_is_bitwise_the_v2_kernel(m, n, tmp_path):
-    """k_jtj3 (the rank-one update done once per row by the storer waves, in LDS) against k_jtj2<NCB, true> (every wave
-    updates the rows it multiplies): same arithmetic, same summation order -> identical bits in J^T J, J^T y and the
-    written-back J. The kernel choice is read once per process, hence the two subprocesses."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for split in (False, True):
-        env = dict(os.environ)
-        env.pop("MIR_LSQ_JTJ_SPLIT", None)
-        if split:
-            env["MIR_LSQ_JTJ_SPLIT"] = "1"
-        out = str(tmp_path / f"o{int(split)}.npz")
-        subprocess.run([sys.executable, os.path.join(root, "scripts", "jtj_dump.py"), str(m), str(n), out], check=True,
-                       env=env, timeout=300)
-        outs.append(np.load(out))
-    for k in ("JJ", "Jy", "Jn"):
-        assert np.array_equal(outs[0][k], outs[1][k]), k
-
-
 def test_jtj_float32():
     rng = np.random.default_rng(9)
     m, n = 5000, 64

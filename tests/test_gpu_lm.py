@@ -355,7 +355,7 @@ def test_repeated_solve_is_bit_reproducible(m, n):
 
 
 @pytest.mark.parametrize("m,n", [(3000, 17), (9000, 33), (20001, 9)])
-def test_speculative_lambda_ladder_is_bitwise_equivalent(m, n, monkeypatch):
+def test_speculative_lambda_ladder_is_bitwise_equivalent(m, n):
     """After a rejection the solver evaluates a ladder of up to 8 lambdas at once (batched residual callback) and
     walks them in the reference's order. With a batched callback that is numerically the same function as the
     single-point one (odd n: workloads.hip falls back to one sweep per point) the result must be bit-identical
@@ -365,9 +365,7 @@ def test_speculative_lambda_ladder_is_bitwise_equivalent(m, n, monkeypatch):
     s = M.LeastSquaresSettings(); s.absTolerance = 1e-12          # force the long noisy rejection tail (quirk Q3)
     st1, st0 = M.Stats(), M.Stats()
     r1, x1 = prob.solve(w["x0"], settings=s, batched=True, stats=st1, flags=M.TIME_KERNELS)
-    monkeypatch.setenv("MIR_LSQ_NO_SPECULATION", "1")
-    r0, x0 = prob.solve(w["x0"], settings=s, batched=True, stats=st0, flags=M.TIME_KERNELS)
-    monkeypatch.delenv("MIR_LSQ_NO_SPECULATION")
+    r0, x0 = prob.solve(w["x0"], settings=s, batched=True, stats=st0, flags=M.TIME_KERNELS, variant=M.VARIANT_NO_SPECULATION)
     assert st0.rejected >= 5                                       # the ladder really had something to do
     assert np.array_equal(x1, x0) and r1.residual == r0.residual and r1.lambda_ == r0.lambda_
     assert (r1.status, r1.iterations, r1.fCalls) == (r0.status, r0.iterations, r0.fCalls)
@@ -389,7 +387,7 @@ def test_stats_and_reentrancy(oracle):
 
 
 @pytest.mark.parametrize("m,n", [(3000, 17), (9000, 32), (20000, 64)])
-def test_null_step_elision_is_bitwise_equivalent(m, n, monkeypatch):
+def test_null_step_elision_is_bitwise_equivalent(m, n):
     """At the end of a noisy solve lambda grows until the rounded step is exactly zero (trial == x bit for bit) long before
     lambda > maxLambda ends the loop (quirk Q3). The callbacks are pure (LS:73-80), so those evaluations are elided: same
     x, residual, lambda, counters (fCalls counts them like the reference) and the same trace, with fewer callback launches."""
@@ -398,13 +396,9 @@ def test_null_step_elision_is_bitwise_equivalent(m, n, monkeypatch):
     s = M.LeastSquaresSettings(); s.absTolerance = 0.0            # an accepted step has dx != 0: never x-converged, always the tail
     out = []
     for skip in (True, False):
-        if not skip:
-            monkeypatch.setenv("MIR_LSQ_NO_NULL_SKIP", "1")
         st, tr = M.Stats(), M.Trace(4096)
-        r, x = prob.solve(w["x0"], settings=s, batched=True, stats=st, trace=tr)
+        r, x = prob.solve(w["x0"], settings=s, batched=True, stats=st, trace=tr, variant=0 if skip else M.VARIANT_NO_NULL_SKIP)
         out.append((r, x, st, tr.records()))
-        if not skip:
-            monkeypatch.delenv("MIR_LSQ_NO_NULL_SKIP")
     (r1, x1, st1, t1), (r0, x0, st0, t0) = out
     assert r1.status == M.LeastSquaresStatus.furtherImprovement == r0.status      # lambda > maxLambda, LS:979
     assert st1.elided_evaluations >= 8 and st0.elided_evaluations == 0

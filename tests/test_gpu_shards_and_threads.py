@@ -1,0 +1,159 @@
+"""Row sharding with R logical shards on ONE GPU and re-entrancy (8b "Threading").
+
+The GPU box allows six processes on the card, so eight shards cannot be eight processes: they are eight HOST THREADS of
+this process, each with its own solver instance, stream, workspace, data shard and a handle of the library's in-process
+communicator group (mir_lsq_comm_create_local_group: device -> pinned host, barrier, sum in rank order, host -> device).
+ctypes releases the GIL for the duration of the C call and the callbacks are native device callbacks, so the eight solves
+really run concurrently -- which makes every one of these tests a re-entrancy test of the library as well.
+
+Reference: the three reductions of a pass are least_squares.d:1052 (J^T y), 1065 (J^T J) and 1115 (||f(trial)||^2)."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import mir_optim_amd as M
+from mir_optim_amd import parallel as PAR
+from mir_optim_amd import workloads as W
+import problems as P
+
+pytestmark = pytest.mark.gpu
+
+
+def run_threads(fns):
+    out, err = [None] * len(fns), [None] * len(fns)
+
+    def wrap(i):
+        try:
+            out[i] = fns[i]()
+        except BaseException as e:     # noqa: BLE001 -- reported below, in the main thread
+            err[i] = e
+    ts = [threading.Thread(target=wrap, args=(i,)) for i in range(len(fns))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(600)
+    assert not any(t.is_alive() for t in ts), "a shard thread hangs"
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+def sharded_solve(m_total, n, world, settings, lower=None, upper=None, x0=None, **kw):
+    comms, close = PAR.local_group(world)
+    probs, stats = [], []
+    for r in range(world):
+        off, ml = PAR.row_shard(m_total, world, r)
+        w = P.tanh_linear(ml, n, row_offset=off)
+        probs.append((W.TanhLinear(w["A"], w["b"]), w))
+        stats.append(M.Stats())
+    start = probs[0][1]["x0"] if x0 is None else x0
+
+    def one(r):
+        prob, w = probs[r]
+        return lambda: prob.solve(start, l=lower, u=upper, settings=settings, comm=comms[r], stats=stats[r], batched=True, **kw)
+    try:
+        res = run_threads([one(r) for r in range(world)])
+    finally:
+        close()
+    return res, stats
+
+
+def oracle_solve(oracle, m_total, n, settings_fn, lower=None, upper=None, x0=None):
+    w = P.tanh_linear(m_total, n)
+    so = oracle.default_settings()
+    settings_fn(so)
+    ctx = oracle.TanhLinearCtx(w["A"].ctypes.data, w["b"].ctypes.data)
+    return oracle.optimize(oracle.native_fn("wlc_tanh_linear_f"), m_total, w["x0"] if x0 is None else x0, lower=lower, upper=upper,
+                           settings=so, fctx=C.addressof(ctx), use_openblas=oracle.load_openblas(threads=8))
+
+
+@pytest.mark.parametrize("m_total,n,world", [(80000, 128, 8), (40004, 256, 8), (30001, 64, 3), (9000, 33, 8)])
+def test_eight_logical_shards_equal_the_unsharded_oracle(oracle, m_total, n, world):
+    """cfg 3's n = 128 and cfg 4's n = 256 (rows split 8 ways, m scaled down), plus ragged shards and an odd n:
+    every rank returns the same bits; x within rtol 1e-6, residual within 1e-9 of the UNSHARDED oracle."""
+    def tol(s):
+        s.absTolerance = 1e-9
+    s = M.LeastSquaresSettings(); tol(s)
+    res, stats = sharded_solve(m_total, n, world, s)
+    r0, x0 = res[0]
+    for r, x in res[1:]:
+        assert np.array_equal(x, x0) and (r.status, r.iterations, r.fCalls, r.residual, r.lambda_) == \
+            (r0.status, r0.iterations, r0.fCalls, r0.residual, r0.lambda_)
+    ro, xo = oracle_solve(oracle, m_total, n, tol)
+    assert int(r0.status) >= 0 and ro.status >= 0
+    assert np.allclose(x0, xo, rtol=1e-6, atol=1e-9), np.abs(x0 - xo).max()
+    assert np.isclose(r0.residual, ro.residual, rtol=1e-9)
+    # payloads of the three exchanges: packed n(n+1)/2 + n, sweep vector 2n + 34, residual sums
+    st = stats[0]
+    assert st.allreduce_calls[0] >= 1 and st.allreduce_elems[0] == st.allreduce_calls[0] * (n * (n + 1) // 2 + n)
+    if n <= 256 and st.jacobian_broyden:
+        assert st.allreduce_elems[1] == st.allreduce_calls[1] * (2 * n + 34)
+    assert st.allreduce_calls[2] >= st.accepted + 1 and st.allreduce_elems[2] >= st.allreduce_calls[2]
+    if n == 128:
+        assert PAR.packed_length(n) == 8384 and st.allreduce_elems[0] % 8384 == 0
+        assert st.allreduce_calls[1] == 0 or st.allreduce_elems[1] // st.allreduce_calls[1] == 290
+
+
+def test_sharded_bounded_problem_runs_boxcqp_on_every_rank(oracle):
+    """Bounds that the unconstrained steps violate: the BOXCQP active-set loop runs, replicated, on all eight shards."""
+    m_total, n, world = 24000, 24, 8
+    w = P.tanh_linear(m_total, n)
+    lo = w["xstar"] - 0.5
+    up = w["xstar"] + 0.5
+    lo[::3] = w["xstar"][::3] + 0.02          # the minimiser is outside the box in every third coordinate
+    x0 = np.clip(w["x0"], lo, up)
+
+    def tol(s):
+        s.absTolerance = 1e-9
+    s = M.LeastSquaresSettings(); tol(s)
+    res, stats = sharded_solve(m_total, n, world, s, lower=lo, upper=up, x0=x0)
+    r0, xg = res[0]
+    for r, x in res[1:]:
+        assert np.array_equal(x, xg) and r.iterations == r0.iterations and r.residual == r0.residual
+    assert stats[0].qp_active_set_passes > 0
+    ro, xo = oracle_solve(oracle, m_total, n, tol, lower=lo, upper=up, x0=x0)
+    assert int(r0.status) >= 0 and ro.status >= 0
+    assert np.all(xg >= lo) and np.all(xg <= up)
+    assert np.allclose(xg, xo, rtol=1e-6, atol=1e-9), np.abs(xg - xo).max()
+    assert np.isclose(r0.residual, ro.residual, rtol=1e-9)
+
+
+def test_one_rank_group_goes_through_every_collective():
+    """A communicator with one rank still calls its all-reduce for each exchange (sum over one rank = identity):
+    same bits as the solve without a communicator, and the payload lengths are the documented ones."""
+    n = 128
+    w = P.tanh_linear(30000, n)
+    prob = W.TanhLinear(w["A"], w["b"])
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
+    comms, close = PAR.local_group(1)
+    st = M.Stats()
+    r1, x1 = prob.solve(w["x0"], settings=s, comm=comms[0], stats=st, batched=True)
+    close()
+    r0, x0 = prob.solve(w["x0"], settings=s, batched=True)
+    assert np.array_equal(x1, x0) and (r1.status, r1.iterations, r1.residual) == (r0.status, r0.iterations, r0.residual)
+    assert st.allreduce_calls[0] == st.jacobian_full + st.jtj_resyncs and st.allreduce_elems[0] == st.allreduce_calls[0] * 8384
+    assert st.allreduce_calls[1] == st.jacobian_broyden and st.allreduce_elems[1] == 290 * st.allreduce_calls[1]
+    assert st.allreduce_calls[2] >= 1
+
+
+def test_two_host_threads_solve_different_problems_concurrently(oracle):
+    """SURVEY 8b "Threading": concurrent solves on disjoint workspaces are legal. Two threads, different shapes (one takes
+    the n <= 128 kernels, one the n = 256 ones, one is bounded), each on its own stream: identical to the solo runs."""
+    w1, w2 = P.tanh_linear(60000, 128), P.tanh_linear(20000, 256)
+    p1, p2 = W.TanhLinear(w1["A"], w1["b"]), W.TanhLinear(w2["A"], w2["b"])
+    lo = w1["xstar"] - 0.3; up = w1["xstar"] + 0.3
+    lo[::5] = w1["xstar"][::5] + 0.01
+    x01 = np.clip(w1["x0"], lo, up)
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
+    solo1 = p1.solve(x01, l=lo, u=up, settings=s, batched=True)
+    solo2 = p2.solve(w2["x0"], settings=s, batched=True)
+    for _ in range(3):
+        (ra, xa), (rb, xb) = run_threads([lambda: p1.solve(x01, l=lo, u=up, settings=s, batched=True),
+                                          lambda: p2.solve(w2["x0"], settings=s, batched=True)])
+        assert np.array_equal(xa, solo1[1]) and (ra.status, ra.iterations, ra.fCalls, ra.residual) == \
+            (solo1[0].status, solo1[0].iterations, solo1[0].fCalls, solo1[0].residual)
+        assert np.array_equal(xb, solo2[1]) and (rb.status, rb.iterations, rb.fCalls, rb.residual) == \
+            (solo2[0].status, solo2[0].iterations, solo2[0].fCalls, solo2[0].residual)
