@@ -221,6 +221,12 @@ typedef struct mir_lsq_stats {
     uint64_t allreduce_elems[3];
     uint64_t broyden_flushes;        /* times the pending rank-one terms were folded into J */
     uint64_t jtj_resyncs;            /* of those, followed by a recomputation of J^T J / J^T y from the flushed J */
+    /* the CALLER's device callbacks, event-timed on the solver's stream (MIR_LSQ_TIME_KERNELS, device-callback mode):
+     * finite-difference evaluations (f / fb / fbRowMajor; points = parameter vectors evaluated) and trial evaluations */
+    double fd_callback_ms;
+    uint64_t fd_callback_calls, fd_callback_points;
+    double trial_callback_ms;
+    uint64_t trial_callback_calls, trial_callback_points;
 } mir_lsq_stats;
 
 /* Optional per-pass trace (not in the reference; a parity-pinning aid: tests compare it event by event with the
@@ -342,6 +348,8 @@ mir_lsq_comm* mir_lsq_comm_create_callback(int nranks, int rank, mir_lsq_allredu
  * A rank that waits longer than 120 s at the barrier gives up (the solve then returns numericError). Returns 0. */
 int mir_lsq_comm_create_local_group(int nranks, mir_lsq_comm** out_comms);
 void mir_lsq_comm_destroy(mir_lsq_comm* comm);
+/* ranks of the communicator as its transport reports them (RCCL: ncclCommCount); -1 on error */
+int mir_lsq_comm_ranks(const mir_lsq_comm* comm);
 
 /* Small device utilities for language bindings that have no HIP runtime of their own. */
 int mir_lsq_device_count(void);

@@ -142,7 +142,10 @@ class Stats(C.Structure):
                 ("jtj_fd_ms", C.c_double), ("jtj_fd_launches", C.c_uint64),
                 ("elided_evaluations", C.c_uint64),
                 ("allreduce_calls", C.c_uint64 * 3), ("allreduce_elems", C.c_uint64 * 3),
-                ("broyden_flushes", C.c_uint64), ("jtj_resyncs", C.c_uint64)]
+                ("broyden_flushes", C.c_uint64), ("jtj_resyncs", C.c_uint64),
+                ("fd_callback_ms", C.c_double), ("fd_callback_calls", C.c_uint64), ("fd_callback_points", C.c_uint64),
+                ("trial_callback_ms", C.c_double), ("trial_callback_calls", C.c_uint64),
+                ("trial_callback_points", C.c_uint64)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if k.startswith("allreduce_") else getattr(self, k)) for k, _ in self._fields_}
@@ -261,6 +264,8 @@ def lib():
         L.mir_lsq_comm_create_callback.restype = C.c_void_p
         L.mir_lsq_comm_create_callback.argtypes = [C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]
         L.mir_lsq_comm_destroy.argtypes = [C.c_void_p]
+        L.mir_lsq_comm_ranks.restype = C.c_int
+        L.mir_lsq_comm_ranks.argtypes = [C.c_void_p]
         L.mir_lsq_device_count.restype = C.c_int
         L.mir_lsq_device_malloc.restype = C.c_void_p
         L.mir_lsq_device_malloc.argtypes = [sz]

@@ -219,7 +219,7 @@ void workspace_destroy(mir_lsq_workspace* ws)
 // ------------------------------------------------------------------------------------------
 // the solver
 // ------------------------------------------------------------------------------------------
-struct EventPair { hipEvent_t a, b; int kind; };   // kind: 0 jtj, 1 jtj+broyden, 2 solve
+struct EventPair { hipEvent_t a, b; int kind; };   // kind: 0 jtj, 1 Broyden pass, 2 solve, 3 FD jtj, 4 FD callbacks, 5 trial callbacks
 
 template <typename T>
 struct Solver {
@@ -389,6 +389,8 @@ struct Solver {
                 else if (e.kind == 1) { stats->jtj_ms += ms; stats->jtj_launches++; stats->jtj_broyden_ms += ms; stats->jtj_broyden_launches++; }
                 else if (e.kind == 2) { stats->solve_ms += ms; stats->solve_launches++; }
                 else if (e.kind == 3) { stats->jtj_ms += ms; stats->jtj_launches++; stats->jtj_fd_ms += ms; stats->jtj_fd_launches++; }
+                else if (e.kind == 4) { stats->fd_callback_ms += ms; stats->fd_callback_calls++; }
+                else if (e.kind == 5) { stats->trial_callback_ms += ms; stats->trial_callback_calls++; }
             }
         }
         for (auto& e : events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -621,22 +623,29 @@ struct Solver {
         if (fbr && plan.fdp && pb == n && sizeof(T) == 8 && !no_fuse) {
             // all 2n points in one sweep, Y[i][2j], Y[i][2j+1] = f(x + h e_j)_i, f(x - h e_j)_i; k_jtj2<., false, true>
             // (jacobian_products) turns the pairs into Jacobian rows on its way to J^T J -- no k_fd_fill pass
+            ev_begin(4);
             fbr(fbctx, m, n, 2 * (size_t)n, B.X, Y);
+            ev_end();
+            if (stats) stats->fd_callback_points += 2 * (uint64_t)n;
             fd_fused = true;
             ret.fCalls += n;
             return ok(hipGetLastError(), "fd batched callback");
         }
         for (size_t j0 = 0; j0 < n; j0 += pb) {
             const size_t pc = (j0 + pb <= n) ? pb : n - j0;
+            ev_begin(4);
             if (fb) {
                 fb(fbctx, m, n, 2 * pc, B.X + 2 * j0 * n, Y);
+                if (stats) stats->fd_callback_points += 2 * (uint64_t)pc;
             } else {
                 for (size_t c = 0; c < pc; ++c) {
                     if (twh_h[j0 + c] == 0) continue;
                     f(fctx, m, n, B.X + (2 * (j0 + c)) * n, Y + (2 * c) * m);
                     f(fctx, m, n, B.X + (2 * (j0 + c) + 1) * n, Y + (2 * c + 1) * m);
+                    if (stats) stats->fd_callback_points += 2;
                 }
             }
+            ev_end();
             dim3 grid((unsigned)((m + 63) / 64), (unsigned)((pc + 31) / 32));
             hipLaunchKernelGGL(k_fd_fill<T>, grid, dim3(256), 0, stream, Y, m, B.twh, B.J, m, (int)n, (int)j0, (int)pc);
         }
@@ -889,8 +898,11 @@ struct Solver {
                 // no host round trip before the residual: it is evaluated speculatively even when the record will
                 // forbid it (gradient converged, QP failure, step guard) -- the decision kernel then ignores it
                 HpScope hp(this, 2);
+                ev_begin(5);
                 if (ks > 1 && fb) fb(fbctx, m, n, (size_t)ks, B.trial, ytr);
                 else for (int k = 0; k < ks; ++k) f(fctx, m, n, B.trial + (size_t)k * n, ytr + (size_t)k * m);
+                ev_end();
+                if (stats) stats->trial_callback_points += (uint64_t)ks;
             } else {
                 // reference contract: the callback needs the trial point on the host
                 ChainRec<T> r0;
@@ -1428,6 +1440,18 @@ int mir_lsq_comm_create_local_group(int nranks, mir_lsq_comm** out_comms)
         out_comms[r] = c;
     }
     return 0;
+}
+
+int mir_lsq_comm_ranks(const mir_lsq_comm* comm)
+{
+    if (!comm) return -1;
+    if (comm->kind == 1) {
+        auto fn = reinterpret_cast<int (*)(void*, int*)>(dlsym(comm->lib, "ncclCommCount"));
+        int cnt = -1;
+        if (!fn || fn(comm->nccl_comm, &cnt) != 0) return -1;
+        return cnt;
+    }
+    return comm->nranks;
 }
 
 void mir_lsq_comm_destroy(mir_lsq_comm* comm)

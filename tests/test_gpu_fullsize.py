@@ -7,8 +7,9 @@ The oracle needs ~3 s per accepted iteration on a 16..64-core host (SURVEY secti
   * absTolerance = 1e-9 (SURVEY 8d's setting): the last acceptance compares rounding noise, so the
     status is xConverged OR furtherImprovement on either side; the minimiser is the same to 1e-6 relative regardless.
 Tolerances (north star): |x_gpu - x_oracle| <= 1e-6 |x|_inf, residual rtol 1e-9."""
-import ctypes as C
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -29,24 +30,30 @@ def cfg3():
     prob.dA.free(); prob.db.free()
 
 
-def oracle_run(oracle, data, abs_tolerance, max_iterations):
-    threads = min(os.cpu_count() or 1, 64)
-    ob = oracle.load_openblas(threads=threads)
-    os.environ["OMP_NUM_THREADS"] = str(threads)
-    so = oracle.default_settings()
-    so.absTolerance = abs_tolerance
-    so.maxIterations = max_iterations
-    ctx = oracle.TanhLinearCtx(data["A"].ctypes.data, data["b"].ctypes.data)
-    return oracle.optimize(oracle.native_fn("wlc_tanh_linear_f"), M_ROWS, data["x0"], settings=so, fctx=C.addressof(ctx),
-                           use_openblas=ob)
+class OracleResult:
+    pass
 
 
-def test_cfg3_full_size_bench_setting_matches_oracle(oracle, cfg3):
+def oracle_run(tmp_path, abs_tolerance, max_iterations):
+    """The oracle in a process of its own (tests/oracle_fullsize_worker.py), same inputs (counter RNG)."""
+    threads = min(os.cpu_count() or 1, 32)
+    out = str(tmp_path / "oracle.npz")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_fullsize_worker.py")
+    p = subprocess.run([sys.executable, worker, str(M_ROWS), str(N), repr(abs_tolerance), str(max_iterations), str(threads), out],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    z = np.load(out)
+    r = OracleResult()
+    r.status, r.iterations, r.fCalls, r.residual = int(z["status"]), int(z["iterations"]), int(z["fCalls"]), float(z["residual"])
+    return r, z["x"]
+
+
+def test_cfg3_full_size_bench_setting_matches_oracle(cfg3, tmp_path):
     data, prob = cfg3
     s = M.LeastSquaresSettings(); s.absTolerance = 1e-5
     st = M.Stats()
     res, x = prob.solve(data["x0"], settings=s, batched=True, stats=st)
-    ro, xo = oracle_run(oracle, data, 1e-5, 1000)
+    ro, xo = oracle_run(tmp_path, 1e-5, 1000)
     assert int(res.status) == ro.status == M.LeastSquaresStatus.xConverged
     assert (res.iterations, res.fCalls) == (ro.iterations, ro.fCalls)
     assert np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max(), np.abs(x - xo).max()
@@ -56,11 +63,11 @@ def test_cfg3_full_size_bench_setting_matches_oracle(oracle, cfg3):
     assert np.abs(x - data["xstar"]).max() < 5e-2
 
 
-def test_cfg3_full_size_survey_setting_matches_oracle(oracle, cfg3):
+def test_cfg3_full_size_survey_setting_matches_oracle(cfg3, tmp_path):
     data, prob = cfg3
     s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
     res, x = prob.solve(data["x0"], settings=s, batched=True)
-    ro, xo = oracle_run(oracle, data, 1e-9, 14)
+    ro, xo = oracle_run(tmp_path, 1e-9, 14)
     ok = (M.LeastSquaresStatus.xConverged, M.LeastSquaresStatus.furtherImprovement)
     assert res.status in ok, res
     assert ro.status in (0, 1, -1)               # -1: the bounded oracle sample stopped at maxIterations = 14
