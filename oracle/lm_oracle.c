@@ -55,6 +55,14 @@ int lmo_openblas_load(const char* path)
     return 0;
 }
 
+/* threads of the oracle's own OpenMP regions (plain-loop syrk, the workload residuals): bench.py's 1-thread row */
+#ifdef _OPENMP
+#include <omp.h>
+void lmo_set_omp_threads(int nthreads) { if (nthreads > 0) omp_set_num_threads(nthreads); }
+#else
+void lmo_set_omp_threads(int nthreads) { (void)nthreads; }
+#endif
+
 int lmo_openblas_set_threads(int nthreads)
 {
     if (!g_ob.handle || !g_ob.set_threads) return -1;

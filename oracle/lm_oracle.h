@@ -152,6 +152,7 @@ void lmo_apply_bounds_s(size_t n, float* x, const float* l, const float* u);
 /* OpenBLAS (scipy.libs) backend control for the cpu_baseline leg. Returns 0 on success. */
 int lmo_openblas_load(const char* path);
 int lmo_openblas_set_threads(int nthreads);
+void lmo_set_omp_threads(int nthreads);
 
 #ifdef __cplusplus
 }

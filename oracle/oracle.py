@@ -128,6 +128,8 @@ def lib():
         L.lmo_openblas_load.argtypes = [C.c_char_p]
         L.lmo_openblas_set_threads.restype = C.c_int
         L.lmo_openblas_set_threads.argtypes = [C.c_int]
+        L.lmo_set_omp_threads.restype = None
+        L.lmo_set_omp_threads.argtypes = [C.c_int]
         L.wlc_uniform.restype = None
         L.wlc_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, C.c_void_p]
         _lib = L

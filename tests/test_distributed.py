@@ -90,13 +90,22 @@ def test_rccl_communicator_world_size_1(oracle):
     import mir_optim_amd as M
     from mir_optim_amd import workloads as W
     comm = PAR.rccl_comm(1, 0, lambda buf: buf)
-    w = P.tanh_linear(30000, 32)
-    prob = W.TanhLinear(w["A"], w["b"])
-    s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
-    r1, x1 = prob.solve(w["x0"], settings=s, comm=comm)
-    r0, x0 = prob.solve(w["x0"], settings=s)
+    assert M.api.lib().mir_lsq_comm_ranks(comm) == 1                  # ncclCommCount
+    for n in (32, 128):
+        w = P.tanh_linear(30000, n)
+        prob = W.TanhLinear(w["A"], w["b"])
+        s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
+        st = M.Stats()
+        r1, x1 = prob.solve(w["x0"], settings=s, comm=comm, stats=st, batched=True)
+        r0, x0 = prob.solve(w["x0"], settings=s, batched=True)
+        assert r1.status >= 0 and np.array_equal(x1, x0) and r1.iterations == r0.iterations   # sum over one rank = identity
+        # every exchange of the solve went through ncclAllReduce with the documented payloads (n = 128: 8384 / 290 / 1+)
+        assert st.allreduce_calls[0] == st.jacobian_full + st.jtj_resyncs >= 1
+        assert st.allreduce_elems[0] == st.allreduce_calls[0] * PAR.packed_length(n)
+        assert st.allreduce_calls[1] == st.jacobian_broyden >= 1 and st.allreduce_elems[1] == st.allreduce_calls[1] * (2 * n + 34)
+        assert st.allreduce_calls[2] >= r1.iterations + 1 and st.allreduce_elems[2] >= st.allreduce_calls[2]
+    assert PAR.packed_length(128) == 8384 and 2 * 128 + 34 == 290
     M.api.lib().mir_lsq_comm_destroy(comm)
-    assert r1.status >= 0 and np.array_equal(x1, x0) and r1.iterations == r0.iterations   # sum over one rank = identity
 
 
 @pytest.mark.gpu
@@ -108,12 +117,17 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     env = dict(os.environ, BENCH_M="200000", BENCH_N="64", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--comm", "gloo-callback"]
+           "--comm", "gloo-callback", "--survey-steps", "1"]
     p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
     d = json.loads(lines[-1])
     assert sum(1 for l in lines if l.startswith('{"metric"')) == 1
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
-    assert d["config"]["m_total"] == 400000 and d["config"]["status"] in ("xConverged", "furtherImprovement", "fConverged", "gConverged")
+    # default = strong scaling: the SAME 200000-row problem split over the two ranks; value = the global solve's it/s
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "strong"
+    assert d["config"]["m_total"] == 200000 and d["config"]["m_per_gpu"] == 100000
+    assert d["config"]["status"] in ("xConverged", "furtherImprovement", "fConverged", "gConverged")
+    assert d["value"] == pytest.approx(d["config"]["iterations_per_solve"] / (d["ms_per_step"] * 1e-3), rel=1e-9)
+    assert d["config"]["survey_setting"]["abs_tolerance"] == 1e-9 and d["config"]["survey_setting"]["value"] > 0
+    assert d["config"]["allreduce_per_solve"]["packed_elems"] == 64 * 65 // 2 + 64
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
