@@ -106,98 +106,11 @@ __device__ inline int block_or(int v, int* red)
     return *red;
 }
 
-// ---------------------------------------------------------------- LDS fast path (n <= 128)
-// potrf_tiled2: register-tiled Cholesky on a 16 x 16 thread grid (thread (tr, tc) holds the entries (16 a + tr,
-// 16 b + tc) of the lower triangle) with ONE barrier per column. The 16 threads that
-// hold column j (already updated by columns < j) publish it UNSCALED, pivot included, into one of two
-// column buffers; after the barrier every thread reads the pivot and the entries it needs, computes
-// 1/sqrt(pivot) itself (no second exchange) and applies the scaled rank-1 update; the holders of
-// column j + 1 then publish into the other buffer. colbuf: 2 n values.
-template <typename T, int NB>
-__device__ __forceinline__ int potrf_tiled2(int n, const T* A, int lda, T* F, int ldf, T* colbuf, T* rdiag)
-{
-    // The matrix is padded to 16 NB with an identity block ([[A, 0], [0, I]] factors as [[L, 0], [0, I]]),
-    // so the inner loops need no "row < n" masks; the loop stops at column n - 1.
-    const int tid = threadIdx.x;
-    const int tr = tid & 15, tc = tid >> 4;
-    T f[NB][NB];
-#pragma unroll
-    for (int a = 0; a < NB; ++a)
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int i = 16 * a + tr, k = 16 * b + tc;
-            if (b <= a) {
-                const T v = A[(i < n ? i : n - 1) + (size_t)(k < n ? k : n - 1) * lda];
-                f[a][b] = (i < n && k < n) ? v : ((i == k) ? T(1) : T(0));
-            } else {
-                f[a][b] = T(0);
-            }
-        }
-    if (tc == 0) {                                             // publish column 0
-#pragma unroll
-        for (int a = 0; a < NB; ++a) colbuf[16 * a + tr] = f[a][0];
-    }
-    int info = 0;
-#pragma unroll
-    for (int JB = 0; JB < NB; ++JB) {
-        if (info != 0 || 16 * JB >= n) break;
-        for (int jc = 0; jc < 16; ++jc) {
-            const int j = 16 * JB + jc;
-            if (j >= n) break;
-            const T* cb = colbuf + (j & 1) * (16 * NB);
-            __syncthreads();                                   // column j (unscaled) is published
-            const T ajj = cb[j];
-            T cvi[NB], cvk[NB];
-#pragma unroll
-            for (int a = JB; a < NB; ++a) { cvi[a] = cb[16 * a + tr]; cvk[a] = cb[16 * a + tc]; }
-            if (!(ajj > 0)) { info = j + 1; break; }           // uniform: every thread reads the same value
-            T rinv, d;
-            rsqrt_sqrt(ajj, rinv, d);
-            T ci[NB], ck[NB];
-#pragma unroll
-            for (int a = JB; a < NB; ++a) { ci[a] = cvi[a] * rinv; ck[a] = cvk[a] * rinv; }
-            ci[JB] = tr > jc ? ci[JB] : T(0);                   // only rows / columns below the pivot take part
-            ck[JB] = tc > jc ? ck[JB] : T(0);
-            if (tc == jc) {                                    // holders of column j keep the final values
-#pragma unroll
-                for (int a = JB + 1; a < NB; ++a) f[a][JB] = ci[a];
-                f[JB][JB] = tr > jc ? ci[JB] : (tr == jc ? d : f[JB][JB]);
-                if (tr == jc) rdiag[j] = rinv;
-            }
-#pragma unroll
-            for (int a = JB; a < NB; ++a)
-#pragma unroll
-                for (int b = JB; b <= a; ++b) f[a][b] -= ci[a] * ck[b];
-            // publish column j + 1 into the other buffer
-            if (j + 1 < n) {
-                T* nb = colbuf + ((j + 1) & 1) * (16 * NB);
-                if (jc < 15) {
-                    if (tc == jc + 1) {
-#pragma unroll
-                        for (int a = JB; a < NB; ++a) nb[16 * a + tr] = f[a][JB];
-                    }
-                } else if (JB + 1 < NB) {
-                    if (tc == 0) {
-#pragma unroll
-                        for (int a = JB + 1; a < NB; ++a) nb[16 * a + tr] = f[a][JB + 1];
-                    }
-                }
-            }
-        }
-    }
-    if (info != 0) return info;
-    __syncthreads();
-#pragma unroll
-    for (int a = 0; a < NB; ++a)
-#pragma unroll
-        for (int b = 0; b <= a; ++b) {
-            const int i = 16 * a + tr, k = 16 * b + tc;
-            if (i < n && k < n && i >= k) F[i + (size_t)k * ldf] = f[a][b];
-        }
-    __syncthreads();
-    return 0;
-}
+}  // namespace mirlsq
+#include "solve_lds.h"
+namespace mirlsq {
 
+// ---------------------------------------------------------------- generic path helpers (factor in global memory)
 // Inverses of the 16 x 16 diagonal blocks of L (lower triangular), one thread per (block, column):
 // column c of inv(L_kk) is the forward substitution L_kk x = e_c. Dinv block k at Dinv + k * 272,
 // element (r, c) at [r + 17 c] (leading dimension 17: row- and column-wise walks are conflict-free).
@@ -225,86 +138,6 @@ __device__ __forceinline__ void invert_diag_blocks(int n, const T* F, int ldf, T
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) Dinv[k * 272 + r + 17 * c] = x[r];
-    }
-    __syncthreads();
-}
-
-// Blocked ?potrs on one wave: x_k = inv(L_kk) z_k by a 16 x 16 product with the precomputed inverse,
-// then z_i -= L_ik x_k for the remaining rows; 2 NB dependent block steps instead of 2 n scalar ones.
-// Lane l holds rows l and l + 64 (K = 2) or l (K = 1). Collective: all threads call; wave 0 works.
-template <typename T, int NB>
-__device__ __forceinline__ void potrs_blocked(int n, const T* F, int ldf, const T* Dinv, T* xv)
-{
-    constexpr int K = (16 * NB + kWave - 1) / kWave;      // rows per lane: l, l + 64, ...
-    __syncthreads();
-    if (threadIdx.x < kWave) {
-        const int lane = threadIdx.x, r = lane & 15;
-        T xr[K];
-#pragma unroll
-        for (int t = 0; t < K; ++t) { const int k = lane + kWave * t; xr[t] = k < n ? xv[k] : T(0); }
-        // ---- forward: L z = b
-#pragma unroll
-        for (int kb = 0; kb < NB; ++kb) {
-            if (16 * kb < n) {
-                constexpr int dummy = 0; (void)dummy;
-                const int t = kb >> 2, q4 = kb & 3;          // block kb lives in register t, lanes 16 q4 .. 16 q4 + 15
-                T zb[16];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) zb[c] = lane_bcast(xr[t], 16 * q4 + c);
-                T xn = 0;
-#pragma unroll
-                for (int c = 0; c < 16; ++c) xn += Dinv[kb * 272 + r + 17 * c] * zb[c];   // entries above the diagonal are 0
-                if ((lane >> 4) == q4) xr[t] = xn;
-                T xb[16];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) xb[c] = lane_bcast(xr[t], 16 * q4 + c);
-#pragma unroll
-                for (int t2 = 0; t2 < K; ++t2) {
-                    const int i = lane + kWave * t2;
-                    const bool below = i >= 16 * (kb + 1) && i < n;
-                    const int ic = i < n ? i : n - 1;
-                    T acc = 0;
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) {
-                        const int col = 16 * kb + c < n ? 16 * kb + c : n - 1;
-                        acc += F[ic + (size_t)col * ldf] * ((16 * kb + c < n) ? xb[c] : T(0));
-                    }
-                    if (below) xr[t2] -= acc;
-                }
-            }
-        }
-        // ---- backward: L^T x = z
-#pragma unroll
-        for (int kb = NB - 1; kb >= 0; --kb) {
-            if (16 * kb < n) {
-                const int t = kb >> 2, q4 = kb & 3;
-                T zb[16];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) zb[c] = lane_bcast(xr[t], 16 * q4 + c);
-                T xn = 0;
-#pragma unroll
-                for (int c = 0; c < 16; ++c) xn += Dinv[kb * 272 + c + 17 * r] * zb[c];   // (inv L_kk)^T (r, c) = inv(c, r)
-                if ((lane >> 4) == q4) xr[t] = xn;
-                T xb[16];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) xb[c] = lane_bcast(xr[t], 16 * q4 + c);
-#pragma unroll
-                for (int t2 = 0; t2 < K; ++t2) {
-                    const int i = lane + kWave * t2;
-                    const bool above = i < 16 * kb;
-                    const int ic = i < n ? i : n - 1;
-                    T acc = 0;
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) {
-                        const int row = 16 * kb + c < n ? 16 * kb + c : n - 1;
-                        acc += F[row + (size_t)ic * ldf] * ((16 * kb + c < n) ? xb[c] : T(0));   // L(16 kb + c, i)
-                    }
-                    if (above) xr[t2] -= acc;
-                }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < K; ++t) { const int k = lane + kWave * t; if (k < n) xv[k] = xr[t]; }
     }
     __syncthreads();
 }
@@ -497,27 +330,22 @@ __device__ __noinline__ void potrs_rows(int n, const T* F, int ldf, const T* Din
     __syncthreads();
 }
 
-// ---------------------------------------------------------------- ?posvx('E','L'), nrhs = 1
+// ---------------------------------------------------------------- ?posvx('E','L'), nrhs = 1, generic path (128 < n <= 256)
 // A: n x n full symmetric, leading dimension lda (overwritten by its equilibrated form).
 // b: right-hand side (overwritten by the scaled rhs). x: solution. s,r,w: n-vectors.
-// F/ldf: factor storage (LDS or global). Returns info (0 = ok, k > 0 = leading minor k not
-// positive definite). Collective over the workgroup.
+// F/ldf: factor storage (global, L2 resident). Returns info (0 = ok, k > 0 = leading minor k not
+// positive definite). Collective over the workgroup. (n <= 128 runs posvx_lds, solve_lds.h.)
 template <typename T, int NB>
 __device__ __forceinline__ int posvx_device(int n, T* A, int lda, T* F, int ldf, T* s, T* b, T* x, T* r, T* w, T* red, long long* dbg = nullptr)
 {
+    static_assert(NB == 0, "the LDS path is posvx_lds");
     MIRLSQ_STAMP(dbg, 2);
-    // fast path (NB > 0): LDS scratch behind the factor: colbuf (2 x 16 NB), rdiag (16 NB), Dinv (NB x 272)
-    T* colbuf = F + (size_t)ldf * (16 * (NB > 0 ? NB : 1));
-    T* rdiag = colbuf + 32 * (NB > 0 ? NB : 1);
-    T* Dinv = rdiag + 16 * (NB > 0 ? NB : 1);
-    (void)colbuf; (void)rdiag; (void)Dinv;
-    // generic path (NB == 0): inverse diagonal blocks, the current diagonal block and its reciprocal pivots
-    __shared__ T gDinv[NB == 0 ? 16 * 272 : 1];
-    __shared__ T gblk[NB == 0 ? 16 * 17 : 1];
-    __shared__ T gpanel[NB == 0 ? kSolveThreads * 17 : 1];
-    __shared__ T grd[NB == 0 ? 16 : 1];
+    // inverse diagonal blocks, the current diagonal block and its reciprocal pivots
+    __shared__ T gDinv[16 * 272];
+    __shared__ T gblk[16 * 17];
+    __shared__ T gpanel[kSolveThreads * 17];
+    __shared__ T grd[16];
     __shared__ int ginfo[1];
-    (void)gDinv; (void)gblk; (void)grd; (void)ginfo; (void)gpanel;
     const int tid = threadIdx.x;
     const T eps = Lim<T>::eps / 2;              // dlamch('Epsilon')
     const T safmin = Lim<T>::min_normal;        // dlamch('Safe minimum')
@@ -548,12 +376,8 @@ __device__ __forceinline__ int posvx_device(int n, T* A, int lda, T* F, int ldf,
 
     MIRLSQ_STAMP(dbg, 3);
     // ?lacpy + ?potrf 'L'
-    if constexpr (NB > 0) {
-        const int info = potrf_tiled2<T, NB>(n, A, lda, F, ldf, colbuf, rdiag);
-        if (info != 0) return info;
-        invert_diag_blocks<T, NB>(n, F, ldf, Dinv);
-    } else {
-        // generic path: factor in global memory, left-looking panels (potrf_panel) + the blocked triangular solves
+    {
+        // factor in global memory, left-looking panels (potrf_panel) + the blocked triangular solves
         const int info = potrf_panel<T>(n, A, lda, F, ldf, gblk, grd, ginfo, gpanel);
         if (info != 0) return info;
         invert_diag_blocks_generic<T>(n, F, ldf, gDinv);
@@ -562,8 +386,7 @@ __device__ __forceinline__ int posvx_device(int n, T* A, int lda, T* F, int ldf,
     MIRLSQ_STAMP(dbg, 4);
     // ?potrs
     if (tid < n) x[tid] = b[tid];
-    if constexpr (NB > 0) potrs_blocked<T, NB>(n, F, ldf, Dinv, x);
-    else potrs_rows<T>(n, F, ldf, gDinv, x, gblk);
+    potrs_rows<T>(n, F, ldf, gDinv, x, gblk);
 
     MIRLSQ_STAMP(dbg, 5);
     // ?porfs: iterative refinement, ITMAX = 5
@@ -603,8 +426,7 @@ __device__ __forceinline__ int posvx_device(int n, T* A, int lda, T* F, int ldf,
         const T berr = block_max(qv, red);
         if (count == 1) MIRLSQ_STAMP(dbg, 12);
         if (berr > eps && 2 * berr <= lstres && count <= 5) {
-            if constexpr (NB > 0) potrs_blocked<T, NB>(n, F, ldf, Dinv, r);
-            else potrs_rows<T>(n, F, ldf, gDinv, r, gblk);
+            potrs_rows<T>(n, F, ldf, gDinv, r, gblk);
             if (tid < n) x[tid] += r[tid];
             lstres = berr;
             __syncthreads();
@@ -626,10 +448,15 @@ __device__ __forceinline__ int posvx_device(int n, T* A, int lda, T* F, int ldf,
 // the reference's loop classifies every variable as free and leaves with `s == n` (QP:265, quirk Q8) and a status other
 // than `solved` -- which is all the LM loop looks at (LS:1080): this variant returns numericError there. One inlined copy
 // of posvx instead of two roughly halves the kernel and relieves its register allocation (512 VGPRs, 786 spilled SGPRs).
+// NB > 0 (n <= 128): every system is solved by posvx_lds (solve_lds.h), which loads its matrix from global memory into
+// LDS itself: the first one from `src0` (n x n full symmetric, leading dimension n) with `shift0` added on the diagonal
+// -- J^T J and lambda for k_lm_solve, P and 0 for the standalone entry --, the reduced ones from sc.A. F is then the LDS
+// block (LdsSolveCfg<NB>::ELEMS elements). NB == 0: the generic path with the factor in global memory (posvx_device).
 template <typename T, int NB, bool BOUNDED = true>
 __device__ __forceinline__ int box_qp_device(int n, const T* Pm, const T* q, const T* l, const T* u, T* x,
                              bool unconstrainedSolution, T relTol, T absTol, uint32_t maxIterations,
-                             SolveScratch<T>& sc, T* F, int ldf, T* red, int* ired, int* iters, bool a_prefilled = false)
+                             SolveScratch<T>& sc, T* F, int ldf, T* red, int* ired, int* iters, bool a_prefilled = false,
+                             const T* src0 = nullptr, T shift0 = T(0))
 {
     const int tid = threadIdx.x;
     T* s = sc.vec;
@@ -644,6 +471,15 @@ __device__ __forceinline__ int box_qp_device(int n, const T* Pm, const T* q, con
     *iters = 0;
     if (n == 0) return 0;                                           // QP:162-163
 
+    if constexpr (NB > 0) {
+        if (!unconstrainedSolution) {                               // QP:168-214
+            T xi = 0;
+            const int info = posvx_lds<T, NB>(n, src0 ? src0 : Pm, n, shift0, tid < n ? -q[tid] : T(0), xi, F, red, ired + 8, sc.dbg);
+            if (info != 0) return 1;                                // QP:212-213 (info == n+1 is never produced)
+            if (tid < n) x[tid] = xi;
+            __syncthreads();
+        }
+    } else
     if (!unconstrainedSolution) {                                   // QP:168-214
         if (!a_prefilled) {                                            // QP:186-189
             const T* __restrict__ src = Pm;
@@ -722,7 +558,14 @@ __device__ __forceinline__ int box_qp_device(int n, const T* Pm, const T* q, con
             b[tid] = -(ks + kc);
         }
         __syncthreads();
-        if (sN) {                                                   // QP:307-325
+        if constexpr (NB > 0) {
+            if (sN) {                                               // QP:307-325
+                T xi = 0;
+                const int info = posvx_lds<T, NB>(sN, sc.A, sN, T(0), tid < sN ? b[tid] : T(0), xi, F, red, ired + 8);
+                if (info != 0) return 1;
+                if (tid < sN) sX[tid] = xi;
+            }
+        } else if (sN) {                                            // QP:307-325
             const int info = posvx_device<T, NB>(sN, sc.A, sN, F, ldf, s, b, sX, r, w, red);
             if (info != 0) return 1;
         }
@@ -761,13 +604,13 @@ __host__ __device__ inline int solve_nb(int n, int elem)
 {
     const int nb = n <= 16 ? 1 : (n <= 32 ? 2 : (n <= 64 ? 4 : (n <= 128 ? 8 : 0)));
     if (nb == 0) return 0;
-    const long bytes = ((long)(n | 1) * 16 * nb + 48 * nb + 272 * nb) * elem;
+    const long bytes = (long)lds_solve_elems(nb) * elem;      // L and A block triangles + three vectors (solve_lds.h)
     return bytes <= kSolveLdsBytes ? nb : 0;
 }
 __host__ __device__ inline size_t solve_lds_bytes(int n, int elem)
 {
     const int nb = solve_nb(n, elem);
-    return nb ? (size_t)((long)(n | 1) * 16 * nb + 48 * nb + 272 * nb) * elem : 0;
+    return nb ? (size_t)lds_solve_elems(nb) * elem : 0;
 }
 
 template <typename T>
@@ -795,7 +638,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ T red[8];
-    __shared__ int ired[8];
+    __shared__ int ired[12];
     const int n = a.n, tid = threadIdx.x;
     const int ldf = n | 1;
     const int kc = blockIdx.x;                       // chain step
@@ -836,8 +679,10 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
     // step bounds LS:1074-1077, P = JJ + lambda I LS:1078-1079 (JJ itself is never modified, so
     // the save/restore of its diagonal at LS:1078/1094 is not needed)
     if (tid < n) { qpl[tid] = a.lower[tid] - a.x[tid]; qpu[tid] = a.upper[tid] - a.x[tid]; }
-    {   // Pm = A = JJ + lambda I, 16 loads in flight per thread (a plain copy loop serialises on
-        // may-alias load/store ordering)
+    if constexpr (NB == 0 || BOUNDED) {
+        // Pm = A = JJ + lambda I in global memory: the generic path factors A, the BOXCQP loop reads Pm. (The LDS path of
+        // an unbounded problem loads JJ + lambda I straight into LDS and needs neither.) 16 loads in flight per thread (a
+        // plain copy loop serialises on may-alias load/store ordering)
         const T* __restrict__ src = a.JJ;
         T* __restrict__ dp = sc.Pm;
         T* __restrict__ da = sc.A;
@@ -862,7 +707,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
     MIRLSQ_STAMP(sc.dbg, 1);
     int qp_iters = 0;
     const int qp = box_qp_device<T, NB, BOUNDED>(n, sc.Pm, a.Jy, qpl, qpu, xq, false, a.set.qpRelTolerance, a.set.qpAbsTolerance,
-                                          a.set.qpMaxIterations, sc, F, ldf, red, ired, &qp_iters, true);   // LS:1080
+                                          a.set.qpMaxIterations, sc, F, ldf, red, ired, &qp_iters, true, a.JJ, lambda);   // LS:1080
 
     MIRLSQ_STAMP(sc.dbg, 7);
     int flags = 0;
@@ -888,15 +733,24 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
         // predicted reduction with the UNDAMPED JJ, LS:1141-1142: t = JJ dx + 2 Jy ; pred = -(t . dx)
         T ti = 0;
         {
-            // thread pair (i, h) sums half of row i (n <= 128) or thread i sums the whole row
+            // thread pair (i, h) sums half of row i (n <= 128) or thread i sums the whole row. On the LDS path the step is
+            // staged in LDS (the solve's vectors are free now), so the loop holds only the loads of J^T J
+            const T* dxv = dx_out;
+            if constexpr (NB > 0) {
+                T* stage = F + LdsSolveCfg<NB>::XV_OFF;
+                if (tid < n) stage[tid] = d;
+                __syncthreads();
+                dxv = stage;
+            }
             const bool pair = n <= kSolveThreads / 2;
             const int i = pair ? tid >> 1 : tid, h = pair ? tid & 1 : 0;
             if (i < n) {
                 const int j0 = pair && h ? n / 2 : 0, j1 = pair && !h ? n / 2 : n;
+                const T* __restrict__ jj = a.JJ;
 #pragma unroll 16
-                for (int j = j0; j < j1; ++j) ti += a.JJ[(size_t)j * n + i] * dx_out[j];
+                for (int j = j0; j < j1; ++j) ti += jj[(size_t)j * n + i] * dxv[j];
                 if (h == 0) ti = ti + 2 * a.Jy[i];
-                ti = ti * dx_out[i];
+                ti = ti * dxv[i];
             }
         }
         pred = -block_sum(ti, red);
@@ -929,7 +783,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_box_qp(BoxQpArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ T red[8];
-    __shared__ int ired[8];
+    __shared__ int ired[12];
     const int n = a.n;
     T* F;
     if constexpr (NB > 0) F = reinterpret_cast<T*>(smem_raw); else F = a.sc.Fg;
