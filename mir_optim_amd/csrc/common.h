@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <utility>
 
 namespace mirlsq {
 
@@ -70,6 +71,33 @@ template <int N> __device__ inline float dpp_row_ror(float v)
     return __int_as_float(dpp_row_ror<N>(__float_as_int(v)));
 }
 
+// broadcast lane N of every row of 16 lanes to the whole row (DPP row_newbcast:N, gfx90a+): a plain VALU move, no
+// SGPR round trip like v_readlane and no LDS access like ds_bpermute
+template <int N> __device__ inline int dpp_row_bcast(int v)
+{
+    // bound_ctrl = 1: no "old" operand to initialise (the source lane always exists inside the row)
+    return __builtin_amdgcn_mov_dpp(v, 0x150 + N, 0xF, 0xF, true);
+}
+template <int N> __device__ inline double dpp_row_bcast(double v)
+{
+    const int lo = dpp_row_bcast<N>(__double2loint(v));
+    const int hi = dpp_row_bcast<N>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+template <int N> __device__ inline float dpp_row_bcast(float v)
+{
+    return __int_as_float(dpp_row_bcast<N>(__float_as_int(v)));
+}
+
+// compile-time loop: f(IntC<0>{}), ..., f(IntC<N - 1>{}) -- for builtins that need constant operands (DPP controls)
+template <int V> struct IntC { static constexpr int value = V; };
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(IntC<Is>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f)
+{
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
 // sum over the 16 lanes that share lane >> 4 (every lane receives the total): rotate-and-add
 template <typename T> __device__ inline T sum16(T v) {
     v += dpp_row_ror<8>(v);
@@ -84,14 +112,20 @@ template <typename T> __device__ inline T wave_sum(T v) {
     v += wave_shfl_xor(v, 32);
     return v;
 }
-template <typename T> __device__ inline T wave_max(T v) {
-#pragma unroll
-    for (int k = 1; k < kWave; k <<= 1) {
-        T o = wave_shfl_xor(v, k);
-        v = o > v ? o : v;
-    }
+template <typename T> __device__ inline T max16(T v) {
+    T o = dpp_row_ror<8>(v); v = o > v ? o : v;
+    o = dpp_row_ror<4>(v); v = o > v ? o : v;
+    o = dpp_row_ror<2>(v); v = o > v ? o : v;
+    o = dpp_row_ror<1>(v); v = o > v ? o : v;
     return v;
 }
+template <typename T> __device__ inline T wave_max(T v) {
+    v = max16(v);
+    T o = wave_shfl_xor(v, 16); v = o > v ? o : v;
+    o = wave_shfl_xor(v, 32); v = o > v ? o : v;
+    return v;
+}
+template <typename T> __device__ inline T wave_min(T v) { return -wave_max(-v); }
 
 // broadcast lane `src` (wave-uniform) of v to every lane through SGPRs (v_readlane), not through LDS
 __device__ inline double lane_bcast(double v, int src)

@@ -267,7 +267,10 @@ hipError_t jtj_run_wide(const JtjPlan& p, const JtjArgs<T>& a, bool broyden, T* 
         const size_t G = (a.m + 3) / 4;
         size_t blocks = (G + 3) / 4;
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(k_broyden_wide<T>, dim3((unsigned)blocks), dim3(256), 0, s, a.Jout, a.y, a.y_old, a.dx, a.dx_dot, a.m, a.n);
+        if (a.n <= 256)
+            hipLaunchKernelGGL(k_broyden_wide<T>, dim3((unsigned)blocks), dim3(256), 0, s, a.Jout, a.y, a.y_old, a.dx, a.dx_dot, a.m, a.n);
+        else
+            hipLaunchKernelGGL(k_broyden_rows<T>, dim3((unsigned)blocks), dim3(256), 0, s, a.Jout, a.y, a.y_old, a.dx, a.dx_dot, a.m, a.n);
     }
     JtjWideArgs<T> w{};
     w.J = a.J; w.y = a.y; w.slabs = a.slabs; w.m = a.m; w.n = a.n;

@@ -233,4 +233,25 @@ __global__ __launch_bounds__(256) void k_broyden_wide(T* __restrict__ J, const T
     }
 }
 
+// The same update for ANY n (used above n = 256): one wave per row, lanes along the row (coalesced), two sweeps over the
+// row (the dot product, then the update; the second one hits L1 / L2).
+template <typename T>
+__global__ __launch_bounds__(256) void k_broyden_rows(T* __restrict__ J, const T* __restrict__ y, const T* __restrict__ y_old,
+                                                      const T* __restrict__ dx, const T* __restrict__ dx_dot, size_t m, int n)
+{
+    const int lane = threadIdx.x & 63;
+    const T neg_d = -(T(1) / *dx_dot);
+    const size_t wave_id = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t row = wave_id; row < m; row += nwaves) {
+        T* rp = J + row * (size_t)n;
+        T part = 0;
+        for (int c = lane; c < n; c += kWave) part += rp[c] * dx[c];
+        part = wave_sum(part);
+        const T t = (y_old[row] - y[row]) + part;      // LS:1003-1004
+        const T u = neg_d * t;                         // LS:1005
+        for (int c = lane; c < n; c += kWave) rp[c] = rp[c] + u * dx[c];   // LS:1006
+    }
+}
+
 }  // namespace mirlsq

@@ -28,6 +28,7 @@
 #include "broyden_lr.h"
 #include "misc_kernels.h"
 #include "solve_kernel.h"
+#include "solve_big.h"
 
 using namespace mirlsq;
 
@@ -271,6 +272,7 @@ struct Solver {
     bool has_bounds = true;    // some lower / upper entry is finite (set in run()); MIR_LSQ_SOLVE_BOUNDED=1 forces the full kernel
     bool tail_null = false;
     int f_in_lds = 0;
+    bool big_solve = false;    // n > 256 (or MIR_LSQ_VARIANT_SOLVE_GENERIC): the any-n solve kernel
     int solve_nb_ = 0;
     size_t solve_lds = 0;
 
@@ -366,6 +368,8 @@ struct Solver {
         }
         y = B.y;
         mB = B.mB;
+        big_solve = n > (uint32_t)kSolveMaxN || (variant & MIR_LSQ_VARIANT_SOLVE_GENERIC) != 0;
+        if (n > (uint32_t)kLrMaxN) lowrank = false;    // the read-only Broyden sweep keeps n <= 256; above, J is rewritten
         solve_nb_ = solve_nb((int)n, (int)sizeof(T));
         f_in_lds = solve_nb_ > 0;
         solve_lds = solve_lds_bytes((int)n, (int)sizeof(T));
@@ -436,6 +440,13 @@ struct Solver {
     }
     hipError_t launch_solve(const LmSolveArgs<T>& a, int ks)
     {
+        if (big_solve) {
+            // any n: one 512-thread workgroup per ladder entry, matrices in global memory (solve_big.h)
+            auto kern = k_lm_solve_big<T>;
+            MIRLSQ_ENSURE_LDS(kern, sizeof(BigLds<T>));
+            hipLaunchKernelGGL(kern, dim3(ks), dim3(kBigThreads), sizeof(BigLds<T>), stream, a);
+            return hipGetLastError();
+        }
         switch (solve_nb_) {
         case 1: return launch_solve_nb<1>(a, ks);
         case 2: return launch_solve_nb<2>(a, ks);
@@ -751,10 +762,6 @@ struct Solver {
             if (!(S->minStepQuality < S->goodStepQuality)) { ret.status = mir_ls_badStepQuality; return ret; }
             if (!(1 <= S->lambdaIncrease && S->lambdaIncrease <= std::sqrt(Lim<T>::max))) { ret.status = mir_ls_badLambdaParams; return ret; }
             if (!(std::sqrt(Lim<T>::min_normal) <= S->lambdaDecrease && S->lambdaDecrease <= 1)) { ret.status = mir_ls_badLambdaParams; return ret; }
-        }
-        if (n > (uint32_t)kSolveMaxN) {
-            std::fprintf(stderr, "[mir_optim_amd] n = %u is not supported by this build (n <= %d)\n", n, kSolveMaxN);
-            return ret;
         }
         if (!device_available()) return ret;
         if (!setup()) { teardown(); return ret; }
@@ -1109,7 +1116,6 @@ int box_qp_entry(const QS* settings, size_t n_, const T* P, const T* q, const T*
 {
     if (iterations) *iterations = 0;
     if (n_ == 0) return mir_box_qp_solved;
-    if (n_ > (size_t)kSolveMaxN) { std::fprintf(stderr, "[mir_optim_amd] box qp: n > %d unsupported\n", kSolveMaxN); return mir_box_qp_numericError; }
     if (!device_available()) return mir_box_qp_numericError;
     const int n = (int)n_;
     size_t off = 0;
@@ -1135,7 +1141,13 @@ int box_qp_entry(const QS* settings, size_t n_, const T* P, const T* q, const T*
         && hipMemcpy((void*)a.l, l, sizeof(T) * n, hipMemcpyHostToDevice) == hipSuccess
         && hipMemcpy((void*)a.u, u, sizeof(T) * n, hipMemcpyHostToDevice) == hipSuccess
         && hipMemcpy((void*)a.x, x, sizeof(T) * n, hipMemcpyHostToDevice) == hipSuccess;
-    if (good) {
+    if (good && n > kSolveMaxN) {
+        // any n: the 512-thread kernel of solve_big.h
+        auto kern = k_box_qp_big<T>;
+        good = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)sizeof(BigLds<T>)) == hipSuccess;
+        if (good) hipLaunchKernelGGL(kern, dim3(1), dim3(kBigThreads), sizeof(BigLds<T>), 0, a);
+    } else if (good) {
         auto launch = [&](auto kern) {
             if (lds > 48 * 1024
                 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess)
@@ -1167,7 +1179,7 @@ int jtj_entry(size_t m, size_t n, T* J, const T* y, const T* y_old, const T* dx,
               void* stream_, float* kernel_ms, uint32_t variant = 0)
 {
     if (!device_available()) return -1;
-    if (n == 0 || n > (size_t)kSolveMaxN || m == 0) return -2;
+    if (n == 0 || m == 0) return -2;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const JtjPlan plan = jtj_plan<T>(m, (int)n, query_num_cu(), variant);
     const size_t packed_len = n * (n + 1) / 2 + n + 8;
@@ -1329,7 +1341,7 @@ int mir_lsq_fd_jtj_d(size_t m, size_t n, const double* Yrm, const double* twh, c
                      double* JJ, double* Jy, void* stream_, float* kernel_ms)
 {
     if (!device_available()) return -1;
-    if (n == 0 || n > (size_t)kSolveMaxN || m == 0) return -2;
+    if (n == 0 || m == 0) return -2;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const JtjPlan plan = jtj_plan<double>(m, (int)n, query_num_cu());
     if (!plan.fdp) return -6;                                   // shape not covered by the fused kernel

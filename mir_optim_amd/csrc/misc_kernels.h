@@ -243,9 +243,11 @@ __global__ __launch_bounds__(kSolveThreads) void k_decide_chain(DecideArgs<T> a)
     }
     __syncthreads();
     const int acc = acc_s;
-    if (acc >= 0 && (int)threadIdx.x < a.n) {
-        a.x[threadIdx.x] = a.trial[(size_t)acc * a.n + threadIdx.x];          // LS:1135
-        a.dx_acc[threadIdx.x] = a.dx_chain[(size_t)acc * a.n + threadIdx.x];
+    if (acc >= 0) {
+        for (int i = threadIdx.x; i < a.n; i += blockDim.x) {
+            a.x[i] = a.trial[(size_t)acc * a.n + i];                          // LS:1135
+            a.dx_acc[i] = a.dx_chain[(size_t)acc * a.n + i];
+        }
     }
 }
 

@@ -1,0 +1,563 @@
+// solve_big.h -- the n x n part of an LM pass for ANY n (used above n = 256): one workgroup of 512 threads per
+// lambda-ladder entry, matrices in global memory (L2 / Infinity-Cache resident), every n-vector loop strided.
+//
+// Same job and same references as solve_kernel.h:
+//   least_squares.d:1053 (gradient test), 1067-1079 (lambda_0, P = J^T J + lambda I, step bounds), 1080 -> boxcqp.d:122-379
+//   (solveBoxQP with ?posvx('E','L') = ?poequ + ?laqsy + ?potrf + ?potrs + ?porfs and the BOXCQP active-set loop),
+//   1087-1110 (NaN guard, step rounding, trial point), 1141-1142 (predicted reduction), 1164 (norm of the trial point).
+// The reference places no limit on n (least_squares.d:911-926 carves the workspace for any n); k_lm_solve keeps one
+// element per thread and stops at 256, this file does not. It favours plain loops over tuning: the factorisation is
+// the left-looking panel scheme of potrf_panel (MFMA 16x16x4 for the contribution of the earlier panels) walked over
+// 512-row chunks, the triangular solves go block by block with one barrier per block. One CU does n^3 / 3 flops here,
+// which is of the order of what the whole GPU spends on J^T J (m n^2) when m is a few hundred times n.
+#pragma once
+
+#include "common.h"
+#include "solve_kernel.h"
+
+namespace mirlsq {
+
+constexpr int kBigThreads = 512;
+constexpr int kBigWaves = kBigThreads / kWave;
+
+// ---------------------------------------------------------------- workgroup collectives over strided partials
+template <typename T, typename WaveOp, typename Op>
+__device__ inline T big_reduce(T v, WaveOp wop, Op op, T* red /* >= kBigWaves */)
+{
+    v = wop(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    T r = red[0];
+#pragma unroll
+    for (int w = 1; w < kBigWaves; ++w) r = op(r, red[w]);
+    return r;
+}
+template <typename T> __device__ inline T big_sum(T v, T* red) { return big_reduce(v, [](T a) { return wave_sum(a); }, [](T a, T b) { return a + b; }, red); }
+template <typename T> __device__ inline T big_max(T v, T* red) { return big_reduce(v, [](T a) { return wave_max(a); }, [](T a, T b) { return a > b ? a : b; }, red); }
+template <typename T> __device__ inline T big_min(T v, T* red) { return big_reduce(v, [](T a) { return wave_min(a); }, [](T a, T b) { return a < b ? a : b; }, red); }
+__device__ inline int big_or(int v, int* ired /* >= kBigWaves */)
+{
+    const unsigned long long b = __ballot(v != 0);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) ired[threadIdx.x >> 6] = b ? 1 : 0;
+    __syncthreads();
+    int r = 0;
+#pragma unroll
+    for (int w = 0; w < kBigWaves; ++w) r |= ired[w];
+    return r;
+}
+
+template <typename T>
+struct BigLds {                 // static LDS of the big-n kernels
+    T span[kBigThreads * 17];   // S of the current chunk (row per thread after the MFMA stage)
+    T blk[16 * 17];             // the current diagonal block L_kk
+    T rd[16];                   // its reciprocal pivots
+    T xk[16];                   // published solution block of a triangular-solve step
+    T red[kBigWaves];
+    int ired[kBigWaves + 4];
+};
+
+// ---------------------------------------------------------------- ?potrf 'L', left-looking by 16-column panels
+// A: n x n full symmetric (lda), F: the factor (ldf), both column-major in global memory. Collective; returns info.
+template <typename T>
+__device__ __noinline__ int potrf_big(int n, const T* A, int lda, T* F, int ldf, BigLds<T>& sm)
+{
+    using Acc = typename Mma<T>::Acc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int nblk = (n + 15) / 16;
+    if (tid == 0) sm.ired[kBigWaves] = 0;
+    __syncthreads();
+    for (int k = 0; k < nblk; ++k) {
+        const int c0 = 16 * k;
+        for (int base = (c0 / kBigThreads) * kBigThreads; base < n; base += kBigThreads) {
+            // ---- 1. S = L[rows, :c0] L[c0:c0+16, :c0]^T for the 64 rows of this wave, on MFMA (skip rows above the panel)
+            if (k > 0 && base + 64 * wave + 63 >= c0) {
+                Acc acc[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = Acc{0, 0, 0, 0};
+                int rowa[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int r = base + 64 * wave + 16 * u + lr; rowa[u] = r < n ? r : n - 1; }
+                const int rowb = c0 + lr < n ? c0 + lr : n - 1;
+                for (int j = 0; j < k; ++j) {
+                    T fa[4][4], fb[4];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const size_t col = (size_t)(16 * j + 4 * s4 + lk) * ldf;
+                        fb[s4] = F[rowb + col];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) fa[s4][u] = F[rowa[u] + col];
+                    }
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc[u] = Mma<T>::mma(fa[s4][u], fb[s4], acc[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        sm.span[(64 * wave + 16 * u + Mma<T>::row(lane, r)) * 17 + lr] = acc[u][r];
+            }
+            __syncthreads();
+            // ---- 2. one row per thread: p = A[i, panel] - S[i, :]
+            const int i = base + tid;
+            const bool active = i < n && i >= c0;
+            const int ic = i < n ? i : n - 1;
+            T p[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int col = c0 + c < n ? c0 + c : n - 1;
+                const T v = A[ic + (size_t)col * lda];
+                const T sv = (k > 0 && i >= c0) ? sm.span[tid * 17 + c] : T(0);
+                p[c] = (active && c0 + c < n) ? v - sv : ((i == c0 + c) ? T(1) : T(0));   // identity padding past n
+            }
+            const bool diag_chunk = base <= c0 && c0 < base + kBigThreads;
+            if (diag_chunk) {
+                // the 16 diagonal rows are one DPP row of wave wd: factor them with row broadcasts, publish L_kk and 1 / pivots
+                const int wd = (c0 - base) >> 6, l0 = (c0 - base) & 63;
+                if (wave == wd && lane >= l0 && lane < l0 + 16) {
+                    const int r = lane - l0;
+                    int bad = 0;
+                    static_for<16>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        const T piv = dpp_row_bcast<c>(p[c]);
+                        if (!(piv > 0)) { if (c0 + c < n && bad == 0) bad = c0 + c + 1; }
+                        T rinv, d;
+                        rsqrt_sqrt(piv > 0 ? piv : T(1), rinv, d);
+                        if (r > c) p[c] *= rinv; else if (r == c) p[c] = d;
+                        if (r == c) sm.rd[c] = rinv;
+                        static_for<16>([&](auto cc2) {
+                            constexpr int c2 = decltype(cc2)::value;
+                            if constexpr (c2 > c) {
+                                const T lc = dpp_row_bcast<c2>(p[c]);
+                                p[c2] -= p[c] * lc;          // rows r <= c: entries above the diagonal only, never read
+                            }
+                        });
+                    });
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) sm.blk[r * 17 + c] = p[c];
+                    if (bad != 0 && r == 0) sm.ired[kBigWaves] = bad;
+                }
+                __syncthreads();
+                const int info = sm.ired[kBigWaves];
+                if (info != 0) return info;                     // uniform
+            }
+            // ---- 3. the rows below the diagonal block solve against L_kk; store the panel
+            if (active && i >= c0 + 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    T v = p[c];
+#pragma unroll
+                    for (int t = 0; t < 16; ++t)
+                        if (t < c) v -= p[t] * sm.blk[c * 17 + t];
+                    p[c] = v * sm.rd[c];
+                }
+            }
+            if (active) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if (c0 + c < n && i >= c0 + c) F[i + (size_t)(c0 + c) * ldf] = p[c];
+            }
+            __syncthreads();                                    // span reusable; the panel rows are visible
+        }
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- ?potrs: L L^T x = z, z in/out (global n-vector)
+template <typename T>
+__device__ __noinline__ void potrs_big(int n, const T* F, int ldf, T* z, BigLds<T>& sm)
+{
+    const int tid = threadIdx.x;
+    const int nblk = (n + 15) / 16;
+    __syncthreads();
+    // forward: L w = z
+    for (int kb = 0; kb < nblk; ++kb) {
+        const int c0 = 16 * kb;
+        if (tid < 256) {                                        // L_kk into LDS
+            const int r = tid & 15, c = tid >> 4;
+            const int gr = c0 + r < n ? c0 + r : n - 1, gc = c0 + c < n ? c0 + c : n - 1;
+            const T v = F[gr + (size_t)gc * ldf];
+            sm.blk[r * 17 + c] = (c0 + r < n && c0 + c < n) ? v : (r == c ? T(1) : T(0));
+        }
+        __syncthreads();
+        if (tid == 0) {                                         // 16 unknowns, forward substitution
+            T x[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                T s = c0 + r < n ? z[c0 + r] : T(0);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) if (q < r) s -= sm.blk[r * 17 + q] * x[q];
+                x[r] = s / sm.blk[r * 17 + r];
+                sm.xk[r] = x[r];
+                if (c0 + r < n) z[c0 + r] = x[r];
+            }
+        }
+        __syncthreads();
+        for (int i = c0 + 16 + tid; i < n; i += kBigThreads) {
+            T acc = 0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc += F[i + (size_t)(c0 + c) * ldf] * sm.xk[c];   // c0 + c < n here: i > c0 + 15
+            z[i] -= acc;
+        }
+        __syncthreads();
+    }
+    // backward: L^T x = w
+    for (int kb = nblk - 1; kb >= 0; --kb) {
+        const int c0 = 16 * kb;
+        if (tid < 256) {
+            const int r = tid & 15, c = tid >> 4;
+            const int gr = c0 + r < n ? c0 + r : n - 1, gc = c0 + c < n ? c0 + c : n - 1;
+            const T v = F[gr + (size_t)gc * ldf];
+            sm.blk[r * 17 + c] = (c0 + r < n && c0 + c < n) ? v : (r == c ? T(1) : T(0));
+        }
+        __syncthreads();
+        if (tid == 0) {                                         // L_kk^T x = z_k, backward substitution
+            T x[16];
+#pragma unroll
+            for (int r = 15; r >= 0; --r) {
+                T s = c0 + r < n ? z[c0 + r] : T(0);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) if (q > r) s -= sm.blk[q * 17 + r] * x[q];
+                x[r] = s / sm.blk[r * 17 + r];
+                sm.xk[r] = x[r];
+                if (c0 + r < n) z[c0 + r] = x[r];
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < c0; i += kBigThreads) {
+            T acc = 0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (c0 + c < n) acc += F[(c0 + c) + (size_t)i * ldf] * sm.xk[c];           // L(c0 + c, i)
+            z[i] -= acc;
+        }
+        __syncthreads();
+    }
+}
+
+// r = b - A x, w = |b| + |A| |x|: one wave per row, lanes along the row (A is symmetric: row i is read as column i)
+template <typename T>
+__device__ __noinline__ void residual_big(int n, const T* A, int lda, const T* b, const T* x, T* r, T* w)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    for (int i = wave; i < n; i += kBigWaves) {
+        T ra = 0, wa = 0;
+        for (int k = lane; k < n; k += kWave) {
+            const T a = A[k + (size_t)i * lda], xv = x[k];
+            ra += a * xv;
+            wa += dabs(a) * dabs(xv);
+        }
+        ra = wave_sum(ra);
+        wa = wave_sum(wa);
+        if (lane == 0) { r[i] = b[i] - ra; w[i] = dabs(b[i]) + wa; }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------- ?posvx('E','L'), nrhs = 1 (same semantics as posvx_device)
+template <typename T>
+__device__ __noinline__ int posvx_big(int n, T* A, int lda, T* F, int ldf, T* s, T* b, T* x, T* r, T* w, BigLds<T>& sm)
+{
+    const int tid = threadIdx.x;
+    const T eps = Lim<T>::eps / 2;
+    const T safmin = Lim<T>::min_normal;
+    // ?poequ
+    T mn = Lim<T>::inf(), mx = -Lim<T>::inf();
+    for (int i = tid; i < n; i += kBigThreads) { const T d = A[i + (size_t)i * lda]; mn = d < mn ? d : mn; mx = d > mx ? d : mx; }
+    const T smin = big_min(mn, sm.red);
+    const T amax = big_max(mx, sm.red);
+    bool rcequ = false;
+    if (smin > 0) {
+        const T scond = dsqrt(smin) / dsqrt(amax);
+        for (int i = tid; i < n; i += kBigThreads) s[i] = T(1) / dsqrt(A[i + (size_t)i * lda]);
+        const T small = safmin / Lim<T>::eps, large = T(1) / small;
+        rcequ = !(scond >= T(0.1) && amax >= small && amax <= large);
+    }
+    __syncthreads();
+    if (rcequ) {                                                // ?laqsy
+        for (int j = tid >> 6; j < n; j += kBigWaves) {
+            const T cj = s[j];
+            for (int i = tid & 63; i < n; i += kWave) A[i + (size_t)j * lda] = cj * s[i] * A[i + (size_t)j * lda];
+        }
+        for (int i = tid; i < n; i += kBigThreads) b[i] = s[i] * b[i];
+    }
+    __syncthreads();
+    const int info = potrf_big<T>(n, A, lda, F, ldf, sm);
+    if (info != 0) return info;
+    for (int i = tid; i < n; i += kBigThreads) x[i] = b[i];
+    potrs_big<T>(n, F, ldf, x, sm);
+    // ?porfs, ITMAX = 5
+    const T safe1 = T(n + 1) * safmin, safe2 = safe1 / eps;
+    T lstres = 3;
+    for (int count = 1;; ++count) {
+        residual_big<T>(n, A, lda, b, x, r, w);
+        T qv = 0;
+        for (int i = tid; i < n; i += kBigThreads) {
+            const T q = (w[i] > safe2) ? dabs(r[i]) / w[i] : (dabs(r[i]) + safe1) / (w[i] + safe1);
+            qv = q > qv ? q : qv;
+        }
+        const T berr = big_max(qv, sm.red);
+        if (berr > eps && 2 * berr <= lstres && count <= 5) {
+            potrs_big<T>(n, F, ldf, r, sm);
+            for (int i = tid; i < n; i += kBigThreads) x[i] += r[i];
+            lstres = berr;
+            __syncthreads();
+            continue;
+        }
+        break;
+    }
+    if (rcequ) for (int i = tid; i < n; i += kBigThreads) x[i] = s[i] * x[i];
+    __syncthreads();
+    return 0;
+}
+
+// ---------------------------------------------------------------- solveBoxQP, boxcqp.d:122-379 (loops over n)
+// A (n x n) must hold the matrix of the unconstrained system on entry (it is overwritten); Pm stays intact.
+template <typename T>
+__device__ __noinline__ int box_qp_big(int n, const T* Pm, const T* q, const T* l, const T* u, T* x, bool unconstrainedSolution,
+                                       T relTol, T absTol, uint32_t maxIterations, SolveScratch<T>& sc, BigLds<T>& sm, int* iters)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    T* s = sc.vec;
+    T* b = sc.vec + 1 * (size_t)n;
+    T* r = sc.vec + 2 * (size_t)n;
+    T* w = sc.vec + 3 * (size_t)n;
+    T* la = sc.vec + 4 * (size_t)n;
+    T* mu = sc.vec + 5 * (size_t)n;
+    T* sX = sc.vec + 6 * (size_t)n;
+    int32_t* SI = sc.ivec;
+    int32_t* flags = sc.ivec + n;
+    const int ldf = n | 1;
+    *iters = 0;
+    if (n == 0) return 0;
+
+    if (!unconstrainedSolution) {                                   // QP:168-214
+        for (int i = tid; i < n; i += kBigThreads) b[i] = -q[i];
+        __syncthreads();
+        const int info = posvx_big<T>(n, sc.A, n, sc.Fg, ldf, s, b, x, r, w, sm);
+        if (info != 0) return 1;
+    }
+    {                                                               // QP:216-219
+        int bad = 0;
+        for (int i = tid; i < n; i += kBigThreads) bad |= !(l[i] <= x[i] && x[i] <= u[i]);
+        if (!big_or(bad, sm.ired)) return 0;
+    }
+    if (!maxIterations) maxIterations = (uint32_t)n * 10 + 100;     // QP:224-226
+    for (int i = tid; i < n; i += kBigThreads) { la[i] = 0; mu[i] = 0; }
+    __syncthreads();
+
+    for (uint32_t step = 0; step < maxIterations; ++step) {         // QP:234
+        *iters = (int)step + 1;
+        // classification QP:239-263; the free-set list SI keeps the reference's ascending order (chunked ballot prefix sum)
+        int sN = 0;
+        for (int base = 0; base < n; base += kBigThreads) {
+            const int i = base + tid;
+            int fl = 2;
+            if (i < n) {
+                const T xi = x[i], li = l[i], ui = u[i];
+                const T xl = xi - li, ux = ui - xi;
+                if (xl < 0 || (xl < relTol + absTol * dabs(li) && la[i] >= 0)) { fl = -1; x[i] = li; mu[i] = 0; }
+                else if (ux < 0 || (ux < relTol + absTol * dabs(ui) && mu[i] >= 0)) { fl = 1; x[i] = ui; la[i] = 0; }
+                else { fl = 0; mu[i] = 0; la[i] = 0; }
+                flags[i] = fl;
+            }
+            const unsigned long long bal = __ballot(fl == 0);
+            __syncthreads();
+            if (lane == 0) sm.ired[wave] = __popcll(bal);
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int wv = 0; wv < kBigWaves; ++wv) { if (wv < wave) before += sm.ired[wv]; total += sm.ired[wv]; }
+            if (fl == 0) SI[sN + before + __popcll(bal & ((1ull << lane) - 1))] = i;
+            sN += total;
+        }
+        __syncthreads();
+        if (sN == n) break;                                         // QP:265-266 (quirk Q8)
+
+        // reduced system QP:282-305, Kahan-Babuska-Neumaier sums over the bound variables, j ascending
+        for (int ii = tid; ii < sN; ii += kBigThreads) {
+            const int i = SI[ii];
+            T ks = q[i], kc = 0;
+            int jj = 0;
+            for (int j = 0; j < n; ++j) {
+                const T pij = Pm[(size_t)j * n + i];
+                const int fj = flags[j];
+                if (fj) {
+                    const T v = pij * (fj < 0 ? l[j] : u[j]);
+                    const T t = ks + v;
+                    if (dabs(ks) >= dabs(v)) kc += (ks - t) + v; else kc += (v - t) + ks;
+                    ks = t;
+                } else {
+                    sc.A[(size_t)jj * sN + ii] = pij;
+                    ++jj;
+                }
+            }
+            b[ii] = -(ks + kc);
+        }
+        __syncthreads();
+        if (sN) {                                                   // QP:307-325
+            const int info = posvx_big<T>(sN, sc.A, sN, sc.Fg, sN | 1, s, b, sX, r, w, sm);
+            if (info != 0) return 1;
+        }
+        for (int ii = tid; ii < sN; ii += kBigThreads) x[SI[ii]] = sX[ii];   // QP:327-329
+        __syncthreads();
+        // multipliers QP:333-337
+        for (int i = tid; i < n; i += kBigThreads) {
+            if (!flags[i]) continue;
+            T v1 = 0, v2 = 0;
+            for (int j = 0; j < i; ++j) v1 += Pm[(size_t)j * n + i] * x[j];
+            for (int j = i; j < n; ++j) v2 += Pm[(size_t)j * n + i] * x[j];
+            const T val = v1 + v2 + q[i];
+            if (flags[i] < 0) la[i] = val; else mu[i] = -val;
+        }
+        __syncthreads();
+        int again = 0;                                              // QP:339-347
+        for (int i = tid; i < n; i += kBigThreads) {
+            const int fi = flags[i];
+            if (fi < 0) again |= !(la[i] >= 0);
+            else if (fi > 0) again |= !(mu[i] >= 0);
+            else again |= !(x[i] >= l[i] && x[i] <= u[i]);
+        }
+        if (big_or(again, sm.ired)) continue;
+        for (int i = tid; i < n; i += kBigThreads) x[i] = dfmax(dfmin(x[i], u[i]), l[i]);   // QP:349
+        __syncthreads();
+        return 0;
+    }
+    return 2;                                                       // QP:378
+}
+
+// ---------------------------------------------------------------- one LM pass, n x n part, any n
+template <typename T>
+__global__ __launch_bounds__(kBigThreads) void k_lm_solve_big(LmSolveArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];     // sizeof(BigLds<T>) > 64 KB: dynamic
+    BigLds<T>& sm = *reinterpret_cast<BigLds<T>*>(big_smem);
+    const int n = a.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kc = blockIdx.x;
+    SolveScratch<T> sc = a.sc[kc];
+    T* dx_out = a.dx + (size_t)kc * n;
+    T* trial_out = a.trial + (size_t)kc * n;
+    T* qpl = sc.vec + 7 * (size_t)n;
+    T* qpu = sc.vec + 8 * (size_t)n;
+    T* tv = sc.vec + 9 * (size_t)n;                  // JJ dx for the predicted reduction
+    T* xq = sc.vec + 10 * (size_t)n;
+
+    if (a.check_grad && !(a.st->jy_inf > a.set.gradTolerance)) {    // LS:1053
+        if (tid == 0) { ChainRec<T> r{}; r.flags = kFlagGradSmall; a.rec[kc] = r; }
+        return;
+    }
+    // lambda_0, LS:1067-1072: the FIRST diagonal entry of maximum modulus, as i?amax picks it
+    T lambda = (kc == 0 && a.lambda_from_state) ? a.st->lambda : a.lam[kc];
+    if (kc == 0 && a.lambda_from_state && !(lambda >= a.set.minLambda)) {
+        T best = -1;
+        int where = 0x7fffffff;
+        for (int i = tid; i < n; i += kBigThreads) {
+            const T dg = dabs(a.JJ[(size_t)i * n + i]);
+            if (dg > best) { best = dg; where = i; }             // ascending i per thread: first maximum
+        }
+        const T mx = big_max(best, sm.red);
+        int cand = (best == mx) ? where : 0x7fffffff;
+#pragma unroll
+        for (int k = 1; k < kWave; k <<= 1) { const int o = __shfl_xor(cand, k, kWave); cand = o < cand ? o : cand; }
+        __syncthreads();
+        if (lane == 0) sm.ired[wave] = cand;
+        __syncthreads();
+        int first = sm.ired[0];
+        for (int wv = 1; wv < kBigWaves; ++wv) first = sm.ired[wv] < first ? sm.ired[wv] : first;
+        lambda = T(0.001) * a.JJ[(size_t)first * n + first];
+        if (!(lambda >= a.set.minLambda)) lambda = 1;
+        __syncthreads();
+    }
+    // step bounds LS:1074-1077; Pm = A = JJ + lambda I, LS:1078-1079
+    for (int i = tid; i < n; i += kBigThreads) { qpl[i] = a.lower[i] - a.x[i]; qpu[i] = a.upper[i] - a.x[i]; }
+    {
+        const size_t nn = (size_t)n * n;
+        for (size_t idx = tid; idx < nn; idx += kBigThreads) {
+            const T v = a.JJ[idx];
+            const T t = (idx % ((size_t)n + 1) == 0) ? v + lambda : v;
+            sc.Pm[idx] = t;
+            sc.A[idx] = t;
+        }
+    }
+    __syncthreads();
+    int qp_iters = 0;
+    const int qp = box_qp_big<T>(n, sc.Pm, a.Jy, qpl, qpu, xq, false, a.set.qpRelTolerance, a.set.qpAbsTolerance,
+                                 a.set.qpMaxIterations, sc, sm, &qp_iters);   // LS:1080
+
+    int flags = 0;
+    T ndd = 0, pred = 0, xn = 0;
+    if (qp == 0) {
+        int fl = 0, moved = 0;
+        T sdd = 0, amx = 0;
+        for (int i = tid; i < n; i += kBigThreads) {
+            T d = xq[i];
+            if (!(d <= d)) fl |= kFlagDxNaN;                         // LS:1087
+            const T xi = a.x[i];
+            d = d + xi;                                              // LS:1096
+            d = d - xi;                                              // LS:1097
+            dx_out[i] = d;
+            const T tr = dfmax(dfmin(d + xi, a.upper[i]), a.lower[i]);   // LS:1108-1110
+            trial_out[i] = tr;
+            if (!(tr <= tr)) fl |= kFlagXNaN;
+            moved |= !(tr == xi);
+            sdd += d * d;
+            const T at = dabs(tr);
+            amx = at > amx ? at : amx;
+        }
+        if (big_or(fl & kFlagDxNaN, sm.ired)) flags |= kFlagDxNaN;
+        if (big_or(fl & kFlagXNaN, sm.ired)) flags |= kFlagXNaN;
+        if (!big_or(moved, sm.ired)) flags |= kFlagNullStep;
+        ndd = big_sum(sdd, sm.red);                                  // LS:1099
+        // predicted reduction with the UNDAMPED JJ, LS:1141-1142: t = JJ dx + 2 Jy ; pred = -(t . dx)
+        for (int i = wave; i < n; i += kBigWaves) {
+            T acc = 0;
+            for (int k = lane; k < n; k += kWave) acc += a.JJ[(size_t)i * n + k] * dx_out[k];
+            acc = wave_sum(acc);
+            if (lane == 0) tv[i] = acc;
+        }
+        __syncthreads();
+        T sp = 0;
+        for (int i = tid; i < n; i += kBigThreads) sp += (tv[i] + 2 * a.Jy[i]) * dx_out[i];
+        pred = -big_sum(sp, sm.red);
+        const T amax = big_max(amx, sm.red);                         // LS:1164, scaled like ?nrm2
+        T sc2 = 0;
+        if (amax > 0)
+            for (int i = tid; i < n; i += kBigThreads) { const T v = trial_out[i] / amax; sc2 += v * v; }
+        xn = amax > 0 ? amax * dsqrt(big_sum(sc2, sm.red)) : T(0);
+        if (!(dsqrt(ndd) < a.set.maxStep)) flags |= kFlagStepTooLong; // LS:1101
+    }
+    if (tid == 0) {
+        ChainRec<T> r{};
+        r.lambda = lambda; r.new_dx_dot = ndd; r.predicted = pred; r.trial_xnorm = xn;
+        r.qp_status = qp; r.qp_iterations = qp_iters; r.flags = flags;
+        a.rec[kc] = r;
+    }
+}
+
+// standalone BOXCQP for any n (mir_solve_box_qp_gpu_* above n = 256)
+template <typename T>
+__global__ __launch_bounds__(kBigThreads) void k_box_qp_big(BoxQpArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
+    BigLds<T>& sm = *reinterpret_cast<BigLds<T>*>(big_smem);
+    const int n = a.n;
+    const size_t nn = (size_t)n * n;
+    // symmetrise the lower triangle (QP:109: only the lower triangle of P is meaningful); A = Pm
+    for (size_t idx = threadIdx.x; idx < nn; idx += kBigThreads) {
+        const size_t i = idx / n, j = idx % n;
+        const T v = i >= j ? a.P[i * n + j] : a.P[j * n + i];
+        a.sc.Pm[idx] = v;
+        a.sc.A[idx] = v;
+    }
+    __syncthreads();
+    int it = 0;
+    const int st = box_qp_big<T>(n, a.sc.Pm, a.q, a.l, a.u, a.x, a.unconstrained != 0, a.relTol, a.absTol, a.maxIterations,
+                                 a.sc, sm, &it);
+    if (threadIdx.x == 0) { a.out[0] = st; a.out[1] = it; }
+}
+
+}  // namespace mirlsq

@@ -79,11 +79,11 @@ struct SolveScratch {    // global scratch, all L2 resident
 #define MIRLSQ_STAMP(ptr, k) do { if ((ptr) && threadIdx.x == 0) (ptr)[k] = wall_clock64(); } while (0)
 
 // ---------------------------------------------------------------- workgroup collectives
-template <typename T, typename Op>
-__device__ inline T block_reduce(T v, Op op, T* red /* >= 4 */)
+// wave stage on DPP row operations (+ two cross-row shuffles), then one LDS exchange between the four waves
+template <typename T, typename WaveOp, typename Op>
+__device__ inline T block_reduce(T v, WaveOp wop, Op op, T* red /* >= 4 */)
 {
-#pragma unroll
-    for (int k = 1; k < kWave; k <<= 1) v = op(v, wave_shfl_xor(v, k));
+    v = wop(v);
     const int wave = threadIdx.x >> 6;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[wave] = v;
@@ -93,9 +93,18 @@ __device__ inline T block_reduce(T v, Op op, T* red /* >= 4 */)
     for (int w = 1; w < kSolveThreads / kWave; ++w) r = op(r, red[w]);
     return r;
 }
-template <typename T> __device__ inline T block_sum(T v, T* red) { return block_reduce(v, [](T a, T b) { return a + b; }, red); }
-template <typename T> __device__ inline T block_max(T v, T* red) { return block_reduce(v, [](T a, T b) { return a > b ? a : b; }, red); }
-template <typename T> __device__ inline T block_min(T v, T* red) { return block_reduce(v, [](T a, T b) { return a < b ? a : b; }, red); }
+template <typename T> __device__ inline T block_sum(T v, T* red)
+{
+    return block_reduce(v, [](T a) { return wave_sum(a); }, [](T a, T b) { return a + b; }, red);
+}
+template <typename T> __device__ inline T block_max(T v, T* red)
+{
+    return block_reduce(v, [](T a) { return wave_max(a); }, [](T a, T b) { return a > b ? a : b; }, red);
+}
+template <typename T> __device__ inline T block_min(T v, T* red)
+{
+    return block_reduce(v, [](T a) { return wave_min(a); }, [](T a, T b) { return a < b ? a : b; }, red);
+}
 __device__ inline int block_or(int v, int* red)
 {
     __syncthreads();
@@ -456,7 +465,7 @@ template <typename T, int NB, bool BOUNDED = true>
 __device__ __forceinline__ int box_qp_device(int n, const T* Pm, const T* q, const T* l, const T* u, T* x,
                              bool unconstrainedSolution, T relTol, T absTol, uint32_t maxIterations,
                              SolveScratch<T>& sc, T* F, int ldf, T* red, int* ired, int* iters, bool a_prefilled = false,
-                             const T* src0 = nullptr, T shift0 = T(0))
+                             const T* src0 = nullptr, T shift0 = T(0), bool* a_in_lds = nullptr)
 {
     const int tid = threadIdx.x;
     T* s = sc.vec;
@@ -474,7 +483,9 @@ __device__ __forceinline__ int box_qp_device(int n, const T* Pm, const T* q, con
     if constexpr (NB > 0) {
         if (!unconstrainedSolution) {                               // QP:168-214
             T xi = 0;
-            const int info = posvx_lds<T, NB>(n, src0 ? src0 : Pm, n, shift0, tid < n ? -q[tid] : T(0), xi, F, red, ired + 8, sc.dbg);
+            bool scaled = false;
+            const int info = posvx_lds<T, NB>(n, src0 ? src0 : Pm, n, shift0, tid < n ? -q[tid] : T(0), xi, F, red, ired + 8, sc.dbg, &scaled);
+            if (a_in_lds) *a_in_lds = !scaled;                      // the LDS copy of A is src0 + shift0 I, unscaled
             if (info != 0) return 1;                                // QP:212-213 (info == n+1 is never produced)
             if (tid < n) x[tid] = xi;
             __syncthreads();
@@ -505,6 +516,7 @@ __device__ __forceinline__ int box_qp_device(int n, const T* Pm, const T* q, con
         if (!block_or(bad, ired)) return 0;
     }
     if constexpr (!BOUNDED) return 1;
+    if (a_in_lds) *a_in_lds = false;                                // the reduced systems reuse the LDS blocks
 
     if (!maxIterations) maxIterations = (uint32_t)n * 10 + 100;     // QP:224-226
     if (tid < n) { la[tid] = 0; mu[tid] = 0; }                      // QP:228-232
@@ -706,8 +718,9 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
 
     MIRLSQ_STAMP(sc.dbg, 1);
     int qp_iters = 0;
+    bool a_in_lds = false;
     const int qp = box_qp_device<T, NB, BOUNDED>(n, sc.Pm, a.Jy, qpl, qpu, xq, false, a.set.qpRelTolerance, a.set.qpAbsTolerance,
-                                          a.set.qpMaxIterations, sc, F, ldf, red, ired, &qp_iters, true, a.JJ, lambda);   // LS:1080
+                                          a.set.qpMaxIterations, sc, F, ldf, red, ired, &qp_iters, true, a.JJ, lambda, &a_in_lds);   // LS:1080
 
     MIRLSQ_STAMP(sc.dbg, 7);
     int flags = 0;
@@ -727,38 +740,82 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
             if (!(tr <= tr)) flags |= kFlagXNaN;
             moved = !(tr == xi);                                     // NaN counts as moved
         }
-        flags = block_or(flags, ired);
-        if (!block_or(moved, ired)) flags |= kFlagNullStep;
-        ndd = block_sum(d * d, red);                                 // LS:1099
         // predicted reduction with the UNDAMPED JJ, LS:1141-1142: t = JJ dx + 2 Jy ; pred = -(t . dx)
         T ti = 0;
-        {
-            // thread pair (i, h) sums half of row i (n <= 128) or thread i sums the whole row. On the LDS path the step is
-            // staged in LDS (the solve's vectors are free now), so the loop holds only the loads of J^T J
-            const T* dxv = dx_out;
-            if constexpr (NB > 0) {
-                T* stage = F + LdsSolveCfg<NB>::XV_OFF;
-                if (tid < n) stage[tid] = d;
-                __syncthreads();
-                dxv = stage;
+        if constexpr (NB > 0) {
+            // The step is staged in LDS (the solve's vectors are free now). When the LDS blocks still hold the unscaled
+            // A = JJ + lambda I of this pass (no equilibration, no active-set iteration), JJ dx is read from them: every
+            // off-diagonal entry of A IS the entry of JJ, and the diagonal term uses JJ_ii fetched from memory -- the same
+            // products as the sweep over global memory below, without its 64 dependent L2 round trips per thread.
+            using LC = LdsSolveCfg<NB>;
+            T* stage = F + LC::XV_OFF;
+            const int i = tid >> 1, h = tid & 1;
+            const T jdiag = (a_in_lds && i < n) ? a.JJ[(size_t)i * n + i] : T(0);
+            if (tid < LC::NV) stage[tid] = tid < n ? d : T(0);
+            __syncthreads();
+            if (a_in_lds) {
+                const T* Ab = F + LC::A_OFF;
+                const int nbl = (n + 15) >> 4, I = i >> 4, r = i & 15;
+                if (i < n) {
+                    T acc[4] = {0, 0, 0, 0};
+                    for (int J = h; J < nbl; J += 2) {
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) {
+                            T av = J <= I ? Ab[blk_off(I, J, r, c)] : Ab[blk_off(J, I, c, r)];
+                            av = (16 * J + c == i) ? jdiag : av;
+                            acc[c & 3] += av * stage[16 * J + c];
+                        }
+                    }
+                    ti = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                    if (h == 0) ti = ti + 2 * a.Jy[i];
+                    ti = ti * stage[i];
+                }
+            } else if (i < n) {
+                const int j0 = h ? n / 2 : 0, j1 = h ? n : n / 2;
+                const T* __restrict__ jj = a.JJ;
+#pragma unroll 16
+                for (int j = j0; j < j1; ++j) ti += jj[(size_t)j * n + i] * stage[j];
+                if (h == 0) ti = ti + 2 * a.Jy[i];
+                ti = ti * stage[i];
             }
+        } else {
+            // thread pair (i, h) sums half of row i (n <= 128) or thread i sums the whole row
             const bool pair = n <= kSolveThreads / 2;
             const int i = pair ? tid >> 1 : tid, h = pair ? tid & 1 : 0;
             if (i < n) {
                 const int j0 = pair && h ? n / 2 : 0, j1 = pair && !h ? n / 2 : n;
-                const T* __restrict__ jj = a.JJ;
 #pragma unroll 16
-                for (int j = j0; j < j1; ++j) ti += jj[(size_t)j * n + i] * dxv[j];
+                for (int j = j0; j < j1; ++j) ti += a.JJ[(size_t)j * n + i] * dx_out[j];
                 if (h == 0) ti = ti + 2 * a.Jy[i];
-                ti = ti * dxv[i];
+                ti = ti * dx_out[i];
             }
         }
-        pred = -block_sum(ti, red);
-        // ||trial||_2 for the relTolerance test, LS:1164 (scaled like ?nrm2)
-        const T amx = block_max(dabs(tr), red);
-        T sc2 = 0;
-        if (tid < n && amx > 0) { const T v = tr / amx; sc2 = v * v; }
-        xn = amx > 0 ? amx * dsqrt(block_sum(sc2, red)) : T(0);
+        // one fused workgroup reduction: ||dx||^2 (LS:1099), t . dx, max |trial|, the OR of the flags and "some entry moved"
+        {
+            __shared__ T fr[3][kSolveThreads / kWave];
+            __shared__ int fi[kSolveThreads / kWave];
+            const T s0 = wave_sum(d * d), s1 = wave_sum(ti), m0 = wave_max(dabs(tr));
+            const unsigned long long bnan = __ballot(flags & kFlagDxNaN), bx = __ballot(flags & kFlagXNaN), bm = __ballot(moved);
+            const int wv = tid >> 6;
+            __syncthreads();
+            if ((tid & 63) == 0) {
+                fr[0][wv] = s0; fr[1][wv] = s1; fr[2][wv] = m0;
+                fi[wv] = (bnan ? kFlagDxNaN : 0) | (bx ? kFlagXNaN : 0) | (bm ? 0x10000 : 0);
+            }
+            __syncthreads();
+            ndd = (fr[0][0] + fr[0][1]) + (fr[0][2] + fr[0][3]);
+            pred = -((fr[1][0] + fr[1][1]) + (fr[1][2] + fr[1][3]));
+            T amx = fr[2][0];
+#pragma unroll
+            for (int w2 = 1; w2 < kSolveThreads / kWave; ++w2) amx = fr[2][w2] > amx ? fr[2][w2] : amx;
+            const int fo = fi[0] | fi[1] | fi[2] | fi[3];
+            flags = fo & 0xffff;
+            if (!(fo & 0x10000)) flags |= kFlagNullStep;
+            // ||trial||_2 for the relTolerance test, LS:1164 (scaled like ?nrm2)
+            T sc2 = 0;
+            if (tid < n && amx > 0) { const T v = tr / amx; sc2 = v * v; }
+            xn = amx > 0 ? amx * dsqrt(block_sum(sc2, red)) : T(0);
+        }
         if (!(dsqrt(ndd) < a.set.maxStep)) flags |= kFlagStepTooLong; // LS:1101
     }
     MIRLSQ_STAMP(sc.dbg, 8);

@@ -12,14 +12,14 @@
 //     (r = lane & 15, c = 4 s + (lane >> 4)) all bank-conflict-free. n = 128: 36 blocks = 78 KB per matrix, 157 KB for
 //     L and A together plus 3 KB of vectors: fits the 160 KB of a CU's LDS;
 //   * ?potrf: right-looking by 16-column panels, three barriers per panel: (1) wave 0 factors the diagonal block in
-//     registers (16 pivots, v_readlane broadcasts, rsqrt + Newton like potrf_panel), (2) one thread per row below solves
+//     registers (16 pivots, DPP row broadcasts, rsqrt + Newton like potrf_panel), (2) one thread per row below solves
 //     its 16 panel entries against it, (3) the trailing update A_IJ -= L_Ik L_Jk^T runs on the matrix cores
 //     (v_mfma_f64_16x16x4: four per block, operands and accumulators straight from / to the LDS blocks);
 //   * the inverses of the diagonal blocks (one thread per column) are stored TRANSPOSED IN THE UNUSED UPPER TRIANGLES
 //     of the diagonal blocks of L (their diagonals are the reciprocal pivots, kept in a vector): no extra storage;
 //   * ?potrs: one thread per row, the vector in registers, ONE barrier per block step: the 16 owners of a diagonal block
-//     are a DPP row -- they form x_k = inv(L_kk) z_k with row rotations (no LDS exchange, no readlane), publish it, and
-//     after the barrier every remaining row subtracts its 16 products from LDS;
+//     are a DPP row -- they form x_k = inv(L_kk) z_k with row broadcasts (row_newbcast: no LDS exchange, no readlane),
+//     publish it, and after the barrier every remaining row subtracts its 16 products from LDS;
 //   * ?porfs: mat-vec with two threads per row from the LDS copy of A (equilibrated when ?laqsy says so), same berr
 //     test and ITMAX = 5 as Netlib.
 // Rows and columns past n are an identity extension, so no routine needs row masks.
@@ -39,18 +39,12 @@ template <int NB> struct LdsSolveCfg {
     static constexpr int RD_OFF = 2 * NBT * kLdsBlk;     // reciprocal pivots
     static constexpr int XV_OFF = RD_OFF + NV;           // published solution block / x for the mat-vec
     static constexpr int ZV_OFF = XV_OFF + NV;           // exchange vector (scales, residual)
-    static constexpr int ELEMS = ZV_OFF + NV;
+    static constexpr int ZERO_OFF = ZV_OFF + NV;         // one element that holds 0 (masked coefficient reads)
+    static constexpr int ELEMS = ZERO_OFF + 2;
 };
-__host__ __device__ constexpr int lds_solve_elems(int nb) { return nb * (nb + 1) * kLdsBlk + 48 * nb; }
+__host__ __device__ constexpr int lds_solve_elems(int nb) { return nb * (nb + 1) * kLdsBlk + 48 * nb + 2; }
 
 __device__ __forceinline__ int blk_off(int I, int J, int r, int c) { return (I * (I + 1) / 2 + J) * kLdsBlk + r + 17 * c; }
-
-// rotate value and tag together by one lane within each row of 16 lanes
-template <typename T> __device__ __forceinline__ void row_rotate(T& v, int& tag)
-{
-    v = dpp_row_ror<1>(v);
-    tag = dpp_row_ror<1>(tag);
-}
 
 // ---- load: L = A = src (+ shift on the diagonal), identity past n. src: n x n full symmetric, leading dimension ld.
 template <typename T, int NB>
@@ -76,6 +70,7 @@ __device__ __forceinline__ void lds_load_blocks(int n, const T* __restrict__ src
             smem[C::L_OFF + o] = v[I * (I + 1) / 2 + J];
             smem[C::A_OFF + o] = v[I * (I + 1) / 2 + J];
         }
+    if (threadIdx.x == 0) smem[C::ZERO_OFF] = T(0);
 }
 
 // ---- ?potrf 'L' in place on the L blocks. Returns info (0, or k: leading minor k not positive definite). Collective.
@@ -98,20 +93,25 @@ __device__ __forceinline__ int lds_potrf(int n, T* smem, int* info_s)
 #pragma unroll
             for (int c = 0; c < 16; ++c) p[c] = L[blk_off(k, k, r, c)];
             int bad = 0;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const T piv = lane_bcast(p[c], c);
+            // pivot c: every lane of the row group gets lane c's / lane c2's value with a DPP row broadcast (a VALU move:
+            // no v_readlane -> SGPR -> VALU round trip, whose wait states dominated the first version of this loop)
+            static_for<16>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                const T piv = dpp_row_bcast<c>(p[c]);
                 if (!(piv > 0)) { if (16 * k + c < n && bad == 0) bad = 16 * k + c + 1; }
                 T rinv, d;
                 rsqrt_sqrt(piv > 0 ? piv : T(1), rinv, d);
                 if (r > c) p[c] *= rinv; else if (r == c) p[c] = d;
                 if (lane == c) rd[16 * k + c] = rinv;
-#pragma unroll
-                for (int c2 = c + 1; c2 < 16; ++c2) {
-                    const T lc = lane_bcast(p[c], c2);       // L[c2][c]
-                    if (r > c) p[c2] -= p[c] * lc;
-                }
-            }
+                static_for<16>([&](auto cc2) {
+                    constexpr int c2 = decltype(cc2)::value;
+                    if constexpr (c2 > c) {
+                        // rows r <= c only touch entries above the diagonal here (c2 > c >= r), which nothing reads: no mask
+                        const T lc = dpp_row_bcast<c2>(p[c]);    // L[c2][c]
+                        p[c2] -= p[c] * lc;
+                    }
+                });
+            });
             if (lane < 16) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c) if (c <= r) L[blk_off(k, k, r, c)] = p[c];
@@ -193,50 +193,50 @@ __device__ __forceinline__ void lds_potrs(int n, T* smem, T& z)
     const int tid = threadIdx.x, I = tid >> 4, r = tid & 15;
     const int nbl = (n + 15) >> 4;
     const bool row = tid < 16 * nbl;
+    constexpr int zoff = C::ZERO_OFF - C::L_OFF;             // an LDS element that holds 0
     // forward: L w = z
     for (int k = 0; k < nbl; ++k) {
         if (row && I == k) {
-            T acc = rd[16 * k + r] * z;                      // inv(r, r) z_r
-            T zr = z;
-            int ci = r;
-#pragma unroll
-            for (int s = 1; s < 16; ++s) {
-                row_rotate(zr, ci);                          // zr = z of row ci of this block
-                const T cf = L[blk_off(k, k, ci < r ? ci : 0, r)];       // inv(r, ci), stored at (ci, r)
-                acc += (ci < r ? cf : T(0)) * zr;
-            }
-            z = acc;
-            xv[16 * k + r] = acc;
+            // x_k = inv(L_kk) z_k inside the DPP row of the 16 owners: the coefficients inv(r, c), c < r, sit at (c, r) of the
+            // diagonal block (addresses known up front: the 16 LDS reads are independent), z_c arrives by row broadcast
+            T acc[4] = {rd[16 * k + r] * z, 0, 0, 0};        // inv(r, r) z_r
+            static_for<16>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                // c >= r: the coefficient is 0 -- read the zero kept at the end of the vectors instead of selecting a double
+                const T cf = L[c < r ? blk_off(k, k, c, r) : zoff];
+                const T zc = dpp_row_bcast<c>(z);
+                acc[c & 3] += cf * zc;
+            });
+            z = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            xv[16 * k + r] = z;
         }
         __syncthreads();
         if (row && I > k) {
-            T acc = 0;
+            T acc[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int c = 0; c < 16; ++c) acc += L[blk_off(I, k, r, c)] * xv[16 * k + c];
-            z -= acc;
+            for (int c = 0; c < 16; ++c) acc[c & 3] += L[blk_off(I, k, r, c)] * xv[16 * k + c];
+            z -= (acc[0] + acc[1]) + (acc[2] + acc[3]);
         }
     }
     // backward: L^T x = w
     for (int k = nbl - 1; k >= 0; --k) {
         if (row && I == k) {
-            T acc = rd[16 * k + r] * z;
-            T zr = z;
-            int ci = r;
-#pragma unroll
-            for (int s = 1; s < 16; ++s) {
-                row_rotate(zr, ci);
-                const T cf = L[blk_off(k, k, r, ci > r ? ci : 15)];      // inv(ci, r), stored at (r, ci)
-                acc += (ci > r ? cf : T(0)) * zr;
-            }
-            z = acc;
-            xv[16 * k + r] = acc;
+            T acc[4] = {rd[16 * k + r] * z, 0, 0, 0};
+            static_for<16>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                const T cf = L[c > r ? blk_off(k, k, r, c) : zoff];   // inv(c, r), c > r, stored at (r, c)
+                const T zc = dpp_row_bcast<c>(z);
+                acc[c & 3] += cf * zc;
+            });
+            z = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            xv[16 * k + r] = z;
         }
         __syncthreads();
         if (row && I < k) {
-            T acc = 0;
+            T acc[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int c = 0; c < 16; ++c) acc += L[blk_off(k, I, c, r)] * xv[16 * k + c];   // L(16 k + c, 16 I + r)
-            z -= acc;
+            for (int c = 0; c < 16; ++c) acc[c & 3] += L[blk_off(k, I, c, r)] * xv[16 * k + c];   // L(16 k + c, 16 I + r)
+            z -= (acc[0] + acc[1]) + (acc[2] + acc[3]);
         }
     }
     __syncthreads();                                         // xv is free again
@@ -297,7 +297,7 @@ __device__ __forceinline__ void lds_residual(int n, T* smem, T bi, T xi, T& ri, 
 // LS:1079). Thread tid < n passes its right-hand-side entry bi and receives its solution entry in xi. Returns info.
 template <typename T, int NB>
 __device__ __forceinline__ int posvx_lds(int n, const T* src, int ld, T shift, T bi, T& xi, T* smem, T* red, int* info_s,
-                                         long long* dbg = nullptr)
+                                         long long* dbg = nullptr, bool* scaled = nullptr)
 {
     using C = LdsSolveCfg<NB>;
     const int tid = threadIdx.x;
@@ -320,6 +320,7 @@ __device__ __forceinline__ int posvx_lds(int n, const T* src, int ld, T shift, T
         const T small = safmin / Lim<T>::eps, large = T(1) / small;
         rcequ = !(scond >= T(0.1) && amax >= small && amax <= large);
     }
+    if (scaled) *scaled = rcequ;
     if (rcequ) {                                             // uniform
         if (tid < C::NV) zv[tid] = si;
         __syncthreads();

@@ -134,6 +134,32 @@ __global__ __launch_bounds__(256) void k_tanh_linear(const T* __restrict__ A, co
     }
 }
 
+// any n (used above n = 256): one wave per row, lanes along the row
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void k_tanh_linear_rows(const T* __restrict__ A, const T* __restrict__ b,
+                                                          const T* __restrict__ x, T* __restrict__ out, size_t m, int n)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t wave_id = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t row = wave_id; row < m; row += nwaves) {
+        const T* rp = A + row * (size_t)n;
+        T s = 0;
+        for (int c = lane; c < n; c += 64) s += rp[c] * x[c];
+        s = sum16(s);
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        const T t = dtanh(s);
+        if constexpr (MODE == 0) {
+            if (lane == 0) out[row] = t - b[row];
+        } else {
+            const T d = 1 - t * t;
+            T* op = out + row * (size_t)n;
+            for (int c = lane; c < n; c += 64) op[c] = d * rp[c];
+        }
+    }
+}
+
 template <typename T, int NCP, int MODE>
 void launch_tanh_linear_ncp(const T* A, const T* b, const T* x, T* out, size_t m, int n, dim3 grid, hipStream_t s)
 {
@@ -151,6 +177,10 @@ void launch_tanh_linear(const T* A, const T* b, const T* x, T* out, size_t m, in
     if (blocks < 1) blocks = 1;
     const int ncp = (n + 31) / 32;                         // column pairs per lane
     dim3 grid((unsigned)blocks);
+    if (ncp > 8) {
+        hipLaunchKernelGGL((k_tanh_linear_rows<T, MODE>), grid, dim3(256), 0, s, A, b, x, out, m, n);
+        return;
+    }
     if (ncp <= 1) launch_tanh_linear_ncp<T, 1, MODE>(A, b, x, out, m, n, grid, s);
     else if (ncp <= 2) launch_tanh_linear_ncp<T, 2, MODE>(A, b, x, out, m, n, grid, s);
     else if (ncp <= 4) launch_tanh_linear_ncp<T, 4, MODE>(A, b, x, out, m, n, grid, s);

@@ -1,0 +1,122 @@
+"""n above 256: the reference accepts any n (least_squares.d:911 reads n = x.length; the workspace carve :913-926 is generic),
+so the drop-in must too. Above 256 the n x n part of a pass runs k_lm_solve_big (csrc/solve_big.h: loops over n, factor in
+global memory, 512 threads), J^T J the tile-pair kernel, Broyden passes rewrite J row by row. Compared with the oracle like
+every other whole-path test (x rtol 1e-6, residual rtol 1e-9); the same kernel is also forced on small n
+(VARIANT_SOLVE_GENERIC) where the tuned kernels provide a second opinion pass by pass."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import mir_optim_amd as M
+from mir_optim_amd import workloads as W
+import problems as P
+from test_gpu_lm import first_noisy_pass
+
+pytestmark = pytest.mark.gpu
+
+
+def spd(n, seed, cond=1e3):
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    d = np.geomspace(1.0, cond, n)
+    return (Q * d) @ Q.T
+
+
+@pytest.mark.parametrize("n", [257, 300, 512, 700])
+def test_boxcqp_any_n_matches_oracle(oracle, n):
+    Pm = spd(n, n)
+    rng = np.random.default_rng(n + 1)
+    q = rng.standard_normal(n) * 3
+    xu = np.linalg.solve(Pm, -q)
+    l = np.where(rng.random(n) < 0.3, xu + 0.05 * np.abs(xu) + 1e-3, -np.inf)     # ~30 % of the lower bounds cut the minimiser off
+    u = np.where(rng.random(n) < 0.2, np.maximum(l, xu) + 0.5, np.inf)
+    st, x, it = M.solveBoxQP(Pm, q, l, u)
+    so, xo, ito = oracle.solve_box_qp(Pm, q, l, u)
+    assert int(st) == so == 0
+    assert it == ito >= 1
+    assert np.array_equal((x == l) | (x == u), (xo == l) | (xo == u))            # same active set
+    assert np.allclose(x, xo, rtol=1e-9, atol=1e-11)
+    # unconstrained = ?posvx alone
+    st, x, it = M.solveBoxQP(Pm, q, np.full(n, -np.inf), np.full(n, np.inf))
+    assert int(st) == 0 and it == 0 and np.allclose(x, xu, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("m,n", [(5000, 300), (7001, 384), (6000, 512)])
+def test_whole_path_above_256_matches_oracle(oracle, m, n):
+    w = P.tanh_linear(m, n)
+    prob = W.TanhLinear(w["A"], w["b"])
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
+    st = M.Stats()
+    res, x = prob.solve(w["x0"], settings=s, stats=st, batched=True)
+    so = oracle.default_settings(); so.absTolerance = 1e-9
+    ctx = oracle.TanhLinearCtx(w["A"].ctypes.data, w["b"].ctypes.data)
+    ro, xo = oracle.optimize(oracle.native_fn("wlc_tanh_linear_f"), m, w["x0"], settings=so, fctx=C.addressof(ctx),
+                             use_openblas=oracle.load_openblas(threads=8))
+    assert int(res.status) >= 0 and ro.status >= 0
+    assert st.jacobian_broyden >= 2
+    assert np.allclose(x, xo, rtol=1e-6, atol=1e-9), np.abs(x - xo).max()
+    assert np.isclose(res.residual, ro.residual, rtol=1e-9)
+
+
+def test_bounded_whole_path_above_256(oracle):
+    m, n = 4000, 300
+    w = P.tanh_linear(m, n)
+    lo = w["xstar"] - 0.5
+    up = w["xstar"] + 0.5
+    lo[::7] = w["xstar"][::7] + 0.02
+    x0 = np.clip(w["x0"], lo, up)
+    prob = W.TanhLinear(w["A"], w["b"])
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
+    st = M.Stats()
+    res, x = prob.solve(x0, l=lo, u=up, settings=s, stats=st, batched=True)
+    so = oracle.default_settings(); so.absTolerance = 1e-9
+    ctx = oracle.TanhLinearCtx(w["A"].ctypes.data, w["b"].ctypes.data)
+    ro, xo = oracle.optimize(oracle.native_fn("wlc_tanh_linear_f"), m, x0, lower=lo, upper=up, settings=so, fctx=C.addressof(ctx))
+    assert st.qp_active_set_passes > 0 and int(res.status) >= 0 and ro.status >= 0
+    assert np.all(x >= lo) and np.all(x <= up)
+    assert np.allclose(x, xo, rtol=1e-6, atol=1e-9), np.abs(x - xo).max()
+    assert np.isclose(res.residual, ro.residual, rtol=1e-9)
+
+
+@pytest.mark.parametrize("m,n,bounded", [(9000, 100, False), (12000, 200, False), (6000, 48, True), (8000, 160, True)])
+def test_generic_solve_kernel_on_small_n_follows_the_tuned_kernels(m, n, bounded):
+    w = P.tanh_linear(m, n)
+    prob = W.TanhLinear(w["A"], w["b"])
+    lo = up = None
+    x0 = w["x0"]
+    if bounded:
+        lo = w["xstar"] - 0.5; up = w["xstar"] + 0.5
+        lo[::4] = w["xstar"][::4] + 0.02
+        x0 = np.clip(x0, lo, up)
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
+    out = []
+    for variant in (0, M.VARIANT_SOLVE_GENERIC):
+        tr, st = M.Trace(4096), M.Stats()
+        r, x = prob.solve(x0, l=lo, u=up, settings=s, trace=tr, stats=st, batched=True, variant=variant)
+        out.append((r, x, tr.records(), st))
+    (r0, x0_, t0, s0), (r1, x1, t1, s1) = out
+    assert int(r0.status) >= 0 and int(r1.status) >= 0
+    if bounded:
+        assert s0.qp_active_set_passes > 0 and s1.qp_active_set_passes > 0
+    assert np.allclose(x1, x0_, rtol=1e-6, atol=1e-9) and np.isclose(r1.residual, r0.residual, rtol=1e-9)
+    K = min(first_noisy_pass(t0), first_noisy_pass(t1), len(t0), len(t1))
+    assert K >= 4
+    for a, b in zip(t0[:K], t1[:K]):
+        assert a[:2] == b[:2] and np.isclose(a[2], b[2], rtol=1e-6) and np.isclose(a[3], b[3], rtol=1e-7, atol=1e-300), (a, b)
+
+
+@pytest.mark.parametrize("m,n", [(3000, 320), (2501, 300), (1000, 513)])
+def test_jtj_above_256(m, n):
+    rng = np.random.default_rng(m + n)
+    J = rng.integers(-4, 5, size=(m, n)).astype(np.float64)
+    y = rng.integers(-3, 4, size=m).astype(np.float64)
+    JJ, Jy, _, _ = M.jtj(J, y)
+    assert np.array_equal(JJ, J.T @ J) and np.array_equal(Jy, J.T @ y)
+    yo = y + rng.integers(-2, 3, size=m)
+    dx = rng.integers(-2, 3, size=n).astype(np.float64) / 4
+    JJ2, Jy2, Jn, _ = M.jtj(J, y, yo, dx)
+    u = -(1.0 / (dx @ dx)) * ((yo - y) + J @ dx)
+    Jr = J + np.outer(u, dx)
+    assert np.allclose(Jn, Jr, rtol=1e-14, atol=1e-13)
+    assert np.allclose(JJ2, Jr.T @ Jr, rtol=1e-12, atol=1e-9) and np.allclose(Jy2, Jr.T @ y, rtol=1e-12, atol=1e-9)
