@@ -303,11 +303,24 @@ int mir_solve_box_qp_gpu_s(const mir_box_qp_settings_s* settings, size_t n, cons
  * (t_stride = m), data: count x m, results: count. All HOST pointers. The LM algorithm, statuses and counters are
  * those of mir_optimize_least_squares_s; problems whose step reaches a finite bound are completed by the general
  * solver (BOXCQP active set) transparently. Returns 0, or a negative value when no device / bad arguments. */
-enum { MIR_LSQ_MODEL_EXP_DECAY = 0, MIR_LSQ_MODEL_EXP3_AFFINE = 1 };
+enum { MIR_LSQ_MODEL_EXP_DECAY = 0, MIR_LSQ_MODEL_EXP3_AFFINE = 1,
+       MIR_LSQ_MODEL_EXP_DECAY_PAD8 = 2 };   /* n = 8: p0 exp(-t p1) + p2 + p3 sin 2t + p4 cos 2t + p5 sin 5t + p6 cos 5t + p7 t
+                                                (BASELINE cfg 5: the exponential decay padded to n = 8 with terms linear in
+                                                their parameters: well conditioned in fp32) */
 int mir_optimize_least_squares_batched_s(const mir_least_squares_settings_s* settings, size_t count, size_t m, int model,
                                          float* x, const float* lower, const float* upper,
                                          const float* t, size_t t_stride, const float* data,
                                          mir_least_squares_result_s* results);
+
+/* The same wave-per-problem kernel on DEVICE-RESIDENT data (every pointer is a device pointer; `results` receives
+ * `count` records in place; enqueued on `stream`, no synchronisation): what bench.py --config cfg5 times. Problems whose
+ * step reaches a finite bound come back with status -100 (MIR_LSQ_BATCHED_NEEDS_GENERAL): the host entry above completes
+ * those with the general solver, this one leaves that to the caller. Returns 0 when the launch succeeded. */
+enum { MIR_LSQ_BATCHED_NEEDS_GENERAL = -100 };
+int mir_lsq_batched_kernel_s(const mir_least_squares_settings_s* settings, size_t count, size_t m, int model,
+                             float* x, const float* lower, const float* upper,
+                             const float* t, size_t t_stride, const float* data,
+                             mir_least_squares_result_s* results, void* stream);
 
 /* Unit-level access to the hot kernels (parity tests and micro-benchmarks). All pointers are
  * DEVICE pointers; stream may be NULL (default stream; the call synchronises before returning).

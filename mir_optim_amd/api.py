@@ -30,7 +30,7 @@ __all__ = [
     "mir_least_squares_work_length", "mir_least_squares_iwork_length", "mir_box_qp_work_length",
     "mir_box_qp_iwork_length", "GpuOptions", "Stats", "lib", "workloads_lib", "device_count",
     "DeviceBuffer", "Stream", "jtj", "fd_jtj", "DEVICE_CALLBACKS", "TIME_KERNELS", "optimizeLeastSquaresBatched",
-    "MODEL_EXP_DECAY", "MODEL_EXP3_AFFINE", "Trace", "TraceRecord", "Spline", "FitSplineResult", "fitSpline",
+    "MODEL_EXP_DECAY", "MODEL_EXP3_AFFINE", "MODEL_EXP_DECAY_PAD8", "ResultS", "Trace", "TraceRecord", "Spline", "FitSplineResult", "fitSpline",
     "fit_spline_residuals", "variant_lr_cap",
     "VARIANT_BROYDEN_REWRITE", "VARIANT_FD_SEPARATE_FILL", "VARIANT_JTJ_RING", "VARIANT_JTJ_STREAM",
     "VARIANT_NO_SPECULATION", "VARIANT_NO_NULL_SKIP", "VARIANT_SOLVE_BOUNDED", "VARIANT_DEBUG_SOLVE",
@@ -39,6 +39,7 @@ __all__ = [
 
 MODEL_EXP_DECAY = 0      # n = 3: p0 exp(-t p1) + p2
 MODEL_EXP3_AFFINE = 1    # n = 8: p0 exp(-t p1) + p2 exp(-t p3) + p4 exp(-t p5) + p6 + p7 t
+MODEL_EXP_DECAY_PAD8 = 2  # n = 8: p0 exp(-t p1) + p2 + p3 sin 2t + p4 cos 2t + p5 sin 5t + p6 cos 5t + p7 t   (cfg 5)
 
 DEVICE_CALLBACKS = 1
 TIME_KERNELS = 2
@@ -122,6 +123,9 @@ class _Rd(C.Structure):
 class _Rs(C.Structure):
     _fields_ = [("status", C.c_int32), ("iterations", C.c_uint32), ("fCalls", C.c_uint32), ("gCalls", C.c_uint32),
                 ("residual", C.c_float), ("lambda_", C.c_float)]
+
+
+ResultS = _Rs
 
 
 class _SliceD(C.Structure):
@@ -254,6 +258,9 @@ def lib():
         L.mir_optimize_least_squares_batched_s.restype = C.c_int
         L.mir_optimize_least_squares_batched_s.argtypes = [C.POINTER(_Ss), sz, sz, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                            C.c_void_p, sz, C.c_void_p, C.c_void_p]
+        L.mir_lsq_batched_kernel_s.restype = C.c_int
+        L.mir_lsq_batched_kernel_s.argtypes = [C.POINTER(_Ss), sz, sz, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, sz, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mir_lsq_workspace_create.restype = C.c_void_p
         L.mir_lsq_workspace_create.argtypes = [sz, sz, sz]
         L.mir_lsq_workspace_destroy.argtypes = [C.c_void_p]

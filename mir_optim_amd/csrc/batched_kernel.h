@@ -20,7 +20,7 @@ namespace mirlsq {
 constexpr int kBatchedNeedsGeneral = -100;
 constexpr int kBatchedNMax = 8;
 
-enum : int { kModelExpDecay = 0, kModelExp3Affine = 1 };
+enum : int { kModelExpDecay = 0, kModelExp3Affine = 1, kModelExpDecayPad8 = 2 };
 
 // residual models: r = model(t, x) - d
 template <int MODEL> struct BatchedModel;
@@ -33,6 +33,19 @@ template <> struct BatchedModel<kModelExp3Affine> {    // sum_{k<3} p_{2k} exp(-
     __device__ static inline float eval(float t, const float* x)
     {
         return x[0] * __expf(-t * x[1]) + x[2] * __expf(-t * x[3]) + x[4] * __expf(-t * x[5]) + x[6] + x[7] * t;
+    }
+};
+
+// BASELINE cfg 5's well-conditioned n = 8 family ("p0 exp(-t p1) + p2 + 5-term variants padded to n = 8"): the
+// exponential decay plus five terms that are LINEAR in their parameters (a two-frequency trigonometric pair and a slope),
+// so the only nonlinearity is the decay and J^T J stays well conditioned in fp32. Precise expf / sinf / cosf (the float
+// oracle evaluates the same expression with libm).
+template <> struct BatchedModel<kModelExpDecayPad8> {
+    static constexpr int n = 8;
+    __device__ static inline float eval(float t, const float* x)
+    {
+        return x[0] * expf(-t * x[1]) + x[2] + x[3] * sinf(2.0f * t) + x[4] * cosf(2.0f * t) + x[5] * sinf(5.0f * t)
+             + x[6] * cosf(5.0f * t) + x[7] * t;
     }
 };
 

@@ -55,7 +55,8 @@ struct mir_lsq_workspace {
     void* ytrial = nullptr;    // kChainMax x m trial residuals (speculative lambda ladder)
     void* ulr = nullptr;       // kLrMax x m pending Broyden columns (broyden_lr.h)
     int device = 0;            // the device the workspace lives on (callbacks' worker threads select it)
-    void* pinned = nullptr;    // small pinned host block (state + trial readback)
+    void* pinned = nullptr;    // small pinned host block (state + trial readback), device-mapped and coherent:
+    void* pinned_dev = nullptr;   // ... its device address (the decision kernels write the state mirror directly)
     void* pinned_y = nullptr;  // m-vector staging (host-callback mode), lazily allocated
     void* pinned_J = nullptr;  // m*n staging for host analytic Jacobians, lazily allocated
     int num_cu = 256;
@@ -196,7 +197,8 @@ mir_lsq_workspace* workspace_create(size_t m, size_t n)
     if (hipGetDevice(&ws->device) != hipSuccess) ws->device = 0;
     if (hipMalloc(&ws->ulr, (size_t)kLrMax * m * sizeof(T)) != hipSuccess
         || hipMalloc(&ws->ytrial, (size_t)kChainMax * m * sizeof(T)) != hipSuccess
-        || hipHostMalloc(&ws->pinned, sizeof(LmState<T>) + (2 * n + 8) * sizeof(T), hipHostMallocDefault) != hipSuccess) {
+        || hipHostMalloc(&ws->pinned, sizeof(LmState<T>) + (2 * n + 8) * sizeof(T), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
+        || hipHostGetDevicePointer(&ws->pinned_dev, ws->pinned, 0) != hipSuccess) {
         std::fprintf(stderr, "[mir_optim_amd] workspace side buffers: allocation failed\n");
         workspace_destroy(ws);
         return nullptr;
@@ -277,6 +279,9 @@ struct Solver {
     size_t solve_lds = 0;
 
     LmState<T>* st_h;      // pinned mirror
+    LmState<T>* st_hd = nullptr;   // its device address
+    T* trial_hd = nullptr;         // device address of trial_h
+    uint32_t seq = 0;              // decision points published so far
     T* trial_h;            // pinned, n
     std::vector<T> twh_h;
     std::vector<EventPair> events;
@@ -346,6 +351,9 @@ struct Solver {
         B = carve<T>(ws->dev, m, n, ws->num_cu);
         device = ws->device;
         st_h = reinterpret_cast<LmState<T>*>(ws->pinned);
+        st_hd = reinterpret_cast<LmState<T>*>(ws->pinned_dev);
+        trial_hd = reinterpret_cast<T*>(static_cast<char*>(ws->pinned_dev) + sizeof(LmState<T>));
+        st_h->seq = 0;
         trial_h = reinterpret_cast<T*>(static_cast<char*>(ws->pinned) + sizeof(LmState<T>));
         if (!stream) {
             if (!ok(hipStreamCreate(&stream), "hipStreamCreate")) return false;
@@ -507,6 +515,29 @@ struct Solver {
             else
                 trace_emit(3, iterations_before + 1, rec[k].lambda, sums[k], sums[k], rec[k].new_dx_dot);
         }
+        return true;
+    }
+
+    // wait for decision point `expect` in the pinned mirror (written by k_init_state / k_decide_chain): a spin on host
+    // memory. The stream is queried now and then so that a failed kernel ends the wait instead of hanging it.
+    bool wait_state(uint32_t expect)
+    {
+        HpScope hp(this, 3);
+        volatile uint32_t* sq = &st_h->seq;
+        for (uint64_t spins = 0;; ++spins) {
+            if (*sq == expect) break;
+            if ((spins & 0xfff) == 0xfff) {
+                const hipError_t q = hipStreamQuery(stream);
+                if (q == hipSuccess) {                       // everything enqueued has run: the image must be there
+                    if (*sq == expect) break;
+                    std::fprintf(stderr, "[mir_optim_amd] decision point %u was not published\n", expect);
+                    return false;
+                }
+                if (q != hipErrorNotReady) return ok(q, "stream query");
+            }
+            __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
         return true;
     }
 
@@ -776,8 +807,8 @@ struct Solver {
             if (!eval_f(B.x, xh, y)) { fail = true; break; }                 // LS:953
             ++ret.fCalls;
             if (!sumsq(y, 0)) { fail = true; break; }                        // LS:955
-            hipLaunchKernelGGL(k_init_state<T>, dim3(1), dim3(1), 0, stream, B.sum, B.st);
-            if (!read_state(nullptr)) { fail = true; break; }
+            hipLaunchKernelGGL(k_init_state<T>, dim3(1), dim3(1), 0, stream, B.sum, B.st, st_hd, ++seq);
+            if (!ok(hipGetLastError(), "init state") || !wait_state(seq)) { fail = true; break; }
         } while (false);
         if (fail) { teardown(); ret.status = mir_ls_numericError; return ret; }
 
@@ -926,9 +957,10 @@ struct Solver {
                 d.sums = B.sum + 1; d.rec = B.rec; d.st = B.st; d.set = sd; d.x = B.x; d.trial = B.trial; d.dx_chain = B.dx;
                 d.dx_acc = B.dx_acc; d.n = (int)n; d.ks = ks; d.check_grad = newJacobian ? 1 : 0;
                 d.lambda_from_state = lambda_from_state ? 1 : 0;
+                d.host_st = st_hd; d.host_x = trial_hd; d.seq = ++seq;
                 hipLaunchKernelGGL(k_decide_chain<T>, dim3(1), dim3(kSolveThreads), 0, stream, d);
             }
-            if (!ok(hipGetLastError(), "decide kernel") || !read_state(B.x)) { fail = true; break; }
+            if (!ok(hipGetLastError(), "decide kernel") || !wait_state(seq)) { fail = true; break; }
 
             if (trace && !trace_round(ks, ret.residual, ret.iterations)) { fail = true; break; }
             const int dec = st_h->decision;
@@ -1223,10 +1255,62 @@ void batched_fallback_f(void* vctx, size_t m, size_t n, const float* x, float* y
     const unsigned blocks = (unsigned)((m + 255) / 256);
     if (c->model == kModelExpDecay)
         hipLaunchKernelGGL(k_batched_model_eval<kModelExpDecay>, dim3(blocks), dim3(256), 0, c->stream, c->t, c->d, x, y, (int)m);
-    else
+    else if (c->model == kModelExp3Affine)
         hipLaunchKernelGGL(k_batched_model_eval<kModelExp3Affine>, dim3(blocks), dim3(256), 0, c->stream, c->t, c->d, x, y, (int)m);
+    else
+        hipLaunchKernelGGL(k_batched_model_eval<kModelExpDecayPad8>, dim3(blocks), dim3(256), 0, c->stream, c->t, c->d, x, y, (int)m);
+}
+inline int batched_model_n(int model)
+{
+    return model == kModelExpDecay ? 3 : ((model == kModelExp3Affine || model == kModelExpDecayPad8) ? 8 : 0);
+}
+
+// fill the settings part of the kernel arguments
+void batched_settings(BatchedArgs& a, const mir_least_squares_settings_s* S)
+{
+    a.set.jacobianEpsilon = S->jacobianEpsilon; a.set.absTolerance = S->absTolerance; a.set.relTolerance = S->relTolerance;
+    a.set.gradTolerance = S->gradTolerance; a.set.maxGoodResidual = S->maxGoodResidual; a.set.maxStep = S->maxStep;
+    a.set.maxLambda = S->maxLambda; a.set.minLambda = S->minLambda; a.set.minStepQuality = S->minStepQuality;
+    a.set.goodStepQuality = S->goodStepQuality; a.set.lambdaIncrease = S->lambdaIncrease; a.set.lambdaDecrease = S->lambdaDecrease;
+    a.set.qpRelTolerance = S->qpSettings.relTolerance; a.set.qpAbsTolerance = S->qpSettings.absTolerance;
+    a.set.qpMaxIterations = S->qpSettings.maxIterations;
+    a.maxIterations = S->maxIterations; a.maxAge = S->maxAge;
+}
+
+// one wavefront per problem, four problems per workgroup; every pointer in `a` is a device pointer
+hipError_t batched_launch(const BatchedArgs& a, int model, hipStream_t stream)
+{
+    const int n = batched_model_n(model);
+    const size_t lds = (size_t)4 * (n + 2) * a.m * sizeof(float);
+    const unsigned blocks = (unsigned)((a.count + 3) / 4);
+    auto launch = [&](auto kern) -> hipError_t {
+        MIRLSQ_ENSURE_LDS(kern, lds);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, a);
+        return hipGetLastError();
+    };
+    if (model == kModelExpDecay) return launch(k_lm_batched<kModelExpDecay>);
+    if (model == kModelExp3Affine) return launch(k_lm_batched<kModelExp3Affine>);
+    return launch(k_lm_batched<kModelExpDecayPad8>);
 }
 }  // namespace
+
+int mir_lsq_batched_kernel_s(const mir_least_squares_settings_s* S, size_t count, size_t m, int model, float* x,
+                             const float* lower, const float* upper, const float* t, size_t t_stride, const float* data,
+                             mir_least_squares_result_s* results, void* stream)
+{
+    const int n = batched_model_n(model);
+    if (!S || !x || !lower || !upper || !t || !data || !results || n == 0 || (t_stride != 0 && t_stride != m)) return -1;
+    if (count == 0) return 0;
+    if (!device_available()) return -2;
+    if (m == 0 || (size_t)4 * (n + 2) * m * sizeof(float) > 160 * 1024 - 512) return -3;
+    static_assert(sizeof(BatchedResult) == sizeof(mir_least_squares_result_s), "the kernel writes the C result records in place");
+    BatchedArgs a{};
+    batched_settings(a, S);
+    a.count = (int)count; a.m = (int)m; a.t_stride = (int)t_stride;
+    a.t = t; a.data = data; a.x = x; a.lower = lower; a.upper = upper;
+    a.results = reinterpret_cast<BatchedResult*>(results);
+    return batched_launch(a, model, static_cast<hipStream_t>(stream)) == hipSuccess ? 0 : -5;
+}
 
 int mir_optimize_least_squares_batched_s(const mir_least_squares_settings_s* S, size_t count, size_t m, int model,
                                          float* x, const float* lower, const float* upper,
@@ -1234,7 +1318,7 @@ int mir_optimize_least_squares_batched_s(const mir_least_squares_settings_s* S, 
                                          mir_least_squares_result_s* results)
 {
     if (!S || !x || !lower || !upper || !t || !data || !results) return -1;
-    const int n = model == kModelExpDecay ? 3 : (model == kModelExp3Affine ? 8 : 0);
+    const int n = batched_model_n(model);
     if (n == 0 || (t_stride != 0 && t_stride != m)) return -1;
     for (size_t i = 0; i < count; ++i) {       // defaults of LeastSquaresResult!T, LS:132-142
         results[i].status = mir_ls_numericError; results[i].iterations = results[i].fCalls = results[i].gCalls = 0;
@@ -1255,13 +1339,8 @@ int mir_optimize_least_squares_batched_s(const mir_least_squares_settings_s* S, 
         return -3;
     }
     BatchedArgs a{};
-    a.set.jacobianEpsilon = S->jacobianEpsilon; a.set.absTolerance = S->absTolerance; a.set.relTolerance = S->relTolerance;
-    a.set.gradTolerance = S->gradTolerance; a.set.maxGoodResidual = S->maxGoodResidual; a.set.maxStep = S->maxStep;
-    a.set.maxLambda = S->maxLambda; a.set.minLambda = S->minLambda; a.set.minStepQuality = S->minStepQuality;
-    a.set.goodStepQuality = S->goodStepQuality; a.set.lambdaIncrease = S->lambdaIncrease; a.set.lambdaDecrease = S->lambdaDecrease;
-    a.set.qpRelTolerance = S->qpSettings.relTolerance; a.set.qpAbsTolerance = S->qpSettings.absTolerance;
-    a.set.qpMaxIterations = S->qpSettings.maxIterations;
-    a.maxIterations = S->maxIterations; a.maxAge = S->maxAge; a.count = (int)count; a.m = (int)m;
+    batched_settings(a, S);
+    a.count = (int)count; a.m = (int)m;
     a.t_stride = (int)t_stride;
     const size_t tb = (t_stride ? count : 1) * m * sizeof(float), db = count * m * sizeof(float), xb = count * n * sizeof(float);
     char* base = nullptr;
@@ -1280,15 +1359,7 @@ int mir_optimize_least_squares_batched_s(const mir_least_squares_settings_s* S, 
     std::vector<BatchedResult> res(count);
     std::vector<float> x0(x, x + count * n);       // starts, for the fallback problems
     if (good && !bad) {
-        const unsigned blocks = (unsigned)((count + 3) / 4);
-        auto launch = [&](auto kern) {
-            if (lds > 48 * 1024
-                && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return false;
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, a);
-            return hipGetLastError() == hipSuccess;
-        };
-        good = model == kModelExpDecay ? launch(k_lm_batched<kModelExpDecay>) : launch(k_lm_batched<kModelExp3Affine>);
+        good = batched_launch(a, model, nullptr) == hipSuccess;
         good = good && hipDeviceSynchronize() == hipSuccess
             && hipMemcpy(res.data(), a.results, count * sizeof(BatchedResult), hipMemcpyDeviceToHost) == hipSuccess
             && hipMemcpy(x, a.x, xb, hipMemcpyDeviceToHost) == hipSuccess;

@@ -51,14 +51,30 @@ __global__ __launch_bounds__(256) void k_sumsq_final(const T* __restrict__ parti
 }
 
 // ---- LS:953-971: state at entry. *sum = ||f(x0)||^2 (already all-reduced).
+// Publish the state to its mirror in pinned, device-mapped host memory: the image first, then -- behind a system-scope
+// fence -- its sequence number, which the host polls instead of waiting on the stream (a stream synchronisation costs a
+// copy-engine round trip plus an interrupt wake-up, tens of microseconds per decision point; a posted write over PCIe a few).
 template <typename T>
-__global__ void k_init_state(const T* sum, LmState<T>* st)
+__device__ inline void publish_state(const LmState<T>& s, LmState<T>* host_st, uint32_t seq)
+{
+    if (!host_st) return;
+    LmState<T> t = s;
+    t.seq = 0;
+    *host_st = t;
+    __threadfence_system();
+    *reinterpret_cast<volatile uint32_t*>(&host_st->seq) = seq;
+    __threadfence_system();
+}
+
+template <typename T>
+__global__ void k_init_state(const T* sum, LmState<T>* st, LmState<T>* host_st, uint32_t seq)
 {
     LmState<T> s{};
     s.lambda = 0;            // LS:966 (no warm start, quirk Q11)
     s.mu = 1;                // LS:969
     s.residual = *sum;       // LS:955
     *st = s;
+    publish_state(s, host_st, seq);
 }
 
 // ---- packed [JJ lower | Jy] -> full symmetric JJ, Jy, ||Jy||_inf (LS:1053).
@@ -175,12 +191,16 @@ struct DecideArgs {
     const T* dx_chain;  // ks x n
     T* dx_acc;          // n: accepted step, kept for the next Broyden update (LS:1004-1006)
     int n, ks, check_grad, lambda_from_state;
+    LmState<T>* host_st;  // pinned mirror (device-mapped) or nullptr
+    T* host_x;            // pinned, n: receives the accepted point
+    uint32_t seq;         // sequence number of this decision point
 };
 
 template <typename T>
 __global__ __launch_bounds__(kSolveThreads) void k_decide_chain(DecideArgs<T> a)
 {
     __shared__ int acc_s;
+    __shared__ LmState<T> s_pub;
     if (threadIdx.x == 0) {
         LmState<T> s = *a.st;
         int dec = kDecideReject, acc = -1;
@@ -239,15 +259,23 @@ __global__ __launch_bounds__(kSolveThreads) void k_decide_chain(DecideArgs<T> a)
         s.rejects = rejects; s.guards = guards; s.qp_active = qpact;
         s.null_tail = (dec == kDecideReject) ? null_tail : 0u;
         *a.st = s;
+        s_pub = s;
         acc_s = acc;
     }
     __syncthreads();
     const int acc = acc_s;
     if (acc >= 0) {
         for (int i = threadIdx.x; i < a.n; i += blockDim.x) {
-            a.x[i] = a.trial[(size_t)acc * a.n + i];                          // LS:1135
+            const T xv = a.trial[(size_t)acc * a.n + i];
+            a.x[i] = xv;                                                      // LS:1135
+            if (a.host_x) a.host_x[i] = xv;
             a.dx_acc[i] = a.dx_chain[(size_t)acc * a.n + i];
         }
+    }
+    if (a.host_st) {
+        __threadfence_system();          // the accepted point is in host memory before the state that announces it
+        __syncthreads();
+        if (threadIdx.x == 0) publish_state(s_pub, a.host_st, a.seq);
     }
 }
 

@@ -40,6 +40,8 @@ struct LmState {
     uint32_t fcalls;           // residual evaluations among them (LS:1112)
     uint32_t rejects, guards, qp_active;
     uint32_t null_tail;        // the last consumed trial of the round was a null step (trial == x): the next ones probably are too
+    uint32_t seq;              // host mirror only: number of the decision point this image belongs to (written last)
+    uint32_t pad1;
 };
 
 // One solve of the lambda ladder (chain step k): everything the acceptance logic needs about it.

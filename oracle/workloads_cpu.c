@@ -90,3 +90,18 @@ void wlc_exp_decay_f(void* vctx, size_t m, size_t n, const double* x, double* y)
         else y[i] = x[0] * exp(-c->t[i] / x[1]) + x[2] - c->data[i];
     }
 }
+
+/* ---- BASELINE cfg 5 family in float: p0 exp(-t p1) + p2 + p3 sin 2t + p4 cos 2t + p5 sin 5t + p6 cos 5t + p7 t - data
+ *      (the expression of BatchedModel<kModelExpDecayPad8> in mir_optim_amd/csrc/batched_kernel.h, evaluated with libm) ---- */
+typedef struct { const float* t; const float* data; } wlc_curve_ctx_s;
+
+void wlc_exp_pad8_f_s(void* vctx, size_t m, size_t n, const float* x, float* y)
+{
+    const wlc_curve_ctx_s* c = (const wlc_curve_ctx_s*)vctx;
+    (void)n;
+    for (size_t i = 0; i < m; ++i) {
+        const float t = c->t[i];
+        y[i] = x[0] * expf(-t * x[1]) + x[2] + x[3] * sinf(2.0f * t) + x[4] * cosf(2.0f * t) + x[5] * sinf(5.0f * t)
+             + x[6] * cosf(5.0f * t) + x[7] * t - c->data[i];
+    }
+}

@@ -9,10 +9,10 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 args="--steps 4 --warmup 1 --no-cpu-baseline --survey-steps 0 $*"
-rocprofv3 --kernel-trace --stats -d "$out/stats" -o stats -- python3 "$root/bench.py" $args > "$out/stats.log" 2>&1 || exit 1
+rocprofv3 --output-format csv --kernel-trace --stats -d "$out/stats" -o stats -- python3 "$root/bench.py" $args > "$out/stats.log" 2>&1 || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace -d "$out/pmc_$c" -o pmc -- python3 "$root/bench.py" $args > "$out/pmc_$c.log" 2>&1 || exit 1
+    rocprofv3 --output-format csv --pmc $c --kernel-trace -d "$out/pmc_$c" -o pmc -- python3 "$root/bench.py" $args > "$out/pmc_$c.log" 2>&1 || exit 1
 done
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --kernel-trace -d "$out/pmc_MFMA" -o pmc \
+rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --kernel-trace -d "$out/pmc_MFMA" -o pmc \
     -- python3 "$root/bench.py" $args > "$out/pmc_MFMA.log" 2>&1 || exit 1
 find "$out" -name "*.csv" | head -20
