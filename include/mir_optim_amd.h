@@ -370,6 +370,7 @@ void* mir_lsq_device_malloc(size_t bytes);
 void mir_lsq_device_free(void* p);
 int mir_lsq_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes, void* stream);
 int mir_lsq_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes, void* stream);
+int mir_lsq_memcpy_d2d(void* dst_device, const void* src_device, size_t bytes, void* stream);   /* asynchronous */
 void* mir_lsq_stream_create(void);
 void mir_lsq_stream_destroy(void* stream);
 int mir_lsq_stream_synchronize(void* stream);

@@ -277,7 +277,7 @@ def lib():
         L.mir_lsq_device_malloc.restype = C.c_void_p
         L.mir_lsq_device_malloc.argtypes = [sz]
         L.mir_lsq_device_free.argtypes = [C.c_void_p]
-        for name in ("mir_lsq_memcpy_h2d", "mir_lsq_memcpy_d2h"):
+        for name in ("mir_lsq_memcpy_h2d", "mir_lsq_memcpy_d2h", "mir_lsq_memcpy_d2d"):
             getattr(L, name).restype = C.c_int
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, sz, C.c_void_p]
         L.mir_lsq_stream_create.restype = C.c_void_p

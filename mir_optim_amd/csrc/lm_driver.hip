@@ -1587,6 +1587,10 @@ int mir_lsq_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream)
     if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
     return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;
 }
+int mir_lsq_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream)
+{
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)) == hipSuccess ? 0 : -1;
+}
 void* mir_lsq_stream_create(void)
 {
     hipStream_t s = nullptr;

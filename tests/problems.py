@@ -114,3 +114,25 @@ def gauss_sum(m, K=5, noise=1e-3):
     lower[2 * K:3 * K] = 1e-3
     upper = np.full(n, INF)
     return dict(t=t, data=data, truth=truth, x0=x0, lower=lower, upper=upper, m=m, n=n, K=K)
+
+
+def cfg5_pad8(count, m=512, noise=0.01):
+    """BASELINE cfg 5: `count` independent fp32 fits of m points, n = 8 (the exponential decay
+    p0 exp(-t p1) + p2 padded to n = 8 with five terms linear in their parameters; per-problem seed = 100 + problem id).
+    Returns (t[m], data[count, m], truth[count, 8], x0[count, 8]) in float32."""
+    t = np.linspace(0.0, 4.0, m, dtype=np.float32)
+    td = t.astype(np.float64)
+    data = np.empty((count, m), dtype=np.float32)
+    truth = np.empty((count, 8), dtype=np.float32)
+    x0 = np.empty((count, 8), dtype=np.float32)
+    basis = np.stack([np.sin(2 * td), np.cos(2 * td), np.sin(5 * td), np.cos(5 * td), td])
+    for k in range(count):
+        u = splitmix64_uniform(100 + k, m + 16)
+        p = np.array([1.0 + u[0], 0.5 + 2.0 * u[1], 0.2 * u[2], 0.6 * u[3] - 0.3, 0.6 * u[4] - 0.3, 0.6 * u[5] - 0.3,
+                      0.6 * u[6] - 0.3, 0.1 * u[7] - 0.05])
+        truth[k] = p
+        data[k] = p[0] * np.exp(-td * p[1]) + p[2] + p[3:] @ basis + noise * (2 * u[16:] - 1)
+        x0[k] = p
+        x0[k, :2] *= 1 + 0.2 * (2 * u[8:10] - 1)
+        x0[k, 2:] += 0.1 * (2 * u[10:16] - 1)
+    return t, data, truth, x0

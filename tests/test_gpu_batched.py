@@ -115,3 +115,41 @@ def test_batched_validation_codes():
     s = M.LeastSquaresSettings(np.float32); s.minStepQuality = 2.0
     res, x = M.optimizeLeastSquaresBatched(M.MODEL_EXP_DECAY, np.nan_to_num(x0, nan=1.0), t, data, settings=s)
     assert all(r.status == M.LeastSquaresStatus.badMinStepQuality for r in res)
+
+
+def test_cfg5_pad8_all_4096_problems_match_the_float_oracle(oracle):
+    """BASELINE cfg 5 as specified: 4096 independent fits, m = 512, n = 8, fp32, jacobianEpsilon = 2^-11, the
+    well-conditioned exponential-decay family padded to n = 8, per-problem seed 100 + id. EVERY problem is compared with
+    the oracle's float instantiation (native float callback evaluating the same expression with libm).
+    fp32 tolerance, stated: the two sides round differently (wave-parallel vs sequential sums, device vs host expf/sinf)
+    and stop on the flat bottom of a noisy fit, where a parameter moves by ~2e-3 between the float and the DOUBLE oracle;
+    so per problem |x_gpu - x_oracle| <= 1e-2 max(1, |x|), residual rtol 1e-3, and over the set the median difference
+    must be an order of magnitude smaller."""
+    import ctypes as C
+
+    class Ctx(C.Structure):
+        _fields_ = [("t", C.c_void_p), ("data", C.c_void_p)]
+    count = 4096
+    t, data, truth, x0 = P.cfg5_pad8(count)
+    res, x = M.optimizeLeastSquaresBatched(M.MODEL_EXP_DECAY_PAD8, x0, t, data)
+    st = np.array([int(r.status) for r in res])
+    resid = np.array([r.residual for r in res])
+    assert np.all(st >= 0), np.unique(st, return_counts=True)             # well conditioned: no numericError anywhere
+    f = oracle.native_fn("wlc_exp_pad8_f_s")
+    xo = np.empty_like(x)
+    ro_res = np.empty(count)
+    ro_st = np.empty(count, dtype=int)
+    for k in range(count):
+        d = np.ascontiguousarray(data[k])
+        ctx = Ctx(t.ctypes.data, d.ctypes.data)
+        ro, xk = oracle.optimize(f, 512, x0[k], dtype=np.float32, fctx=C.addressof(ctx))
+        xo[k], ro_res[k], ro_st[k] = xk, ro.residual, ro.status
+    assert np.all(ro_st >= 0)
+    err = np.abs(x - xo) / np.maximum(1.0, np.abs(xo))
+    assert err.max() <= 1e-2, (err.max(), np.unravel_index(err.argmax(), err.shape))
+    assert np.median(err.max(axis=1)) <= 1e-3
+    assert np.allclose(resid, ro_res, rtol=1e-3, atol=0)
+    noise_floor = 512 * (0.01 ** 2) / 3
+    assert abs(np.mean(resid) / noise_floor - 1) < 0.05                    # and both sit on the noise floor of the data
+    it = np.array([r.iterations for r in res])
+    assert it.min() >= 2 and it.max() < 1000
