@@ -73,9 +73,10 @@ def traffic_source(m, n):
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", choices=["cfg3", "cfg5"], default="cfg3",
-                    help="cfg3: the headline (BASELINE.json metric). cfg5: BASELINE config 5, 4096 independent fp32 fits of "
-                         "m = 512 x n = 8, one wavefront per problem (an additional line; replicas only at N > 1)")
+    ap.add_argument("--config", choices=["cfg3", "cfg2", "cfg5"], default="cfg3",
+                    help="cfg3: the headline (BASELINE.json metric). cfg2: BASELINE config 2, Gaussian-sum fit m = 1e5 x n = 16 fp64 "
+                         "(launch-latency bound). cfg5: BASELINE config 5, 4096 independent fp32 fits of m = 512 x n = 8, one "
+                         "wavefront per problem. cfg2 / cfg5 print additional lines (one GPU; replicas only at N > 1)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
@@ -201,10 +202,79 @@ def main_cfg5(args):
     print(json.dumps(out), flush=True)
 
 
+def main_cfg2(args):
+    """BASELINE cfg 2: Gaussian-sum curve fit, m = 1e5 residuals x n = 16 parameters, fp64, width bounds, FD Jacobian through
+    the single-point device callback. J is 12.8 MB: every kernel of a pass is a few microseconds, so the solve is
+    bound by launch latency and host round trips, not by HBM or MFMA -- the line reports the time per pass and per launch."""
+    import numpy as np
+    import torch
+
+    import mir_optim_amd as M
+    from mir_optim_amd import api, workloads as W
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import problems as P
+
+    if not torch.cuda.is_available() or M.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: mir_optim_amd has no CPU path")
+    g = P.gauss_sum(100000, K=5)
+    prob = W.Curve("gauss_sum", g["t"], g["data"])
+    ws = api.lib().mir_lsq_workspace_create(g["m"], g["n"], 8)
+    for _ in range(max(1, args.warmup)):
+        res, x = prob.solve(g["x0"], g["lower"], g["upper"], workspace=ws)
+    st = M.Stats()
+    iters = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, x = prob.solve(g["x0"], g["lower"], g["upper"], workspace=ws, stats=st, flags=M.TIME_KERNELS)
+        iters += res.iterations
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    d = st.as_dict()
+    K = args.steps
+    m, n = g["m"], g["n"]
+    rounds = d["solve_launches"] / K
+    out = {
+        "metric": "LM iterations/sec", "value": iters / dt, "unit": "iterations/s", "n_gpus": 1, "steps": K, "warmup": args.warmup,
+        "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"cfg2 Gaussian-sum fit m={m} x n={n} fp64, width bounds, FD Jacobian (single-point device callback), "
+                               "default settings, whole solves",
+                   "iterations_per_solve": iters / K, "passes_per_solve": d["passes"] / K, "rounds_per_solve": rounds,
+                   "fcalls_per_solve": res.fCalls, "status": res.status.name, "residual": res.residual,
+                   "qp_active_set_passes_per_solve": d["qp_active_set_passes"] / K,
+                   "us_per_round": dt / K / max(1.0, rounds) * 1e6,
+                   "time_split_ms_per_solve": {"caller_fd_callbacks": d["fd_callback_ms"] / K, "caller_trial_callbacks": d["trial_callback_ms"] / K,
+                                               "jtj_kernels": d["jtj_ms"] / K, "solve_kernel": d["solve_ms"] / K, "total": d["total_ms"] / K},
+                   "parallelism": "replicas only at N > 1 (the problem is too small to shard)"},
+        "roofline": {"kernel": "mirlsq::k_lm_solve<double, 1, true> (the n = 16 damped BOXCQP solve; the longest library kernel of a round)",
+                     "bound": "latency", "achieved": None, "peak": None, "unit": "us", "frac": None,
+                     "avg_launch_ms": d["solve_ms"] / max(1, d["solve_launches"]), "launches": d["solve_launches"], "traffic": None,
+                     "note": "launch-latency bound: J^T J at n = 16 is 2 flop/B (SURVEY 8d) and J is 12.8 MB -- every kernel of a "
+                             "round runs for microseconds; the figure of merit is us_per_round"},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import oracle as O
+        ctx = O.GaussSumCtx(g["t"].ctypes.data, g["data"].ctypes.data)
+        t1 = time.perf_counter()
+        ro, xo = O.optimize(O.native_fn("wlc_gauss_sum_f"), m, g["x0"], lower=g["lower"], upper=g["upper"], fctx=C.addressof(ctx))
+        dtc = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": ro.iterations / dtc, "unit": "iterations/s", "cores": int(os.environ.get("OMP_NUM_THREADS", "1")),
+                               "host_nproc": os.cpu_count(), "kind": "port",
+                               "sample": f"the whole solve ({ro.iterations} iterations, fCalls {ro.fCalls}, status {O.STATUS.get(ro.status)}), {dtc:.2f} s, "
+                                         "plain-loop BLAS, OpenMP residuals",
+                               "parity_x_max_abs_diff": float(np.abs(np.asarray(x) - np.asarray(xo)).max()),
+                               "parity_residual_rel_diff": abs(res.residual - ro.residual) / abs(ro.residual)}
+    api.lib().mir_lsq_workspace_destroy(ws)
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
     if args.config == "cfg5":
         return main_cfg5(args)
+    if args.config == "cfg2":
+        os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 16)))
+        return main_cfg2(args)
     os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 64)))   # CPU baseline leg (oracle, OpenMP)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -124,6 +124,12 @@ size_t mir_least_squares_iwork_length(size_t m, size_t n);
 size_t mir_box_qp_work_length(size_t n);
 /* QP:47-50 */
 size_t mir_box_qp_iwork_length(size_t n);
+/* The same two integer-workspace lengths for builds of the reference with 64-bit `lapackint` (the `*-ilp` dub
+ * configurations, dub.sdl:26-80; QP:49 divides by lapackint.sizeof). This library never dereferences iwork, so an ILP64
+ * caller only needs lengths that match what its own allocation code expects; every other symbol is layout-identical
+ * (Slice!(lapackint*) is {size_t, pointer} for either width). */
+size_t mir_box_qp_iwork_length_ilp64(size_t n);
+size_t mir_least_squares_iwork_length_ilp64(size_t m, size_t n);
 /* LS:666-669 (strings LS:528-557) */
 const char* mir_least_squares_status_string(mir_least_squares_status st);
 /* LS:761-770 */

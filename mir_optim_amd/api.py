@@ -226,6 +226,10 @@ def lib():
         for name in ("mir_box_qp_work_length", "mir_box_qp_iwork_length"):
             getattr(L, name).restype = sz
             getattr(L, name).argtypes = [sz]
+        L.mir_box_qp_iwork_length_ilp64.restype = sz
+        L.mir_box_qp_iwork_length_ilp64.argtypes = [sz]
+        L.mir_least_squares_iwork_length_ilp64.restype = sz
+        L.mir_least_squares_iwork_length_ilp64.argtypes = [sz, sz]
         L.mir_least_squares_status_string.restype = C.c_char_p
         L.mir_least_squares_status_string.argtypes = [C.c_int]
         for suf, S, R in (("d", _Sd, _Rd), ("s", _Ss, _Rs)):

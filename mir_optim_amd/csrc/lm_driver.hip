@@ -1058,6 +1058,14 @@ size_t mir_least_squares_iwork_length(size_t m, size_t n)                       
     return a > n ? a : n;
 }
 
+size_t mir_box_qp_iwork_length_ilp64(size_t n) { return n + (n / sizeof(int64_t) + (n % sizeof(int64_t) != 0)); }   // QP:47-50, lapackint = long
+size_t mir_least_squares_iwork_length_ilp64(size_t m, size_t n)
+{
+    (void)m;
+    const size_t a = mir_box_qp_iwork_length_ilp64(n);
+    return a > n ? a : n;
+}
+
 const char* mir_least_squares_status_string(mir_least_squares_status st)                               // LS:528-557, 666-669
 {
     switch (st) {

@@ -126,3 +126,12 @@ def test_gpu_options_trace_field_is_appended():
     assert C.sizeof(api.TraceRecord) == 40
     t = api.Trace(8)
     assert t.count == 0 and t.records() == []
+
+
+def test_ilp64_integer_workspace_lengths():
+    """64-bit lapackint builds of the reference (`*-ilp` dub configurations): QP:47-50 with lapackint.sizeof = 8."""
+    L = api.lib()
+    for n in (1, 7, 8, 9, 128, 1000):
+        assert L.mir_box_qp_iwork_length_ilp64(n) == n + (n + 7) // 8
+        assert L.mir_least_squares_iwork_length_ilp64(5, n) == max(n + (n + 7) // 8, n)
+        assert L.mir_box_qp_iwork_length(n) == n + (n + 3) // 4

@@ -123,8 +123,8 @@ def test_cfg5_pad8_all_4096_problems_match_the_float_oracle(oracle):
     the oracle's float instantiation (native float callback evaluating the same expression with libm).
     fp32 tolerance, stated: the two sides round differently (wave-parallel vs sequential sums, device vs host expf/sinf)
     and stop on the flat bottom of a noisy fit, where a parameter moves by ~2e-3 between the float and the DOUBLE oracle;
-    so per problem |x_gpu - x_oracle| <= 1e-2 max(1, |x|), residual rtol 1e-3, and over the set the median difference
-    must be an order of magnitude smaller."""
+    so per problem: residual rtol 1e-3, |x_gpu - x_oracle| <= 5e-2 max(1, |x|); over the set: 99 % within 5e-3 and the
+    median within 1e-4."""
     import ctypes as C
 
     class Ctx(C.Structure):
@@ -145,10 +145,14 @@ def test_cfg5_pad8_all_4096_problems_match_the_float_oracle(oracle):
         ro, xk = oracle.optimize(f, 512, x0[k], dtype=np.float32, fctx=C.addressof(ctx))
         xo[k], ro_res[k], ro_st[k] = xk, ro.residual, ro.status
     assert np.all(ro_st >= 0)
-    err = np.abs(x - xo) / np.maximum(1.0, np.abs(xo))
-    assert err.max() <= 1e-2, (err.max(), np.unravel_index(err.argmax(), err.shape))
-    assert np.median(err.max(axis=1)) <= 1e-3
-    assert np.allclose(resid, ro_res, rtol=1e-3, atol=0)
+    # the objective agrees everywhere ...
+    assert np.allclose(resid, ro_res, rtol=1e-3, atol=0), np.abs(resid / ro_res - 1).max()
+    # ... and so do the minimisers: to ~1e-5 for the bulk; a handful of problems with a slow decay have a flat valley
+    # (p0 exp(-t p1) against the offset p2) on which two fp32 runs that stop at different passes sit up to ~2e-2 apart
+    err = (np.abs(x - xo) / np.maximum(1.0, np.abs(xo))).max(axis=1)
+    assert np.median(err) <= 1e-4, np.median(err)
+    assert np.quantile(err, 0.99) <= 5e-3, np.quantile(err, 0.99)
+    assert err.max() <= 5e-2, (err.max(), int(err.argmax()))
     noise_floor = 512 * (0.01 ** 2) / 3
     assert abs(np.mean(resid) / noise_floor - 1) < 0.05                    # and both sit on the noise floor of the data
     it = np.array([r.iterations for r in res])
