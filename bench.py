@@ -486,7 +486,8 @@ def main():
                                          "frac": tf / F64_MFMA_PEAK_TF, "avg_call_ms": ms, "calls": st["fd_callback_calls"],
                                          "points_per_call": pts, "algorithmic_bytes_per_call": by,
                                          "algorithmic_GBs": by / (ms * 1e-3) / 1e9,
-                                         "traffic": pmc_field("k_tanh_linear_batched_dma", m, n, "hbm_bytes_per_launch"),
+                                         "traffic": pmc_field(f"k_tanh_linear_batched_dma<{n // 4}, true>", m, n, "hbm_bytes_per_launch"),
+                                         "mfma_util_pmc": pmc_field(f"k_tanh_linear_batched_dma<{n // 4}, true>", m, n, "mfma_util"),
                                          "traffic_source": traffic_source(m, n)}
         if st["trial_callback_calls"]:
             ms = st["trial_callback_ms"] / st["trial_callback_calls"]

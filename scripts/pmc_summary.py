@@ -10,7 +10,7 @@ import collections, csv, glob, json, os, sys
 src, dst = sys.argv[1], sys.argv[2]
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    files = glob.glob(os.path.join(src, f"pmc_{c}", "*", "*counter_collection.csv"))
+    files = glob.glob(os.path.join(src, f"pmc_{c}", "**", "*counter_collection.csv"), recursive=True)
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(files[0])):
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
@@ -19,7 +19,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, (n, v) in agg.items():
         out.setdefault(k, {})[c + "_KB_per_launch"] = v / n
         out[k]["launches_" + c] = n
-mf = glob.glob(os.path.join(src, "pmc_MFMA", "*", "*counter_collection.csv"))
+mf = glob.glob(os.path.join(src, "pmc_MFMA", "**", "*counter_collection.csv"), recursive=True)
 if mf:
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(mf[0])):
@@ -39,7 +39,7 @@ for k, d in out.items():
     d["hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0          # FETCH_SIZE doubled: gfx950 correction
 os.makedirs(dst, exist_ok=True)
 json.dump({"note": "rocprofv3 --pmc, separate passes; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024; "
-                   "command: bench.py --steps 2 --warmup 1 --no-cpu-baseline (cfg3, m=1e6, n=128)",
+                   "command: scripts/profile_bench.sh (bench.py --steps 4 --warmup 1 --no-cpu-baseline --survey-steps 0; cfg3, m=1e6, n=128)",
            "kernels": out}, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 for k in sorted(out, key=lambda k: -out[k]["hbm_bytes_per_launch"])[:8]:
     print(f"{k[:60]:60s} {out[k]['hbm_bytes_per_launch'] / 1e9:8.3f} GB/launch   MFMA util {out[k].get('mfma_util', 0.0):.3f}")
