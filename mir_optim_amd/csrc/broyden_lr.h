@@ -49,6 +49,7 @@ struct LrArgs {
     size_t m;
     int n;
     int k;
+    const int32_t* guard;   // optional: the kernel does nothing when *guard == 0 (rounds enqueued ahead of time)
 };
 
 template <typename T, int NCP, bool VEC>
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(256) void k_broyden_lr(const LrArgs<T> a)
     const int q = lane >> 4, p = lane & 15;
     const int n = a.n, k = a.k;
     const size_t m = a.m;
+    if (a.guard && *a.guard == 0) return;
 
     // coef[l] = D_l . dx for the pending columns (wave w takes l = w, w + 4, ...)
     for (int l = wave; l < k; l += 4) {
@@ -162,8 +164,10 @@ __global__ __launch_bounds__(256) void k_broyden_lr(const LrArgs<T> a)
 
 // sum the per-block partial vectors in a fixed order: blockDim = 256 = 32 entries x 8 block ranges
 template <typename T>
-__global__ __launch_bounds__(256) void k_lr_reduce(const T* __restrict__ partials, int nparts, int len, T* __restrict__ out)
+__global__ __launch_bounds__(256) void k_lr_reduce(const T* __restrict__ partials, int nparts, int len, T* __restrict__ out,
+                                                   const int32_t* guard = nullptr)
 {
+    if (guard && *guard == 0) return;
     __shared__ T part[8][32];
     const int es = threadIdx.x & 31, sp = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + es;
@@ -188,8 +192,10 @@ __global__ __launch_bounds__(256) void k_lr_reduce(const T* __restrict__ partial
 // D_k = dx (block n). `lr` is the (all-reduced) vector of k_lr_reduce.
 template <typename T>
 __global__ __launch_bounds__(256) void k_lr_finish(const T* __restrict__ lr, T* __restrict__ D, const T* __restrict__ dx,
-                                                   int k, int n, T* __restrict__ JJ, T* __restrict__ Jy, LmState<T>* st)
+                                                   int k, int n, T* __restrict__ JJ, T* __restrict__ Jy, LmState<T>* st,
+                                                   const int32_t* guard = nullptr)
 {
+    if (guard && *guard == 0) return;
     __shared__ T v[kLrMaxN];
     __shared__ T red[4];
     const T* __restrict__ w = lr + 2 * n;

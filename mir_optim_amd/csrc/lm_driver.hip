@@ -197,7 +197,7 @@ mir_lsq_workspace* workspace_create(size_t m, size_t n)
     if (hipGetDevice(&ws->device) != hipSuccess) ws->device = 0;
     if (hipMalloc(&ws->ulr, (size_t)kLrMax * m * sizeof(T)) != hipSuccess
         || hipMalloc(&ws->ytrial, (size_t)kChainMax * m * sizeof(T)) != hipSuccess
-        || hipHostMalloc(&ws->pinned, sizeof(LmState<T>) + (2 * n + 8) * sizeof(T), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
+        || hipHostMalloc(&ws->pinned, 2 * sizeof(LmState<T>) + (3 * n + 8) * sizeof(T), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
         || hipHostGetDevicePointer(&ws->pinned_dev, ws->pinned, 0) != hipSuccess) {
         std::fprintf(stderr, "[mir_optim_amd] workspace side buffers: allocation failed\n");
         workspace_destroy(ws);
@@ -269,19 +269,31 @@ struct Solver {
     // Everything that touches them goes through these members (never through B.y / B.mB directly).
     T* y = nullptr;
     T* mB = nullptr;
+    T* fr = nullptr;     // third m-vector: the trial residual of a round goes here; accepting rotates (y, mB, fr) <- (fr, y, mB)
     // null steps (trial == x bit for bit; kFlagNullStep): once a round ended on one, the next round's solves are looked
     // at before the callbacks are launched, and when every entry is a null step nothing is evaluated
     bool has_bounds = true;    // some lower / upper entry is finite (set in run()); MIR_LSQ_SOLVE_BOUNDED=1 forces the full kernel
     bool tail_null = false;
+    // ---- rounds enqueued ahead of time (pipelining of the host): while the GPU runs round r, the host already enqueues
+    // the round that follows IF r is accepted without any exit test firing -- Broyden sweep, solve, trial residual,
+    // decision -- behind a device-side guard (LmState::spec_ok, set by k_decide_chain of round r). If r ends differently the
+    // guarded kernels return at once and the host enqueues the right round as before. Results are bit-identical with and
+    // without it (MIR_LSQ_VARIANT_NO_PIPELINE); what disappears is the launch latency between accepted rounds.
+    bool spec_enqueue = false;     // set while the kernels of such a round are being enqueued
+    bool pipeline = true;          // allowed at all for this solve (see setup())
+    size_t spec_events_from = 0;   // events of the round enqueued ahead of time start here
     int f_in_lds = 0;
     bool big_solve = false;    // n > 256 (or MIR_LSQ_VARIANT_SOLVE_GENERIC): the any-n solve kernel
     int solve_nb_ = 0;
     size_t solve_lds = 0;
 
-    LmState<T>* st_h;      // pinned mirror
-    LmState<T>* st_hd = nullptr;   // its device address
-    T* trial_hd = nullptr;         // device address of trial_h
-    uint32_t seq = 0;              // decision points published so far
+    LmState<T>* st_h;      // pinned mirror of the decision point being processed (one of st_slot[])
+    LmState<T>* st_slot[2] = {nullptr, nullptr};     // the two mirrors, host and device addresses
+    LmState<T>* st_slot_d[2] = {nullptr, nullptr};
+    T* x_slot[2] = {nullptr, nullptr};               // accepted point of decision point seq at x_slot[seq & 1]
+    T* x_slot_d[2] = {nullptr, nullptr};
+    T* x_h = nullptr;              // x mirror of the decision point being processed
+    uint32_t seq = 0;              // decision points enqueued so far
     T* trial_h;            // pinned, n
     std::vector<T> twh_h;
     std::vector<EventPair> events;
@@ -319,7 +331,7 @@ struct Solver {
         if (!time_kernels) return;
         HpScope hp(this, 0);
         EventPair p{};
-        p.kind = kind;
+        p.kind = spec_enqueue ? kind + 100 : kind;       // rounds enqueued ahead of time: counted only once they are committed
         (void)hipEventCreate(&p.a);
         (void)hipEventCreate(&p.b);
         (void)hipEventRecord(p.a, stream);
@@ -350,11 +362,17 @@ struct Solver {
         plan = jtj_plan<T>(m, (int)n, ws->num_cu, variant);
         B = carve<T>(ws->dev, m, n, ws->num_cu);
         device = ws->device;
-        st_h = reinterpret_cast<LmState<T>*>(ws->pinned);
-        st_hd = reinterpret_cast<LmState<T>*>(ws->pinned_dev);
-        trial_hd = reinterpret_cast<T*>(static_cast<char*>(ws->pinned_dev) + sizeof(LmState<T>));
-        st_h->seq = 0;
-        trial_h = reinterpret_cast<T*>(static_cast<char*>(ws->pinned) + sizeof(LmState<T>));
+        // pinned block: [state mirror 0 | state mirror 1 | x mirror 0 | x mirror 1 | staging vector]; decision point `seq`
+        // is published into mirror seq & 1, so a round enqueued ahead of time cannot overwrite the one the host still reads
+        for (int k = 0; k < 2; ++k) {
+            st_slot[k] = reinterpret_cast<LmState<T>*>(ws->pinned) + k;
+            st_slot_d[k] = reinterpret_cast<LmState<T>*>(ws->pinned_dev) + k;
+            x_slot[k] = reinterpret_cast<T*>(static_cast<char*>(ws->pinned) + 2 * sizeof(LmState<T>)) + (size_t)k * n;
+            x_slot_d[k] = reinterpret_cast<T*>(static_cast<char*>(ws->pinned_dev) + 2 * sizeof(LmState<T>)) + (size_t)k * n;
+            st_slot[k]->seq = 0;
+        }
+        st_h = st_slot[0];
+        trial_h = reinterpret_cast<T*>(static_cast<char*>(ws->pinned) + 2 * sizeof(LmState<T>)) + 2 * (size_t)n;   // staging vector
         if (!stream) {
             if (!ok(hipStreamCreate(&stream), "hipStreamCreate")) return false;
             own_stream = true;
@@ -376,8 +394,11 @@ struct Solver {
         }
         y = B.y;
         mB = B.mB;
+        fr = B.ytmp;
         big_solve = n > (uint32_t)kSolveMaxN || (variant & MIR_LSQ_VARIANT_SOLVE_GENERIC) != 0;
         if (n > (uint32_t)kLrMaxN) lowrank = false;    // the read-only Broyden sweep keeps n <= 256; above, J is rewritten
+        pipeline = device_cb && lowrank && !big_solve && !trace && !dbg_solve && !(variant & MIR_LSQ_VARIANT_NO_PIPELINE)
+            && (!comm || comm->kind == 1);      // host-mediated communicators synchronise the stream inside every exchange
         solve_nb_ = solve_nb((int)n, (int)sizeof(T));
         f_in_lds = solve_nb_ > 0;
         solve_lds = solve_lds_bytes((int)n, (int)sizeof(T));
@@ -395,6 +416,7 @@ struct Solver {
                                  "longest single call %.3f\n", hp_ms[0], hp_ms[1], hp_ms[2], hp_ms[3], hp_ms[4], hp_ms[5]);
         if (stats) {
             for (auto& e : events) {
+                if (e.kind < 0 || e.kind >= 100) continue;       // a round enqueued ahead of time whose guard stayed closed
                 float ms = 0;
                 (void)hipEventElapsedTime(&ms, e.a, e.b);
                 if (e.kind == 0) { stats->jtj_ms += ms; stats->jtj_launches++; }
@@ -481,7 +503,7 @@ struct Solver {
     bool allreduce(T* buf, size_t count, int kind)
     {
         HpScope hp(this, 1);
-        if (stats) { stats->allreduce_calls[kind]++; stats->allreduce_elems[kind] += count; }
+        if (stats && !spec_enqueue) { stats->allreduce_calls[kind]++; stats->allreduce_elems[kind] += count; }
         return comm_allreduce<T>(comm, buf, count, stream) == 0;
     }
 
@@ -523,6 +545,8 @@ struct Solver {
     bool wait_state(uint32_t expect)
     {
         HpScope hp(this, 3);
+        st_h = st_slot[expect & 1];
+        x_h = x_slot[expect & 1];
         volatile uint32_t* sq = &st_h->seq;
         for (uint64_t spins = 0;; ++spins) {
             if (*sq == expect) break;
@@ -568,18 +592,23 @@ struct Solver {
                 if (stats) stats->jtj_resyncs++;
             }
         }
+        // spec_enqueue: the pass is enqueued behind the device-side guard before the host knows whether it will be needed; the
+        // host-side bookkeeping (lr_k, statistics) is done when the round is committed (commit_spec_round)
+        const int32_t* guard = spec_enqueue ? &B.st->spec_ok : nullptr;
         LrArgs<T> a{};
         a.J = B.J; a.U = U; a.D = B.lrD; a.dx = B.dx_acc; a.dx_dot = &B.st->dx_dot; a.y = y_dev; a.y_old = yold_dev;
-        a.partials = B.lrpart; a.m = m; a.n = (int)n; a.k = lr_k;
+        a.partials = B.lrpart; a.m = m; a.n = (int)n; a.k = lr_k; a.guard = guard;
         const int nblk = lr_blocks(m, ws->num_cu), len = lr_len((int)n);
         ev_begin(1);
         if (!ok(lr_sweep<T>(a, nblk, stream), "broyden sweep")) return false;
         ev_end();
-        hipLaunchKernelGGL(k_lr_reduce<T>, dim3((len + 31) / 32), dim3(256), 0, stream, B.lrpart, nblk, len, B.lrvec);
+        hipLaunchKernelGGL(k_lr_reduce<T>, dim3((len + 31) / 32), dim3(256), 0, stream, B.lrpart, nblk, len, B.lrvec, guard);
         if (comm && !allreduce(B.lrvec, (size_t)len, 1)) return false;
-        hipLaunchKernelGGL(k_lr_finish<T>, dim3(n + 1), dim3(256), 0, stream, B.lrvec, B.lrD, B.dx_acc, lr_k, (int)n, B.JJ, B.Jy, B.st);
-        if (stats) stats->broyden_lr_columns += (uint64_t)lr_k;
-        ++lr_k;
+        hipLaunchKernelGGL(k_lr_finish<T>, dim3(n + 1), dim3(256), 0, stream, B.lrvec, B.lrD, B.dx_acc, lr_k, (int)n, B.JJ, B.Jy, B.st, guard);
+        if (!spec_enqueue) {
+            if (stats) stats->broyden_lr_columns += (uint64_t)lr_k;
+            ++lr_k;
+        }
         return ok(hipGetLastError(), "broyden finish");
     }
 
@@ -734,18 +763,18 @@ struct Solver {
             p[j] = save;
         }
         // Staging: the CURRENT mBuffer (it holds y_old, which is dead while the Jacobian is refreshed in full: the next
-        // Broyden update only comes after another accepted step has rewritten it) and the spare m-vector -- never the live
-        // residual `y`, whichever of the two physical buffers it is in after the role swaps of the accepted steps.
+        // Broyden update only comes after another accepted step has rewritten it) and the free m-vector `fr` -- never the
+        // live residual `y`, whichever of the three physical buffers it is in after the rotations of the accepted steps.
         std::lock_guard<std::mutex> lk(fd_mutex);
         if (twh != 0) {
             if (hipMemcpyAsync(mB, s->yp, m * sizeof(T), hipMemcpyHostToDevice, stream) != hipSuccess
-                || hipMemcpyAsync(B.ytmp, s->ym, m * sizeof(T), hipMemcpyHostToDevice, stream) != hipSuccess) {
+                || hipMemcpyAsync(fr, s->ym, m * sizeof(T), hipMemcpyHostToDevice, stream) != hipSuccess) {
                 fd_failed = true;
                 return;
             }
         }
         hipLaunchKernelGGL(k_fd_fill_col<T>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream,
-                           mB, B.ytmp, twh, B.J, m, (int)n, (int)j);
+                           mB, fr, twh, B.J, m, (int)n, (int)j);
         if (hipStreamSynchronize(stream) != hipSuccess) fd_failed = true;
     }
     bool fd_host()
@@ -774,6 +803,84 @@ struct Solver {
         }
         ret.gCalls += 1;                                             // LS:1014
         return true;
+    }
+
+    // the n x n part of a round (LS:1053-1110, 1141-1142) for ks ladder entries
+    bool enqueue_solve(int ks, const T* lam, bool check_grad, bool lambda_from_state)
+    {
+        LmSolveArgs<T> a{};
+        a.JJ = B.JJ; a.Jy = B.Jy; a.x = B.x; a.lower = B.lower; a.upper = B.upper;
+        a.dx = B.dx; a.trial = B.trial; a.st = B.st; a.rec = B.rec; a.set = sd; a.n = (int)n;
+        for (int k = 0; k < kChainMax; ++k) { a.sc[k] = B.sc[k]; a.lam[k] = (lam && k < ks) ? lam[k] : T(0); }
+        a.f_in_lds = f_in_lds;
+        a.check_grad = check_grad ? 1 : 0;
+        a.lambda_from_state = lambda_from_state ? 1 : 0;
+        a.lambda_from_device = spec_enqueue ? 1 : 0;
+        a.guard = spec_enqueue ? &B.st->spec_ok : nullptr;
+        if (!dbg_solve) a.sc[0].dbg = nullptr;
+        ev_begin(2);
+        {
+            HpScope hp(this, 4);
+            if (!ok(launch_solve(a, ks), "solve launch")) return false;
+        }
+        ev_end();
+        return true;
+    }
+
+    // the decision of a round (LS:1080-1161) for ks trials whose sums of squares are in B.sum + 1; publishes decision point ++seq
+    bool enqueue_decide(int ks, bool check_grad, bool lambda_from_state, bool next_round_enqueued_ahead)
+    {
+        DecideArgs<T> d{};
+        d.sums = B.sum + 1; d.rec = B.rec; d.st = B.st; d.set = sd; d.x = B.x; d.trial = B.trial; d.dx_chain = B.dx;
+        d.dx_acc = B.dx_acc; d.n = (int)n; d.ks = ks; d.check_grad = check_grad ? 1 : 0;
+        d.lambda_from_state = lambda_from_state ? 1 : 0;
+        ++seq;
+        d.host_st = st_slot_d[seq & 1]; d.host_x = x_slot_d[seq & 1]; d.seq = seq;
+        d.guard = spec_enqueue ? &B.st->spec_ok : nullptr;
+        d.spec_static = next_round_enqueued_ahead ? 1 : 0;
+        d.maxIterations = S->maxIterations;
+        hipLaunchKernelGGL(k_decide_chain<T>, dim3(1), dim3(kSolveThreads), 0, stream, d);
+        return ok(hipGetLastError(), "decide kernel");
+    }
+
+    // Enqueue, behind the guard, the round that follows an ACCEPTED round with one trial: Broyden sweep with the roles the
+    // residual buffers will have after the rotation (y_new = fr, y_old = y), the solve with lambda taken from the device
+    // state, f(trial) into mB (dead: it held y_old of the round in flight, whose Broyden pass comes earlier in the stream),
+    // its sum of squares and the decision. The host-side bookkeeping waits for commit_spec_round().
+    bool enqueue_spec_round(bool chain_next)
+    {
+        spec_enqueue = true;
+        spec_events_from = events.size();
+        bool good = broyden_lowrank(fr, y) && enqueue_solve(1, nullptr, true, false);
+        if (good) {
+            HpScope hp(this, 2);
+            ev_begin(5);
+            f(fctx, m, n, B.trial, mB);
+            ev_end();
+            good = sumsq(mB, 1, 1, m) && enqueue_decide(1, true, false, chain_next);
+        }
+        spec_enqueue = false;
+        return good;
+    }
+    // the round enqueued ahead of time is the one the reference runs next: do now what the host does when it enqueues a
+    // Broyden round itself
+    void commit_spec_round()
+    {
+        for (size_t i = spec_events_from; i < events.size(); ++i) if (events[i].kind >= 100) events[i].kind -= 100;
+        if (stats) {
+            stats->jacobian_broyden++;
+            stats->broyden_lr_columns += (uint64_t)lr_k;
+            stats->trial_callback_points += 1;
+            if (comm) {
+                stats->allreduce_calls[1]++; stats->allreduce_elems[1] += (uint64_t)lr_len((int)n);
+                stats->allreduce_calls[2]++; stats->allreduce_elems[2] += 1;
+            }
+        }
+        ++lr_k;
+    }
+    void drop_spec_round()
+    {
+        for (size_t i = spec_events_from; i < events.size(); ++i) if (events[i].kind >= 100) events[i].kind = -1;
     }
 
     Result run()
@@ -807,7 +914,8 @@ struct Solver {
             if (!eval_f(B.x, xh, y)) { fail = true; break; }                 // LS:953
             ++ret.fCalls;
             if (!sumsq(y, 0)) { fail = true; break; }                        // LS:955
-            hipLaunchKernelGGL(k_init_state<T>, dim3(1), dim3(1), 0, stream, B.sum, B.st, st_hd, ++seq);
+            ++seq;
+            hipLaunchKernelGGL(k_init_state<T>, dim3(1), dim3(1), 0, stream, B.sum, B.st, st_slot_d[seq & 1], seq);
             if (!ok(hipGetLastError(), "init state") || !wait_state(seq)) { fail = true; break; }
         } while (false);
         if (fail) { teardown(); ret.status = mir_ls_numericError; return ret; }
@@ -816,6 +924,9 @@ struct Solver {
         bool fConverged = ret.residual <= S->maxGoodResidual;                // LS:956
         bool needJacobian = true;                                            // LS:959
         bool last_rejected = false;
+        bool spec_live = false;            // the round at the top of the loop is already enqueued (guard open)
+        bool live_round_static = false;    // ... and its decision may open the guard of a further round
+        uint32_t spec_seq = 0;
         const bool speculate = device_cb && !no_speculation;        // ladder trials: one fb call, or ks calls of f
         uint32_t age = maxAge;
         ret.lambda = 0;
@@ -839,6 +950,25 @@ struct Solver {
                 if (nan) { ret.status = mir_ls_numericError; break; }
             }
             bool newJacobian = false;
+            int ks = 1;
+            bool lambda_from_state = false, skip_eval = false;
+            T* ytr = fr;
+            uint32_t round_seq = 0;
+            if (spec_live) {
+                // this round is already in the stream (enqueue_spec_round of the previous iteration) and its guard is open
+                spec_live = false;
+                if (!needJacobian || !(age < maxAge) || lr_k >= lr_cap) {
+                    std::fprintf(stderr, "[mir_optim_amd] internal error: the round enqueued ahead of time is not the next round\n");
+                    fail = true;
+                    break;
+                }
+                needJacobian = false;
+                newJacobian = true;
+                last_rejected = false;
+                age++;
+                commit_spec_round();
+                round_seq = spec_seq;
+            } else {
             if (needJacobian) {                                              // LS:996-1063
                 needJacobian = false;
                 newJacobian = true;
@@ -876,8 +1006,7 @@ struct Solver {
             // first accepted one are discarded, so results, counters and callback-visible semantics of accepted
             // points are unchanged. The ladder stops where the reference's top-of-loop checks would intervene
             // (lambda > maxLambda LS:979, forced refresh LS:984).
-            const bool lambda_from_state = !(ret.lambda >= S->minLambda);     // first pass: lambda_0 rule inside the kernel
-            int ks = 1;
+            lambda_from_state = !(ret.lambda >= S->minLambda);                // first pass: lambda_0 rule inside the kernel
             T lam[kChainMax];
             lam[0] = ret.lambda;
             if (speculate && !newJacobian && !lambda_from_state && last_rejected) {
@@ -890,22 +1019,7 @@ struct Solver {
                     lam[ks++] = l2;
                 }
             }
-            {
-                LmSolveArgs<T> a{};
-                a.JJ = B.JJ; a.Jy = B.Jy; a.x = B.x; a.lower = B.lower; a.upper = B.upper;
-                a.dx = B.dx; a.trial = B.trial; a.st = B.st; a.rec = B.rec; a.set = sd; a.n = (int)n;
-                for (int k = 0; k < kChainMax; ++k) { a.sc[k] = B.sc[k]; a.lam[k] = k < ks ? lam[k] : T(0); }
-                a.f_in_lds = f_in_lds;
-                a.check_grad = newJacobian ? 1 : 0;
-                a.lambda_from_state = lambda_from_state ? 1 : 0;
-                if (!dbg_solve) a.sc[0].dbg = nullptr;
-                ev_begin(2);
-                {
-                    HpScope hp(this, 4);
-                    if (!ok(launch_solve(a, ks), "solve launch")) { fail = true; break; }
-                }
-                ev_end();
-            }
+            if (!enqueue_solve(ks, lam, newJacobian, lambda_from_state)) { fail = true; break; }
             if (dbg_solve) {
                 long long h[16];
                 if (hipMemcpy(h, B.sc[0].dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
@@ -914,7 +1028,6 @@ struct Solver {
             }
 
             // null-step probe: one small read-back instead of ks residual evaluations, only while the tail is running
-            bool skip_eval = false;
             if (device_cb && tail_null && last_rejected && !newJacobian && !no_null_skip) {
                 HpScope hp(this, 3);
                 ChainRec<T> rr[kChainMax];
@@ -925,11 +1038,8 @@ struct Solver {
                 if (skip_eval && stats) stats->elided_evaluations += (uint64_t)ks;
             }
 
-            // trial residuals -> ytr (k-th vector at ytr + k * m); with one trial they go straight into mB
-            T* ytr = mB;
-            if (ks > 1) {
-                    ytr = static_cast<T*>(ws->ytrial);
-            }
+            // trial residuals -> ytr (k-th vector at ytr + k * m); with one trial they go straight into the free buffer
+            if (ks > 1) ytr = static_cast<T*>(ws->ytrial);
             if (skip_eval) {
                 // every trial of the round equals x: the decision kernel substitutes the residual it already has
             } else if (device_cb) {
@@ -952,15 +1062,31 @@ struct Solver {
                 if (!no_f && !eval_f(B.trial, trial_h, ytr)) { fail = true; break; }
             }
             if (!skip_eval && !sumsq(ytr, 1, ks, m)) { fail = true; break; }
-            {
-                DecideArgs<T> d{};
-                d.sums = B.sum + 1; d.rec = B.rec; d.st = B.st; d.set = sd; d.x = B.x; d.trial = B.trial; d.dx_chain = B.dx;
-                d.dx_acc = B.dx_acc; d.n = (int)n; d.ks = ks; d.check_grad = newJacobian ? 1 : 0;
-                d.lambda_from_state = lambda_from_state ? 1 : 0;
-                d.host_st = st_hd; d.host_x = trial_hd; d.seq = ++seq;
-                hipLaunchKernelGGL(k_decide_chain<T>, dim3(1), dim3(kSolveThreads), 0, stream, d);
+            }   // !spec_live
+
+            // Can the round after this one be enqueued before this one's decision is known? Only the common case is covered:
+            // one trial now, and -- if it is accepted and no exit test fires (decided on the device, k_decide_chain) -- a
+            // Broyden pass next that needs neither a full refresh (age) nor a flush of the pending terms (lr_k).
+            bool decide_static;
+            if (round_seq == 0) {
+                decide_static = pipeline && ks == 1 && !skip_eval && age < maxAge && lr_k < lr_cap;
+                if (!enqueue_decide(ks, newJacobian, lambda_from_state, decide_static)) { fail = true; break; }
+                round_seq = seq;
+            } else {
+                decide_static = live_round_static;       // this round's decision was enqueued with that permission
             }
-            if (!ok(hipGetLastError(), "decide kernel") || !wait_state(seq)) { fail = true; break; }
+            bool spec_enqueued = false, next_static = false;
+            if (decide_static) {
+                next_static = (age + 1) < maxAge && (lr_k + 1) < lr_cap;      // what the round after the next one will see
+                if (!enqueue_spec_round(next_static)) { fail = true; break; }
+                spec_enqueued = true;
+                spec_seq = seq;
+            }
+            if (!wait_state(round_seq)) { fail = true; break; }
+            if (spec_enqueued) {
+                if (st_h->spec_ok) { spec_live = true; live_round_static = next_static; }
+                else drop_spec_round();
+            }
 
             if (trace && !trace_round(ks, ret.residual, ret.iterations)) { fail = true; break; }
             const int dec = st_h->decision;
@@ -985,11 +1111,11 @@ struct Solver {
 
             needJacobian = true;                                             // LS:1132-1139
             ret.iterations = st_h->iterations;
-            for (uint32_t i = 0; i < n; ++i) xh[i] = trial_h[i];             // trial_h holds the new x (read_state(B.x))
-            if (ytr != mB) {
-                if (!ok(hipMemcpyAsync(mB, ytr + (size_t)st_h->accepted_k * m, m * sizeof(T), hipMemcpyDeviceToDevice, stream), "D2D y")) { fail = true; break; }
+            for (uint32_t i = 0; i < n; ++i) xh[i] = x_h[i];                 // the decision kernel published the new x
+            if (ytr != fr) {
+                if (!ok(hipMemcpyAsync(fr, ytr + (size_t)st_h->accepted_k * m, m * sizeof(T), hipMemcpyDeviceToDevice, stream), "D2D y")) { fail = true; break; }
             }
-            { T* t = y; y = mB; mB = t; }
+            { T* t = mB; mB = y; y = fr; fr = t; }                           // swap(mBuffer, y) of LS:1136 as a rotation of three
             ret.residual = st_h->residual;
             fConverged = ret.residual <= S->maxGoodResidual;
             if (stats) stats->accepted++;

@@ -194,6 +194,9 @@ struct DecideArgs {
     LmState<T>* host_st;  // pinned mirror (device-mapped) or nullptr
     T* host_x;            // pinned, n: receives the accepted point
     uint32_t seq;         // sequence number of this decision point
+    const int32_t* guard; // optional: the kernel does nothing when *guard == 0 (rounds enqueued ahead of time)
+    int spec_static;      // the host has enqueued (or will enqueue) the NEXT round behind st->spec_ok: decide whether it may run
+    uint32_t maxIterations;
 };
 
 template <typename T>
@@ -201,6 +204,12 @@ __global__ __launch_bounds__(kSolveThreads) void k_decide_chain(DecideArgs<T> a)
 {
     __shared__ int acc_s;
     __shared__ LmState<T> s_pub;
+    {   // the guard is the flag this kernel rewrites further down: one thread reads it, everybody takes that value
+        __shared__ int go;
+        if (threadIdx.x == 0) go = !(a.guard && *a.guard == 0);
+        __syncthreads();
+        if (!go) return;
+    }
     if (threadIdx.x == 0) {
         LmState<T> s = *a.st;
         int dec = kDecideReject, acc = -1;
@@ -255,6 +264,16 @@ __global__ __launch_bounds__(kSolveThreads) void k_decide_chain(DecideArgs<T> a)
             dec = kDecideAccept;
             break;
         }
+        // May the round the host has enqueued ahead of time run? Only when this one ended in a plain acceptance and none of
+        // the reference's exit / refresh tests fires before the next pass (LS:974, 979, 990, 1144, 1164-1173, 1175): then the
+        // next pass is a Broyden update + one solve, which is exactly what was enqueued.
+        int spec = 0;
+        if (a.spec_static && dec == kDecideAccept) {
+            const T dxn = dsqrt(s.dx_dot);
+            spec = !(s.residual <= a.set.maxGoodResidual) && s.iterations < a.maxIterations && (s.lambda <= a.set.maxLambda)
+                && !(s.flags & kFlagXNaN) && (dxn > a.set.absTolerance && s.trial_xnorm > dxn * a.set.relTolerance);
+        }
+        s.spec_ok = spec;
         s.decision = dec; s.accepted_k = acc; s.consumed = consumed; s.fcalls = fcalls;
         s.rejects = rejects; s.guards = guards; s.qp_active = qpact;
         s.null_tail = (dec == kDecideReject) ? null_tail : 0u;

@@ -446,12 +446,13 @@ __global__ __launch_bounds__(kBigThreads) void k_lm_solve_big(LmSolveArgs<T> a)
     T* tv = sc.vec + 9 * (size_t)n;                  // JJ dx for the predicted reduction
     T* xq = sc.vec + 10 * (size_t)n;
 
+    if (a.guard && *a.guard == 0) return;
     if (a.check_grad && !(a.st->jy_inf > a.set.gradTolerance)) {    // LS:1053
         if (tid == 0) { ChainRec<T> r{}; r.flags = kFlagGradSmall; a.rec[kc] = r; }
         return;
     }
     // lambda_0, LS:1067-1072: the FIRST diagonal entry of maximum modulus, as i?amax picks it
-    T lambda = (kc == 0 && a.lambda_from_state) ? a.st->lambda : a.lam[kc];
+    T lambda = (kc == 0 && (a.lambda_from_state || a.lambda_from_device)) ? a.st->lambda : a.lam[kc];
     if (kc == 0 && a.lambda_from_state && !(lambda >= a.set.minLambda)) {
         T best = -1;
         int where = 0x7fffffff;

@@ -41,7 +41,8 @@ struct LmState {
     uint32_t rejects, guards, qp_active;
     uint32_t null_tail;        // the last consumed trial of the round was a null step (trial == x): the next ones probably are too
     uint32_t seq;              // host mirror only: number of the decision point this image belongs to (written last)
-    uint32_t pad1;
+    int32_t spec_ok;           // set by the decision kernel: the round enqueued ahead of time behind this flag is the one the
+                               // reference would run next (accepted step, no exit test fired): its kernels may execute
 };
 
 // One solve of the lambda ladder (chain step k): everything the acceptance logic needs about it.
@@ -645,6 +646,8 @@ struct LmSolveArgs {
     int f_in_lds;
     int check_grad;        // a new Jy was just computed: apply the gradient test LS:1053 first (chain of 1)
     int lambda_from_state; // step 0 takes st->lambda and applies the lambda_0 rule LS:1067-1072
+    int lambda_from_device; // step 0 takes st->lambda as it is (a round enqueued before the host has seen the previous decision)
+    const int32_t* guard;  // optional: the kernel does nothing when *guard == 0 (rounds enqueued ahead of time)
 };
 
 template <typename T, int NB, bool BOUNDED = true>
@@ -665,6 +668,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
     T* qpu = sc.vec + 8 * (size_t)n;
     T* xq = sc.vec + 10 * (size_t)n;
 
+    if (a.guard && *a.guard == 0) return;
     MIRLSQ_STAMP(sc.dbg, 0);
     if (sc.dbg && threadIdx.x == 0) sc.dbg[9] = clock64();
     // gradient test, LS:1053: stop before touching lambda when ||Jy||_inf <= gradTolerance
@@ -674,7 +678,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
     }
 
     // lambda_0, LS:1067-1072 (first element of maximum |diag|, as i?amax picks it)
-    T lambda = (kc == 0 && a.lambda_from_state) ? a.st->lambda : a.lam[kc];
+    T lambda = (kc == 0 && (a.lambda_from_state || a.lambda_from_device)) ? a.st->lambda : a.lam[kc];
     if (kc == 0 && a.lambda_from_state && !(lambda >= a.set.minLambda)) {
         const T dg = tid < n ? dabs(a.JJ[(size_t)tid * n + tid]) : T(-1);
         const T mx = block_max(dg, red);

@@ -422,3 +422,31 @@ def test_null_step_elision_host_callbacks(oracle):
     assert (res.iterations, res.fCalls, res.gCalls) == (ro.iterations, ro.fCalls, ro.gCalls)
     assert np.array_equal(x, xo) or np.allclose(x, xo, rtol=1e-12)
     assert calls[0] < res.fCalls                                                  # some evaluations were elided
+
+
+@pytest.mark.parametrize("m,n,bounded", [(20000, 32, False), (9000, 17, False), (50000, 128, False), (12000, 24, True), (30000, 256, False)])
+def test_rounds_enqueued_ahead_of_time_change_nothing(m, n, bounded):
+    """While the GPU runs a round, the host enqueues the next one behind a device-side guard (pipelined rounds).
+    Guard closed -> the kernels return at once; guard open -> they are exactly the kernels the host would have launched.
+    So x, residual, lambda, status and every counter are bit-identical with VARIANT_NO_PIPELINE."""
+    w = P.tanh_linear(m, n)
+    prob = W.TanhLinear(w["A"], w["b"])
+    lo = up = None
+    x0 = w["x0"]
+    if bounded:
+        lo = w["xstar"] - 0.5; up = w["xstar"] + 0.5
+        lo[::4] = w["xstar"][::4] + 0.02
+        x0 = np.clip(x0, lo, up)
+    for tol in (1e-5, 1e-12):
+        s = M.LeastSquaresSettings(); s.absTolerance = tol
+        out = []
+        for variant in (0, M.VARIANT_NO_PIPELINE):
+            st = M.Stats()
+            r, x = prob.solve(x0, l=lo, u=up, settings=s, batched=True, stats=st, flags=M.TIME_KERNELS, variant=variant)
+            out.append((r, x, st))
+        (r1, x1, s1), (r0, x0_, s0) = out
+        assert np.array_equal(x1, x0_) and r1.residual == r0.residual and r1.lambda_ == r0.lambda_
+        assert (r1.status, r1.iterations, r1.fCalls) == (r0.status, r0.iterations, r0.fCalls)
+        for k in ("passes", "accepted", "rejected", "jacobian_full", "jacobian_broyden", "broyden_lr_columns", "broyden_flushes",
+                  "jtj_resyncs", "jtj_launches", "jtj_broyden_launches", "solve_launches", "trial_callback_points", "elided_evaluations"):
+            assert getattr(s1, k) == getattr(s0, k), (k, getattr(s1, k), getattr(s0, k))
