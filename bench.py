@@ -103,6 +103,10 @@ def parse():
     ap.add_argument("--stall-bound", type=float, default=8.0,
                     help="RCCL only: upper bound (s, from communicator creation) of the warm-up loop that waits for RCCL's "
                          "asynchronous initialisation stall to pass (it ends as soon as a stall has been seen and has passed)")
+    ap.add_argument("--variant", type=int, default=0, help="MIR_LSQ_VARIANT_* bits for A/B runs (0 = product path)")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="do not bracket kernels with HIP events in the timed region (A/B of the instrumentation overhead; the "
+                         "roofline objects are then empty)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-1thread", action="store_true")
     ap.add_argument("--cpu-iterations", type=int, default=6, help="accepted iterations of the CPU sample")
@@ -220,13 +224,14 @@ def main_cfg2(args):
     prob = W.Curve("gauss_sum", g["t"], g["data"])
     ws = api.lib().mir_lsq_workspace_create(g["m"], g["n"], 8)
     for _ in range(max(1, args.warmup)):
-        res, x = prob.solve(g["x0"], g["lower"], g["upper"], workspace=ws)
+        res, x = prob.solve(g["x0"], g["lower"], g["upper"], workspace=ws, variant=args.variant)
     st = M.Stats()
     iters = 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res, x = prob.solve(g["x0"], g["lower"], g["upper"], workspace=ws, stats=st, flags=M.TIME_KERNELS)
+        res, x = prob.solve(g["x0"], g["lower"], g["upper"], workspace=ws, stats=st, variant=args.variant,
+                            flags=0 if args.no_kernel_timing else M.TIME_KERNELS)
         iters += res.iterations
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -342,7 +347,7 @@ def main():
         torch.cuda.synchronize()
 
     def solve(stats=None, flags=0, s=settings):
-        return prob.solve(data["x0"], settings=s, stats=stats, flags=flags, comm=comm, workspace=ws,
+        return prob.solve(data["x0"], settings=s, stats=stats, flags=flags, comm=comm, workspace=ws, variant=args.variant,
                           batched={"batched": True, "pointmajor": "pointmajor", "serial": False}[args.fd])
 
     # RCCL finishes part of its initialisation asynchronously: a few seconds after ncclCommInitRank every HIP launch of the
@@ -382,7 +387,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for _ in range(count):
-            r, xx = solve(stats=st, flags=M.TIME_KERNELS, s=s)
+            r, xx = solve(stats=st, flags=0 if args.no_kernel_timing else M.TIME_KERNELS, s=s)
             iters += r.iterations
         barrier()
         dt = time.perf_counter() - t0

@@ -212,7 +212,8 @@ typedef struct mir_lsq_stats {
     double jtj_broyden_ms;
     double solve_ms;                 /* n x n damped solve kernel */
     uint64_t solve_launches;
-    double fd_ms;                    /* finite-difference refresh incl. callbacks */
+    double fd_ms;                    /* finite-difference refresh, host wall clock: host-callback mode only (device-callback
+                                        refreshes are asynchronous: see fd_callback_ms) */
     double total_ms;                 /* whole call, host wall clock */
     uint64_t qp_active_set_passes;   /* passes in which BOXCQP's active-set loop ran */
     uint64_t broyden_lr_columns;     /* sum over the Broyden sweeps of the pending columns each one read (broyden_lr.h) */

@@ -407,6 +407,13 @@ class DeviceBuffer:
         if lib().mir_lsq_memcpy_h2d(self.ptr, array.ctypes.data, self.nbytes, None) != 0:
             raise RuntimeError("H2D copy failed")
 
+    def upload_at(self, byte_offset, array):
+        """Copy `array` into the allocation at `byte_offset` (building a large device array piece by piece)."""
+        array = np.ascontiguousarray(array, dtype=self.dtype)
+        assert 0 <= byte_offset and byte_offset + array.nbytes <= self.nbytes
+        if lib().mir_lsq_memcpy_h2d(self.ptr + byte_offset, array.ctypes.data, array.nbytes, None) != 0:
+            raise RuntimeError("H2D copy failed")
+
     def download(self):
         out = np.empty(self.shape, dtype=self.dtype)
         if lib().mir_lsq_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes, None) != 0:

@@ -55,6 +55,7 @@ struct mir_lsq_workspace {
     void* ytrial = nullptr;    // kChainMax x m trial residuals (speculative lambda ladder)
     void* ulr = nullptr;       // kLrMax x m pending Broyden columns (broyden_lr.h)
     int device = 0;            // the device the workspace lives on (callbacks' worker threads select it)
+    std::vector<hipEvent_t> event_pool;   // MIR_LSQ_TIME_KERNELS: events are created once and reused by later solves
     void* pinned = nullptr;    // small pinned host block (state + trial readback), device-mapped and coherent:
     void* pinned_dev = nullptr;   // ... its device address (the decision kernels write the state mirror directly)
     void* pinned_y = nullptr;  // m-vector staging (host-callback mode), lazily allocated
@@ -209,6 +210,7 @@ mir_lsq_workspace* workspace_create(size_t m, size_t n)
 void workspace_destroy(mir_lsq_workspace* ws)
 {
     if (!ws) return;
+    for (hipEvent_t e : ws->event_pool) (void)hipEventDestroy(e);
     if (ws->dev) (void)hipFree(ws->dev);
     if (ws->ypanel) (void)hipFree(ws->ypanel);
     if (ws->ytrial) (void)hipFree(ws->ytrial);
@@ -332,8 +334,16 @@ struct Solver {
         HpScope hp(this, 0);
         EventPair p{};
         p.kind = spec_enqueue ? kind + 100 : kind;       // rounds enqueued ahead of time: counted only once they are committed
-        (void)hipEventCreate(&p.a);
-        (void)hipEventCreate(&p.b);
+        // events come from the workspace's pool (created on first use, reused by every later solve on this workspace)
+        if (ws->event_pool.size() < 2 * (events.size() + 1)) {
+            hipEvent_t ea, eb;
+            (void)hipEventCreate(&ea);
+            (void)hipEventCreate(&eb);
+            ws->event_pool.push_back(ea);
+            ws->event_pool.push_back(eb);
+        }
+        p.a = ws->event_pool[2 * events.size()];
+        p.b = ws->event_pool[2 * events.size() + 1];
         (void)hipEventRecord(p.a, stream);
         events.push_back(p);
     }
@@ -427,8 +437,7 @@ struct Solver {
                 else if (e.kind == 5) { stats->trial_callback_ms += ms; stats->trial_callback_calls++; }
             }
         }
-        for (auto& e : events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-        events.clear();
+        events.clear();                                  // the events themselves stay in the workspace's pool
         for (auto& s : slots) {
             if (s.p) std::free(s.p);
             if (s.yp) (void)hipHostFree(s.yp);
@@ -926,6 +935,7 @@ struct Solver {
         bool last_rejected = false;
         bool spec_live = false;            // the round at the top of the loop is already enqueued (guard open)
         bool live_round_static = false;    // ... and its decision may open the guard of a further round
+        bool spec_predict = true;          // the last first trial after a Jacobian update was accepted
         uint32_t spec_seq = 0;
         const bool speculate = device_cb && !no_speculation;        // ladder trials: one fb call, or ks calls of f
         uint32_t age = maxAge;
@@ -986,10 +996,10 @@ struct Solver {
                     if (g) okj = analytic_jacobian();                        // LS:1011-1015
                     else okj = device_cb ? fd_device() : fd_host();          // LS:1016-1050
                     if (!okj) { fail = true; break; }
-                    if (stats) {
-                        (void)hipStreamSynchronize(stream);
+                    // fd_ms: host-callback mode is synchronous anyway (wall clock); in device-callback mode the refresh is only
+                    // ENQUEUED here -- no stream synchronisation for the sake of a statistic: fd_callback_ms (events) covers it
+                    if (stats && !device_cb)
                         stats->fd_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-                    }
                     if (!jacobian_products(false, y, mB)) { fail = true; break; }
                     trace_emit(0, ret.iterations, ret.lambda, ret.residual, 0, st_h->dx_dot);
                 }
@@ -1069,7 +1079,7 @@ struct Solver {
             // Broyden pass next that needs neither a full refresh (age) nor a flush of the pending terms (lr_k).
             bool decide_static;
             if (round_seq == 0) {
-                decide_static = pipeline && ks == 1 && !skip_eval && age < maxAge && lr_k < lr_cap;
+                decide_static = pipeline && spec_predict && ks == 1 && !skip_eval && age < maxAge && lr_k < lr_cap;
                 if (!enqueue_decide(ks, newJacobian, lambda_from_state, decide_static)) { fail = true; break; }
                 round_seq = seq;
             } else {
@@ -1087,6 +1097,9 @@ struct Solver {
                 if (st_h->spec_ok) { spec_live = true; live_round_static = next_static; }
                 else drop_spec_round();
             }
+            // one-bit predictor: enqueue ahead only while first trials are being accepted (the rejection tail of a noisy fit
+            // would waste a guarded round per miss)
+            if (ks == 1 && newJacobian) spec_predict = st_h->decision == kDecideAccept;
 
             if (trace && !trace_round(ks, ret.residual, ret.iterations)) { fail = true; break; }
             const int dec = st_h->decision;

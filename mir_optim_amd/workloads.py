@@ -84,6 +84,22 @@ class TanhLinear(DeviceProblem):
         self.fbr = _addr("wl_tanh_linear_fbr_d") if dtype == np.float64 else None
 
 
+class TanhLinearView(TanhLinear):
+    """The tanh-linear problem over rows [row0, row0 + m) of device arrays that already hold A (row-major, n columns) and b
+    (f64): several row shards -- and the unsharded problem -- as views of one resident data set."""
+
+    def __init__(self, dA, db, row0, m, n, stream=None):
+        self.dtype = np.float64
+        self.m, self.n = int(m), int(n)
+        self.stream = stream or api.Stream()
+        self.dA, self.db = dA, db                      # kept alive; not owned
+        self.ctx = _TanhCtx(dA.ptr + int(row0) * int(n) * 8, db.ptr + int(row0) * 8, self.stream.handle)
+        self.f = _addr("wl_tanh_linear_f_d")
+        self.g = _addr("wl_tanh_linear_g_d")
+        self.fb = _addr("wl_tanh_linear_fb_d")
+        self.fbr = _addr("wl_tanh_linear_fbr_d")
+
+
 class Curve(DeviceProblem):
     """kind = 'gauss_sum' | 'exp_decay0' | 'exp_decay1'."""
 

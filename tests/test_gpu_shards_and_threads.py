@@ -157,3 +157,44 @@ def test_two_host_threads_solve_different_problems_concurrently(oracle):
             (solo1[0].status, solo1[0].iterations, solo1[0].fCalls, solo1[0].residual)
         assert np.array_equal(xb, solo2[1]) and (rb.status, rb.iterations, rb.fCalls, rb.residual) == \
             (solo2[0].status, solo2[0].iterations, solo2[0].fCalls, solo2[0].residual)
+
+
+def test_cfg4_full_size_eight_logical_shards_on_one_gpu():
+    """BASELINE cfg 4 at FULL size on the one visible GPU: m = 8e6 x n = 256 fp64 (J alone is 16 GB; 288 GB of HBM hold the
+    data set, eight shard workspaces and the unsharded one), rows split over EIGHT logical shards -- eight host threads,
+    eight solver instances, the in-process communicator standing in for RCCL -- against the UNSHARDED solve of the same
+    8e6-row problem on the same GPU. The oracle cannot run this size in test time (2.1 TFLOP per finite-difference refresh
+    on the host); its parity at this shape is established 8-way at m = 40004 above. Here: every rank returns the same bits,
+    and the sharded answer equals the unsharded one up to the order of the row reductions (x rtol 1e-9, residual 1e-11)."""
+    m_shard, n, world = 1_000_000, 256, 8
+    m_total = m_shard * world
+    dA = M.DeviceBuffer(nbytes=m_total * n * 8, dtype=np.float64, shape=(m_total, n))
+    db = M.DeviceBuffer(nbytes=m_total * 8, dtype=np.float64, shape=(m_total,))
+    x0 = xstar = None
+    for r in range(world):                                       # 2 GB of host memory at a time
+        d = W.tanh_linear_data(m_shard, n, row_offset=r * m_shard)
+        dA.upload_at(r * m_shard * n * 8, d["A"])
+        db.upload_at(r * m_shard * 8, d["b"])
+        x0, xstar = d["x0"], d["xstar"]
+        del d
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-5
+    comms, close = PAR.local_group(world)
+    probs = [W.TanhLinearView(dA, db, r * m_shard, m_shard, n) for r in range(world)]
+    stats = [M.Stats() for _ in range(world)]
+    try:
+        res = run_threads([(lambda r=r: probs[r].solve(x0, settings=s, comm=comms[r], stats=stats[r], batched=True)) for r in range(world)])
+    finally:
+        close()
+    r0, xs = res[0]
+    for r, x in res[1:]:
+        assert np.array_equal(x, xs) and (r.status, r.iterations, r.fCalls, r.residual) == (r0.status, r0.iterations, r0.fCalls, r0.residual)
+    st = stats[0]
+    assert st.allreduce_calls[0] == st.jacobian_full + st.jtj_resyncs and st.allreduce_elems[0] == st.allreduce_calls[0] * PAR.packed_length(256)
+    assert PAR.packed_length(256) == 33152 and st.allreduce_elems[1] == st.allreduce_calls[1] * (2 * 256 + 34)
+    whole = W.TanhLinearView(dA, db, 0, m_total, n)
+    ru, xu = whole.solve(x0, settings=s, batched=True)
+    assert int(r0.status) >= 0 and r0.status == ru.status and r0.iterations == ru.iterations
+    assert np.allclose(xs, xu, rtol=1e-9, atol=1e-12), np.abs(xs - xu).max()
+    assert np.isclose(r0.residual, ru.residual, rtol=1e-11)
+    assert np.abs(xu - xstar).max() < 1e-2                       # and it is the minimiser of the generating model
+    dA.free(); db.free()
