@@ -852,22 +852,17 @@ struct Solver {
         return ok(hipGetLastError(), "decide kernel");
     }
 
-    // Enqueue, behind the guard, the round that follows an ACCEPTED round with one trial: Broyden sweep with the roles the
-    // residual buffers will have after the rotation (y_new = fr, y_old = y), the solve with lambda taken from the device
-    // state, f(trial) into mB (dead: it held y_old of the round in flight, whose Broyden pass comes earlier in the stream),
-    // its sum of squares and the decision. The host-side bookkeeping waits for commit_spec_round().
-    bool enqueue_spec_round(bool chain_next)
+    // Enqueue, behind the guard, the LIBRARY part of the round that follows an ACCEPTED round with one trial: the Broyden
+    // sweep with the roles the residual buffers will have after the rotation (y_new = fr, y_old = y) and the solve with
+    // lambda taken from the device state. The caller's residual callback is NOT enqueued ahead of time: it cannot be guarded
+    // (a full sweep over the caller's data per miss -- measured at cfg 3: two misses per solve cost more than the launch
+    // latency the scheme hides); the host enqueues it, the sum of squares and the decision once the round is committed,
+    // while the GPU is busy with the sweep and the solve. The host-side bookkeeping waits for commit_spec_round().
+    bool enqueue_spec_round()
     {
         spec_enqueue = true;
         spec_events_from = events.size();
-        bool good = broyden_lowrank(fr, y) && enqueue_solve(1, nullptr, true, false);
-        if (good) {
-            HpScope hp(this, 2);
-            ev_begin(5);
-            f(fctx, m, n, B.trial, mB);
-            ev_end();
-            good = sumsq(mB, 1, 1, m) && enqueue_decide(1, true, false, chain_next);
-        }
+        const bool good = broyden_lowrank(fr, y) && enqueue_solve(1, nullptr, true, false);
         spec_enqueue = false;
         return good;
     }
@@ -879,11 +874,7 @@ struct Solver {
         if (stats) {
             stats->jacobian_broyden++;
             stats->broyden_lr_columns += (uint64_t)lr_k;
-            stats->trial_callback_points += 1;
-            if (comm) {
-                stats->allreduce_calls[1]++; stats->allreduce_elems[1] += (uint64_t)lr_len((int)n);
-                stats->allreduce_calls[2]++; stats->allreduce_elems[2] += 1;
-            }
+            if (comm) { stats->allreduce_calls[1]++; stats->allreduce_elems[1] += (uint64_t)lr_len((int)n); }
         }
         ++lr_k;
     }
@@ -934,9 +925,7 @@ struct Solver {
         bool needJacobian = true;                                            // LS:959
         bool last_rejected = false;
         bool spec_live = false;            // the round at the top of the loop is already enqueued (guard open)
-        bool live_round_static = false;    // ... and its decision may open the guard of a further round
         bool spec_predict = true;          // the last first trial after a Jacobian update was accepted
-        uint32_t spec_seq = 0;
         const bool speculate = device_cb && !no_speculation;        // ladder trials: one fb call, or ks calls of f
         uint32_t age = maxAge;
         ret.lambda = 0;
@@ -963,7 +952,7 @@ struct Solver {
             int ks = 1;
             bool lambda_from_state = false, skip_eval = false;
             T* ytr = fr;
-            uint32_t round_seq = 0;
+            bool solve_enqueued = false;
             if (spec_live) {
                 // this round is already in the stream (enqueue_spec_round of the previous iteration) and its guard is open
                 spec_live = false;
@@ -977,8 +966,8 @@ struct Solver {
                 last_rejected = false;
                 age++;
                 commit_spec_round();
-                round_seq = spec_seq;
-            } else {
+                solve_enqueued = true;
+            }
             if (needJacobian) {                                              // LS:996-1063
                 needJacobian = false;
                 newJacobian = true;
@@ -1016,7 +1005,7 @@ struct Solver {
             // first accepted one are discarded, so results, counters and callback-visible semantics of accepted
             // points are unchanged. The ladder stops where the reference's top-of-loop checks would intervene
             // (lambda > maxLambda LS:979, forced refresh LS:984).
-            lambda_from_state = !(ret.lambda >= S->minLambda);                // first pass: lambda_0 rule inside the kernel
+            lambda_from_state = !solve_enqueued && !(ret.lambda >= S->minLambda);   // first pass: lambda_0 rule inside the kernel
             T lam[kChainMax];
             lam[0] = ret.lambda;
             if (speculate && !newJacobian && !lambda_from_state && last_rejected) {
@@ -1029,7 +1018,7 @@ struct Solver {
                     lam[ks++] = l2;
                 }
             }
-            if (!enqueue_solve(ks, lam, newJacobian, lambda_from_state)) { fail = true; break; }
+            if (!solve_enqueued && !enqueue_solve(ks, lam, newJacobian, lambda_from_state)) { fail = true; break; }
             if (dbg_solve) {
                 long long h[16];
                 if (hipMemcpy(h, B.sc[0].dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
@@ -1072,30 +1061,17 @@ struct Solver {
                 if (!no_f && !eval_f(B.trial, trial_h, ytr)) { fail = true; break; }
             }
             if (!skip_eval && !sumsq(ytr, 1, ks, m)) { fail = true; break; }
-            }   // !spec_live
 
             // Can the round after this one be enqueued before this one's decision is known? Only the common case is covered:
             // one trial now, and -- if it is accepted and no exit test fires (decided on the device, k_decide_chain) -- a
             // Broyden pass next that needs neither a full refresh (age) nor a flush of the pending terms (lr_k).
-            bool decide_static;
-            if (round_seq == 0) {
-                decide_static = pipeline && spec_predict && ks == 1 && !skip_eval && age < maxAge && lr_k < lr_cap;
-                if (!enqueue_decide(ks, newJacobian, lambda_from_state, decide_static)) { fail = true; break; }
-                round_seq = seq;
-            } else {
-                decide_static = live_round_static;       // this round's decision was enqueued with that permission
-            }
-            bool spec_enqueued = false, next_static = false;
-            if (decide_static) {
-                next_static = (age + 1) < maxAge && (lr_k + 1) < lr_cap;      // what the round after the next one will see
-                if (!enqueue_spec_round(next_static)) { fail = true; break; }
-                spec_enqueued = true;
-                spec_seq = seq;
-            }
+            const bool decide_static = pipeline && spec_predict && ks == 1 && !skip_eval && age < maxAge && lr_k < lr_cap;
+            if (!enqueue_decide(ks, newJacobian, lambda_from_state, decide_static)) { fail = true; break; }
+            const uint32_t round_seq = seq;
+            if (decide_static && !enqueue_spec_round()) { fail = true; break; }
             if (!wait_state(round_seq)) { fail = true; break; }
-            if (spec_enqueued) {
-                if (st_h->spec_ok) { spec_live = true; live_round_static = next_static; }
-                else drop_spec_round();
+            if (decide_static) {
+                if (st_h->spec_ok) spec_live = true; else drop_spec_round();
             }
             // one-bit predictor: enqueue ahead only while first trials are being accepted (the rejection tail of a noisy fit
             // would waste a guarded round per miss)
