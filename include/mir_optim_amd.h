@@ -198,7 +198,9 @@ enum {
     MIR_LSQ_VARIANT_NO_RESYNC = 1u << 9,         /* do not recompute J^T J / J^T y from J when the pending Broyden terms are
                                                     folded into it (the recurrence then runs until the next full refresh) */
     MIR_LSQ_VARIANT_SOLVE_GENERIC = 1u << 10,    /* the any-n solve path (biglinalg.h) also for n <= 256 */
-    MIR_LSQ_VARIANT_NO_PIPELINE = 1u << 11,      /* never enqueue a round before the previous decision is known */
+    MIR_LSQ_VARIANT_PIPELINE = 1u << 11,         /* enqueue the library part of the next Broyden round behind a device-side
+                                                    guard before the current decision is known (bit-identical results;
+                                                    measured: no gain on one GPU, so it is not the default) */
     MIR_LSQ_VARIANT_LR_CAP_SHIFT = 16            /* bits 16..20: fold the pending Broyden terms into J after this many
                                                     updates (1..16; 0 = 16) */
 };

@@ -34,7 +34,7 @@ __all__ = [
     "fit_spline_residuals", "variant_lr_cap",
     "VARIANT_BROYDEN_REWRITE", "VARIANT_FD_SEPARATE_FILL", "VARIANT_JTJ_RING", "VARIANT_JTJ_STREAM",
     "VARIANT_NO_SPECULATION", "VARIANT_NO_NULL_SKIP", "VARIANT_SOLVE_BOUNDED", "VARIANT_DEBUG_SOLVE",
-    "VARIANT_HOST_PROFILE", "VARIANT_NO_RESYNC", "VARIANT_SOLVE_GENERIC", "VARIANT_NO_PIPELINE",
+    "VARIANT_HOST_PROFILE", "VARIANT_NO_RESYNC", "VARIANT_SOLVE_GENERIC", "VARIANT_PIPELINE",
 ]
 
 MODEL_EXP_DECAY = 0      # n = 3: p0 exp(-t p1) + p2
@@ -56,7 +56,7 @@ VARIANT_DEBUG_SOLVE = 1 << 7
 VARIANT_HOST_PROFILE = 1 << 8
 VARIANT_NO_RESYNC = 1 << 9
 VARIANT_SOLVE_GENERIC = 1 << 10
-VARIANT_NO_PIPELINE = 1 << 11
+VARIANT_PIPELINE = 1 << 11
 
 
 def variant_lr_cap(k):

@@ -280,7 +280,7 @@ struct Solver {
     // the round that follows IF r is accepted without any exit test firing -- Broyden sweep, solve, trial residual,
     // decision -- behind a device-side guard (LmState::spec_ok, set by k_decide_chain of round r). If r ends differently the
     // guarded kernels return at once and the host enqueues the right round as before. Results are bit-identical with and
-    // without it (MIR_LSQ_VARIANT_NO_PIPELINE); what disappears is the launch latency between accepted rounds.
+    // without it (tests/test_gpu_lm.py); what disappears is the launch latency between accepted rounds.
     bool spec_enqueue = false;     // set while the kernels of such a round are being enqueued
     bool pipeline = true;          // allowed at all for this solve (see setup())
     size_t spec_events_from = 0;   // events of the round enqueued ahead of time start here
@@ -407,7 +407,9 @@ struct Solver {
         fr = B.ytmp;
         big_solve = n > (uint32_t)kSolveMaxN || (variant & MIR_LSQ_VARIANT_SOLVE_GENERIC) != 0;
         if (n > (uint32_t)kLrMaxN) lowrank = false;    // the read-only Broyden sweep keeps n <= 256; above, J is rewritten
-        pipeline = device_cb && lowrank && !big_solve && !trace && !dbg_solve && !(variant & MIR_LSQ_VARIANT_NO_PIPELINE)
+        // opt-in (MIR_LSQ_VARIANT_PIPELINE): measured on one MI355X it does not pay -- cfg 3 7.08 ms per solve with it, 7.02
+        // without; cfg 2 2.92 against 3.00 ms (scripts/ab_bench.sh) -- the stream is already busy > 97 % of a solve
+        pipeline = device_cb && lowrank && !big_solve && !trace && !dbg_solve && (variant & MIR_LSQ_VARIANT_PIPELINE)
             && (!comm || comm->kind == 1);      // host-mediated communicators synchronise the stream inside every exchange
         solve_nb_ = solve_nb((int)n, (int)sizeof(T));
         f_in_lds = solve_nb_ > 0;
