@@ -14,6 +14,7 @@
 #include "../../include/mir_optim_amd.h"
 #include "common.h"
 #include "jtj_fdp.h"
+#include "jtj_fdp8.h"
 #include "jtj_kernel.h"
 #include "jtj_ring8.h"
 #include "jtj_wide.h"
@@ -50,6 +51,8 @@ struct JtjPlan {
     bool ring8 = false;     // 128 < n <= 256, f64, n % 16 == 0, m even: eight-wave LDS-DMA ring (jtj_ring8.h)
     bool fdp = false;       // f64, n <= 128, any m: producer / consumer kernel (jtj_fdp.h) for the finite-difference J^T J
     bool fdp_plain = false; // ... and, n even, for the plain J^T J
+    bool fdp8 = false;      // f64, 128 < n <= 256, n % 32 == 0, any m: eight producer + consumer waves (jtj_fdp8.h), FD J^T J only
+    int fdp8_nblk = 0, fdp8_slab_len = 0;
     int njobs = 1;
 };
 
@@ -94,6 +97,13 @@ JtjPlan jtj_plan(size_t m, int n, int num_cu, uint32_t variant = 0)
     const int nacc = p.ncb * (p.ncb + 1) / 2;
     p.slab_len = (nacc * 4 + p.ncb) * kWave;
     const bool stream = (variant & MIR_LSQ_VARIANT_JTJ_STREAM) != 0;
+    if (sizeof(T) == 8 && n > 128 && n <= 256 && n % 32 == 0 && !stream) {
+        p.fdp8 = true;
+        const size_t stot = (m + 15) / 16;
+        const size_t want = (stot + 7) / 8;                    // at least ~8 stages per workgroup
+        p.fdp8_nblk = (int)(want < (size_t)num_cu ? (want ? want : 1) : (size_t)num_cu);   // one workgroup per CU
+        p.fdp8_slab_len = p.slab_len;
+    }
     if (sizeof(T) == 8 && n > 128 && n <= 256 && n % 16 == 0 && m % 2 == 0 && !stream) {
         p.ring8 = true;
         p.lds = jtj8_lds_rt(p.ncb);
@@ -296,10 +306,40 @@ hipError_t jtj_run(const JtjPlan& p, const JtjArgs<T>& a, bool broyden, T* packe
     return jtj_reduce_slabs<T>(p, a, packed, s);
 }
 
+// ---- k_jtj_fdp8: the finite-difference J^T J for 128 < n <= 256 (jtj_fdp8.h)
+template <int NCB>
+hipError_t jtj_fdp8_one(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t s)
+{
+    using FC = JtjFdp8Cfg<NCB>;
+    MIRLSQ_ENSURE_LDS(k_jtj_fdp8<NCB>, (size_t)FC::LDS_BYTES);
+    hipLaunchKernelGGL(k_jtj_fdp8<NCB>, dim3(p.fdp8_nblk), dim3(FC::THREADS), FC::LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+template <typename T>
+hipError_t jtj_fdp8_launch(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
+{
+    if constexpr (sizeof(T) == 8) {
+        switch (p.ncb) {
+        case 10: return jtj_fdp8_one<10>(p, a, s);
+        case 12: return jtj_fdp8_one<12>(p, a, s);
+        case 14: return jtj_fdp8_one<14>(p, a, s);
+        case 16: return jtj_fdp8_one<16>(p, a, s);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
 // ---- finite-difference panel (a.J: m x 2n row-major, a.twh) -> a.Jout, packed
 template <typename T>
 hipError_t jtj_run_fd(const JtjPlan& p, const JtjArgs<T>& a, T* packed, hipStream_t s)
 {
+    if (p.fdp8) {
+        const hipError_t e = jtj_fdp8_launch<T>(p, a, s);
+        if (e != hipSuccess) return e;
+        const int rb = (p.fdp8_slab_len + 31) / 32;
+        hipLaunchKernelGGL(k_jtj_slab_reduce<T>, dim3(rb), dim3(256), 0, s, a.slabs, p.fdp8_nblk, p.fdp8_slab_len, p.ncb, a.n, packed);
+        return hipGetLastError();
+    }
     if (!p.fdp) return hipErrorInvalidValue;
     const hipError_t e = jtj_fdp_launch<T, true>(p, a, s);
     if (e != hipSuccess) return e;

@@ -118,7 +118,9 @@ size_t slab_elems(size_t m, size_t n, int num_cu)
 {
     const JtjPlan a = jtj_plan<T>(m, (int)n, num_cu, 0), b = jtj_plan<T>(m, (int)n, num_cu, MIR_LSQ_VARIANT_JTJ_STREAM);
     const size_t ea = (size_t)a.nblk * a.njobs * a.slab_len, eb = (size_t)b.nblk * b.njobs * b.slab_len;
-    return ea > eb ? ea : eb;
+    const size_t ec = (size_t)a.fdp8_nblk * a.fdp8_slab_len;
+    const size_t e = ea > eb ? ea : eb;
+    return e > ec ? e : ec;
 }
 
 template <typename T>
@@ -702,7 +704,7 @@ struct Solver {
         }
         T* Y = static_cast<T*>(ws->ypanel);
         const bool no_fuse = (variant & MIR_LSQ_VARIANT_FD_SEPARATE_FILL) != 0;
-        if (fbr && plan.fdp && pb == n && sizeof(T) == 8 && !no_fuse) {
+        if (fbr && (plan.fdp || plan.fdp8) && pb == n && sizeof(T) == 8 && !no_fuse) {
             // all 2n points in one sweep, Y[i][2j], Y[i][2j+1] = f(x + h e_j)_i, f(x - h e_j)_i; k_jtj2<., false, true>
             // (jacobian_products) turns the pairs into Jacobian rows on its way to J^T J -- no k_fd_fill pass
             ev_begin(4);
@@ -1540,11 +1542,12 @@ int mir_lsq_fd_jtj_d(size_t m, size_t n, const double* Yrm, const double* twh, c
     if (n == 0 || m == 0) return -2;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const JtjPlan plan = jtj_plan<double>(m, (int)n, query_num_cu());
-    if (!plan.fdp) return -6;                                   // shape not covered by the fused kernel
+    if (!plan.fdp && !plan.fdp8) return -6;                     // shape not covered by a fused kernel
     const size_t packed_len = n * (n + 1) / 2 + n + 8;
     double *slabs = nullptr, *packed = nullptr;
     LmState<double>* st = nullptr;
-    if (hipMalloc((void**)&slabs, sizeof(double) * (size_t)plan.nblk * plan.njobs * plan.slab_len) != hipSuccess) return -3;
+    const size_t slab_count = plan.fdp8 ? (size_t)plan.fdp8_nblk * plan.fdp8_slab_len : (size_t)plan.nblk * plan.njobs * plan.slab_len;
+    if (hipMalloc((void**)&slabs, sizeof(double) * slab_count) != hipSuccess) return -3;
     if (hipMalloc((void**)&packed, sizeof(double) * packed_len) != hipSuccess) { (void)hipFree(slabs); return -3; }
     if (hipMalloc((void**)&st, sizeof(LmState<double>)) != hipSuccess) { (void)hipFree(slabs); (void)hipFree(packed); return -3; }
     int rc = 0;

@@ -30,7 +30,9 @@ def ref_fill(Yrm, twh):
 
 @pytest.mark.parametrize("m,n", [(4096, 128), (5000, 16), (30, 32), (2, 48), (10002, 64), (7778, 80), (12344, 96),
                                  (6, 112), (100000, 128), (4097, 128), (10001, 64), (1, 16), (33, 32), (7777, 112),
-                                 (5000, 100), (3001, 7), (2048, 17), (999, 33), (6000, 127), (40, 1), (12345, 90)])
+                                 (5000, 100), (3001, 7), (2048, 17), (999, 33), (6000, 127), (40, 1), (12345, 90),
+                                 # 128 < n <= 256, n % 32 == 0: k_jtj_fdp8 (eight producer + consumer waves, jtj_fdp8.h)
+                                 (4096, 256), (5001, 160), (33, 192), (10003, 224), (50000, 256), (1, 256), (17, 160)])
 def test_fd_jtj_exact_integers(m, n):
     rng = np.random.default_rng(m + n)
     Yrm = rng.integers(-8, 9, size=(m, 2 * n)).astype(np.float64)
@@ -67,7 +69,8 @@ def test_ring_and_streaming_variants_agree_with_producer_consumer_kernels(m, n):
         assert np.array_equal(Jy, Jr.T @ y) or np.allclose(Jy, Jr.T @ y, rtol=1e-15, atol=0)
 
 
-@pytest.mark.parametrize("m,n", [(20000, 128), (9998, 32), (50, 16), (33334, 112), (5000, 100), (7001, 9), (3000, 126)])
+@pytest.mark.parametrize("m,n", [(20000, 128), (9998, 32), (50, 16), (33334, 112), (5000, 100), (7001, 9), (3000, 126),
+                                 (20000, 256), (7001, 192), (2049, 160), (30001, 224)])
 def test_fd_jtj_random(m, n):
     rng = np.random.default_rng(7 * m + n)
     base = rng.standard_normal((m, 1))
@@ -116,7 +119,8 @@ def test_row_major_batched_residual_equals_point_major(m, n):
 @pytest.mark.parametrize("m,n,bounded", [(20000, 32, False), (50000, 128, False), (4096, 16, False), (30000, 64, False),
                                          (7000, 48, False), (3000, 16, True), (10000, 96, True), (20001, 32, False),
                                          (9999, 128, False), (5001, 80, True), (9973, 100, False), (6000, 7, False),
-                                         (8000, 33, True), (12000, 90, False)])
+                                         (8000, 33, True), (12000, 90, False), (30000, 256, False), (9001, 192, True),
+                                         (12000, 160, False)])
 def test_fused_fd_solve_matches_fill_pass(m, n, bounded):
     w = P.tanh_linear(m, n)
     prob = W.TanhLinear(w["A"], w["b"])
