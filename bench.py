@@ -390,13 +390,16 @@ def main():
     flush_c_stdio()     # every rank: RCCL's init banner leaves the C stdio buffer now, not at process exit
 
     def timed(count, s):
-        st = M.Stats()
+        # two statistics records: `st` for the steps whose kernels are bracketed with HIP events (its per-launch figures --
+        # milliseconds, pending columns, points per call -- all refer to the same launches), `st_all` for every step (counters)
+        st, st_plain = M.Stats(), M.Stats()
         iters = 0
         every = max(1, args.timing_every)
         barrier()
         t0 = time.perf_counter()
         for i in range(count):
-            r, xx = solve(stats=st, flags=M.TIME_KERNELS if (not args.no_kernel_timing and i % every == 0) else 0, s=s)
+            timed_step = not args.no_kernel_timing and i % every == 0
+            r, xx = solve(stats=st if timed_step else st_plain, flags=M.TIME_KERNELS if timed_step else 0, s=s)
             iters += r.iterations
         barrier()
         dt = time.perf_counter() - t0
@@ -404,9 +407,12 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device=ctl_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        return st.as_dict(), iters, dt, r, xx
+        d, dp = st.as_dict(), st_plain.as_dict()
+        d["all"] = {k: (d[k] + dp[k]) if not isinstance(d[k], list) else [a + b for a, b in zip(d[k], dp[k])] for k in d}
+        return d, iters, dt, r, xx
 
     st, iters, dt, res, x = timed(args.steps, settings)
+    sta = st["all"]
     timed_steps = len(range(0, args.steps, max(1, args.timing_every))) if not args.no_kernel_timing else 0
     if res.status < 0:
         raise SystemExit(f"solver failed: {res}")
@@ -418,7 +424,7 @@ def main():
         st9, it9, dt9, r9, _ = timed(args.survey_steps, s9)
         survey = {"abs_tolerance": 1e-9, "value": it9 / dt9, "unit": "iterations/s", "steps": args.survey_steps,
                   "ms_per_solve": dt9 / args.survey_steps * 1e3, "iterations_per_solve": it9 / args.survey_steps,
-                  "passes_per_solve": st9["passes"] / args.survey_steps, "status": r9.status.name, "residual": r9.residual}
+                  "passes_per_solve": st9["all"]["passes"] / args.survey_steps, "status": r9.status.name, "residual": r9.residual}
 
     out = None
     if rank == 0:
@@ -530,23 +536,23 @@ def main():
                 "m_total": m_total, "m_per_gpu": m, "n": n, "scaling": args.scaling,
                 "parallelism": f"rows sharded x{world}, " + ("RCCL all-reduce" if args.comm == "rccl" else "gloo callback all-reduce (rehearsal)"),
                 "rccl_ranks": api.lib().mir_lsq_comm_ranks(comm) if (comm and args.comm == "rccl") else None,
-                "allreduce_per_solve": {"packed_calls": st["allreduce_calls"][0] / K, "packed_elems": st["allreduce_elems"][0] / max(1, st["allreduce_calls"][0]),
-                                        "sweep_calls": st["allreduce_calls"][1] / K, "sweep_elems": st["allreduce_elems"][1] / max(1, st["allreduce_calls"][1]),
-                                        "scalar_calls": st["allreduce_calls"][2] / K},
+                "allreduce_per_solve": {"packed_calls": sta["allreduce_calls"][0] / K, "packed_elems": sta["allreduce_elems"][0] / max(1, sta["allreduce_calls"][0]),
+                                        "sweep_calls": sta["allreduce_calls"][1] / K, "sweep_elems": sta["allreduce_elems"][1] / max(1, sta["allreduce_calls"][1]),
+                                        "scalar_calls": sta["allreduce_calls"][2] / K},
                 "rccl_stall_probe": stall if t_comm is not None else None,
                 "abs_tolerance": args.abs_tolerance,
                 "abs_tolerance_note": "1e-5: every accept/reject decision of the solve has margin; at the survey's 1e-9 the last "
                                       "acceptance compares rounding noise (12 it / 16 passes or 11 it / 56 passes): see survey_setting",
                 "survey_setting": survey,
                 "iterations_per_solve": iters / K, "status": res.status.name,
-                "passes_per_solve": st["passes"] / K, "fcalls_per_solve": res.fCalls,
-                "jacobian_full_per_solve": st["jacobian_full"] / K, "residual": res.residual,
+                "passes_per_solve": sta["passes"] / K, "fcalls_per_solve": res.fCalls,
+                "jacobian_full_per_solve": sta["jacobian_full"] / K, "residual": res.residual,
                 "kernel_timing": f"HIP events on the solver's stream in {timed_steps} of the {K} timed steps (every {max(1, args.timing_every)}th)",
                 "time_split_ms_per_solve": {
                     "caller_fd_callbacks": st["fd_callback_ms"] / KT, "caller_trial_callbacks": st["trial_callback_ms"] / KT,
                     "jtj_fd_kernel": st["jtj_fd_ms"] / KT, "broyden_sweep": st["jtj_broyden_ms"] / KT,
                     "solve_kernel": st["solve_ms"] / KT, "library_kernels": lib_ms, "caller_kernels": user_ms,
-                    "total_wall": st["total_ms"] / K},
+                    "total_wall": sta["total_ms"] / K},
             },
             "roofline": dominant,
             other_key: other,

@@ -462,21 +462,32 @@ def optimizeLeastSquares(f, m, x, l=None, u=None, g=None, tm=None, settings=None
         settings = LeastSquaresSettings(dtype)
     ft = _ftype(dtype)
     keep = []
+    errors = []      # exceptions raised inside Python callbacks: ctypes would print and swallow them and the solve would go
+                     # on with garbage -- they are recorded, the outputs poisoned with NaN (the solver then ends with
+                     # numericError at its next check, LS:990 / 1117) and the first one is re-raised after the C call returns
 
     def wrap_f(fn):
         def cb(_ctx, m_, n_, xp, yp):
-            xv = np.ctypeslib.as_array(xp, shape=(n_,))
             yv = np.ctypeslib.as_array(yp, shape=(m_,))
-            yv[:] = 0
-            fn(xv, yv)
+            try:
+                xv = np.ctypeslib.as_array(xp, shape=(n_,))
+                yv[:] = 0
+                fn(xv, yv)
+            except BaseException as e:      # noqa: BLE001 -- re-raised below
+                errors.append(e)
+                yv[:] = np.nan
         return cb
 
     def wrap_g(fn):
         def cb(_ctx, m_, n_, xp, Jp):
-            xv = np.ctypeslib.as_array(xp, shape=(n_,))
             Jv = np.ctypeslib.as_array(Jp, shape=(m_ * n_,)).reshape(m_, n_)
-            Jv[:] = 0
-            fn(xv, Jv)
+            try:
+                xv = np.ctypeslib.as_array(xp, shape=(n_,))
+                Jv[:] = 0
+                fn(xv, Jv)
+            except BaseException as e:      # noqa: BLE001
+                errors.append(e)
+                Jv[:] = np.nan
         return cb
 
     fptr = _as_fnptr(f, ft, wrap_f, keep)
@@ -484,7 +495,10 @@ def optimizeLeastSquares(f, m, x, l=None, u=None, g=None, tm=None, settings=None
     tmptr = C.c_void_p(None)
     if tm is not None:
         def tm_cb(_ctx, count, task, taskfn):
-            tm(count, lambda total, tid, i: taskfn(task, total, tid, i))
+            try:
+                tm(count, lambda total, tid, i: taskfn(task, total, tid, i))
+            except BaseException as e:      # noqa: BLE001
+                errors.append(e)
         tmc = TM_FN(tm_cb)
         keep.append(tmc)
         tmptr = C.cast(tmc, C.c_void_p)
@@ -505,6 +519,8 @@ def optimizeLeastSquares(f, m, x, l=None, u=None, g=None, tm=None, settings=None
         raw = fn(C.byref(settings), m, n, x.ctypes.data, lo.ctypes.data, up.ctypes.data, work_slice, iwork_slice,
                  fContext, fptr, gContext, gptr, None, tmptr)
     del keep
+    if errors:
+        raise errors[0]
     return LeastSquaresResult(raw), x
 
 

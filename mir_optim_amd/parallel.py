@@ -48,18 +48,29 @@ class HostAllreduceComm:
         self.allreduce_numpy = allreduce_numpy
         L = api.lib()
 
+        self.errors = []     # exceptions inside the callback (ctypes would swallow them): see check()
+
         def cb(_ctx, dev_ptr, count, stream):
             host = np.empty(count, dtype=np.float64)
-            if L.mir_lsq_memcpy_d2h(host.ctypes.data, dev_ptr, count * 8, stream) != 0:
-                raise RuntimeError("D2H failed in all-reduce callback")
-            self.allreduce_numpy(host)
+            try:
+                if L.mir_lsq_memcpy_d2h(host.ctypes.data, dev_ptr, count * 8, stream) != 0:
+                    raise RuntimeError("D2H failed in all-reduce callback")
+                self.allreduce_numpy(host)
+            except BaseException as e:      # noqa: BLE001 -- poison the payload: the solve ends with numericError
+                self.errors.append(e)
+                host[:] = np.nan
             if L.mir_lsq_memcpy_h2d(dev_ptr, host.ctypes.data, count * 8, stream) != 0:
-                raise RuntimeError("H2D failed in all-reduce callback")
+                self.errors.append(RuntimeError("H2D failed in all-reduce callback"))
 
         self._cb = api.ALLREDUCE_FN(cb)
         self.handle = L.mir_lsq_comm_create_callback(world, rank, self._cb, None)
         if not self.handle:
             raise RuntimeError("mir_lsq_comm_create_callback failed")
+
+    def check(self):
+        """Re-raise the first exception a callback recorded (call after the solve returns)."""
+        if self.errors:
+            raise self.errors[0]
 
     def close(self):
         if self.handle:

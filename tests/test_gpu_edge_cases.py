@@ -139,3 +139,19 @@ def test_x0_on_bounds_and_mixed_infinite_bounds(oracle):
     ref[free] = lsq_linear(A[:, free], b - A[:, ~free] @ l[~free], bounds=(l[free], u[free]), tol=1e-14).x
     assert res.status >= 0 and np.all(x >= l) and np.all(x <= u) and x[4] == 0.2
     assert np.allclose(x, xo, rtol=1e-6, atol=1e-9) and np.allclose(x, ref, rtol=1e-5, atol=1e-7)
+
+
+def test_python_callback_exception_is_reraised_not_swallowed():
+    """an exception inside a ctypes callback used to be printed and swallowed, the solve continued on
+    garbage. Now the output is poisoned with NaN (the solver stops with numericError at its next check) and the exception
+    is re-raised when the C call returns."""
+    calls = {"n": 0}
+
+    def f(x, y):
+        calls["n"] += 1
+        if calls["n"] == 4:
+            raise ValueError("boom in the residual callback")
+        y[0] = 10 * (x[1] - x[0] ** 2); y[1] = 1 - x[0]
+    with pytest.raises(ValueError, match="boom"):
+        M.optimizeLeastSquares(f, 2, np.array([-1.2, 1.0]))
+    assert calls["n"] < 40                                     # it did not run the whole solve on garbage
