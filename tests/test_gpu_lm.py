@@ -117,7 +117,7 @@ def test_reference_unittests_trace_equals_oracle_trace(oracle, name):
     """Host-callback mode on the reference's own unittest problems (m <= 20, n <= 3): here the GPU path and the oracle
     run the same few flops per reduction, so the complete trace -- every event, counter and lambda; 51 rejected passes
     for T3b -- must be the same. Values agree to ~1e-14 until the first finite-difference refresh after a step and to
-    ~1e-7 after it: with the reference's absolute step 2^-26 (Q10) the FD Jacobian carries eps |f| / h ~ 1e-8 of
+    ~1e-8 after it: with the reference's absolute step 2^-26 (Q10) the FD Jacobian carries eps |f| / h ~ 1e-8 of
     rounding noise that any 1e-14 change of x re-draws."""
     p = getattr(P, name)()
     tr = M.Trace()
@@ -140,7 +140,11 @@ def test_reference_unittests_trace_equals_oracle_trace(oracle, name):
     assert [g[:2] for g in got] == [e[:2] for e in ev]
     for g, e in zip(got, ev):
         assert np.isclose(g[2], e[2], rtol=1e-12), (g, e)                # lambda: products of exact constants
-        assert np.allclose(g[3:], e[3:], rtol=2e-5, atol=1e-10 * (1 + ev[0][3])), (g, e)   # atol: noise floor of a zero-residual fit
+        # residual and trial residual: 1e-7 (measured <= 6e-9, scripts/trace_diff.py; round 1 allowed 2e-5, which hid a staging
+        # defect of 1.5e-8 -- tests/test_gpu_host_fd_staging.py); atol: noise floor of a zero-residual fit.
+        assert np.allclose(g[3:5], e[3:5], rtol=1e-7, atol=1e-10 * (1 + ev[0][3])), (g, e)
+        # dx.dx of the tiny steps at the end of a noisy fit is itself a finite-difference-noise quantity (measured 5e-5 on T4)
+        assert np.isclose(g[5], e[5], rtol=1e-3, atol=1e-10 * (1 + ev[0][3])), (g, e)
 
 
 def test_nothrow_tier_and_exception(oracle):
@@ -235,7 +239,7 @@ def test_pass_by_pass_trajectory_matches_oracle(oracle, m, n, bounded, mode):
     kinds = {g[0] for g in got[:K]}
     assert {0, 1, 3} <= kinds
     for k, (g, e) in enumerate(zip(got[:K], ev[:K])):
-        assert np.isclose(g[2], e[2], rtol=1e-6), ("lambda", k, g, e)
+        assert np.isclose(g[2], e[2], rtol=1e-8), ("lambda", k, g, e)          # measured <= 5e-10 (scripts/trace_diff.py)
         assert np.isclose(g[3], e[3], rtol=1e-7), ("residual", k, g, e)
         assert np.isclose(g[4], e[4], rtol=1e-7, atol=1e-300), ("trial residual", k, g, e)
         assert np.isclose(g[5], e[5], rtol=1e-3, atol=1e-22), ("dx_dot", k, g, e)
