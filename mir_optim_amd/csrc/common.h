@@ -43,6 +43,10 @@ template <> struct Mma<double> {
         return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
     }
     __host__ __device__ static inline int row(int lane, int r) { return (lane >> 4) + 4 * r; }
+    // accumulator row c lives in lane group crow_group(c), register crow_reg(c)
+    // accumulator row h (lane group h & 3, register h >> 2) relabelled so that a lane group owns FOUR CONSECUTIVE indices:
+    // perm(h) = 4 (h & 3) + (h >> 2) (an involution); group g, register q <-> index 4 g + q
+    __host__ __device__ static constexpr int perm(int h) { return 4 * (h & 3) + (h >> 2); }
 };
 template <> struct Mma<float> {
     using Acc = __attribute__((ext_vector_type(4))) float;
@@ -50,6 +54,7 @@ template <> struct Mma<float> {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
     }
     __host__ __device__ static inline int row(int lane, int r) { return 4 * (lane >> 4) + r; }
+    __host__ __device__ static constexpr int perm(int h) { return h; }     // group g already owns rows 4 g .. 4 g + 3
 };
 
 template <typename T> __device__ inline T wave_shfl_xor(T v, int mask) { return __shfl_xor(v, mask, kWave); }
@@ -87,6 +92,58 @@ template <int N> __device__ inline double dpp_row_bcast(double v)
 template <int N> __device__ inline float dpp_row_bcast(float v)
 {
     return __int_as_float(dpp_row_bcast<N>(__float_as_int(v)));
+}
+
+// Lanes of ONE wave exchanging data through LDS without a workgroup barrier: the DS operations of a wave execute in order,
+// but the COMPILER assumes data-race freedom -- without this it keeps a value a lane loaded earlier when only other lanes
+// stored to the address since (seen: the reload sunk into the storing lanes' branch). No instruction is emitted.
+__device__ inline void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// sum over each quad of lanes (4 l .. 4 l + 3), every lane receives the total: DPP quad_perm [1,0,3,2] then [2,3,0,1]
+template <int CTRL> __device__ inline int dpp_quad(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
+template <int CTRL> __device__ inline double dpp_quad(double v)
+{
+    const int lo = dpp_quad<CTRL>(__double2loint(v));
+    const int hi = dpp_quad<CTRL>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL> __device__ inline float dpp_quad(float v) { return __int_as_float(dpp_quad<CTRL>(__float_as_int(v))); }
+template <typename T> __device__ inline T quad_sum(T v)
+{
+    v += dpp_quad<0xB1>(v);
+    v += dpp_quad<0x4E>(v);
+    return v;
+}
+
+// lane (i, k = lane >> 4) <- register k of lane (i, JB): one row of the 4 x 4 (register x lane group) transpose, on the gfx950
+// swap instructions (v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of the second;
+// v_permlane32_swap: upper 32 lanes of the first <-> lower 32 lanes of the second). VALU only: no LDS round trip.
+template <int JB> __device__ inline int group_pick(int r0, int r1, int r2, int r3)
+{
+    const auto a = __builtin_amdgcn_permlane16_swap(r0, r1, false, false);   // a[0] = r0g0 r1g0 r0g2 r1g2, a[1] = r0g1 r1g1 r0g3 r1g3
+    const auto b = __builtin_amdgcn_permlane16_swap(r2, r3, false, false);
+    if constexpr ((JB & 1) == 0) {
+        const auto s = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);   // s[0] = r0g0 r1g0 r2g0 r3g0, s[1] = r0g2 .. r3g2
+        return JB == 0 ? s[0] : s[1];
+    } else {
+        const auto s = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+        return JB == 1 ? s[0] : s[1];
+    }
+}
+template <int JB> __device__ inline double group_pick(double r0, double r1, double r2, double r3)
+{
+    const int lo = group_pick<JB>(__double2loint(r0), __double2loint(r1), __double2loint(r2), __double2loint(r3));
+    const int hi = group_pick<JB>(__double2hiint(r0), __double2hiint(r1), __double2hiint(r2), __double2hiint(r3));
+    return __hiloint2double(hi, lo);
+}
+template <int JB> __device__ inline float group_pick(float r0, float r1, float r2, float r3)
+{
+    return __int_as_float(group_pick<JB>(__float_as_int(r0), __float_as_int(r1), __float_as_int(r2), __float_as_int(r3)));
 }
 
 // compile-time loop: f(IntC<0>{}), ..., f(IntC<N - 1>{}) -- for builtins that need constant operands (DPP controls)
@@ -143,13 +200,18 @@ __device__ inline float lane_bcast(float v, int src)
 // dependent chain than sqrt() followed by a division; used on the Cholesky pivot path)
 __device__ inline void rsqrt_sqrt(double a, double& rinv, double& d)
 {
-    double r = __builtin_amdgcn_rsq(a);
-    r = r * (1.5 - 0.5 * a * r * r);
-    r = r * (1.5 - 0.5 * a * r * r);
-    double s = a * r;
-    s = fma(0.5 * r, fma(-s, s, a), s);          // sqrt: one correction step
-    r = fma(r, fma(-s, r, 1.0), r);              // 1/sqrt consistent with s
-    rinv = r; d = s;
+    // v_rsq_f64, one coupled (Goldschmidt) step for sqrt and 1 / (2 sqrt), two residual corrections of the root, one of the
+    // reciprocal: 10 dependent operations (the chain is on the critical path of every Cholesky pivot)
+    const double y = __builtin_amdgcn_rsq(a);
+    double g = a * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    g = fma(fma(-g, g, a), h, g);
+    g = fma(fma(-g, g, a), h, g);
+    const double rh = h + h;
+    rinv = fma(fma(-g, rh, 1.0), rh, rh);
+    d = g;
 }
 __device__ inline void rsqrt_sqrt(float a, float& rinv, float& d)
 {

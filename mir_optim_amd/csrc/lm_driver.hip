@@ -165,7 +165,7 @@ Buffers<T> carve(void* base, size_t m, size_t n, int num_cu)
         b.sc[k].ivec = (int32_t*)take(2 * n, sizeof(int32_t));
         b.sc[k].dbg = nullptr;
     }
-    b.sc[0].dbg = (long long*)take(16, sizeof(long long));
+    b.sc[0].dbg = (long long*)take(32, sizeof(long long));
     dbg_all = b.sc[0].dbg;
     (void)dbg_all;
     b.bytes = off;
@@ -1024,10 +1024,11 @@ struct Solver {
             }
             if (!solve_enqueued && !enqueue_solve(ks, lam, newJacobian, lambda_from_state)) { fail = true; break; }
             if (dbg_solve) {
-                long long h[16];
-                if (hipMemcpy(h, B.sc[0].dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
+                long long h[32];
+                if (hipMemcpy(h, B.sc[0].dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
                     std::fprintf(stderr, "[solve dbg] (10ns ticks) build %lld  copy/equil %lld  scale %lld  potrf %lld  potrs %lld  refine %lld  epilogue %lld  total %lld  shader MHz %.0f  [matvec1 %lld berr %lld]\n",
                                  h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[8] - h[7], h[8] - h[0], (double)(h[10] - h[9]) / (double)(h[8] - h[0]) * 100.0, h[11] - h[5], h[12] - h[11]);
+                }
             }
 
             // null-step probe: one small read-back instead of ks residual evaluations, only while the tail is running

@@ -74,6 +74,8 @@ __device__ __forceinline__ void lds_load_blocks(int n, const T* __restrict__ src
 }
 
 // ---- ?potrf 'L' in place on the L blocks. Returns info (0, or k: leading minor k not positive definite). Collective.
+constexpr int kInfoBase = 0x40000000;                      // *info_s = kInfoBase - (first bad pivot, 1-based), 0 = none
+
 template <typename T, int NB>
 __device__ __forceinline__ int lds_potrf(int n, T* smem, int* info_s)
 {
@@ -84,42 +86,97 @@ __device__ __forceinline__ int lds_potrf(int n, T* smem, int* info_s)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) *info_s = 0;
     const int nbl = (n + 15) >> 4;                           // blocks that hold real rows
-    for (int k = 0; k < nbl; ++k) {
-        __syncthreads();                                     // block (k, k) carries every earlier panel's update
-        // ---- (1) the diagonal block, wave 0, row per lane (lanes 16..63 shadow rows 0..15 and write nothing)
-        if (wave == 0) {
-            const int r = lane & 15;
-            T p[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) p[c] = L[blk_off(k, k, r, c)];
-            int bad = 0;
-            // pivot c: every lane of the row group gets lane c's / lane c2's value with a DPP row broadcast (a VALU move:
-            // no v_readlane -> SGPR -> VALU round trip, whose wait states dominated the first version of this loop)
-            static_for<16>([&](auto cc) {
-                constexpr int c = decltype(cc)::value;
-                const T piv = dpp_row_bcast<c>(p[c]);
-                if (!(piv > 0)) { if (16 * k + c < n && bad == 0) bad = 16 * k + c + 1; }
-                T rinv, d;
-                rsqrt_sqrt(piv > 0 ? piv : T(1), rinv, d);
-                if (r > c) p[c] *= rinv; else if (r == c) p[c] = d;
-                if (lane == c) rd[16 * k + c] = rinv;
-                static_for<16>([&](auto cc2) {
-                    constexpr int c2 = decltype(cc2)::value;
-                    if constexpr (c2 > c) {
-                        // rows r <= c only touch entries above the diagonal here (c2 > c >= r), which nothing reads: no mask
-                        const T lc = dpp_row_bcast<c2>(p[c]);    // L[c2][c]
-                        p[c2] -= p[c] * lc;
-                    }
+    // ---- (1) the diagonal block k on wave 0, kept in the MFMA accumulator layout under the relabelling Mma::perm: lane
+    //      (i = lane & 15, g = lane >> 4), register q holds A[row perm(i)][column 4 g + q] (the block is symmetric), so lane
+    //      group g owns the four-column panel g. Panel jb: its group factors the four columns on the VALU (pivot and
+    //      multipliers broadcast inside the 16-lane group: DPP), then every later column gets the rank-4 update as ONE
+    //      v_mfma 16x16x4 whose k-slot t operand is panel column t -- moved from group jb to group t by three permlane swaps.
+    //      The first version updated the 15 - c later columns of every pivot c one DPP broadcast + FMA at a time
+    //      (120 x 28 cycles: 2.8 us per block; one MFMA per pivot: 3.4 us, the 16-pass MFMA latency sits on the chain).
+    auto factor_diag = [&](int k, Acc acc) {
+        const int i = lane & 15, g = lane >> 4;
+        const int r = Mma<T>::perm(i);                       // the matrix row of this lane
+        int bad = 0;
+        static_for<4>([&](auto jj) {
+            constexpr int jb = decltype(jj)::value;
+            if (g == jb) {
+                static_for<4>([&](auto tt) {
+                    constexpr int t = decltype(tt)::value;
+                    constexpr int c = 4 * jb + t;
+                    const T piv = dpp_row_bcast<Mma<T>::perm(c)>(acc[t]);
+                    if (!(piv > 0)) { if (16 * k + c < n && bad == 0) bad = 16 * k + c + 1; }
+                    T rinv, d;
+                    rsqrt_sqrt(piv > 0 ? piv : T(1), rinv, d);
+                    acc[t] = r > c ? acc[t] * rinv : (r == c ? d : acc[t]);
+                    if (r == c) rd[16 * k + c] = rinv;
+                    static_for<4>([&](auto uu) {
+                        constexpr int t2 = decltype(uu)::value;
+                        if constexpr (t2 > t) {
+                            const T l = dpp_row_bcast<Mma<T>::perm(4 * jb + t2)>(acc[t]);   // L[c2][c]
+                            acc[t2] -= acc[t] * l;           // rows <= c: entries above the diagonal, which nothing reads
+                        }
+                    });
                 });
-            });
-            if (lane < 16) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) if (c <= r) L[blk_off(k, k, r, c)] = p[c];
             }
-            if (bad != 0 && lane == 0) *info_s = bad;
+            if constexpr (jb < 3) {
+                const T x = group_pick<jb>(acc[0], acc[1], acc[2], acc[3]);      // lane (i, t) <- L[perm(i)][4 jb + t]
+                const T v = r > 4 * jb + 3 ? x : T(0);       // columns up to this panel are final: their operand is zero
+                acc = Mma<T>::mma(-v, v, acc);               // A[r][c] -= sum_t L[r][4 jb + t] L[c][4 jb + t],  r, c > 4 jb + 3
+            }
+        });
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = 4 * g + q;
+            if (c <= r) L[blk_off(k, k, r, c)] = acc[q];
         }
-        __syncthreads();
-        if (*info_s != 0) return *info_s;                    // uniform
+        // the first bad pivot (?potrf's info): groups see different pivots, keep the smallest index. Encoded so that 0 = none.
+        if (bad != 0 && i == 0) atomicMax(info_s, kInfoBase - bad);
+    };
+    // block (I, I) in that layout / its update by panel k
+    auto load_diag = [&](int I) {
+        Acc acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = L[blk_off(I, I, Mma<T>::perm(lane & 15), 4 * (lane >> 4) + q)];
+        return acc;
+    };
+    auto apply_panel_diag = [&](int k, int I, Acc acc) {     // acc -= L_Ik L_Ik^T
+        const int pr = Mma<T>::perm(lane & 15), lk = lane >> 4;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const T a = L[blk_off(I, k, pr, 4 * s4 + lk)];
+            acc = Mma<T>::mma(-a, a, acc);
+        }
+        return acc;
+    };
+    auto load_block = [&](int I, int J) {
+        Acc acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = L[blk_off(I, J, Mma<T>::row(lane, q), lane & 15)];
+        return acc;
+    };
+    auto apply_panel = [&](int k, int I, int J, Acc acc) {   // acc -= L_Ik L_Jk^T
+        const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const T a = -L[blk_off(I, k, lr, 4 * s4 + lk)];
+            const T b = L[blk_off(J, k, lr, 4 * s4 + lk)];
+            acc = Mma<T>::mma(a, b, acc);
+        }
+        return acc;
+    };
+    // ---- (3) trailing update of one block on the matrix cores: block (I, J), k < J <= I, -= L_Ik L_Jk^T
+    auto update_block = [&](int k, int I, int J) {
+        const Acc acc = apply_panel(k, I, J, load_block(I, J));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) L[blk_off(I, J, Mma<T>::row(lane, q), lane & 15)] = acc[q];
+    };
+    // Look-ahead: wave 0 brings block (k + 1, k + 1) up to date and factors it WHILE waves 1..3 apply panel k to the rest of
+    // the trailing matrix -- the serial 16-pivot factorisation (~1.9 us) was a third of a panel step with three idle waves.
+    __syncthreads();                                         // the blocks are loaded
+    if (wave == 0) factor_diag(0, load_diag(0));
+    for (int k = 0; k < nbl; ++k) {
+        __syncthreads();                                     // block (k, k) is factored; column k carries every earlier update
+        if (*info_s != 0) return kInfoBase - *info_s;        // uniform
         if (k + 1 >= nbl) break;
         // ---- (2) rows below the diagonal block against L_kk: one thread per row
         if (tid < 16 * (nbl - 1 - k)) {
@@ -139,25 +196,18 @@ __device__ __forceinline__ int lds_potrf(int n, T* smem, int* info_s)
             for (int c = 0; c < 16; ++c) L[blk_off(I, k, r, c)] = p[c];
         }
         __syncthreads();
-        // ---- (3) trailing update on the matrix cores: block (I, J), k < J <= I, -= L_Ik L_Jk^T
+        // ---- (3) + (1) of the next panel
         {
             const int rem = nbl - 1 - k, cnt = rem * (rem + 1) / 2;
-            const int lr = lane & 15, lk = lane >> 4;
-            for (int idx = wave; idx < cnt; idx += kSolveThreads / kWave) {
-                int ii = 0;
-                while ((ii + 1) * (ii + 2) / 2 <= idx) ++ii;
-                const int I = k + 1 + ii, J = k + 1 + (idx - ii * (ii + 1) / 2);
-                Acc acc;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = L[blk_off(I, J, Mma<T>::row(lane, q), lr)];
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    const T a = -L[blk_off(I, k, lr, 4 * s4 + lk)];
-                    const T b = L[blk_off(J, k, lr, 4 * s4 + lk)];
-                    acc = Mma<T>::mma(a, b, acc);
+            if (wave == 0) {
+                const Acc d = apply_panel_diag(k, k + 1, load_diag(k + 1));
+                factor_diag(k + 1, d);                       // block (k + 1, k + 1) goes from LDS through the registers once
+            } else {
+                for (int idx = wave; idx < cnt; idx += kSolveThreads / kWave - 1) {
+                    int ii = 0;
+                    while ((ii + 1) * (ii + 2) / 2 <= idx) ++ii;
+                    update_block(k, k + 1 + ii, k + 1 + (idx - ii * (ii + 1) / 2));
                 }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) L[blk_off(I, J, Mma<T>::row(lane, q), lr)] = acc[q];
             }
         }
     }
@@ -182,64 +232,171 @@ __device__ __forceinline__ int lds_potrf(int n, T* smem, int* info_s)
     return 0;
 }
 
-// ---- ?potrs: thread i < 16 NB holds z_i (the right-hand side on entry, the solution on return). Collective.
+// ---- ?potrs on ONE wave, left-looking, no workgroup barrier inside: the vector sits in LDS and is solved in place block
+//      by block. Lane (r = lane >> 2, h = lane & 3) works on row r of the current diagonal block and on every fourth column;
+//      step j: z_j -= sum_{k < j} L_jk x_k (a DPP quad sum), then x_j = inv(L_jj) z_j through a 16-value exchange in LDS
+//      (DS operations of one wave execute in order: wave_lds_fence for the compiler, no barrier). Software-pipelined and fully
+//      unrolled: the products with x_0 .. x_{j-1} for step j + 1 are loaded before and summed WHILE step j's exchange is in
+//      flight, so only the k = j - 1 term, two quad sums and two LDS write -> read exchanges (~160 cycles each, measured) are
+//      on the chain of a step: ~550 cycles, 5.8 us at n = 128. Earlier versions: every row a thread with one workgroup
+//      barrier + two LDS round trips per block step (9 us), then this lane layout with a run-time k loop (also 9 us: each k
+//      iteration waited for its own loads). All four lanes of a quad store the (identical) results: no divergent branch.
+//      Thread i < 16 NB passes z_i in and gets x_i back.
 template <typename T, int NB>
-__device__ __forceinline__ void lds_potrs(int n, T* smem, T& z)
+__device__ __forceinline__ T lds_potrs(int n, T* smem, T z)
 {
     using C = LdsSolveCfg<NB>;
     const T* L = smem + C::L_OFF;
     const T* rd = smem + C::RD_OFF;
-    T* xv = smem + C::XV_OFF;
-    const int tid = threadIdx.x, I = tid >> 4, r = tid & 15;
+    T* zv = smem + C::ZV_OFF;                                // the vector, solved in place
+    T* xk = smem + C::XV_OFF;                                // 16-value exchange inside the wave
+    const int tid = threadIdx.x;
     const int nbl = (n + 15) >> 4;
-    const bool row = tid < 16 * nbl;
     constexpr int zoff = C::ZERO_OFF - C::L_OFF;             // an LDS element that holds 0
-    // forward: L w = z
-    for (int k = 0; k < nbl; ++k) {
-        if (row && I == k) {
-            // x_k = inv(L_kk) z_k inside the DPP row of the 16 owners: the coefficients inv(r, c), c < r, sit at (c, r) of the
-            // diagonal block (addresses known up front: the 16 LDS reads are independent), z_c arrives by row broadcast
-            T acc[4] = {rd[16 * k + r] * z, 0, 0, 0};        // inv(r, r) z_r
-            static_for<16>([&](auto cc) {
-                constexpr int c = decltype(cc)::value;
-                // c >= r: the coefficient is 0 -- read the zero kept at the end of the vectors instead of selecting a double
-                const T cf = L[c < r ? blk_off(k, k, c, r) : zoff];
-                const T zc = dpp_row_bcast<c>(z);
-                acc[c & 3] += cf * zc;
-            });
-            z = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-            xv[16 * k + r] = z;
-        }
-        __syncthreads();
-        if (row && I > k) {
-            T acc[4] = {0, 0, 0, 0};
+    if (tid < C::NV) zv[tid] = z;
+    __syncthreads();
+    if (tid < kWave) {
+        const int r = tid >> 2, h = tid & 3;
+        // one block step: x_j = D (z_j - pre - Lc . x_kc), D = inv(L_jj) (FWD) or its transpose; then the off-chain sum for the
+        // next step. FWD: next = j + 1, products with blocks k <= j - 1 (x_j follows as that step's chain term).
+        T pre = 0;
+        static_for<NB>([&](auto jj) {                        // forward: L w = z
+            constexpr int j = decltype(jj)::value;
+            if (j < nbl) {
+                T lc[4], zc[4];
+                if constexpr (j > 0) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) acc[c & 3] += L[blk_off(I, k, r, c)] * xv[16 * k + c];
-            z -= (acc[0] + acc[1]) + (acc[2] + acc[3]);
-        }
-    }
-    // backward: L^T x = w
-    for (int k = nbl - 1; k >= 0; --k) {
-        if (row && I == k) {
-            T acc[4] = {rd[16 * k + r] * z, 0, 0, 0};
-            static_for<16>([&](auto cc) {
-                constexpr int c = decltype(cc)::value;
-                const T cf = L[c > r ? blk_off(k, k, r, c) : zoff];   // inv(c, r), c > r, stored at (r, c)
-                const T zc = dpp_row_bcast<c>(z);
-                acc[c & 3] += cf * zc;
-            });
-            z = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-            xv[16 * k + r] = z;
-        }
-        __syncthreads();
-        if (row && I < k) {
-            T acc[4] = {0, 0, 0, 0};
+                    for (int cc = 0; cc < 4; ++cc) { lc[cc] = L[blk_off(j, j - 1, r, h + 4 * cc)]; zc[cc] = zv[16 * (j - 1) + h + 4 * cc]; }
+                }
+                const T zj = zv[16 * j + r];
+                T cf[4];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) acc[c & 3] += L[blk_off(k, I, c, r)] * xv[16 * k + c];   // L(16 k + c, 16 I + r)
-            z -= (acc[0] + acc[1]) + (acc[2] + acc[3]);
-        }
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int c = h + 4 * cc;
+                    const T t = L[c < r ? blk_off(j, j, c, r) : zoff];           // inv(r, c), c < r, stored at (c, r)
+                    cf[cc] = t;
+                }
+                const T dg = rd[16 * j + r];
+                // loads of the off-chain products of step j + 1
+                T lo[j > 0 ? 4 * j : 1], zo[j > 0 ? 4 * j : 1];
+                if constexpr (j > 0 && j + 1 < NB) {
+                    static_for<j>([&](auto kk) {
+                        constexpr int k = decltype(kk)::value;
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) { lo[4 * k + cc] = L[blk_off(j + 1, k, r, h + 4 * cc)]; zo[4 * k + cc] = zv[16 * k + h + 4 * cc]; }
+                    });
+                }
+                T acc = pre;
+                if constexpr (j > 0) {
+                    T a1 = lc[1] * zc[1];
+                    acc += lc[0] * zc[0];
+                    a1 += lc[3] * zc[3];
+                    acc += lc[2] * zc[2];
+                    acc += a1;
+                }
+                acc = quad_sum(acc);
+                const T zr = zj - acc;
+                xk[r] = zr;                                  // the four lanes of a quad store the same value: no branch
+                wave_lds_fence();
+                T xs[4];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) xs[cc] = xk[h + 4 * cc];
+                __builtin_amdgcn_sched_barrier(0);           // the exchange is in flight: this is where the off-chain sum belongs
+                pre = 0;
+                if constexpr (j > 0 && j + 1 < NB) {
+                    T p1 = 0;
+#pragma unroll
+                    for (int e = 0; e < 4 * j; e += 2) { pre += lo[e] * zo[e]; p1 += lo[e + 1] * zo[e + 1]; }
+                    pre += p1;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                T s0 = 0, s1 = 0;
+#pragma unroll
+                for (int cc = 0; cc < 4; cc += 2) {
+                    s0 += ((h + 4 * cc) == r ? dg : cf[cc]) * xs[cc];
+                    s1 += ((h + 4 * cc + 4) == r ? dg : cf[cc + 1]) * xs[cc + 1];
+                }
+                const T s = quad_sum(s0 + s1);
+                zv[16 * j + r] = s;
+                wave_lds_fence();
+            }
+        });
+        // backward: L^T x = w. Step j (from nbl - 1 down): chain term k = j + 1, off-chain k >= j + 2. Unrolled over
+        // d = NB - 1 - j so that the compile-time index runs upwards; blocks >= nbl hold nothing and are skipped at run time.
+        pre = 0;
+        static_for<NB>([&](auto dd) {
+            constexpr int j = NB - 1 - decltype(dd)::value;
+            if (j < nbl) {
+                const bool chain = j + 1 < nbl;
+                T lc[4], zc[4];
+                if constexpr (j + 1 < NB) {
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        lc[cc] = L[chain ? blk_off(j + 1, j, h + 4 * cc, r) : zoff];            // L(16 (j + 1) + c, 16 j + r)
+                        zc[cc] = zv[16 * (j + 1) + h + 4 * cc];
+                    }
+                }
+                const T zj = zv[16 * j + r];
+                T cf[4];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int c = h + 4 * cc;
+                    cf[cc] = L[c > r ? blk_off(j, j, r, c) : zoff];              // inv(c, r), c > r, stored at (r, c)
+                }
+                const T dg = rd[16 * j + r];
+                constexpr int NO = (j > 0 && j + 1 < NB) ? NB - 1 - j : 0;       // off-chain blocks of step j - 1: k = j + 1 .. NB - 1
+                T lo[NO > 0 ? 4 * NO : 1], zo[NO > 0 ? 4 * NO : 1];
+                if constexpr (NO > 0) {
+                    static_for<NO>([&](auto kk) {
+                        constexpr int k = j + 1 + decltype(kk)::value;
+                        const bool in = k < nbl;
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) {
+                            lo[4 * (k - j - 1) + cc] = L[in ? blk_off(k, j - 1, h + 4 * cc, r) : zoff];
+                            zo[4 * (k - j - 1) + cc] = zv[16 * k + h + 4 * cc];
+                        }
+                    });
+                }
+                T acc = pre;
+                if constexpr (j + 1 < NB) {
+                    T a1 = lc[1] * zc[1];
+                    acc += lc[0] * zc[0];
+                    a1 += lc[3] * zc[3];
+                    acc += lc[2] * zc[2];
+                    acc += a1;
+                }
+                acc = quad_sum(acc);
+                const T zr = zj - acc;
+                xk[r] = zr;                                  // the four lanes of a quad store the same value: no branch
+                wave_lds_fence();
+                T xs[4];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) xs[cc] = xk[h + 4 * cc];
+                __builtin_amdgcn_sched_barrier(0);
+                pre = 0;
+                if constexpr (NO > 0) {
+                    T p1 = 0;
+#pragma unroll
+                    for (int e = 0; e < 4 * NO; e += 2) { pre += lo[e] * zo[e]; p1 += lo[e + 1] * zo[e + 1]; }
+                    pre += p1;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                T s0 = 0, s1 = 0;
+#pragma unroll
+                for (int cc = 0; cc < 4; cc += 2) {
+                    s0 += ((h + 4 * cc) == r ? dg : cf[cc]) * xs[cc];
+                    s1 += ((h + 4 * cc + 4) == r ? dg : cf[cc + 1]) * xs[cc + 1];
+                }
+                const T s = quad_sum(s0 + s1);
+                zv[16 * j + r] = s;
+                wave_lds_fence();
+            }
+        });
     }
-    __syncthreads();                                         // xv is free again
+    __syncthreads();
+    if (tid < C::NV) z = zv[tid];
+    __syncthreads();                                         // zv / xv are free again
+    return z;
 }
 
 // ---- r_i = b_i - (A x)_i, w_i = |b_i| + (|A| |x|)_i for the row of thread tid (valid for tid < n). x is published
@@ -345,7 +502,7 @@ __device__ __forceinline__ int posvx_lds(int n, const T* src, int ld, T shift, T
     MIRLSQ_STAMP(dbg, 4);
 
     T x = tid < n ? bi : T(0);
-    lds_potrs<T, NB>(n, smem, x);
+    x = lds_potrs<T, NB>(n, smem, x);
     MIRLSQ_STAMP(dbg, 5);
 
     // ?porfs: iterative refinement, ITMAX = 5
@@ -361,7 +518,7 @@ __device__ __forceinline__ int posvx_lds(int n, const T* src, int ld, T shift, T
         if (count == 1) MIRLSQ_STAMP(dbg, 12);
         if (berr > eps && 2 * berr <= lstres && count <= 5) {
             T dz = tid < n ? ri : T(0);
-            lds_potrs<T, NB>(n, smem, dz);
+            dz = lds_potrs<T, NB>(n, smem, dz);
             x += dz;
             lstres = berr;
             continue;
