@@ -211,7 +211,7 @@ def main_cfg5(args):
 
 def main_cfg2(args):
     """BASELINE cfg 2: Gaussian-sum curve fit, m = 1e5 residuals x n = 16 parameters, fp64, width bounds, FD Jacobian through
-    the single-point device callback. J is 12.8 MB: every kernel of a pass is a few microseconds, so the solve is
+    the device callbacks (--fd batched: one launch for the 2n points of a refresh; --fd serial: one per point). J is 12.8 MB: every kernel of a pass is a few microseconds, so the solve is
     bound by launch latency and host round trips, not by HBM or MFMA -- the line reports the time per pass and per launch."""
     import numpy as np
     import torch
@@ -226,21 +226,22 @@ def main_cfg2(args):
     g = P.gauss_sum(100000, K=5)
     prob = W.Curve("gauss_sum", g["t"], g["data"])
     ws = api.lib().mir_lsq_workspace_create(g["m"], g["n"], 8)
+    fdb = {"batched": True, "pointmajor": "pointmajor", "serial": False}[args.fd]   # 2n FD points per launch, or one call per point
     for _ in range(max(1, args.warmup)):
-        res, x = prob.solve(g["x0"], g["lower"], g["upper"], workspace=ws, variant=args.variant)
+        res, x = prob.solve(g["x0"], g["lower"], g["upper"], workspace=ws, variant=args.variant, batched=fdb)
     # the timed region carries NO kernel events: at ~6 event pairs per round and 41 rounds per solve they cost 0.9 ms of a
     # 3 ms solve (scripts/ab_bench.sh); the per-kernel split comes from a second, instrumented pass of the same solves
     iters = 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res, x = prob.solve(g["x0"], g["lower"], g["upper"], workspace=ws, variant=args.variant)
+        res, x = prob.solve(g["x0"], g["lower"], g["upper"], workspace=ws, variant=args.variant, batched=fdb)
         iters += res.iterations
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     st = M.Stats()
     for _ in range(args.steps):
-        prob.solve(g["x0"], g["lower"], g["upper"], workspace=ws, stats=st, variant=args.variant, flags=M.TIME_KERNELS)
+        prob.solve(g["x0"], g["lower"], g["upper"], workspace=ws, stats=st, variant=args.variant, flags=M.TIME_KERNELS, batched=fdb)
     d = st.as_dict()
     K = args.steps
     m, n = g["m"], g["n"]
@@ -248,8 +249,9 @@ def main_cfg2(args):
     out = {
         "metric": "LM iterations/sec", "value": iters / dt, "unit": "iterations/s", "n_gpus": 1, "steps": K, "warmup": args.warmup,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"cfg2 Gaussian-sum fit m={m} x n={n} fp64, width bounds, FD Jacobian (single-point device callback), "
-                               "default settings, whole solves",
+        "config": {"workload": f"cfg2 Gaussian-sum fit m={m} x n={n} fp64, width bounds, FD Jacobian ("
+                               + ("batched device callback: the 2n points of a refresh in one launch" if fdb else "single-point device callback")
+                               + "), default settings, whole solves",
                    "iterations_per_solve": iters / K, "passes_per_solve": d["passes"] / K, "rounds_per_solve": rounds,
                    "fcalls_per_solve": res.fCalls, "status": res.status.name, "residual": res.residual,
                    "qp_active_set_passes_per_solve": d["qp_active_set_passes"] / K,
@@ -303,9 +305,11 @@ def main():
 
     if not torch.cuda.is_available() or M.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: mir_optim_amd has no CPU path")
-    torch.cuda.set_device(local_rank % torch.cuda.device_count() if args.comm == "gloo-callback" else local_rank)
+    share = args.comm == "gloo-callback" or os.environ.get("BENCH_SHARE_GPU") == "1"   # rehearsals: ranks share the GPUs there are
+    torch.cuda.set_device(local_rank % torch.cuda.device_count() if share else local_rank)
     comm = None
     comm_obj = None
+    comm_fallback = None
     t_comm = None
     distributed = world > 1 or args.force_comm or os.environ.get("MIR_LSQ_FORCE_COMM") == "1"
     ctl_dev = "cpu"
@@ -326,12 +330,35 @@ def main():
             t = torch.from_numpy(buf).to(ctl_dev)
             dist.broadcast(t, 0)
             return t.cpu().numpy()
+        comm_fallback = None
+        if args.comm == "rccl":
+            # the solver's own RCCL communicator (xGMI), id via torch.distributed; checked with one all-reduce of a known
+            # payload before anything is timed. If ANY rank fails to create or verify it, every rank falls back to the callback
+            # communicator over the control plane -- slower, labelled in config, but a measured line instead of a crash.
+            err = None
+            try:
+                comm = PAR.rccl_comm(world, rank, bcast)
+                if api.lib().mir_lsq_comm_ranks(comm) != world:
+                    err = f"ncclCommCount = {api.lib().mir_lsq_comm_ranks(comm)}, expected {world}"
+                elif not PAR.check_comm(comm, world, rank):
+                    err = "all-reduce self-check returned wrong sums"
+            except Exception as e:      # noqa: BLE001
+                err = repr(e)
+            flag = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64, device=ctl_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if flag.item() > 0:
+                print(f"[bench] rank {rank}: RCCL communicator unusable ({err or 'on another rank'}); falling back to the callback "
+                      "communicator over torch.distributed", file=sys.stderr, flush=True)
+                if comm:
+                    api.lib().mir_lsq_comm_destroy(comm)
+                comm = None
+                comm_fallback = err or "failure on another rank"
+                args.comm = "gloo-callback"
+            else:
+                t_comm = time.perf_counter()
         if args.comm == "gloo-callback":
             comm_obj = PAR.HostAllreduceComm(world, rank, PAR.torch_allreduce_numpy(dist))
             comm = comm_obj.handle
-        else:
-            comm = PAR.rccl_comm(world, rank, bcast)  # the solver's own RCCL communicator (xGMI), id via torch.distributed
-            t_comm = time.perf_counter()
 
     n = args.n
     if args.scaling == "strong":
@@ -534,8 +561,10 @@ def main():
                             f"absTolerance={args.abs_tolerance:g}, whole solves x0 -> termination, {args.scaling} scaling "
                             f"({m} rows on rank 0)",
                 "m_total": m_total, "m_per_gpu": m, "n": n, "scaling": args.scaling,
-                "parallelism": f"rows sharded x{world}, " + ("RCCL all-reduce" if args.comm == "rccl" else "gloo callback all-reduce (rehearsal)"),
+                "parallelism": f"rows sharded x{world}, " + ("RCCL all-reduce" if args.comm == "rccl" else
+                                                                 "gloo callback all-reduce (" + ("FALLBACK: RCCL unusable" if comm_fallback else "rehearsal") + ")"),
                 "rccl_ranks": api.lib().mir_lsq_comm_ranks(comm) if (comm and args.comm == "rccl") else None,
+                "rccl_fallback_reason": comm_fallback,
                 "allreduce_per_solve": {"packed_calls": sta["allreduce_calls"][0] / K, "packed_elems": sta["allreduce_elems"][0] / max(1, sta["allreduce_calls"][0]),
                                         "sweep_calls": sta["allreduce_calls"][1] / K, "sweep_elems": sta["allreduce_elems"][1] / max(1, sta["allreduce_calls"][1]),
                                         "scalar_calls": sta["allreduce_calls"][2] / K},

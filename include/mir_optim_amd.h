@@ -373,6 +373,11 @@ int mir_lsq_comm_create_local_group(int nranks, mir_lsq_comm** out_comms);
 void mir_lsq_comm_destroy(mir_lsq_comm* comm);
 /* ranks of the communicator as its transport reports them (RCCL: ncclCommCount); -1 on error */
 int mir_lsq_comm_ranks(const mir_lsq_comm* comm);
+/* Sum `count` doubles (floats) of the DEVICE buffer `buf` over the communicator's ranks, in place, ordered on `stream` -- the
+ * collective the solver issues for the three exchanges of a pass (least_squares.d:1052, 1065, 1115), exposed so that a caller
+ * can check a communicator before the first solve (bench.py does). Returns 0 on success. */
+int mir_lsq_comm_allreduce_d(mir_lsq_comm* comm, double* buf, size_t count, void* stream);
+int mir_lsq_comm_allreduce_s(mir_lsq_comm* comm, float* buf, size_t count, void* stream);
 
 /* Small device utilities for language bindings that have no HIP runtime of their own. */
 int mir_lsq_device_count(void);

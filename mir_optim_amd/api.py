@@ -278,6 +278,9 @@ def lib():
         L.mir_lsq_comm_destroy.argtypes = [C.c_void_p]
         L.mir_lsq_comm_ranks.restype = C.c_int
         L.mir_lsq_comm_ranks.argtypes = [C.c_void_p]
+        for name in ("mir_lsq_comm_allreduce_d", "mir_lsq_comm_allreduce_s"):
+            getattr(L, name).restype = C.c_int
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, sz, C.c_void_p]
         L.mir_lsq_device_count.restype = C.c_int
         L.mir_lsq_device_malloc.restype = C.c_void_p
         L.mir_lsq_device_malloc.argtypes = [sz]

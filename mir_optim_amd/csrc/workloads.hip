@@ -204,6 +204,28 @@ __global__ __launch_bounds__(256) void k_gauss_sum(const T* __restrict__ t, cons
     }
 }
 
+// P points in one launch (the batched callback of mir_lsq_gpu_options): element e <-> (row i, point k);
+// RM = false: Y[k m + i] (point-major), RM = true: Y[i P + k] (row-major, the layout of the fused finite-difference kernel)
+template <typename T, bool RM>
+__global__ __launch_bounds__(256) void k_gauss_sum_batched(const T* __restrict__ t, const T* __restrict__ data,
+                                                           const T* __restrict__ X, T* __restrict__ Y, size_t m, int n, int P)
+{
+    const int K = (n - 1) / 3;
+    const size_t total = m * (size_t)P;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = RM ? e / P : e % m;
+        const int k = (int)(RM ? e % P : e / m);
+        const T* x = X + (size_t)k * n;
+        const T ti = t[i];
+        T s = x[3 * K];
+        for (int q = 0; q < K; ++q) {
+            const T d = ti - x[K + q], w = x[2 * K + q];
+            s += x[q] * dexp(-(d * d) / (2 * w * w));
+        }
+        Y[e] = s - data[i];
+    }
+}
+
 // ---- exponential decay: kind 0: p0 exp(-t p1) - data ; kind 1: p0 exp(-t / p1) + p2 - data
 template <typename T>
 __global__ __launch_bounds__(256) void k_exp_decay(const T* __restrict__ t, const T* __restrict__ data,
@@ -771,6 +793,18 @@ void wl_gauss_sum_f_s(void* vctx, size_t m, size_t n, const float* x, float* y)
     auto* c = static_cast<wl_curve_ctx*>(vctx);
     hipLaunchKernelGGL(k_gauss_sum<float>, dim3(blocks_for(m)), dim3(256), 0, (hipStream_t)c->stream,
                        (const float*)c->t, (const float*)c->data, x, y, m, (int)n);
+}
+void wl_gauss_sum_fb_d(void* vctx, size_t m, size_t n, size_t p, const double* X, double* Y)
+{
+    auto* c = static_cast<wl_curve_ctx*>(vctx);
+    hipLaunchKernelGGL((k_gauss_sum_batched<double, false>), dim3(blocks_for(m * p)), dim3(256), 0, (hipStream_t)c->stream,
+                       (const double*)c->t, (const double*)c->data, X, Y, m, (int)n, (int)p);
+}
+void wl_gauss_sum_fbr_d(void* vctx, size_t m, size_t n, size_t p, const double* X, double* Y)
+{
+    auto* c = static_cast<wl_curve_ctx*>(vctx);
+    hipLaunchKernelGGL((k_gauss_sum_batched<double, true>), dim3(blocks_for(m * p)), dim3(256), 0, (hipStream_t)c->stream,
+                       (const double*)c->t, (const double*)c->data, X, Y, m, (int)n, (int)p);
 }
 void wl_exp_decay_f_d(void* vctx, size_t m, size_t n, const double* x, double* y)
 {

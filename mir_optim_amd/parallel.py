@@ -41,6 +41,18 @@ def rccl_comm(world, rank, broadcast_bytes):
     return comm
 
 
+def check_comm(comm, world, rank, count=8384):
+    """One all-reduce of a known payload through the communicator (the packed J^T J + J^T y length of n = 128 by default):
+    rank r contributes (r + 1) (k % 7 + 1) at element k. True when every element comes back as the exact sum."""
+    buf = np.arange(count, dtype=np.float64) % 7 + 1
+    d = api.DeviceBuffer(buf * (rank + 1))
+    if api.lib().mir_lsq_comm_allreduce_d(comm, d.ptr, count, None) != 0:
+        return False
+    got = d.download()
+    d.free()
+    return bool(np.array_equal(got, buf * (world * (world + 1) // 2)))
+
+
 class HostAllreduceComm:
     """Callback communicator: device buffer -> host -> `allreduce_numpy(buf)` (in place, sum) -> device."""
 

@@ -114,4 +114,6 @@ class Curve(DeviceProblem):
         suf = "d" if dtype == np.float64 else "s"
         self.f = _addr(("wl_gauss_sum_f_" if kind == "gauss_sum" else "wl_exp_decay_f_") + suf)
         self.g = None
-        self.fb = None
+        gs64 = kind == "gauss_sum" and dtype == np.float64
+        self.fb = _addr("wl_gauss_sum_fb_d") if gs64 else None       # batched residuals: one launch for the 2n FD points
+        self.fbr = _addr("wl_gauss_sum_fbr_d") if gs64 else None

@@ -91,6 +91,7 @@ def test_rccl_communicator_world_size_1(oracle):
     from mir_optim_amd import workloads as W
     comm = PAR.rccl_comm(1, 0, lambda buf: buf)
     assert M.api.lib().mir_lsq_comm_ranks(comm) == 1                  # ncclCommCount
+    assert PAR.check_comm(comm, 1, 0)                                 # mir_lsq_comm_allreduce_d: the bench's self-check
     for n in (32, 128):
         w = P.tanh_linear(30000, n)
         prob = W.TanhLinear(w["A"], w["b"])
@@ -131,3 +132,21 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert d["config"]["survey_setting"]["abs_tolerance"] == 1e-9 and d["config"]["survey_setting"]["value"] > 0
     assert d["config"]["allreduce_per_solve"]["packed_elems"] == 64 * 65 // 2 + 64
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
+
+
+@pytest.mark.gpu
+def test_bench_falls_back_when_rccl_is_unusable():
+    """bench.py --comm rccl with two ranks on ONE GPU: RCCL refuses two ranks on the same device (ncclCommInitRank fails on
+    both), every rank takes the same decision over the control plane and the run continues on the callback communicator --
+    one JSON line that says so, instead of a crash or a hang in the driver's multi-GPU run."""
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, BENCH_M="100000", BENCH_N="32", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2",
+               BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--survey-steps", "0", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    d = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{"metric"')][-1])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_fallback_reason"] and "callback" in d["config"]["parallelism"]
+    assert d["config"]["status"] in ("xConverged", "furtherImprovement", "fConverged", "gConverged") and d["value"] > 0

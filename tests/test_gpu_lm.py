@@ -338,6 +338,39 @@ def test_cfg2_gauss_sum_full_size(oracle):
     assert np.allclose(x, g["truth"], rtol=5e-3, atol=1e-3)
 
 
+def test_gauss_sum_batched_callback_equals_pointwise(oracle):
+    """workloads.hip: the batched Gaussian-sum callbacks (point-major and row-major) produce the per-point kernel's values,
+    and the solve through them ends where the per-point solve and the oracle end."""
+    import ctypes as C
+    from mir_optim_amd import api
+    g = P.gauss_sum(30000, K=5)
+    m, n = g["m"], g["n"]
+    prob = W.Curve("gauss_sum", g["t"], g["data"])
+    rng = np.random.default_rng(5)
+    p = 2 * n
+    X = np.asarray(g["x0"])[None, :] * (1 + 0.01 * rng.standard_normal((p, n)))
+    dX = api.DeviceBuffer(X)
+    dYb, dYr, dY1 = (api.DeviceBuffer(np.zeros((p, m))) for _ in range(3))
+    WL = api.workloads_lib()
+    ctx = C.c_void_p(C.addressof(prob.ctx))
+    WL.wl_gauss_sum_fb_d(ctx, C.c_size_t(m), C.c_size_t(n), C.c_size_t(p), C.c_void_p(dX.ptr), C.c_void_p(dYb.ptr))
+    WL.wl_gauss_sum_fbr_d(ctx, C.c_size_t(m), C.c_size_t(n), C.c_size_t(p), C.c_void_p(dX.ptr), C.c_void_p(dYr.ptr))
+    for k in range(p):
+        WL.wl_gauss_sum_f_d(ctx, C.c_size_t(m), C.c_size_t(n), C.c_void_p(dX.ptr + k * n * 8), C.c_void_p(dY1.ptr + k * m * 8))
+    prob.stream.synchronize()
+    Y1 = dY1.download()
+    assert np.array_equal(dYb.download(), Y1)
+    assert np.array_equal(dYr.download().reshape(m, p).T, Y1)
+    r1, x1 = prob.solve(g["x0"], g["lower"], g["upper"])
+    rb, xb = prob.solve(g["x0"], g["lower"], g["upper"], batched=True)
+    rp, xp = prob.solve(g["x0"], g["lower"], g["upper"], batched="pointmajor")
+    octx = oracle.GaussSumCtx(g["t"].ctypes.data, g["data"].ctypes.data)
+    ro, xo = oracle.optimize(oracle.native_fn("wlc_gauss_sum_f"), m, g["x0"], lower=g["lower"], upper=g["upper"], fctx=C.addressof(octx))
+    for r, x in ((r1, x1), (rb, xb), (rp, xp)):
+        assert r.status >= 0 and np.allclose(x, xo, rtol=1e-6, atol=1e-9) and np.isclose(r.residual, ro.residual, rtol=1e-8)
+    assert rb.fCalls == r1.fCalls and rp.fCalls == r1.fCalls          # the reference's counter: one per evaluated point
+
+
 @pytest.mark.parametrize("m,n", [(60000, 128), (40000, 256), (50000, 64), (30000, 208)])
 def test_repeated_solve_is_bit_reproducible(m, n):
     """The whole path is deterministic (fixed-order reductions, no float atomics): repeated solves are
