@@ -34,6 +34,21 @@ if mf:
         e["gui_active_cycles_per_xcd"] = gui / 8.0
         e["mfma_mops_f64_per_launch"] = d["SQ_INSTS_VALU_MFMA_MOPS_F64"] / n
         e["mfma_util"] = busy / (gui / 8.0 * 1024.0) if gui else 0.0
+# optional SQ / LDS passes (pmc_SQ1, pmc_SQ2): per-launch averages of each counter, kept for the kernels that are not
+# bandwidth-bound (k_lm_solve runs as ONE workgroup: wave cycles, VALU / LDS / SALU instructions, LDS bank conflicts)
+for sq in ("pmc_SQ1", "pmc_SQ2"):
+    files = glob.glob(os.path.join(src, sq, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.defaultdict(lambda: collections.defaultdict(int))
+    for r in csv.DictReader(open(files[0])):
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[k][r["Counter_Name"]] += 1
+    for k, d in agg.items():
+        if "k_lm_solve" in k or "k_decide" in k or "k_lr_" in k or "k_broyden" in k or "k_jtj" in k:
+            out.setdefault(k, {})["sq_per_launch"] = {**out.get(k, {}).get("sq_per_launch", {}), **{c: v / cnt[k][c] for c, v in d.items()}}
 for k, d in out.items():
     f, w = d.get("FETCH_SIZE_KB_per_launch", 0.0), d.get("WRITE_SIZE_KB_per_launch", 0.0)
     d["hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0          # FETCH_SIZE doubled: gfx950 correction

@@ -15,4 +15,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --kernel-trace -d "$out/pmc_MFMA" -o pmc \
     -- python3 "$root/bench.py" $args > "$out/pmc_MFMA.log" 2>&1 || exit 1
+# SQ / LDS view of the latency-bound kernels (k_lm_solve: one workgroup): two passes of four counters each
+rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU --kernel-trace -d "$out/pmc_SQ1" -o pmc \
+    -- python3 "$root/bench.py" $args > "$out/pmc_SQ1.log" 2>&1 || echo "SQ pass 1 failed (counter set not available?)"
+rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --kernel-trace -d "$out/pmc_SQ2" -o pmc \
+    -- python3 "$root/bench.py" $args > "$out/pmc_SQ2.log" 2>&1 || echo "SQ pass 2 failed (counter set not available?)"
 find "$out" -name "*.csv" | head -20
