@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void k_broyden_lr(const LrArgs<T> a)
 #pragma unroll
         for (int c = 0; c < NCP; ++c) {
             if constexpr (VEC) {
-                const P2 t = *reinterpret_cast<const P2*>(rp + coff[c]);
+                typedef T lr_v2 __attribute__((ext_vector_type(2)));
+                const lr_v2 t = __builtin_nontemporal_load(reinterpret_cast<const lr_v2*>(rp + coff[c]));   // J is swept once per pass and is larger than the Infinity Cache
                 v0[c] = t.x;
                 v1[c] = t.y;
             } else {
@@ -268,7 +269,8 @@ __global__ __launch_bounds__(256) void k_lr_flush(T* __restrict__ J, const T* __
 #pragma unroll
         for (int c = 0; c < NCP; ++c) {
             if constexpr (VEC) {
-                const P2 t = *reinterpret_cast<const P2*>(rp + coff[c]);
+                typedef T lr_v2 __attribute__((ext_vector_type(2)));
+                const lr_v2 t = __builtin_nontemporal_load(reinterpret_cast<const lr_v2*>(rp + coff[c]));
                 v0[c] = t.x;
                 v1[c] = t.y;
             } else {
@@ -288,7 +290,11 @@ __global__ __launch_bounds__(256) void k_lr_flush(T* __restrict__ J, const T* __
 #pragma unroll
             for (int c = 0; c < NCP; ++c) {
                 if constexpr (VEC) {
-                    if (ok0[c]) { P2 t; t.x = v0[c]; t.y = v1[c]; *reinterpret_cast<P2*>(rp + coff[c]) = t; }
+                    if (ok0[c]) {
+                        typedef T lr_v2 __attribute__((ext_vector_type(2)));
+                        lr_v2 t; t.x = v0[c]; t.y = v1[c];
+                        __builtin_nontemporal_store(t, reinterpret_cast<lr_v2*>(rp + coff[c]));
+                    }
                 } else {
                     if (ok0[c]) rp[coff[c]] = v0[c];
                     if (ok1[c]) rp[coff[c] + 1] = v1[c];

@@ -92,7 +92,7 @@ __device__ __forceinline__ void fdp_producer(const JtjArgs<double>& a, double* s
         for (int i = 0; i < NI; ++i) {
             size_t row = row0 + jrow(i);
             row = row < m ? row : m - 1;
-            b[i] = Y[row * (size_t)nr + jcol_v[kd(i)]];
+            b[i] = __builtin_nontemporal_load(&Y[row * (size_t)nr + jcol_v[kd(i)]]);   // read once: keep it out of the caches' way
         }
         size_t yr = row0 + (lane & (C::RP - 1));
         yr = yr < m ? yr : m - 1;
@@ -219,7 +219,7 @@ __device__ __forceinline__ void fdp_consumer(const JtjArgs<double>& a, const dou
                     T* wp = a.Jout + row * (size_t)a.n;    // the problem's n: row stride of J; padding columns stay in LDS
 #pragma unroll
                     for (int c = 0; c < NCB; ++c)
-                        if (c % 2 == ROLE - 2) { if (16 * c + p < a.n) wp[16 * c + p] = g.v[c]; }
+                        if (c % 2 == ROLE - 2) { if (16 * c + p < a.n) __builtin_nontemporal_store(g.v[c], &wp[16 * c + p]); }
                 }
             }
             if constexpr (ROLE == 0) {

@@ -75,7 +75,7 @@ __device__ __forceinline__ void jtj_fdp8_body(const JtjArgs<double>& a, double* 
         for (int i = 0; i < NI; ++i) {
             size_t row = row0 + prow[i];
             row = row < m ? row : m - 1;
-            b[i] = Y[row * (size_t)N + pcol[i]];
+            b[i] = __builtin_nontemporal_load(&Y[row * (size_t)N + pcol[i]]);   // the panel is read once
         }
         size_t yr = row0 + (lane & (C::RP - 1));
         yr = yr < m ? yr : m - 1;
@@ -93,7 +93,7 @@ __device__ __forceinline__ void jtj_fdp8_body(const JtjArgs<double>& a, double* 
             const bool rok = row < m;
             v = rok ? v : 0.0;                             // rows past m contribute nothing
             slot[(C::RP * ROLE + prow[i]) * C::LDJ + pcol[i]] = v;
-            if (rok) a.Jout[row * (size_t)N + pcol[i]] = v;
+            if (rok) __builtin_nontemporal_store(v, &a.Jout[row * (size_t)N + pcol[i]]);
         }
         if (lane < C::RP) slot[C::RS * C::LDJ + C::RP * ROLE + lane] = (row0 + lane < m) ? yb : 0.0;
     };

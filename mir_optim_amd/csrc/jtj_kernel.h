@@ -362,7 +362,7 @@ __device__ __forceinline__ void jtj2_body(const JtjArgs<double>& a, unsigned cha
             const int ins = ROLE + 2 * k;
             size_t off = base + (size_t)(ins * 64 + lane) * 16;
             if (off + 16 > total) off = base;            // rows past m: any valid bytes (masked by the consumers)
-            __builtin_amdgcn_global_load_lds((jtj_gbl_ptr)(Jb + off), (jtj_lds_ptr)(slot + ins * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((jtj_gbl_ptr)(Jb + off), (jtj_lds_ptr)(slot + ins * 1024), 16, 0, 2 /* nt: J is swept once per pass */);
         }
     };
     // y / y_old chunks (128 rows each) are issued by role 1, two chunks ahead, in the same in-order queue

@@ -66,7 +66,7 @@ __device__ __forceinline__ void jtj8_body(const JtjArgs<double>& a, const bool b
             const int ins = ROLE + 2 * k;
             size_t off = base + (size_t)(ins * 64 + lane) * 16;
             if (off + 16 > total) off = base;            // rows past m: any valid bytes (zeroed by the storers)
-            __builtin_amdgcn_global_load_lds((jtj_gbl_ptr)(Jb + off), (jtj_lds_ptr)(slot + ins * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((jtj_gbl_ptr)(Jb + off), (jtj_lds_ptr)(slot + ins * 1024), 16, 0, 2 /* nt: J is swept once per pass */);
         }
     };
     const unsigned char* yb = reinterpret_cast<const unsigned char*>(a.y);

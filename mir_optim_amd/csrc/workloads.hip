@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256) void k_tanh_linear(const T* __restrict__ A, co
 #pragma unroll
         for (int c = 0; c < NCP; ++c) {
             if constexpr (VEC) {                           // n even: a pair never straddles the row end
-                const P2 t = *reinterpret_cast<const P2*>(rp + coff[c]);
+                typedef T wl_v2 __attribute__((ext_vector_type(2)));
+                const wl_v2 t = __builtin_nontemporal_load(reinterpret_cast<const wl_v2*>(rp + coff[c]));   // A is swept once per call
                 v0[c] = t.x;
                 v1[c] = t.y;
             } else {
@@ -391,7 +392,7 @@ __device__ __forceinline__ void tlb_loader(const double* __restrict__ A, const d
             row = row < m ? row : m - 1;                        // rows past m: valid bytes, never stored
             const int piece = sp ^ tlb_sigma(R & 15);
             __builtin_amdgcn_global_load_lds((wl_gbl_ptr)(Ab + (row * C::N + 2 * piece) * 8),
-                                             (wl_lds_ptr)(slot + ins * 1024), 16, 0, 0);
+                                             (wl_lds_ptr)(slot + ins * 1024), 16, 0, 2 /* nt */);
         }
         if constexpr (LOADER == 1) {
             size_t row = row0 + (lane >> 1);
@@ -676,7 +677,11 @@ __global__ __launch_bounds__(256) void k_tanh_linear_multi(const double* __restr
         const double* rp = A + (rok ? row : m - 1) * (size_t)n;
         double2 v[NCP];
 #pragma unroll
-        for (int c = 0; c < NCP; ++c) v[c] = *reinterpret_cast<const double2*>(rp + coff[c]);
+        for (int c = 0; c < NCP; ++c) {
+            typedef double wl_d2 __attribute__((ext_vector_type(2)));
+            const wl_d2 t = __builtin_nontemporal_load(reinterpret_cast<const wl_d2*>(rp + coff[c]));
+            v[c] = make_double2(t.x, t.y);
+        }
         const double bv = b[rok ? row : m - 1];
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
