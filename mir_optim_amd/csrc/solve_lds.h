@@ -139,14 +139,17 @@ __device__ __forceinline__ int lds_potrf(int n, T* smem, int* info_s)
         for (int q = 0; q < 4; ++q) acc[q] = L[blk_off(I, I, Mma<T>::perm(lane & 15), 4 * (lane >> 4) + q)];
         return acc;
     };
-    auto apply_panel_diag = [&](int k, int I, Acc acc) {     // acc -= L_Ik L_Ik^T
+    auto apply_panel_diag = [&](int k, int I, Acc acc) {     // acc -= L_Ik L_Ik^T (two MFMA chains: this is on wave 0's critical path)
         const int pr = Mma<T>::perm(lane & 15), lk = lane >> 4;
+        T a[4];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const T a = L[blk_off(I, k, pr, 4 * s4 + lk)];
-            acc = Mma<T>::mma(-a, a, acc);
-        }
-        return acc;
+        for (int s4 = 0; s4 < 4; ++s4) a[s4] = L[blk_off(I, k, pr, 4 * s4 + lk)];
+        Acc acc2 = Acc{0, 0, 0, 0};
+        acc = Mma<T>::mma(-a[0], a[0], acc);
+        acc2 = Mma<T>::mma(-a[1], a[1], acc2);
+        acc = Mma<T>::mma(-a[2], a[2], acc);
+        acc2 = Mma<T>::mma(-a[3], a[3], acc2);
+        return acc + acc2;
     };
     auto load_block = [&](int I, int J) {
         Acc acc;
@@ -203,10 +206,35 @@ __device__ __forceinline__ int lds_potrf(int n, T* smem, int* info_s)
                 const Acc d = apply_panel_diag(k, k + 1, load_diag(k + 1));
                 factor_diag(k + 1, d);                       // block (k + 1, k + 1) goes from LDS through the registers once
             } else {
-                for (int idx = wave; idx < cnt; idx += kSolveThreads / kWave - 1) {
+                // two blocks per step: the four MFMAs of a block are one dependent chain (64 issue cycles + the result wait
+                // each), a second independent chain fills it
+                constexpr int NW = kSolveThreads / kWave - 1;
+                auto blk = [&](int idx, int& I, int& J) {
                     int ii = 0;
                     while ((ii + 1) * (ii + 2) / 2 <= idx) ++ii;
-                    update_block(k, k + 1 + ii, k + 1 + (idx - ii * (ii + 1) / 2));
+                    I = k + 1 + ii;
+                    J = k + 1 + (idx - ii * (ii + 1) / 2);
+                };
+                for (int idx = wave; idx < cnt; idx += 2 * NW) {
+                    int I0, J0, I1, J1;
+                    blk(idx, I0, J0);
+                    if (idx + NW < cnt) {
+                        blk(idx + NW, I1, J1);
+                        Acc a0 = load_block(I0, J0), a1 = load_block(I1, J1);
+                        const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            a0 = Mma<T>::mma(-L[blk_off(I0, k, lr, 4 * s4 + lk)], L[blk_off(J0, k, lr, 4 * s4 + lk)], a0);
+                            a1 = Mma<T>::mma(-L[blk_off(I1, k, lr, 4 * s4 + lk)], L[blk_off(J1, k, lr, 4 * s4 + lk)], a1);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            L[blk_off(I0, J0, Mma<T>::row(lane, q), lr)] = a0[q];
+                            L[blk_off(I1, J1, Mma<T>::row(lane, q), lr)] = a1[q];
+                        }
+                    } else {
+                        update_block(k, I0, J0);
+                    }
                 }
             }
         }
