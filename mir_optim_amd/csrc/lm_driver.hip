@@ -433,6 +433,7 @@ struct Solver {
     void teardown()
     {
         if (stream) (void)hipStreamSynchronize(stream);
+        if (host_profile) std::fprintf(stderr, "[host profile] J %p  FD panel %p  y %p\n", (void*)B.J, ws->ypanel, (void*)B.y);
         if (host_profile)
             std::fprintf(stderr, "[host profile] events %.3f ms  all-reduce calls %.3f  trial callbacks %.3f  readback+sync %.3f  solve launch %.3f  "
                                  "longest single call %.3f\n", hp_ms[0], hp_ms[1], hp_ms[2], hp_ms[3], hp_ms[4], hp_ms[5]);
