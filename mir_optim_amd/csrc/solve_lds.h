@@ -240,9 +240,30 @@ __device__ __forceinline__ int lds_potrf(int n, T* smem, int* info_s)
         }
     }
     __syncthreads();
-    // ---- inverses of the diagonal blocks: thread (k, c) forms column c of inv(L_kk) by forward substitution and stores
-    //      its strictly-lower entries inv(r, c), r > c, TRANSPOSED at (c, r) -- the unused upper triangle of block (k, k)
-    if (tid < 16 * nbl) {
+    // ---- inverses of the diagonal blocks, stored TRANSPOSED in the unused upper triangles: inv(r, c), r > c, at (c, r).
+    //      Both forms do the same operations in the same order (bitwise the same inverse).
+    if (nbl <= 3) {
+        // few blocks: all 16 columns of a block at once, 16 lanes per column (lane r holds x_r of its column c): right-looking
+        // forward substitution, step q broadcasts the finished x_q inside the 16-lane group (DPP) and every later row
+        // subtracts L(r, q) x_q -- 0.6 us per block (n = 16: the factorisation 5.3 -> 3.4 us)
+        const int c = tid >> 4, r = tid & 15;
+        constexpr int zoff = C::ZERO_OFF - C::L_OFF;
+        for (int k = 0; k < nbl; ++k) {
+            T lrow[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) lrow[q] = L[q < r ? blk_off(k, k, r, q) : zoff];   // only the lower triangle is read
+            const T ri = rd[16 * k + r];
+            T v = r == c ? T(1) : T(0);
+            static_for<16>([&](auto qq) {
+                constexpr int q = decltype(qq)::value;
+                if (r == q) v *= ri;
+                const T xq = dpp_row_bcast<q>(v);
+                if (r > q) v -= lrow[q] * xq;
+            });
+            if (r > c) L[blk_off(k, k, c, r)] = v;
+        }
+    } else if (tid < 16 * nbl) {
+        // many blocks: thread (k, c) forms column c of inv(L_kk) on its own, all blocks in parallel (2.5 us, any n)
         const int k = tid >> 4, c = tid & 15;
         T x[16];
 #pragma unroll
