@@ -247,6 +247,7 @@ struct Solver {
     void* fbctx; FB fb;
     FB fbr = nullptr;          // batched residual callback writing Y row-major (m x p): finite differences fused into k_jtj2
     bool fd_fused = false;     // the FD panel of this refresh is row-major in ws->ypanel and J has not been filled yet
+    int sums_pending = 0;      // > 0: the trial sums of this round are still stage-1 partials (k_decide_chain finishes them)
     uint32_t fd_batch;
     bool device_cb;
     bool time_kernels;
@@ -509,12 +510,14 @@ struct Solver {
     }
 
     // ---- ||v_k||^2 for k < count vectors (stride vstride) -> B.sum[slot + k] on device (all-reduced over row shards)
-    bool sumsq(const T* v, int slot, int count = 1, size_t vstride = 0)
+    //      defer_final (single GPU, trial sums): stage 2 is left to k_decide_chain (sums_pending = the partial count)
+    bool sumsq(const T* v, int slot, int count = 1, size_t vstride = 0, bool defer_final = false)
     {
         int nb = (int)((m + 4095) / 4096);
         if (nb > kPartials) nb = kPartials;
         if (nb < 1) nb = 1;
         hipLaunchKernelGGL(k_sumsq_partial<T>, dim3(nb, count), dim3(256), 0, stream, v, m, B.partials, vstride, kPartials);
+        if (defer_final && !comm) { sums_pending = nb; return ok(hipGetLastError(), "sumsq"); }
         hipLaunchKernelGGL(k_sumsq_final<T>, dim3(count), dim3(256), 0, stream, B.partials, nb, B.sum + slot, kPartials);
         if (comm && !allreduce(B.sum + slot, (size_t)count, 2)) return false;
         return ok(hipGetLastError(), "sumsq");
@@ -861,6 +864,8 @@ struct Solver {
         d.guard = spec_enqueue ? &B.st->spec_ok : nullptr;
         d.spec_static = next_round_enqueued_ahead ? 1 : 0;
         d.maxIterations = S->maxIterations;
+        d.partials = B.partials; d.nparts = sums_pending; d.pstride = kPartials;
+        sums_pending = 0;
         hipLaunchKernelGGL(k_decide_chain<T>, dim3(1), dim3(kSolveThreads), 0, stream, d);
         return ok(hipGetLastError(), "decide kernel");
     }
@@ -1074,7 +1079,7 @@ struct Solver {
                     || (r0.flags & (kFlagDxNaN | kFlagStepTooLong)) || null_step;
                 if (!no_f && !eval_f(B.trial, trial_h, ytr)) { fail = true; break; }
             }
-            if (!skip_eval && !sumsq(ytr, 1, ks, m)) { fail = true; break; }
+            if (!skip_eval && !sumsq(ytr, 1, ks, m, true)) { fail = true; break; }
 
             // Can the round after this one be enqueued before this one's decision is known? Only the common case is covered:
             // one trial now, and -- if it is accepted and no exit test fires (decided on the device, k_decide_chain) -- a

@@ -36,18 +36,26 @@ __global__ __launch_bounds__(256) void k_sumsq_partial(const T* __restrict__ v0,
     if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// Stage 2: one block sums the partials in a fixed order into *out.
+// Stage 2: one block of 256 threads sums the partials in a fixed order. Collective; thread 0 returns the sum. Also run by
+// k_decide_chain itself when there is no all-reduce between the two stages: same order, same bits.
+template <typename T>
+__device__ inline T sumsq_final_block(const T* __restrict__ partials, int nparts, T* red /* 4 */)
+{
+    T s = 0;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += partials[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const T tot = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();                                         // red may be reused
+    return tot;
+}
 template <typename T>
 __global__ __launch_bounds__(256) void k_sumsq_final(const T* __restrict__ partials0, int nparts, T* __restrict__ out, int pstride = 0)
 {
     __shared__ T red[4];
-    const T* __restrict__ partials = partials0 + (size_t)blockIdx.x * pstride;
-    T s = 0;
-    for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += partials[i];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    const T tot = sumsq_final_block(partials0 + (size_t)blockIdx.x * pstride, nparts, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = tot;
 }
 
 // ---- LS:953-971: state at entry. *sum = ||f(x0)||^2 (already all-reduced).
@@ -197,6 +205,8 @@ struct DecideArgs {
     const int32_t* guard; // optional: the kernel does nothing when *guard == 0 (rounds enqueued ahead of time)
     int spec_static;      // the host has enqueued (or will enqueue) the NEXT round behind st->spec_ok: decide whether it may run
     uint32_t maxIterations;
+    const T* partials;    // nparts > 0: sums[k] is still the nparts stage-1 partials at partials + k pstride (no all-reduce
+    int nparts, pstride;  // sits between the stages: single GPU) -- this kernel runs stage 2 itself, one launch less per round
 };
 
 template <typename T>
@@ -209,6 +219,14 @@ __global__ __launch_bounds__(kSolveThreads) void k_decide_chain(DecideArgs<T> a)
         if (threadIdx.x == 0) go = !(a.guard && *a.guard == 0);
         __syncthreads();
         if (!go) return;
+    }
+    static_assert(kSolveThreads == 256, "sumsq_final_block is written for 256 threads");
+    if (a.nparts > 0) {
+        __shared__ T red[4];
+        for (int k = 0; k < a.ks; ++k) {
+            const T tot = sumsq_final_block(a.partials + (size_t)k * a.pstride, a.nparts, red);
+            if (threadIdx.x == 0) a.sums[k] = tot;           // read back by thread 0 below (and by the host's trace)
+        }
     }
     if (threadIdx.x == 0) {
         LmState<T> s = *a.st;
