@@ -2,24 +2,27 @@
 //
 // Replaces mir-lapack's posvx as the reference calls it (boxcqp.d:194, 310; Netlib ?posvx = ?poequ + ?laqsy + ?potrf +
 // ?potrs + ?porfs; ?pocon and the forward-error bound are not computed: they only feed rcond / ferr, which the reference
-// ignores, boxcqp.d:212, 323). The first version of this path (potrf_tiled2 / potrs_blocked, round 1) took ~150 us at
+// ignores, boxcqp.d:212, 323). Round 1's path (potrf_tiled2 / potrs_blocked) took ~150 us at
 // n = 128 -- 13 % of a cfg-3 solve on one CU and most of a strong-scaled one: a column-by-column Cholesky (1 100 cycles
 // per column), one-wave triangular solves built on v_readlane broadcasts, and refinement mat-vecs that fetched the matrix
-// from L2 one dependent round trip at a time. This version keeps BOTH the factor and the matrix in LDS:
+// from L2 one dependent round trip at a time. This one keeps BOTH the factor and the matrix in LDS (74 us at n = 128):
 //
 //   * storage: the lower BLOCK triangle of 16 x 16 blocks, block (I, J), J <= I, at ((I (I + 1) / 2 + J) * 272), element
 //     (r, c) at r + 17 c. The leading dimension 17 makes row walks, column walks and the MFMA operand pattern
 //     (r = lane & 15, c = 4 s + (lane >> 4)) all bank-conflict-free. n = 128: 36 blocks = 78 KB per matrix, 157 KB for
 //     L and A together plus 3 KB of vectors: fits the 160 KB of a CU's LDS;
-//   * ?potrf: right-looking by 16-column panels, three barriers per panel: (1) wave 0 factors the diagonal block in
-//     registers (16 pivots, DPP row broadcasts, rsqrt + Newton like potrf_panel), (2) one thread per row below solves
-//     its 16 panel entries against it, (3) the trailing update A_IJ -= L_Ik L_Jk^T runs on the matrix cores
-//     (v_mfma_f64_16x16x4: four per block, operands and accumulators straight from / to the LDS blocks);
-//   * the inverses of the diagonal blocks (one thread per column) are stored TRANSPOSED IN THE UNUSED UPPER TRIANGLES
-//     of the diagonal blocks of L (their diagonals are the reciprocal pivots, kept in a vector): no extra storage;
-//   * ?potrs: one thread per row, the vector in registers, ONE barrier per block step: the 16 owners of a diagonal block
-//     are a DPP row -- they form x_k = inv(L_kk) z_k with row broadcasts (row_newbcast: no LDS exchange, no readlane),
-//     publish it, and after the barrier every remaining row subtracts its 16 products from LDS;
+//   * ?potrf: right-looking by 16-column panels with look-ahead, two barriers per panel: (1) one thread per row below the
+//     diagonal block solves its 16 panel entries against L_kk, (2) wave 0 brings block (k + 1, k + 1) up to date and factors
+//     it -- in the MFMA accumulator layout: four-column panels on the VALU (DPP row broadcasts, v_rsq_f64 + Goldschmidt),
+//     rank-4 updates as one MFMA each, operands moved between lane groups by permlane swaps -- WHILE waves 1..3 apply
+//     panel k to the rest of the trailing matrix (v_mfma_f64_16x16x4, operands and accumulators straight from / to the LDS
+//     blocks, two independent chains per wave);
+//   * the inverses of the diagonal blocks are stored TRANSPOSED IN THE UNUSED UPPER TRIANGLES of the diagonal blocks of L
+//     (their diagonals are the reciprocal pivots, kept in a vector): no extra storage;
+//   * ?potrs: ONE wave, no workgroup barrier inside: lane (row r of the block, quarter h of its columns), the vector solved
+//     in place in LDS block by block, fully unrolled and software-pipelined (the products with finished blocks are summed
+//     while the current block's 16-value exchange is in flight); wave_lds_fence() keeps the compiler from reusing values
+//     other lanes have overwritten;
 //   * ?porfs: mat-vec with two threads per row from the LDS copy of A (equilibrated when ?laqsy says so), same berr
 //     test and ITMAX = 5 as Netlib.
 // Rows and columns past n are an identity extension, so no routine needs row masks.
