@@ -252,17 +252,18 @@ void k_jtj(JtjArgs<T> a)
 
 // Sum the per-workgroup slabs in a fixed order and scatter into the packed buffer
 //   packed[ i (i + 1) / 2 + j ] = (J^T J)_{ij}, j <= i ;  packed[ n (n + 1) / 2 + j ] = (J^T y)_j
-// blockDim = 256 = 32 slab elements x 8 slab ranges.
+// blockDim = 1024 = 32 slab elements x 32 slab ranges (8 loads in flight per thread, at most two dependent round trips).
 template <typename T>
-__global__ __launch_bounds__(256) void k_jtj_slab_reduce(const T* __restrict__ slabs, int nslabs, int slab_len,
-                                                         int ncb, int n, T* __restrict__ packed)
+__global__ __launch_bounds__(1024) void k_jtj_slab_reduce(const T* __restrict__ slabs, int nslabs, int slab_len,
+                                                          int ncb, int n, T* __restrict__ packed)
 {
-    __shared__ T part[8][32];
+    constexpr int RANGES = 32;                               // blockDim = 1024 = 32 entries x 32 slab ranges
+    __shared__ T part[RANGES][33];
     const int es = threadIdx.x & 31, sp = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + es;
     T s = 0;
     if (e < slab_len) {
-        const int per = (nslabs + 7) / 8;
+        const int per = (nslabs + RANGES - 1) / RANGES;
         const int b0 = sp * per, b1 = (b0 + per < nslabs) ? b0 + per : nslabs;
 #pragma unroll 8
         for (int b = b0; b < b1; ++b) s += slabs[(size_t)b * slab_len + e];
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void k_jtj_slab_reduce(const T* __restrict__ s
     if (sp == 0 && e < slab_len) {
         T tot = part[0][es];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) tot += part[k][es];
+        for (int k = 1; k < RANGES; ++k) tot += part[k][es];
         const int nacc = ncb * (ncb + 1) / 2;
         const int reg = e / kWave, lane = e % kWave;
         if (reg < nacc * 4) {

@@ -157,7 +157,7 @@ template <typename T>
 inline hipError_t jtj_reduce_slabs(const JtjPlan& p, const JtjArgs<T>& a, T* packed, hipStream_t s)
 {
     const int rb = (p.slab_len + 31) / 32;
-    hipLaunchKernelGGL(k_jtj_slab_reduce<T>, dim3(rb), dim3(256), 0, s, a.slabs, p.nblk, p.slab_len, p.ncb, a.n, packed);
+    hipLaunchKernelGGL(k_jtj_slab_reduce<T>, dim3(rb), dim3(1024), 0, s, a.slabs, p.nblk, p.slab_len, p.ncb, a.n, packed);
     return hipGetLastError();
 }
 
@@ -337,7 +337,7 @@ hipError_t jtj_run_fd(const JtjPlan& p, const JtjArgs<T>& a, T* packed, hipStrea
         const hipError_t e = jtj_fdp8_launch<T>(p, a, s);
         if (e != hipSuccess) return e;
         const int rb = (p.fdp8_slab_len + 31) / 32;
-        hipLaunchKernelGGL(k_jtj_slab_reduce<T>, dim3(rb), dim3(256), 0, s, a.slabs, p.fdp8_nblk, p.fdp8_slab_len, p.ncb, a.n, packed);
+        hipLaunchKernelGGL(k_jtj_slab_reduce<T>, dim3(rb), dim3(1024), 0, s, a.slabs, p.fdp8_nblk, p.fdp8_slab_len, p.ncb, a.n, packed);
         return hipGetLastError();
     }
     if (!p.fdp) return hipErrorInvalidValue;

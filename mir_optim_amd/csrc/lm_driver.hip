@@ -627,7 +627,7 @@ struct Solver {
         ev_begin(1);
         if (!ok(lr_sweep<T>(a, nblk, stream), "broyden sweep")) return false;
         ev_end();
-        hipLaunchKernelGGL(k_lr_reduce<T>, dim3((len + 31) / 32), dim3(256), 0, stream, B.lrpart, nblk, len, B.lrvec, guard);
+        hipLaunchKernelGGL(k_lr_reduce<T>, dim3((len + 31) / 32), dim3(32 * kReduceRanges), 0, stream, B.lrpart, nblk, len, B.lrvec, guard);
         if (comm && !allreduce(B.lrvec, (size_t)len, 1)) return false;
         hipLaunchKernelGGL(k_lr_finish<T>, dim3(n + 1), dim3(256), 0, stream, B.lrvec, B.lrD, B.dx_acc, lr_k, (int)n, B.JJ, B.Jy, B.st, guard);
         if (!spec_enqueue) {
