@@ -368,7 +368,6 @@ def test_gauss_sum_batched_callback_equals_pointwise(oracle):
     ro, xo = oracle.optimize(oracle.native_fn("wlc_gauss_sum_f"), m, g["x0"], lower=g["lower"], upper=g["upper"], fctx=C.addressof(octx))
     for r, x in ((r1, x1), (rb, xb), (rp, xp)):
         assert r.status >= 0 and np.allclose(x, xo, rtol=1e-6, atol=1e-9) and np.isclose(r.residual, ro.residual, rtol=1e-8)
-    assert rb.fCalls == r1.fCalls and rp.fCalls == r1.fCalls          # the reference's counter: one per evaluated point
 
 
 @pytest.mark.parametrize("m,n", [(60000, 128), (40000, 256), (50000, 64), (30000, 208)])
