@@ -25,11 +25,13 @@ def main():
     so.absTolerance = abs_tol
     so.maxIterations = max_it
     ctx = O.TanhLinearCtx(data["A"].ctypes.data, data["b"].ctypes.data)
+    events = []                                  # the oracle's per-pass trace: (event, iterations, lambda, residual, trial, dx.dx)
     t0 = time.perf_counter()
-    ro, xo = O.optimize(O.native_fn("wlc_tanh_linear_f"), m, data["x0"], settings=so, fctx=C.addressof(ctx), use_openblas=ob)
+    ro, xo = O.optimize(O.native_fn("wlc_tanh_linear_f"), m, data["x0"], settings=so, fctx=C.addressof(ctx), use_openblas=ob,
+                        trace=lambda *a: events.append(a))
     dt = time.perf_counter() - t0
     np.savez(out, x=xo, status=ro.status, iterations=ro.iterations, fCalls=ro.fCalls, residual=ro.residual, seconds=dt,
-             openblas=int(bool(ob)), threads=threads)
+             openblas=int(bool(ob)), threads=threads, trace=np.array(events, dtype=np.float64).reshape(-1, 6))
 
 
 if __name__ == "__main__":

@@ -45,6 +45,7 @@ def oracle_run(tmp_path, abs_tolerance, max_iterations):
     z = np.load(out)
     r = OracleResult()
     r.status, r.iterations, r.fCalls, r.residual = int(z["status"]), int(z["iterations"]), int(z["fCalls"]), float(z["residual"])
+    r.trace = [tuple(t) for t in z["trace"]]
     return r, z["x"]
 
 
@@ -52,8 +53,19 @@ def test_cfg3_full_size_bench_setting_matches_oracle(cfg3, tmp_path):
     data, prob = cfg3
     s = M.LeastSquaresSettings(); s.absTolerance = 1e-5
     st = M.Stats()
-    res, x = prob.solve(data["x0"], settings=s, batched=True, stats=st)
+    tr = M.Trace(256)
+    res, x = prob.solve(data["x0"], settings=s, batched=True, stats=st, trace=tr)
     ro, xo = oracle_run(tmp_path, 1e-5, 1000)
+    # pass by pass (mir_lsq_trace vs the oracle's trace): the same events in the same order -- two full refreshes, four Broyden
+    # updates, six accepted passes -- with the same damping, residuals and step lengths. Tolerances as measured at this size
+    # (printed on failure): lambda is a product of exact constants until rho enters it; the sums of squares of 1e6 terms
+    # agree to ~1e-13; dx.dx of the last, 1e-6-long steps carries the finite-difference noise of J (h = 2^-26).
+    got = tr.records()
+    assert [(int(g[0]), int(g[1])) for g in got] == [(int(e[0]), int(e[1])) for e in ro.trace], (got, ro.trace)
+    for g, e in zip(got, ro.trace):
+        assert np.isclose(g[2], e[2], rtol=1e-6), (g, e)
+        assert np.allclose(g[3:5], e[3:5], rtol=1e-9), (g, e)
+        assert np.isclose(g[5], e[5], rtol=1e-4), (g, e)
     assert int(res.status) == ro.status == M.LeastSquaresStatus.xConverged
     assert (res.iterations, res.fCalls) == (ro.iterations, ro.fCalls)
     assert np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max(), np.abs(x - xo).max()
