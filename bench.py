@@ -107,7 +107,7 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not bracket kernels with HIP events in the timed region (A/B of the instrumentation overhead; the "
                          "roofline objects are then empty)")
-    ap.add_argument("--timing-every", type=int, default=4,
+    ap.add_argument("--timing-every", type=int, default=10,
                     help="bracket the kernels with HIP events in every k-th step of the timed region (an event record costs a "
                          "few microseconds on the stream: ~0.2 ms per cfg-3 solve when every step is instrumented)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
