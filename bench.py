@@ -85,9 +85,11 @@ def parse():
                     help="rows of the global problem (strong) or per GPU (weak)")
     ap.add_argument("--n", type=int, default=int(os.environ.get("BENCH_N", 128)))
     ap.add_argument("--scaling", choices=["strong", "weak"], default=os.environ.get("BENCH_SCALING", "strong"))
-    ap.add_argument("--fd", choices=["batched", "pointmajor", "serial"], default="batched",
-                    help="finite differences through the batched residual callbacks (row-major panel, fill fused into the "
-                         "J^T J kernel), through the point-major batched callback + k_fd_fill, or one call per point")
+    ap.add_argument("--fd", choices=["batched", "rowmajor", "pointmajor", "serial"], default="batched",
+                    help="finite differences through the batched residual callbacks -- batched: the m x n row-major DIFFERENCE "
+                         "panel (n <= 128; the caller's kernel subtracts the (+h, -h) pair, the library's fused kernel scales, writes J "
+                         "and forms J^T J); rowmajor: the m x 2n row-major pair panel, same fused kernel; pointmajor: the point-major "
+                         "batched callback + k_fd_fill -- or one call per point (serial)")
     ap.add_argument("--abs-tolerance", type=float, default=1e-5,
                     help="LeastSquaresSettings.absTolerance of the headline number (DESIGN.md section 5)")
     ap.add_argument("--survey-steps", type=int, default=10,
@@ -226,7 +228,7 @@ def main_cfg2(args):
     g = P.gauss_sum(100000, K=5)
     prob = W.Curve("gauss_sum", g["t"], g["data"])
     ws = api.lib().mir_lsq_workspace_create(g["m"], g["n"], 8)
-    fdb = {"batched": True, "pointmajor": "pointmajor", "serial": False}[args.fd]   # 2n FD points per launch, or one call per point
+    fdb = {"batched": True, "rowmajor": "rowmajor", "pointmajor": "pointmajor", "serial": False}[args.fd]   # 2n FD points per launch, or one call per point
     for _ in range(max(1, args.warmup)):
         res, x = prob.solve(g["x0"], g["lower"], g["upper"], workspace=ws, variant=args.variant, batched=fdb)
     # the timed region carries NO kernel events: at ~6 event pairs per round and 41 rounds per solve they cost 0.9 ms of a
@@ -383,7 +385,7 @@ def main():
 
     def solve(stats=None, flags=0, s=settings):
         return prob.solve(data["x0"], settings=s, stats=stats, flags=flags, comm=comm, workspace=ws, variant=args.variant,
-                          batched={"batched": True, "pointmajor": "pointmajor", "serial": False}[args.fd])
+                          batched={"batched": True, "rowmajor": "rowmajor", "pointmajor": "pointmajor", "serial": False}[args.fd])
 
     # RCCL finishes part of its initialisation asynchronously: a few seconds after ncclCommInitRank every HIP launch of the
     # process stalls once or twice for 60-150 ms (measured on a one-GPU box with --force-comm: 160-310 it/s when that lands
@@ -482,12 +484,16 @@ def main():
         jtj_flops = m * n * (n + 1.0) + 2.0 * m * n
         if nfd:
             fd_ms = st["jtj_fd_ms"] / nfd
-            fd_name = f"mirlsq::k_jtj_fdp<{ncb}, true>" if n <= 128 else f"mirlsq::k_jtj_fdp8<{ncb}>"
-            fd_bytes = 8.0 * (3.0 * m * n + m)                # read the m x 2n panel and y, write J
+            diff_panel = args.fd == "batched" and n <= 128 and n % 2 == 0       # the m x n difference panel (fbRowMajorDiff)
+            fd_name = (f"mirlsq::k_jtj_fdp<{ncb}, false, true>" if diff_panel else f"mirlsq::k_jtj_fdp<{ncb}, true, false>") if n <= 128 \
+                else f"mirlsq::k_jtj_fdp8<{ncb}>"
+            # read the panel (m x n differences, or m x 2n pairs) and y, write J
+            fd_bytes = 8.0 * ((2.0 if diff_panel else 3.0) * m * n + m)
             fd_rate = fd_bytes / (fd_ms * 1e-3) / 1e9
             fresh = {
-                "kernel": fd_name + " (finite-difference rows from the (+h, -h) panel -> J, J^T J + J^T y on f64 MFMA 16x16x4, "
-                                    "register-staged producer waves + MFMA consumer waves)",
+                "kernel": fd_name + (" (finite-difference rows from the m x n DIFFERENCE panel" if diff_panel else
+                                     " (finite-difference rows from the (+h, -h) pair panel")
+                                  + " -> J, J^T J + J^T y on f64 MFMA 16x16x4, register-staged producer waves + MFMA consumer waves)",
                 "bound": "hbm", "achieved": fd_rate, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fd_rate / HBM_PEAK_GBS,
                 "traffic": pmc_field(fd_name, m, n, "hbm_bytes_per_launch"), "traffic_source": traffic_source(m, n),
                 "algorithmic_bytes_per_launch": fd_bytes, "avg_launch_ms": fd_ms,
@@ -526,16 +532,18 @@ def main():
             else:
                 fl = 2.0 * m * n * pts                          # A[m x n] . X^T[n x p]; + one tanh per output
                 tf = fl / (ms * 1e-3) / 1e12
-                by = 8.0 * (m * n + m * pts + m)                # read A once, write the panel
+                diff_panel = args.fd == "batched" and n <= 128 and n % 2 == 0
+                by = 8.0 * (m * n + m * pts * (0.5 if diff_panel else 1.0) + m)   # read A once, write the panel
                 kn = "k_tanh_linear_batched_dma"
+                kn_full = f"k_tanh_linear_batched_dma<{n // 4}, true, {'true' if diff_panel else 'false'}>"
                 user["residual_gemm"] = {"kernel": f"wl {kn} (caller side: the 2n finite-difference points as one A . X^T GEMM on f64 MFMA "
-                                                   "+ tanh epilogue, writes the m x 2n panel)",
+                                                   "+ tanh epilogue, writes the " + ("m x n difference panel)" if diff_panel else "m x 2n panel)"),
                                          "bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                                          "frac": tf / F64_MFMA_PEAK_TF, "avg_call_ms": ms, "calls": st["fd_callback_calls"],
                                          "points_per_call": pts, "algorithmic_bytes_per_call": by,
                                          "algorithmic_GBs": by / (ms * 1e-3) / 1e9,
-                                         "traffic": pmc_field(f"k_tanh_linear_batched_dma<{n // 4}, true>", m, n, "hbm_bytes_per_launch"),
-                                         "mfma_util_pmc": pmc_field(f"k_tanh_linear_batched_dma<{n // 4}, true>", m, n, "mfma_util"),
+                                         "traffic": pmc_field(kn_full, m, n, "hbm_bytes_per_launch"),
+                                         "mfma_util_pmc": pmc_field(kn_full, m, n, "mfma_util"),
                                          "traffic_source": traffic_source(m, n)}
         if st["trial_callback_calls"]:
             ms = st["trial_callback_ms"] / st["trial_callback_calls"]

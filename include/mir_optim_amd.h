@@ -278,6 +278,14 @@ typedef struct mir_lsq_gpu_options {
                                         no separate column-fill pass: the 2n points are evaluated in one call and the
                                         J^T J kernel forms the Jacobian rows from the (+h, -h) pairs while it writes J.
                                         Read only when struct_size covers it; `fb` is still used for lambda-ladder trials */
+    void* fbRowMajorDiff;            /* optional mir_lsq_batched_function_d (f64, even n <= 128), context fbContext: called with the
+                                        p = 2n finite-difference points X = [x + h e_0, x - h e_0, x + h e_1, ...] and writes the
+                                        m x n ROW-major DIFFERENCE panel D[i * n + j] = f(X_2j)_i - f(X_2j+1)_i -- the caller's
+                                        kernel does the reference's copy + axpy(-1) (LS:1041, 1045) on its way out, every one of
+                                        the 2n residual vectors is still evaluated. The panel between the caller's kernel and
+                                        the library's is then m x n instead of m x 2n: 2 GB less HBM traffic per refresh at
+                                        m = 1e6, n = 128 (1 GB not written, 1 GB not read), bitwise the same Jacobian.
+                                        Preferred over fbRowMajor when both are given. Read only when struct_size covers it */
 } mir_lsq_gpu_options;
 
 /* Same algorithm and result contract as mir_optimize_least_squares_{d,s}; x/l/u stay host
@@ -350,6 +358,10 @@ int mir_lsq_jtj_variant_d(size_t m, size_t n, double* J, const double* y, const 
  * JJ = J^T J (full symmetric) and Jy = J^T y. */
 int mir_lsq_fd_jtj_d(size_t m, size_t n, const double* Yrm, const double* twh, const double* y, double* J,
                      double* JJ, double* Jy, void* stream, float* kernel_ms);
+/* The same from the m x n row-major DIFFERENCE panel D[i][j] = f(x + h e_j)_i - f(x - h e_j)_i (what a fbRowMajorDiff callback
+ * writes; f64, even n <= 128, else -6): J = D * (1 / twh) column-wise (zero for twh = 0), JJ, Jy. */
+int mir_lsq_fd_diff_jtj_d(size_t m, size_t n, const double* Drm, const double* twh, const double* y, double* J,
+                          double* JJ, double* Jy, void* stream, float* kernel_ms);
 
 /* Workspace: device buffers for one (m, n, element size) problem, reusable across calls. */
 mir_lsq_workspace* mir_lsq_workspace_create(size_t m, size_t n, size_t elem_size);

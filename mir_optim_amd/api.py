@@ -187,7 +187,7 @@ class GpuOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("flags", C.c_uint32), ("stream", C.c_void_p), ("comm", C.c_void_p),
                 ("workspace", C.c_void_p), ("fbContext", C.c_void_p), ("fb", C.c_void_p), ("fd_batch", C.c_uint32),
                 ("variant", C.c_uint32), ("stats", C.POINTER(Stats)), ("trace", C.POINTER(_TraceHeader)),
-                ("fbRowMajor", C.c_void_p)]
+                ("fbRowMajor", C.c_void_p), ("fbRowMajorDiff", C.c_void_p)]
 
     def __init__(self, **kw):
         super().__init__(**kw)
@@ -257,6 +257,9 @@ def lib():
                                             C.c_void_p, C.POINTER(C.c_float), C.c_uint32]
         L.mir_lsq_comm_create_local_group.restype = C.c_int
         L.mir_lsq_comm_create_local_group.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.mir_lsq_fd_diff_jtj_d.restype = C.c_int
+        L.mir_lsq_fd_diff_jtj_d.argtypes = [sz, sz, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.POINTER(C.c_float)]
         L.mir_lsq_fd_jtj_d.restype = C.c_int
         L.mir_lsq_fd_jtj_d.argtypes = [sz, sz, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]
@@ -621,13 +624,14 @@ def jtj(J, y, y_old=None, dx=None, dtype=np.float64, variant=0):
     return out
 
 
-def fd_jtj(Yrm, twh, y):
+def fd_jtj(Yrm, twh, y, diff=False):
     """Unit-level access to the J^T J kernel with the finite-difference fill fused in (mir_lsq_fd_jtj_d).
-    Yrm: m x 2n row-major (+h / -h residual pairs). Returns (J, JJ full symmetric, Jy, kernel_ms)."""
+    Yrm: m x 2n row-major (+h / -h residual pairs) -- or, diff=True, the m x n difference panel (mir_lsq_fd_diff_jtj_d).
+    Returns (J, JJ full symmetric, Jy, kernel_ms)."""
     L = lib()
     Yrm = np.ascontiguousarray(Yrm, dtype=np.float64)
     m, n2 = Yrm.shape
-    n = n2 // 2
+    n = n2 if diff else n2 // 2
     dY = DeviceBuffer(Yrm)
     dt = DeviceBuffer(np.ascontiguousarray(twh, dtype=np.float64))
     dy = DeviceBuffer(np.ascontiguousarray(y, dtype=np.float64))
@@ -635,7 +639,7 @@ def fd_jtj(Yrm, twh, y):
     dJJ = DeviceBuffer(nbytes=n * n * 8, dtype=np.float64, shape=(n, n))
     dJy = DeviceBuffer(nbytes=n * 8, dtype=np.float64, shape=(n,))
     ms = C.c_float(0)
-    rc = L.mir_lsq_fd_jtj_d(m, n, dY.ptr, dt.ptr, dy.ptr, dJ.ptr, dJJ.ptr, dJy.ptr, None, C.byref(ms))
+    rc = (L.mir_lsq_fd_diff_jtj_d if diff else L.mir_lsq_fd_jtj_d)(m, n, dY.ptr, dt.ptr, dy.ptr, dJ.ptr, dJJ.ptr, dJy.ptr, None, C.byref(ms))
     if rc != 0:
         raise RuntimeError(f"mir_lsq_fd_jtj_d failed: {rc}")
     out = dJ.download(), dJJ.download(), dJy.download(), ms.value

@@ -124,7 +124,10 @@ __device__ __forceinline__ void fdp_producer(const JtjArgs<double>& a, double* s
 // Plain variant (FD = false): the source is J itself (m x n row-major, n even so that a row starts on a 16-byte
 // boundary); a producer copies its RP rows of every stage into the LDS slot -- NI = NCB 16-byte loads per lane over the
 // padded row (pairs past n read a valid address and are stored as zeros). Nothing is written back.
-template <int NCB>
+// DIFF: the source is the m x n DIFFERENCE panel D[i][j] = f(x + h e_j)_i - f(x - h e_j)_i (the caller's kernel has already
+// done LS:1041 + LS:1045, mir_lsq_gpu_options.fbRowMajorDiff); the producer applies scal(1 / twh) (LS:1047, zero columns for
+// collapsed intervals LS:1046) on the way to LDS and the consumers write the Jacobian rows out as in the pair-panel mode.
+template <int NCB, bool DIFF = false>
 __device__ __forceinline__ void fdp_producer_plain(const JtjArgs<double>& a, double* smem, int lane, int w, size_t s0, size_t S)
 {
     using C = JtjFdpCfg<NCB, false>;
@@ -146,6 +149,15 @@ __device__ __forceinline__ void fdp_producer_plain(const JtjArgs<double>& a, dou
         pad[i] = 2 * jp >= nr;
         pcol[i] = pad[i] ? 0 : jp;
     }
+    double inv0[DIFF ? NI : 1], inv1[DIFF ? NI : 1];       // 1 / twh of the pair's two columns (0: collapsed interval)
+    if constexpr (DIFF) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const double t0 = a.twh[2 * pcol[i]], t1 = a.twh[2 * pcol[i] + 1];
+            inv0[i] = t0 == 0 ? 0.0 : 1.0 / t0;
+            inv1[i] = t1 == 0 ? 0.0 : 1.0 / t1;
+        }
+    }
 
     fdp_v2d b[NI];
     double yb = 0;
@@ -155,7 +167,8 @@ __device__ __forceinline__ void fdp_producer_plain(const JtjArgs<double>& a, dou
         for (int i = 0; i < NI; ++i) {
             size_t row = row0 + prow[i];
             row = row < m ? row : m - 1;
-            b[i] = Jp[row * hr + pcol[i]];
+            if constexpr (DIFF) b[i] = __builtin_nontemporal_load(&Jp[row * hr + pcol[i]]);   // the panel is read once
+            else b[i] = Jp[row * hr + pcol[i]];
         }
         size_t yr = row0 + (lane & (C::RP - 1));
         yr = yr < m ? yr : m - 1;
@@ -167,6 +180,10 @@ __device__ __forceinline__ void fdp_producer_plain(const JtjArgs<double>& a, dou
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             fdp_v2d v = b[i];
+            if constexpr (DIFF) {
+                v.x = inv0[i] == 0 ? 0.0 : v.x * inv0[i];      // scal(1 / twh, Jj), LS:1047 (LS:1046: zero column)
+                v.y = inv1[i] == 0 ? 0.0 : v.y * inv1[i];
+            }
             if (pad[i] || row0 + prow[i] >= m) v = fdp_v2d{0.0, 0.0};
             *reinterpret_cast<fdp_v2d*>(slot + w * C::RP * n + 2 * (64 * i + lane)) = v;
         }
@@ -182,7 +199,7 @@ __device__ __forceinline__ void fdp_producer_plain(const JtjArgs<double>& a, dou
     }
 }
 
-template <int NCB, int ROLE, bool FD = true>
+template <int NCB, int ROLE, bool FD = true, bool DIFF = false>
 __device__ __forceinline__ void fdp_consumer(const JtjArgs<double>& a, const double* smem, int lane, size_t s0, size_t S)
 {
     using T = double;
@@ -212,7 +229,7 @@ __device__ __forceinline__ void fdp_consumer(const JtjArgs<double>& a, const dou
             if constexpr (ROLE == 0) g.y = slot[C::RS * n + 4 * gi + q];
         };
         auto side = [&](int gi, const Grp& g) {
-            if constexpr (FD && ROLE >= 2) {
+            if constexpr ((FD || DIFF) && ROLE >= 2) {
                 // the Jacobian rows leave through roles 2 and 3 (column blocks c = ROLE (mod 2))
                 const size_t row = row0 + 4 * gi + q;
                 if (row < m) {
@@ -268,9 +285,10 @@ __device__ __forceinline__ void fdp_consumer(const JtjArgs<double>& a, const dou
     }
 }
 
-template <int NCB, bool FD = true>
+template <int NCB, bool FD = true, bool DIFF = false>
 __global__ __launch_bounds__(kJtjFdpThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_jtj_fdp(JtjArgs<double> a)
 {
+    static_assert(!(FD && DIFF), "DIFF uses the plain stage layout");
     using C = JtjFdpCfg<NCB, FD>;
     extern __shared__ __attribute__((aligned(16))) unsigned char fdp_smem[];
     double* smem = reinterpret_cast<double*>(fdp_smem);
@@ -283,12 +301,12 @@ __global__ __launch_bounds__(kJtjFdpThreads) __attribute__((amdgpu_waves_per_eu(
     const size_t s1 = s0 + per < Stot ? s0 + per : Stot;
     const size_t S = s1 - s0;
 
-    if (wave == 0) fdp_consumer<NCB, 0, FD>(a, smem, lane, s0, S);
-    else if (wave == 1) fdp_consumer<NCB, 1, FD>(a, smem, lane, s0, S);
-    else if (wave == 2) fdp_consumer<NCB, 2, FD>(a, smem, lane, s0, S);
-    else if (wave == 3) fdp_consumer<NCB, 3, FD>(a, smem, lane, s0, S);
+    if (wave == 0) fdp_consumer<NCB, 0, FD, DIFF>(a, smem, lane, s0, S);
+    else if (wave == 1) fdp_consumer<NCB, 1, FD, DIFF>(a, smem, lane, s0, S);
+    else if (wave == 2) fdp_consumer<NCB, 2, FD, DIFF>(a, smem, lane, s0, S);
+    else if (wave == 3) fdp_consumer<NCB, 3, FD, DIFF>(a, smem, lane, s0, S);
     else if constexpr (FD) fdp_producer<NCB>(a, smem, lane, wave - 4, s0, S);
-    else fdp_producer_plain<NCB>(a, smem, lane, wave - 4, s0, S);
+    else fdp_producer_plain<NCB, DIFF>(a, smem, lane, wave - 4, s0, S);
 }
 
 }  // namespace mirlsq

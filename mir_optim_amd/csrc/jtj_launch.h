@@ -187,27 +187,27 @@ hipError_t jtj_stream(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
 }
 
 // ---- k_jtj_fdp: producer / consumer waves (jtj_fdp.h); FD = the finite-difference panel is the source
-template <int NCB, bool FD>
+template <int NCB, bool FD, bool DIFF = false>
 hipError_t jtj_fdp_one(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t s)
 {
     using FC = JtjFdpCfg<NCB, FD>;
-    MIRLSQ_ENSURE_LDS((k_jtj_fdp<NCB, FD>), (size_t)FC::LDS_BYTES);
-    hipLaunchKernelGGL((k_jtj_fdp<NCB, FD>), dim3(p.nblk), dim3(FC::THREADS), FC::LDS_BYTES, s, a);
+    MIRLSQ_ENSURE_LDS((k_jtj_fdp<NCB, FD, DIFF>), (size_t)FC::LDS_BYTES);
+    hipLaunchKernelGGL((k_jtj_fdp<NCB, FD, DIFF>), dim3(p.nblk), dim3(FC::THREADS), FC::LDS_BYTES, s, a);
     return hipGetLastError();
 }
-template <typename T, bool FD>
+template <typename T, bool FD, bool DIFF = false>
 hipError_t jtj_fdp_launch(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
 {
     if constexpr (sizeof(T) == 8) {
         switch (p.ncb) {
-        case 1: return jtj_fdp_one<1, FD>(p, a, s);
-        case 2: return jtj_fdp_one<2, FD>(p, a, s);
-        case 3: return jtj_fdp_one<3, FD>(p, a, s);
-        case 4: return jtj_fdp_one<4, FD>(p, a, s);
-        case 5: return jtj_fdp_one<5, FD>(p, a, s);
-        case 6: return jtj_fdp_one<6, FD>(p, a, s);
-        case 7: return jtj_fdp_one<7, FD>(p, a, s);
-        case 8: return jtj_fdp_one<8, FD>(p, a, s);
+        case 1: return jtj_fdp_one<1, FD, DIFF>(p, a, s);
+        case 2: return jtj_fdp_one<2, FD, DIFF>(p, a, s);
+        case 3: return jtj_fdp_one<3, FD, DIFF>(p, a, s);
+        case 4: return jtj_fdp_one<4, FD, DIFF>(p, a, s);
+        case 5: return jtj_fdp_one<5, FD, DIFF>(p, a, s);
+        case 6: return jtj_fdp_one<6, FD, DIFF>(p, a, s);
+        case 7: return jtj_fdp_one<7, FD, DIFF>(p, a, s);
+        case 8: return jtj_fdp_one<8, FD, DIFF>(p, a, s);
         }
     }
     return hipErrorInvalidValue;
@@ -342,6 +342,17 @@ hipError_t jtj_run_fd(const JtjPlan& p, const JtjArgs<T>& a, T* packed, hipStrea
     }
     if (!p.fdp) return hipErrorInvalidValue;
     const hipError_t e = jtj_fdp_launch<T, true>(p, a, s);
+    if (e != hipSuccess) return e;
+    return jtj_reduce_slabs<T>(p, a, packed, s);
+}
+
+// ---- finite-difference DIFFERENCE panel (a.J: m x n row-major, D_ij = f(x + h e_j)_i - f(x - h e_j)_i; a.twh) -> a.Jout, packed
+//      (f64, n <= 128, n even: JtjPlan::fdp_plain)
+template <typename T>
+hipError_t jtj_run_fd_diff(const JtjPlan& p, const JtjArgs<T>& a, T* packed, hipStream_t s)
+{
+    if (!p.fdp_plain) return hipErrorInvalidValue;
+    const hipError_t e = jtj_fdp_launch<T, false, true>(p, a, s);
     if (e != hipSuccess) return e;
     return jtj_reduce_slabs<T>(p, a, packed, s);
 }

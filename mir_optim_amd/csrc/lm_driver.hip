@@ -246,7 +246,8 @@ struct Solver {
     void* tmctx; mir_least_squares_thread_manager tm;
     void* fbctx; FB fb;
     FB fbr = nullptr;          // batched residual callback writing Y row-major (m x p): finite differences fused into k_jtj2
-    bool fd_fused = false;     // the FD panel of this refresh is row-major in ws->ypanel and J has not been filled yet
+    FB fbd = nullptr;          // batched residual callback writing the m x n row-major DIFFERENCE panel (fbRowMajorDiff)
+    int fd_fused = 0;          // 1: the (+h, -h) pair panel, 2: the difference panel of this refresh is in ws->ypanel and J has not been filled yet
     int sums_pending = 0;      // > 0: the trial sums of this round are still stage-1 partials (k_decide_chain finishes them)
     uint32_t fd_batch;
     bool device_cb;
@@ -661,10 +662,11 @@ struct Solver {
         if (!broyden && fd_fused) {
             // the row-major FD panel is still in ws->ypanel: one kernel forms the Jacobian rows (LS:1041-1047), writes
             // them to J and accumulates J^T J / J^T y from the same registers
-            fd_fused = false;
+            const bool diff = fd_fused == 2;
+            fd_fused = 0;
             a.J = static_cast<const T*>(ws->ypanel); a.twh = B.twh;
             ev_begin(3);
-            if (!ok(jtj_run_fd<T>(plan, a, B.packed, stream), "fd + jtj kernel")) return false;
+            if (!ok(diff ? jtj_run_fd_diff<T>(plan, a, B.packed, stream) : jtj_run_fd<T>(plan, a, B.packed, stream), "fd + jtj kernel")) return false;
             ev_end();
         } else {
             ev_begin(broyden ? 1 : 0);
@@ -707,7 +709,9 @@ struct Solver {
         }
         if (pb < 1) pb = 1;
         if (fb && fd_batch && fd_batch / 2 < pb) pb = fd_batch / 2 ? fd_batch / 2 : 1;
-        const size_t need = 2 * pb * m * sizeof(T);
+        const bool no_fuse = (variant & MIR_LSQ_VARIANT_FD_SEPARATE_FILL) != 0;
+        const bool use_diff = fbd && plan.fdp_plain && pb == n && sizeof(T) == 8 && !no_fuse;   // m x n difference panel
+        const size_t need = (use_diff ? 1 : 2) * pb * m * sizeof(T);
         if (ws->ypanel_bytes < need) {
             if (ws->ypanel) (void)hipFree(ws->ypanel);
             ws->ypanel = nullptr; ws->ypanel_bytes = 0;
@@ -715,7 +719,17 @@ struct Solver {
             ws->ypanel_bytes = need;
         }
         T* Y = static_cast<T*>(ws->ypanel);
-        const bool no_fuse = (variant & MIR_LSQ_VARIANT_FD_SEPARATE_FILL) != 0;
+        if (use_diff) {
+            // all 2n points in one sweep, the caller's kernel hands over D[i][j] = f(x + h e_j)_i - f(x - h e_j)_i (LS:1041, 1045);
+            // k_jtj_fdp<., false, true> (jacobian_products) scales the columns (LS:1047), writes J and accumulates J^T J / J^T y
+            ev_begin(4);
+            fbd(fbctx, m, n, 2 * (size_t)n, B.X, Y);
+            ev_end();
+            if (stats) stats->fd_callback_points += 2 * (uint64_t)n;
+            fd_fused = 2;
+            ret.fCalls += n;
+            return ok(hipGetLastError(), "fd batched callback");
+        }
         if (fbr && (plan.fdp || plan.fdp8) && pb == n && sizeof(T) == 8 && !no_fuse) {
             // all 2n points in one sweep, Y[i][2j], Y[i][2j+1] = f(x + h e_j)_i, f(x - h e_j)_i; k_jtj2<., false, true>
             // (jacobian_products) turns the pairs into Jacobian rows on its way to J^T J -- no k_fd_fill pass
@@ -723,7 +737,7 @@ struct Solver {
             fbr(fbctx, m, n, 2 * (size_t)n, B.X, Y);
             ev_end();
             if (stats) stats->fd_callback_points += 2 * (uint64_t)n;
-            fd_fused = true;
+            fd_fused = 1;
             ret.fCalls += n;
             return ok(hipGetLastError(), "fd batched callback");
         }
@@ -1167,6 +1181,8 @@ typename Abi<T>::Result solve_entry(const typename Abi<T>::Settings* settings, s
         if (opt->struct_size >= offsetof(mir_lsq_gpu_options, trace) + sizeof(void*)) s.trace = opt->trace;
         if (opt->struct_size >= offsetof(mir_lsq_gpu_options, fbRowMajor) + sizeof(void*) && s.device_cb)
             s.fbr = reinterpret_cast<typename Abi<T>::FB>(opt->fbRowMajor);
+        if (opt->struct_size >= offsetof(mir_lsq_gpu_options, fbRowMajorDiff) + sizeof(void*) && s.device_cb)
+            s.fbd = reinterpret_cast<typename Abi<T>::FB>(opt->fbRowMajorDiff);
         if (s.trace) s.trace->count = 0;
     }
     return s.run();
@@ -1550,14 +1566,29 @@ int mir_lsq_jtj_variant_d(size_t m, size_t n, double* J, const double* y, const 
 {
     return jtj_entry<double>(m, n, J, y, y_old, dx, broyden, JJ, Jy, stream, kernel_ms, variant);
 }
+namespace {
+int fd_jtj_entry(size_t m, size_t n, const double* Yrm, const double* twh, const double* y, double* J,
+                 double* JJ, double* Jy, void* stream_, float* kernel_ms, bool diff);
+}
 int mir_lsq_fd_jtj_d(size_t m, size_t n, const double* Yrm, const double* twh, const double* y, double* J,
                      double* JJ, double* Jy, void* stream_, float* kernel_ms)
+{
+    return fd_jtj_entry(m, n, Yrm, twh, y, J, JJ, Jy, stream_, kernel_ms, false);
+}
+int mir_lsq_fd_diff_jtj_d(size_t m, size_t n, const double* Drm, const double* twh, const double* y, double* J,
+                          double* JJ, double* Jy, void* stream_, float* kernel_ms)
+{
+    return fd_jtj_entry(m, n, Drm, twh, y, J, JJ, Jy, stream_, kernel_ms, true);
+}
+namespace {
+int fd_jtj_entry(size_t m, size_t n, const double* Yrm, const double* twh, const double* y, double* J,
+                 double* JJ, double* Jy, void* stream_, float* kernel_ms, bool diff)
 {
     if (!device_available()) return -1;
     if (n == 0 || m == 0) return -2;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const JtjPlan plan = jtj_plan<double>(m, (int)n, query_num_cu());
-    if (!plan.fdp && !plan.fdp8) return -6;                     // shape not covered by a fused kernel
+    if (diff ? !plan.fdp_plain : (!plan.fdp && !plan.fdp8)) return -6;   // shape not covered by a fused kernel
     const size_t packed_len = n * (n + 1) / 2 + n + 8;
     double *slabs = nullptr, *packed = nullptr;
     LmState<double>* st = nullptr;
@@ -1572,7 +1603,7 @@ int mir_lsq_fd_jtj_d(size_t m, size_t n, const double* Yrm, const double* twh, c
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, stream);
-    if (jtj_run_fd<double>(plan, a, packed, stream) != hipSuccess) rc = -4;
+    if ((diff ? jtj_run_fd_diff<double>(plan, a, packed, stream) : jtj_run_fd<double>(plan, a, packed, stream)) != hipSuccess) rc = -4;
     (void)hipEventRecord(e1, stream);
     hipLaunchKernelGGL(k_unpack_grad<double>, dim3((unsigned)n + 1), dim3(128), 0, stream, packed, (int)n, JJ, Jy, st);
     if (hipStreamSynchronize(stream) != hipSuccess) rc = -5;
@@ -1581,6 +1612,7 @@ int mir_lsq_fd_jtj_d(size_t m, size_t n, const double* Yrm, const double* twh, c
     (void)hipFree(slabs); (void)hipFree(packed); (void)hipFree(st);
     return rc;
 }
+}  // namespace
 int mir_lsq_jtj_s(size_t m, size_t n, float* J, const float* y, const float* y_old, const float* dx, int broyden,
                   float* JJ, float* Jy, void* stream, float* kernel_ms)
 {

@@ -33,6 +33,14 @@ template <typename T> __device__ inline T sum16(T v)
     return v;
 }
 
+// the value of the neighbouring lane (lane ^ 1): DPP quad_perm [1, 0, 3, 2]
+__device__ inline double lane_pair_swap(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
 // tanh for the synthetic residuals: 1 - 2 / (exp(2|x|) + 1) with a degree-13 exp polynomial and a Newton-refined
 // reciprocal, ~35 fp64 instructions instead of libm's ~135 (absolute error ~2e-16; the residual tanh(.) - b only
 // needs absolute accuracy). The same function is used by the single-point and the batched kernels.
@@ -416,7 +424,10 @@ __device__ __forceinline__ void tlb_loader(const double* __restrict__ A, const d
 
 // RM: Y is m x P row-major (point k's residual of row i at Y[i P + k]; 16 lanes of a row = 128 contiguous bytes) --
 // the layout the solver's fused finite-difference J^T J kernel consumes (mir_lsq_gpu_options.fbRowMajor)
-template <int NK, bool ALIGNED, int GROUP, bool RM = false>
+// DIFF (with RM): points come in (+h, -h) pairs (2 j, 2 j + 1) -- adjacent lanes -- and Y is the m x P/2 row-major DIFFERENCE
+// panel D[i][j] = y_{2j}[i] - y_{2j+1}[i] (mir_lsq_gpu_options.fbRowMajorDiff): the even lane of a pair subtracts its
+// neighbour's residual (a DPP move) and stores; half the panel bytes of RM
+template <int NK, bool ALIGNED, int GROUP, bool RM = false, bool DIFF = false>
 __device__ __forceinline__ void tlb_compute(const double* __restrict__ X, double* __restrict__ Y, size_t m, int P,
                                             unsigned char* smem, int lane, int wave, size_t S, int nchunks)
 {
@@ -445,8 +456,8 @@ __device__ __forceinline__ void tlb_compute(const double* __restrict__ X, double
         double xf[NK];
 #pragma unroll
         for (int s = 0; s < NK; ++s) xf[s] = X[(size_t)pl * C::N + 8 * (s >> 1) + 2 * fq + (s & 1)];
-        double* yp = RM ? Y + pl : Y + (size_t)pl * m;
-        const size_t ldr = RM ? (size_t)P : 1;                  // distance between consecutive rows of one point
+        double* yp = DIFF ? Y + (pl >> 1) : (RM ? Y + pl : Y + (size_t)pl * m);
+        const size_t ldr = DIFF ? (size_t)(P >> 1) : (RM ? (size_t)P : 1);   // distance between consecutive rows of one point
 
         // TILES == 2: acc0 / acc1 are the two row tiles of the stage; TILES == 1: the even / odd column pairs of the
         // one tile (two independent chains either way), summed into acc0 at the end
@@ -486,7 +497,16 @@ __device__ __forceinline__ void tlb_compute(const double* __restrict__ X, double
             const double y0 = dtanh(acc[0]) - b0.x, y1 = dtanh(acc[1]) - b0.y;
             const double y2 = dtanh(acc[2]) - b1.x, y3 = dtanh(acc[3]) - b1.y;
             const size_t ra = row0 + 2 * fq, rb = row0 + 8 + 2 * fq;
-            if constexpr (RM) {
+            if constexpr (DIFF) {
+                const double d0 = y0 - lane_pair_swap(y0), d1 = y1 - lane_pair_swap(y1);     // f(x + h e_j) - f(x - h e_j), LS:1041 + 1045
+                const double d2 = y2 - lane_pair_swap(y2), d3 = y3 - lane_pair_swap(y3);
+                if ((fr & 1) == 0) {
+                    if (FULL || ra < m) yp[ra * ldr] = d0;
+                    if (FULL || ra + 1 < m) yp[(ra + 1) * ldr] = d1;
+                    if (FULL || rb < m) yp[rb * ldr] = d2;
+                    if (FULL || rb + 1 < m) yp[(rb + 1) * ldr] = d3;
+                }
+            } else if constexpr (RM) {
                 if (FULL || ra < m) yp[ra * ldr] = y0;
                 if (FULL || ra + 1 < m) yp[(ra + 1) * ldr] = y1;
                 if (FULL || rb < m) yp[rb * ldr] = y2;
@@ -545,7 +565,7 @@ __device__ __forceinline__ void tlb_compute(const double* __restrict__ X, double
     }
 }
 
-template <int NK, bool RM = false>
+template <int NK, bool RM = false, bool DIFF = false>
 __global__ __launch_bounds__(TlbCfg<NK>::THREADS) void k_tanh_linear_batched_dma(const double* __restrict__ A,
                                                                                   const double* __restrict__ b,
                                                                                   const double* __restrict__ X,
@@ -564,8 +584,8 @@ __global__ __launch_bounds__(TlbCfg<NK>::THREADS) void k_tanh_linear_batched_dma
     else if (wave == C::COMPUTE_WAVES + 1) tlb_loader<NK, 1>(A, b, m, tlb_smem, lane, S, F);
     else {
         if constexpr (RM) {
-            if (wave < 4) tlb_compute<NK, false, 0, true>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
-            else tlb_compute<NK, false, 1, true>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
+            if (wave < 4) tlb_compute<NK, false, 0, true, DIFF>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
+            else tlb_compute<NK, false, 1, true, DIFF>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
         } else {
             const bool aligned = ((m & 1) == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
             if (wave < 4) {
@@ -579,18 +599,18 @@ __global__ __launch_bounds__(TlbCfg<NK>::THREADS) void k_tanh_linear_batched_dma
     }
 }
 
-template <int NK, bool RM = false>
+template <int NK, bool RM = false, bool DIFF = false>
 bool launch_tlb_dma(const double* A, const double* b, const double* X, double* Y, size_t m, int P, hipStream_t s)
 {
     using C = TlbCfg<NK>;
     static bool attr_ok = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(k_tanh_linear_batched_dma<NK, RM>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k_tanh_linear_batched_dma<NK, RM, DIFF>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) == hipSuccess;
     }();
     if (!attr_ok) return false;
     const size_t Stot = (m + C::ROWS - 1) / C::ROWS;
     const unsigned grid = (unsigned)(Stot < 256 ? Stot : 256);
-    hipLaunchKernelGGL((k_tanh_linear_batched_dma<NK, RM>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, s, A, b, X, Y, m, P);
+    hipLaunchKernelGGL((k_tanh_linear_batched_dma<NK, RM, DIFF>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, s, A, b, X, Y, m, P);
     return true;
 }
 
@@ -609,6 +629,39 @@ __global__ __launch_bounds__(256) void k_tanh_linear_batched_rm_generic(const do
         for (int j = 0; j < n; ++j) s0 += a[j] * x[j];
         Y[e] = dtanh(s0) - b[i];
     }
+}
+
+// difference panel for shapes the DMA kernel does not cover: one thread per (row, column), two dot products
+__global__ __launch_bounds__(256) void k_tanh_linear_batched_diff_generic(const double* __restrict__ A, const double* __restrict__ b,
+                                                                          const double* __restrict__ X, double* __restrict__ D,
+                                                                          size_t m, int n, int P)
+{
+    const int nc = P / 2;
+    const size_t total = m * (size_t)nc;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = e / nc;
+        const int j = (int)(e % nc);
+        const double* a = A + i * (size_t)n;
+        const double* xp = X + (size_t)(2 * j) * n;
+        const double* xm = xp + n;
+        double sp = 0, sm = 0;
+        for (int k = 0; k < n; ++k) { sp += a[k] * xp[k]; sm += a[k] * xm[k]; }
+        const double yp = dtanh(sp) - b[i], ym = dtanh(sm) - b[i];
+        D[e] = yp - ym;
+    }
+}
+
+void launch_tanh_linear_batched_diff(const double* A, const double* b, const double* X, double* D, size_t m, int n, int P,
+                                     hipStream_t s)
+{
+    if (m >= 32 && P % 16 == 0) {                          // whole 16-point MFMA tiles: no clamped lanes, whose pairs would store zeros
+        if (n == 128 && launch_tlb_dma<32, true, true>(A, b, X, D, m, P, s)) return;
+        if (n == 64 && launch_tlb_dma<16, true, true>(A, b, X, D, m, P, s)) return;
+        if (n == 32 && launch_tlb_dma<8, true, true>(A, b, X, D, m, P, s)) return;
+    }
+    size_t blocks = (m * (size_t)(P / 2) + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_tanh_linear_batched_diff_generic, dim3((unsigned)(blocks ? blocks : 1)), dim3(256), 0, s, A, b, X, D, m, n, P);
 }
 
 void launch_tanh_linear_batched_rm(const double* A, const double* b, const double* X, double* Y, size_t m, int n, int P,
@@ -760,6 +813,13 @@ void wl_tanh_linear_fbr_d(void* vctx, size_t m, size_t n, size_t p, const double
 {
     auto* c = static_cast<wl_tanh_linear_ctx*>(vctx);
     launch_tanh_linear_batched_rm((const double*)c->A, (const double*)c->b, X, Y, m, (int)n, (int)p, (hipStream_t)c->stream);
+}
+// the same p = 2n points [x + h e_0, x - h e_0, ...] with the m x n row-major DIFFERENCE panel written
+// (mir_lsq_gpu_options.fbRowMajorDiff): D[i n + j] = f(X_2j)_i - f(X_2j+1)_i
+void wl_tanh_linear_fbd_d(void* vctx, size_t m, size_t n, size_t p, const double* X, double* D)
+{
+    auto* c = static_cast<wl_tanh_linear_ctx*>(vctx);
+    launch_tanh_linear_batched_diff((const double*)c->A, (const double*)c->b, X, D, m, (int)n, (int)p, (hipStream_t)c->stream);
 }
 void wl_tanh_linear_f_s(void* vctx, size_t m, size_t n, const float* x, float* y)
 {

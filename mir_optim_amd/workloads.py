@@ -56,6 +56,8 @@ class DeviceProblem:
             o.fd_batch = fd_batch
             if getattr(self, "fbr", None) is not None and batched != "pointmajor":
                 o.fbRowMajor = self.fbr          # row-major FD panel: the fill is fused into the J^T J kernel
+            if getattr(self, "fbd", None) is not None and batched not in ("pointmajor", "rowmajor"):
+                o.fbRowMajorDiff = self.fbd      # m x n difference panel: half the bytes between the two kernels
         if stats is not None:
             o.stats = C.pointer(stats)
         if trace is not None:
@@ -82,6 +84,7 @@ class TanhLinear(DeviceProblem):
         self.g = _addr("wl_tanh_linear_g_" + suf)
         self.fb = _addr("wl_tanh_linear_fb_d") if dtype == np.float64 else None
         self.fbr = _addr("wl_tanh_linear_fbr_d") if dtype == np.float64 else None
+        self.fbd = _addr("wl_tanh_linear_fbd_d") if dtype == np.float64 else None
 
 
 class TanhLinearView(TanhLinear):
@@ -98,6 +101,7 @@ class TanhLinearView(TanhLinear):
         self.g = _addr("wl_tanh_linear_g_d")
         self.fb = _addr("wl_tanh_linear_fb_d")
         self.fbr = _addr("wl_tanh_linear_fbr_d")
+        self.fbd = _addr("wl_tanh_linear_fbd_d")
 
 
 class Curve(DeviceProblem):

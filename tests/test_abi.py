@@ -117,12 +117,13 @@ def test_no_gpu_means_loud_numeric_error_not_a_cpu_path(capfd):
 
 
 def test_gpu_options_trace_field_is_appended():
-    """mir_lsq_gpu_options is versioned by struct_size: `trace` was appended after `stats`, `fbRowMajor` after `trace`;
-    older callers (64- and 72-byte structs) stay valid. Offsets as declared in include/mir_optim_amd.h."""
+    """mir_lsq_gpu_options is versioned by struct_size: `trace` was appended after `stats`, `fbRowMajor` after `trace`,
+    `fbRowMajorDiff` after that; older callers (64-, 72- and 80-byte structs) stay valid. Offsets as declared in
+    include/mir_optim_amd.h."""
     import ctypes as C
     from mir_optim_amd import api
-    assert C.sizeof(api.GpuOptions) == 80 and api.GpuOptions.stats.offset == 56 and api.GpuOptions.trace.offset == 64
-    assert api.GpuOptions.fbRowMajor.offset == 72
+    assert C.sizeof(api.GpuOptions) == 88 and api.GpuOptions.stats.offset == 56 and api.GpuOptions.trace.offset == 64
+    assert api.GpuOptions.fbRowMajor.offset == 72 and api.GpuOptions.fbRowMajorDiff.offset == 80
     assert C.sizeof(api.TraceRecord) == 40
     t = api.Trace(8)
     assert t.count == 0 and t.records() == []

@@ -161,3 +161,72 @@ def test_collapsed_interval_gives_zero_column_through_the_fused_path():
     r2, x2 = prob.solve(w["x0"], l=lo, u=up, settings=s, batched="pointmajor")
     assert x1[5] == w["x0"][5] == x2[5]
     assert int(r1.status) >= 0 and np.allclose(x1, x2, rtol=1e-6, atol=1e-9) and np.isclose(r1.residual, r2.residual, rtol=1e-9)
+
+
+# ---- the m x n DIFFERENCE panel (mir_lsq_gpu_options.fbRowMajorDiff, k_jtj_fdp<., false, true>) --------------------------------
+
+@pytest.mark.parametrize("m,n", [(4096, 128), (5000, 16), (30, 32), (2, 48), (10002, 64), (7778, 80), (6, 112), (100000, 128),
+                                 (4097, 128), (1, 16), (12345, 90), (5000, 100), (33, 2)])
+def test_fd_diff_panel_gives_the_pair_panel_jacobian_bit_for_bit(m, n):
+    """D = Y+ + (-1) Y- formed by the caller (LS:1041, 1045), scal(1 / twh) by the kernel (LS:1047): the same J as from the pair
+    panel, bit for bit, incl. a clipped and a collapsed interval; J^T J / J^T y exact on exact-integer inputs."""
+    rng = np.random.default_rng(11 * m + n)
+    for integers in (True, False):
+        Yrm = rng.integers(-8, 9, size=(m, 2 * n)).astype(np.float64) if integers else rng.standard_normal((m, 2 * n))
+        twh = np.full(n, 2.0 ** -25)
+        twh[rng.integers(0, n)] = 2.0 ** -26
+        if n > 3:
+            twh[3] = 0.0
+        y = rng.integers(-4, 5, size=m).astype(np.float64) if integers else rng.standard_normal(m)
+        D = Yrm[:, 0::2].copy()
+        D += -1.0 * Yrm[:, 1::2]
+        Jp, JJp, Jyp, _ = M.fd_jtj(Yrm, twh, y)
+        Jd, JJd, Jyd, _ = M.fd_jtj(D, twh, y, diff=True)
+        assert np.array_equal(Jd, Jp) and np.array_equal(Jd, ref_fill(Yrm, twh))
+        assert np.array_equal(JJd, JJd.T)
+        if integers:
+            assert np.array_equal(JJd, Jd.T @ Jd) or np.allclose(JJd, Jd.T @ Jd, rtol=1e-15, atol=0)
+            assert np.array_equal(Jyd, Jd.T @ y) or np.allclose(Jyd, Jd.T @ y, rtol=1e-15, atol=0)
+        else:
+            scale = np.sqrt(np.outer(np.diag(JJp), np.diag(JJp))) + 1e-300
+            assert np.max(np.abs(JJd - JJp) / scale) < 1e-13 and np.allclose(Jyd, Jyp, rtol=1e-10, atol=1e-13 * np.abs(Jyp).max())
+
+
+@pytest.mark.parametrize("m,n", [(40000, 128), (10002, 64), (5001, 32), (3000, 16), (2049, 100)])
+def test_user_side_difference_kernel_is_the_pair_kernel_minus(m, n):
+    """workloads.hip: wl_tanh_linear_fbd_d writes exactly column 2j minus column 2j + 1 of what wl_tanh_linear_fbr_d writes."""
+    w = P.tanh_linear(m, n)
+    prob = W.TanhLinear(w["A"], w["b"])
+    rng = np.random.default_rng(n)
+    p = 2 * n
+    X = np.repeat(w["x0"][None, :], p, axis=0)
+    h = 2.0 ** -26
+    X[np.arange(p), np.arange(p) // 2] += h * (1 - 2 * (np.arange(p) % 2))
+    X += 1e-3 * rng.standard_normal((1, n))
+    dX = api.DeviceBuffer(X)
+    dY = api.DeviceBuffer(np.zeros((m, p)))
+    dD = api.DeviceBuffer(np.zeros((m, n)))
+    WL = api.workloads_lib()
+    ctx = C.c_void_p(C.addressof(prob.ctx))
+    WL.wl_tanh_linear_fbr_d(ctx, C.c_size_t(m), C.c_size_t(n), C.c_size_t(p), C.c_void_p(dX.ptr), C.c_void_p(dY.ptr))
+    WL.wl_tanh_linear_fbd_d(ctx, C.c_size_t(m), C.c_size_t(n), C.c_size_t(p), C.c_void_p(dX.ptr), C.c_void_p(dD.ptr))
+    prob.stream.synchronize()
+    Y, D = dY.download(), dD.download()
+    assert np.array_equal(D, Y[:, 0::2] - Y[:, 1::2])
+    assert np.abs(D).max() > 0
+
+
+@pytest.mark.parametrize("m,n", [(60000, 128), (30000, 64), (20001, 32), (9000, 100)])
+def test_solve_through_the_difference_panel_equals_the_pair_panel_solve(oracle, m, n):
+    w = P.tanh_linear(m, n)
+    prob = W.TanhLinear(w["A"], w["b"])
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-7
+    sd, sp = M.Stats(), M.Stats()
+    rd, xd = prob.solve(w["x0"], settings=s, batched=True, stats=sd)            # difference panel (fbRowMajorDiff)
+    rp, xp = prob.solve(w["x0"], settings=s, batched="rowmajor", stats=sp)      # pair panel (fbRowMajor)
+    assert rd.status >= 0 and rd.status == rp.status and rd.fCalls == rp.fCalls
+    if n % 64 == 0:          # same stage partition in both kernels: the same bits all the way
+        assert np.array_equal(xd, xp) and rd.residual == rp.residual and rd.iterations == rp.iterations
+    else:
+        assert np.allclose(xd, xp, rtol=1e-9, atol=1e-12) and np.isclose(rd.residual, rp.residual, rtol=1e-12)
+    assert sd.jacobian_full == sp.jacobian_full >= 1
