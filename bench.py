@@ -484,9 +484,10 @@ def main():
         jtj_flops = m * n * (n + 1.0) + 2.0 * m * n
         if nfd:
             fd_ms = st["jtj_fd_ms"] / nfd
-            diff_panel = args.fd == "batched" and n <= 128 and n % 2 == 0       # the m x n difference panel (fbRowMajorDiff)
+            # the m x n difference panel (fbRowMajorDiff)
+            diff_panel = args.fd == "batched" and ((n <= 128 and n % 2 == 0) or n in (192, 256))
             fd_name = (f"mirlsq::k_jtj_fdp<{ncb}, false, true>" if diff_panel else f"mirlsq::k_jtj_fdp<{ncb}, true, false>") if n <= 128 \
-                else f"mirlsq::k_jtj_fdp8<{ncb}>"
+                else f"mirlsq::k_jtj_fdp8<{ncb}, {'true' if diff_panel else 'false'}>"
             # read the panel (m x n differences, or m x 2n pairs) and y, write J
             fd_bytes = 8.0 * ((2.0 if diff_panel else 3.0) * m * n + m)
             fd_rate = fd_bytes / (fd_ms * 1e-3) / 1e9
@@ -532,7 +533,7 @@ def main():
             else:
                 fl = 2.0 * m * n * pts                          # A[m x n] . X^T[n x p]; + one tanh per output
                 tf = fl / (ms * 1e-3) / 1e12
-                diff_panel = args.fd == "batched" and n <= 128 and n % 2 == 0
+                diff_panel = args.fd == "batched" and ((n <= 128 and n % 2 == 0) or n in (192, 256))
                 by = 8.0 * (m * n + m * pts * (0.5 if diff_panel else 1.0) + m)   # read A once, write the panel
                 kn = "k_tanh_linear_batched_dma"
                 kn_full = f"k_tanh_linear_batched_dma<{n // 4}, true, {'true' if diff_panel else 'false'}>"

@@ -41,7 +41,9 @@ template <int NCB> struct JtjFdp8Cfg {
     static_assert(N % 32 == 0, "a wave's two rows must be a whole number of 64-pair loads");
 };
 
-template <int NCB, int ROLE>
+// DIFF: a.J is the m x N row-major DIFFERENCE panel D[i][j] = f(x + h e_j)_i - f(x - h e_j)_i (mir_lsq_gpu_options.fbRowMajorDiff):
+// a 16-byte load is two columns of one row, half as many loads per stage; the producer applies scal(1 / twh) only.
+template <int NCB, int ROLE, bool DIFF = false>
 __device__ __forceinline__ void jtj_fdp8_body(const JtjArgs<double>& a, double* smem, int lane, size_t s0, size_t S)
 {
     using T = double;
@@ -49,23 +51,29 @@ __device__ __forceinline__ void jtj_fdp8_body(const JtjArgs<double>& a, double* 
     using C = JtjFdp8Cfg<NCB>;
     constexpr int NACC = jtj_nacc<NCB>();
     constexpr int N = C::N;
-    constexpr int NI = C::NI;
+    constexpr int NI = DIFF ? C::NI / 2 : C::NI;
+    constexpr int NPR = DIFF ? N / 2 : N;                  // 16-byte loads per panel row
     const int q = lane >> 4, p = lane & 15;
     const size_t m = a.m;
-    const fdp_v2d* __restrict__ Y = reinterpret_cast<const fdp_v2d*>(a.J);   // m x N pairs
+    const fdp_v2d* __restrict__ Y = reinterpret_cast<const fdp_v2d*>(a.J);   // m x N pairs (DIFF: m x N / 2 column pairs)
 
     // ---- producer side: load i of this lane is pair (row prow[i] of the wave's two rows, column pcol[i])
+    //      (DIFF: columns 2 pcol[i], 2 pcol[i] + 1)
     int prow[NI], pcol[NI];
-    T inv[NI];
+    T inv[NI], inv1[DIFF ? NI : 1];
     bool zc[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int f = 64 * i + lane;
-        prow[i] = f / N;
-        pcol[i] = f % N;
-        const T t = a.twh[pcol[i]];
+        prow[i] = f / NPR;
+        pcol[i] = f % NPR;
+        const T t = a.twh[DIFF ? 2 * pcol[i] : pcol[i]];
         zc[i] = t == 0;                                    // collapsed interval: zero column (LS:1046)
         inv[i] = zc[i] ? 0.0 : 1.0 / t;                    // LS:1047
+        if constexpr (DIFF) {
+            const T t1 = a.twh[2 * pcol[i] + 1];
+            inv1[i] = t1 == 0 ? 0.0 : 1.0 / t1;
+        }
     }
     fdp_v2d b[NI];
     T yb = 0;
@@ -75,7 +83,7 @@ __device__ __forceinline__ void jtj_fdp8_body(const JtjArgs<double>& a, double* 
         for (int i = 0; i < NI; ++i) {
             size_t row = row0 + prow[i];
             row = row < m ? row : m - 1;
-            b[i] = __builtin_nontemporal_load(&Y[row * (size_t)N + pcol[i]]);   // the panel is read once
+            b[i] = __builtin_nontemporal_load(&Y[row * (size_t)NPR + pcol[i]]);   // the panel is read once
         }
         size_t yr = row0 + (lane & (C::RP - 1));
         yr = yr < m ? yr : m - 1;
@@ -86,14 +94,22 @@ __device__ __forceinline__ void jtj_fdp8_body(const JtjArgs<double>& a, double* 
         const size_t row0 = (s0 + t) * C::RS + C::RP * (size_t)ROLE;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            T d = b[i].x;                                  // copy(mBuffer, Jj)       LS:1041
-            d += -1.0 * b[i].y;                            // axpy(-1, mBuffer, Jj)   LS:1045
-            T v = zc[i] ? 0.0 : d * inv[i];                // scal(1 / twh, Jj)       LS:1047
             const size_t row = row0 + prow[i];
             const bool rok = row < m;
-            v = rok ? v : 0.0;                             // rows past m contribute nothing
-            slot[(C::RP * ROLE + prow[i]) * C::LDJ + pcol[i]] = v;
-            if (rok) __builtin_nontemporal_store(v, &a.Jout[row * (size_t)N + pcol[i]]);
+            if constexpr (DIFF) {
+                fdp_v2d v;                                 // the caller did LS:1041 + 1045; scal(1 / twh, Jj), LS:1047
+                v.x = (zc[i] || !rok) ? 0.0 : b[i].x * inv[i];
+                v.y = (inv1[i] == 0 || !rok) ? 0.0 : b[i].y * inv1[i];
+                *reinterpret_cast<fdp_v2d*>(slot + (C::RP * ROLE + prow[i]) * C::LDJ + 2 * pcol[i]) = v;
+                if (rok) __builtin_nontemporal_store(v, reinterpret_cast<fdp_v2d*>(a.Jout + row * (size_t)N + 2 * pcol[i]));
+            } else {
+                T d = b[i].x;                              // copy(mBuffer, Jj)       LS:1041
+                d += -1.0 * b[i].y;                        // axpy(-1, mBuffer, Jj)   LS:1045
+                T v = zc[i] ? 0.0 : d * inv[i];            // scal(1 / twh, Jj)       LS:1047
+                v = rok ? v : 0.0;                         // rows past m contribute nothing
+                slot[(C::RP * ROLE + prow[i]) * C::LDJ + pcol[i]] = v;
+                if (rok) __builtin_nontemporal_store(v, &a.Jout[row * (size_t)N + pcol[i]]);
+            }
         }
         if (lane < C::RP) slot[C::RS * C::LDJ + C::RP * ROLE + lane] = (row0 + lane < m) ? yb : 0.0;
     };
@@ -159,7 +175,7 @@ __device__ __forceinline__ void jtj_fdp8_body(const JtjArgs<double>& a, double* 
         }
 }
 
-template <int NCB>
+template <int NCB, bool DIFF = false>
 __global__ __launch_bounds__(JtjFdp8Cfg<NCB>::THREADS, 1) void k_jtj_fdp8(JtjArgs<double> a)
 {
     using C = JtjFdp8Cfg<NCB>;
@@ -173,14 +189,14 @@ __global__ __launch_bounds__(JtjFdp8Cfg<NCB>::THREADS, 1) void k_jtj_fdp8(JtjArg
     const size_t s1 = s0 + per < Stot ? s0 + per : Stot;
     const size_t S = s1 - s0;
     switch (wave) {
-    case 0: jtj_fdp8_body<NCB, 0>(a, smem, lane, s0, S); break;
-    case 1: jtj_fdp8_body<NCB, 1>(a, smem, lane, s0, S); break;
-    case 2: jtj_fdp8_body<NCB, 2>(a, smem, lane, s0, S); break;
-    case 3: jtj_fdp8_body<NCB, 3>(a, smem, lane, s0, S); break;
-    case 4: jtj_fdp8_body<NCB, 4>(a, smem, lane, s0, S); break;
-    case 5: jtj_fdp8_body<NCB, 5>(a, smem, lane, s0, S); break;
-    case 6: jtj_fdp8_body<NCB, 6>(a, smem, lane, s0, S); break;
-    default: jtj_fdp8_body<NCB, 7>(a, smem, lane, s0, S); break;
+    case 0: jtj_fdp8_body<NCB, 0, DIFF>(a, smem, lane, s0, S); break;
+    case 1: jtj_fdp8_body<NCB, 1, DIFF>(a, smem, lane, s0, S); break;
+    case 2: jtj_fdp8_body<NCB, 2, DIFF>(a, smem, lane, s0, S); break;
+    case 3: jtj_fdp8_body<NCB, 3, DIFF>(a, smem, lane, s0, S); break;
+    case 4: jtj_fdp8_body<NCB, 4, DIFF>(a, smem, lane, s0, S); break;
+    case 5: jtj_fdp8_body<NCB, 5, DIFF>(a, smem, lane, s0, S); break;
+    case 6: jtj_fdp8_body<NCB, 6, DIFF>(a, smem, lane, s0, S); break;
+    default: jtj_fdp8_body<NCB, 7, DIFF>(a, smem, lane, s0, S); break;
     }
 }
 

@@ -307,23 +307,30 @@ hipError_t jtj_run(const JtjPlan& p, const JtjArgs<T>& a, bool broyden, T* packe
 }
 
 // ---- k_jtj_fdp8: the finite-difference J^T J for 128 < n <= 256 (jtj_fdp8.h)
-template <int NCB>
+template <int NCB, bool DIFF = false>
 hipError_t jtj_fdp8_one(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t s)
 {
     using FC = JtjFdp8Cfg<NCB>;
-    MIRLSQ_ENSURE_LDS(k_jtj_fdp8<NCB>, (size_t)FC::LDS_BYTES);
-    hipLaunchKernelGGL(k_jtj_fdp8<NCB>, dim3(p.fdp8_nblk), dim3(FC::THREADS), FC::LDS_BYTES, s, a);
+    MIRLSQ_ENSURE_LDS((k_jtj_fdp8<NCB, DIFF>), (size_t)FC::LDS_BYTES);
+    hipLaunchKernelGGL((k_jtj_fdp8<NCB, DIFF>), dim3(p.fdp8_nblk), dim3(FC::THREADS), FC::LDS_BYTES, s, a);
     return hipGetLastError();
 }
-template <typename T>
+template <typename T, bool DIFF = false>
 hipError_t jtj_fdp8_launch(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
 {
     if constexpr (sizeof(T) == 8) {
-        switch (p.ncb) {
-        case 10: return jtj_fdp8_one<10>(p, a, s);
-        case 12: return jtj_fdp8_one<12>(p, a, s);
-        case 14: return jtj_fdp8_one<14>(p, a, s);
-        case 16: return jtj_fdp8_one<16>(p, a, s);
+        if constexpr (DIFF) {                              // two columns per 16-byte load: whole loads per row need n % 64 == 0
+            switch (p.ncb) {
+            case 12: return jtj_fdp8_one<12, true>(p, a, s);
+            case 16: return jtj_fdp8_one<16, true>(p, a, s);
+            }
+        } else {
+            switch (p.ncb) {
+            case 10: return jtj_fdp8_one<10>(p, a, s);
+            case 12: return jtj_fdp8_one<12>(p, a, s);
+            case 14: return jtj_fdp8_one<14>(p, a, s);
+            case 16: return jtj_fdp8_one<16>(p, a, s);
+            }
         }
     }
     return hipErrorInvalidValue;
@@ -347,10 +354,18 @@ hipError_t jtj_run_fd(const JtjPlan& p, const JtjArgs<T>& a, T* packed, hipStrea
 }
 
 // ---- finite-difference DIFFERENCE panel (a.J: m x n row-major, D_ij = f(x + h e_j)_i - f(x - h e_j)_i; a.twh) -> a.Jout, packed
-//      (f64, n <= 128, n even: JtjPlan::fdp_plain)
+//      (f64; n <= 128, n even: JtjPlan::fdp_plain; n = 192, 256: k_jtj_fdp8)
+inline bool jtj_fd_diff_ok(const JtjPlan& p, int n) { return p.fdp_plain || (p.fdp8 && n % 64 == 0); }
 template <typename T>
 hipError_t jtj_run_fd_diff(const JtjPlan& p, const JtjArgs<T>& a, T* packed, hipStream_t s)
 {
+    if (p.fdp8 && a.n % 64 == 0) {
+        const hipError_t e = jtj_fdp8_launch<T, true>(p, a, s);
+        if (e != hipSuccess) return e;
+        const int rb = (p.fdp8_slab_len + 31) / 32;
+        hipLaunchKernelGGL(k_jtj_slab_reduce<T>, dim3(rb), dim3(1024), 0, s, a.slabs, p.fdp8_nblk, p.fdp8_slab_len, p.ncb, a.n, packed);
+        return hipGetLastError();
+    }
     if (!p.fdp_plain) return hipErrorInvalidValue;
     const hipError_t e = jtj_fdp_launch<T, false, true>(p, a, s);
     if (e != hipSuccess) return e;

@@ -710,7 +710,7 @@ struct Solver {
         if (pb < 1) pb = 1;
         if (fb && fd_batch && fd_batch / 2 < pb) pb = fd_batch / 2 ? fd_batch / 2 : 1;
         const bool no_fuse = (variant & MIR_LSQ_VARIANT_FD_SEPARATE_FILL) != 0;
-        const bool use_diff = fbd && plan.fdp_plain && pb == n && sizeof(T) == 8 && !no_fuse;   // m x n difference panel
+        const bool use_diff = fbd && jtj_fd_diff_ok(plan, (int)n) && pb == n && sizeof(T) == 8 && !no_fuse;   // m x n difference panel
         const size_t need = (use_diff ? 1 : 2) * pb * m * sizeof(T);
         if (ws->ypanel_bytes < need) {
             if (ws->ypanel) (void)hipFree(ws->ypanel);
@@ -1588,7 +1588,7 @@ int fd_jtj_entry(size_t m, size_t n, const double* Yrm, const double* twh, const
     if (n == 0 || m == 0) return -2;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const JtjPlan plan = jtj_plan<double>(m, (int)n, query_num_cu());
-    if (diff ? !plan.fdp_plain : (!plan.fdp && !plan.fdp8)) return -6;   // shape not covered by a fused kernel
+    if (diff ? !jtj_fd_diff_ok(plan, (int)n) : (!plan.fdp && !plan.fdp8)) return -6;   // shape not covered by a fused kernel
     const size_t packed_len = n * (n + 1) / 2 + n + 8;
     double *slabs = nullptr, *packed = nullptr;
     LmState<double>* st = nullptr;

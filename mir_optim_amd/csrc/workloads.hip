@@ -655,6 +655,7 @@ void launch_tanh_linear_batched_diff(const double* A, const double* b, const dou
                                      hipStream_t s)
 {
     if (m >= 32 && P % 16 == 0) {                          // whole 16-point MFMA tiles: no clamped lanes, whose pairs would store zeros
+        if (n == 256 && launch_tlb_dma<64, true, true>(A, b, X, D, m, P, s)) return;
         if (n == 128 && launch_tlb_dma<32, true, true>(A, b, X, D, m, P, s)) return;
         if (n == 64 && launch_tlb_dma<16, true, true>(A, b, X, D, m, P, s)) return;
         if (n == 32 && launch_tlb_dma<8, true, true>(A, b, X, D, m, P, s)) return;

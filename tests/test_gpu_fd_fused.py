@@ -166,7 +166,8 @@ def test_collapsed_interval_gives_zero_column_through_the_fused_path():
 # ---- the m x n DIFFERENCE panel (mir_lsq_gpu_options.fbRowMajorDiff, k_jtj_fdp<., false, true>) --------------------------------
 
 @pytest.mark.parametrize("m,n", [(4096, 128), (5000, 16), (30, 32), (2, 48), (10002, 64), (7778, 80), (6, 112), (100000, 128),
-                                 (4097, 128), (1, 16), (12345, 90), (5000, 100), (33, 2)])
+                                 (4097, 128), (1, 16), (12345, 90), (5000, 100), (33, 2),
+                                 (4096, 256), (5001, 192), (50000, 256), (1, 256), (17, 192)])
 def test_fd_diff_panel_gives_the_pair_panel_jacobian_bit_for_bit(m, n):
     """D = Y+ + (-1) Y- formed by the caller (LS:1041, 1045), scal(1 / twh) by the kernel (LS:1047): the same J as from the pair
     panel, bit for bit, incl. a clipped and a collapsed interval; J^T J / J^T y exact on exact-integer inputs."""
@@ -192,7 +193,7 @@ def test_fd_diff_panel_gives_the_pair_panel_jacobian_bit_for_bit(m, n):
             assert np.max(np.abs(JJd - JJp) / scale) < 1e-13 and np.allclose(Jyd, Jyp, rtol=1e-10, atol=1e-13 * np.abs(Jyp).max())
 
 
-@pytest.mark.parametrize("m,n", [(40000, 128), (10002, 64), (5001, 32), (3000, 16), (2049, 100)])
+@pytest.mark.parametrize("m,n", [(40000, 128), (10002, 64), (5001, 32), (3000, 16), (2049, 100), (20000, 256), (4001, 192)])
 def test_user_side_difference_kernel_is_the_pair_kernel_minus(m, n):
     """workloads.hip: wl_tanh_linear_fbd_d writes exactly column 2j minus column 2j + 1 of what wl_tanh_linear_fbr_d writes."""
     w = P.tanh_linear(m, n)
@@ -216,7 +217,7 @@ def test_user_side_difference_kernel_is_the_pair_kernel_minus(m, n):
     assert np.abs(D).max() > 0
 
 
-@pytest.mark.parametrize("m,n", [(60000, 128), (30000, 64), (20001, 32), (9000, 100)])
+@pytest.mark.parametrize("m,n", [(60000, 128), (30000, 64), (20001, 32), (9000, 100), (30000, 256), (10001, 192)])
 def test_solve_through_the_difference_panel_equals_the_pair_panel_solve(oracle, m, n):
     w = P.tanh_linear(m, n)
     prob = W.TanhLinear(w["A"], w["b"])
