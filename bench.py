@@ -90,6 +90,9 @@ def parse():
                          "panel (n <= 128; the caller's kernel subtracts the (+h, -h) pair, the library's fused kernel scales, writes J "
                          "and forms J^T J); rowmajor: the m x 2n row-major pair panel, same fused kernel; pointmajor: the point-major "
                          "batched callback + k_fd_fill -- or one call per point (serial)")
+    ap.add_argument("--gemm-read-a-once", action="store_true",
+                    help="caller side, --fd batched: the difference-panel GEMM sweeps A once (stage-outer variant: 2.1 instead of "
+                         "3.1 GB per call at cfg 3, ~3 %% slower -- the kernel is MFMA-bound; A/B only)")
     ap.add_argument("--abs-tolerance", type=float, default=1e-5,
                     help="LeastSquaresSettings.absTolerance of the headline number (DESIGN.md section 5)")
     ap.add_argument("--survey-steps", type=int, default=10,
@@ -372,6 +375,7 @@ def main():
         row0 = rank * m
     data = W.tanh_linear_data(m, n, row_offset=row0)
     prob = W.TanhLinear(data["A"], data["b"])
+    prob.ctx.read_a_once = 1 if args.gemm_read_a_once else 0
     settings = M.LeastSquaresSettings()
     settings.absTolerance = args.abs_tolerance
     ws = api.lib().mir_lsq_workspace_create(m, n, 8)

@@ -33,6 +33,15 @@ template <typename T> __device__ inline T sum16(T v)
     return v;
 }
 
+// compile-time loop: f(integral_constant<int, 0>{}), ..., f(integral_constant<int, N - 1>{})
+template <int N, typename F, int I = 0> __device__ __forceinline__ void wl_static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        wl_static_for<N, F, I + 1>(static_cast<F&&>(f));
+    }
+}
+
 // the value of the neighbouring lane (lane ^ 1): DPP quad_perm [1, 0, 3, 2]
 __device__ inline double lane_pair_swap(double v)
 {
@@ -565,11 +574,161 @@ __device__ __forceinline__ void tlb_compute(const double* __restrict__ X, double
     }
 }
 
+// ---- difference panel with A read ONCE (p == 2n finite-difference points X = [x + h e_0, x - h e_0, x + h e_1, ...], the
+//      contract of mir_lsq_gpu_options.fbRowMajorDiff). The stage loop is the OUTER loop and the point chunks the inner one: a
+//      32-row stage of A is DMA'd into LDS once and multiplied with every chunk of points before the ring moves on (the sweep
+//      above streams A once per 128-point chunk: 4.1 GB instead of 3.1 at n = 128). What made that impossible for general X
+//      is the B operand: 64 VGPRs of X fragments per chunk. Here every row of X is x except in ONE coordinate, so a lane keeps
+//      the fragments of x itself (read from rows of X that leave the coordinate alone) plus, per chunk, the one perturbed value
+//      and where it goes: the operand of k-step s is a select between the two -- the same numbers the chunked sweep feeds the
+//      matrix cores, every product of the dense GEMM is still computed.
+template <int NK, int GROUP>
+__device__ __forceinline__ void tlb_compute_once(const double* __restrict__ X, double* __restrict__ D, size_t m,
+                                                 unsigned char* smem, int lane, int wave, size_t S)
+{
+    using C = TlbCfg<NK>;
+    using Acc = __attribute__((ext_vector_type(4))) double;
+    constexpr int N = C::N, P = 2 * C::N;
+    constexpr int NCH = (P + C::CHUNK - 1) / C::CHUNK;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int v = fq ^ tlb_sigma(fr);
+    int laddr[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) laddr[k] = fr * N * 8 + ((4 * k) ^ v) * 16;
+
+    // fragments of the base point: k-step s multiplies column k = 8 (s >> 1) + 2 fq + (s & 1); rows 2k and 2k + 1 of X perturb it
+    double xb[NK];
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
+        const int k = 8 * (s >> 1) + 2 * fq + (s & 1);
+        xb[s] = X[(size_t)((2 * k + 2) % P) * N + k];
+    }
+    // per chunk: this lane's point, the k-step that carries its perturbed coordinate (if this lane's k-slot has it), the value
+    bool act[NCH], hit[NCH];
+    int sstar[NCH];
+    double xs[NCH];
+    double* dp[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        act[c] = c * C::CHUNK + wave * 16 < P;                  // wave-uniform
+        int pl = c * C::CHUNK + wave * 16 + fr;
+        pl = pl < P ? pl : P - 1;
+        const int j = pl >> 1;
+        hit[c] = fq == ((j >> 1) & 3);
+        sstar[c] = 2 * (j >> 3) + (j & 1);
+        xs[c] = X[(size_t)pl * N + j];
+        dp[c] = D + j;
+    }
+    constexpr size_t ldr = N;                                   // D is m x n row-major
+
+    auto mfma_stage = [&](size_t st, auto cc, Acc& acc0, Acc& acc1) {
+        constexpr int c = decltype(cc)::value;
+        const unsigned char* slot = smem + (st % C::NS) * C::STAGE_BYTES;
+        acc0 = Acc{0, 0, 0, 0};
+        acc1 = Acc{0, 0, 0, 0};
+        auto xop = [&](int s) { return (hit[c] && sstar[c] == s) ? xs[c] : xb[s]; };
+        if constexpr (C::TILES == 2) {
+#pragma unroll
+            for (int j = 0; j < NK / 2; ++j) {
+                const int off = laddr[j & 3] + (j >> 2) * 256;
+                const double2 a0 = *reinterpret_cast<const double2*>(slot + off);
+                const double2 a1 = *reinterpret_cast<const double2*>(slot + off + 16 * N * 8);
+                const double x0 = xop(2 * j), x1 = xop(2 * j + 1);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, x0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, x0, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, x1, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, x1, acc1, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NK / 2; j += 2) {
+                const double2 a0 = *reinterpret_cast<const double2*>(slot + laddr[j & 3] + (j >> 2) * 256);
+                const double2 a1 = *reinterpret_cast<const double2*>(slot + laddr[(j + 1) & 3] + ((j + 1) >> 2) * 256);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, xop(2 * j), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, xop(2 * j + 2), acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, xop(2 * j + 1), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, xop(2 * j + 3), acc1, 0, 0, 0);
+            }
+            acc0 += acc1;
+        }
+    };
+    auto epilogue_tile = [&](const Acc& acc, size_t row0, const unsigned char* bslot, double* yp, bool full) {
+        const double2 b0 = *reinterpret_cast<const double2*>(bslot + 16 * fq);
+        const double2 b1 = *reinterpret_cast<const double2*>(bslot + 64 + 16 * fq);
+        const double y0 = dtanh(acc[0]) - b0.x, y1 = dtanh(acc[1]) - b0.y;
+        const double y2 = dtanh(acc[2]) - b1.x, y3 = dtanh(acc[3]) - b1.y;
+        const double d0 = y0 - lane_pair_swap(y0), d1 = y1 - lane_pair_swap(y1);         // f(x + h e_j) - f(x - h e_j), LS:1041 + 1045
+        const double d2 = y2 - lane_pair_swap(y2), d3 = y3 - lane_pair_swap(y3);
+        const size_t ra = row0 + 2 * fq, rb = row0 + 8 + 2 * fq;
+        if ((fr & 1) == 0) {
+            if (full || ra < m) yp[ra * ldr] = d0;
+            if (full || ra + 1 < m) yp[(ra + 1) * ldr] = d1;
+            if (full || rb < m) yp[rb * ldr] = d2;
+            if (full || rb + 1 < m) yp[(rb + 1) * ldr] = d3;
+        }
+    };
+    auto epilogue = [&](const Acc& e0, const Acc& e1, size_t st, auto cc) {
+        constexpr int c = decltype(cc)::value;
+        const size_t row0 = (blockIdx.x + st * (size_t)gridDim.x) * C::ROWS;
+        const unsigned char* bs = smem + C::B_OFF + (st % C::NSB) * 256;
+        const bool full = st + 1 < S;                            // only the last stage of a workgroup can be partial
+        epilogue_tile(e0, row0, bs, dp[c], full);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (C::TILES == 2) {
+            epilogue_tile(e1, row0 + 16, bs + 128, dp[c], full);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // Same phase scheme as tlb_compute over the flat sequence (stage 0, chunk 0), (stage 0, chunk 1), ..., one barrier per STAGE.
+    Acc acc0, acc1;
+    if constexpr (GROUP == 0) {
+        for (size_t st = 0; st < S; ++st) {
+            __builtin_amdgcn_s_barrier();                       // stage st is complete in LDS
+            wl_static_for<NCH>([&](auto cc) {
+                if (act[decltype(cc)::value]) {
+                    mfma_stage(st, cc, acc0, acc1);
+                    epilogue(acc0, acc1, st, cc);
+                }
+            });
+        }
+    } else {
+        for (size_t st = 0; st < S; ++st) {
+            wl_static_for<NCH>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                if constexpr (c == 0) {
+                    __builtin_amdgcn_s_barrier();
+                    if (st > 0) {                               // the pending tile is (st - 1, last active chunk)
+                        wl_static_for<NCH>([&](auto pp) {
+                            constexpr int pc = decltype(pp)::value;
+                            constexpr bool last = pc == NCH - 1;
+                            if (act[pc] && (last || !act[pc + (last ? 0 : 1)])) epilogue(acc0, acc1, st - 1, pp);
+                        });
+                    }
+                    if (act[0]) mfma_stage(st, cc, acc0, acc1);
+                } else {
+                    if (act[c]) {                               // act[c] implies act[c - 1]: a wave's chunks fill up from 0
+                        epilogue(acc0, acc1, st, std::integral_constant<int, c - 1>{});
+                        mfma_stage(st, cc, acc0, acc1);
+                    }
+                }
+            });
+        }
+        if (S > 0) {
+            wl_static_for<NCH>([&](auto pp) {
+                constexpr int pc = decltype(pp)::value;
+                constexpr bool last = pc == NCH - 1;
+                if (act[pc] && (last || !act[pc + (last ? 0 : 1)])) epilogue(acc0, acc1, S - 1, pp);
+            });
+        }
+    }
+}
+
 template <int NK, bool RM = false, bool DIFF = false>
 __global__ __launch_bounds__(TlbCfg<NK>::THREADS) void k_tanh_linear_batched_dma(const double* __restrict__ A,
                                                                                   const double* __restrict__ b,
                                                                                   const double* __restrict__ X,
-                                                                                  double* __restrict__ Y, size_t m, int P)
+                                                                                  double* __restrict__ Y, size_t m, int P,
+                                                                                  int read_a_once)
 {
     using C = TlbCfg<NK>;
     extern __shared__ __attribute__((aligned(16))) unsigned char tlb_smem[];
@@ -578,11 +737,19 @@ __global__ __launch_bounds__(TlbCfg<NK>::THREADS) void k_tanh_linear_batched_dma
     const size_t Stot = (m + C::ROWS - 1) / C::ROWS;
     const size_t S = blockIdx.x < Stot ? (Stot - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;   // stages blockIdx.x + k grid
     const int nchunks = (P + C::CHUNK - 1) / C::CHUNK;
-    const size_t F = S * (size_t)nchunks;                       // flat (chunk, stage) sequence: the ring never drains
+    // the finite-difference points of fbRowMajorDiff, on request: A is read once (2.1 instead of 3.1 GB per call at n = 128,
+    // and 3 % SLOWER: the kernel is MFMA-bound and the operand selects are extra VALU work -- not the default)
+    const bool once = DIFF && read_a_once && P == 2 * C::N;
+    const size_t F = once ? S : S * (size_t)nchunks;            // flat (chunk, stage) sequence: the ring never drains
     if (S == 0) return;
     if (wave == C::COMPUTE_WAVES) tlb_loader<NK, 0>(A, b, m, tlb_smem, lane, S, F);
     else if (wave == C::COMPUTE_WAVES + 1) tlb_loader<NK, 1>(A, b, m, tlb_smem, lane, S, F);
-    else {
+    else if (DIFF && once) {
+        if constexpr (DIFF) {
+            if (wave < 4) tlb_compute_once<NK, 0>(X, Y, m, tlb_smem, lane, wave, S);     // waves w and w + 4 share a SIMD
+            else tlb_compute_once<NK, 1>(X, Y, m, tlb_smem, lane, wave, S);
+        }
+    } else {
         if constexpr (RM) {
             if (wave < 4) tlb_compute<NK, false, 0, true, DIFF>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
             else tlb_compute<NK, false, 1, true, DIFF>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
@@ -600,7 +767,7 @@ __global__ __launch_bounds__(TlbCfg<NK>::THREADS) void k_tanh_linear_batched_dma
 }
 
 template <int NK, bool RM = false, bool DIFF = false>
-bool launch_tlb_dma(const double* A, const double* b, const double* X, double* Y, size_t m, int P, hipStream_t s)
+bool launch_tlb_dma(const double* A, const double* b, const double* X, double* Y, size_t m, int P, hipStream_t s, int read_a_once = 0)
 {
     using C = TlbCfg<NK>;
     static bool attr_ok = [] {
@@ -610,7 +777,7 @@ bool launch_tlb_dma(const double* A, const double* b, const double* X, double* Y
     if (!attr_ok) return false;
     const size_t Stot = (m + C::ROWS - 1) / C::ROWS;
     const unsigned grid = (unsigned)(Stot < 256 ? Stot : 256);
-    hipLaunchKernelGGL((k_tanh_linear_batched_dma<NK, RM, DIFF>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, s, A, b, X, Y, m, P);
+    hipLaunchKernelGGL((k_tanh_linear_batched_dma<NK, RM, DIFF>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, s, A, b, X, Y, m, P, read_a_once);
     return true;
 }
 
@@ -652,13 +819,13 @@ __global__ __launch_bounds__(256) void k_tanh_linear_batched_diff_generic(const 
 }
 
 void launch_tanh_linear_batched_diff(const double* A, const double* b, const double* X, double* D, size_t m, int n, int P,
-                                     hipStream_t s)
+                                     hipStream_t s, int read_a_once)
 {
     if (m >= 32 && P % 16 == 0) {                          // whole 16-point MFMA tiles: no clamped lanes, whose pairs would store zeros
-        if (n == 256 && launch_tlb_dma<64, true, true>(A, b, X, D, m, P, s)) return;
-        if (n == 128 && launch_tlb_dma<32, true, true>(A, b, X, D, m, P, s)) return;
-        if (n == 64 && launch_tlb_dma<16, true, true>(A, b, X, D, m, P, s)) return;
-        if (n == 32 && launch_tlb_dma<8, true, true>(A, b, X, D, m, P, s)) return;
+        if (n == 256 && launch_tlb_dma<64, true, true>(A, b, X, D, m, P, s, read_a_once)) return;
+        if (n == 128 && launch_tlb_dma<32, true, true>(A, b, X, D, m, P, s, read_a_once)) return;
+        if (n == 64 && launch_tlb_dma<16, true, true>(A, b, X, D, m, P, s, read_a_once)) return;
+        if (n == 32 && launch_tlb_dma<8, true, true>(A, b, X, D, m, P, s, read_a_once)) return;
     }
     size_t blocks = (m * (size_t)(P / 2) + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
@@ -786,7 +953,7 @@ inline uint64_t splitmix64_mix(uint64_t z)
 extern "C" {
 
 // contexts: device data pointers + the stream the solver was given (mir_lsq_gpu_options.stream)
-struct wl_tanh_linear_ctx { const void* A; const void* b; void* stream; };
+struct wl_tanh_linear_ctx { const void* A; const void* b; void* stream; int read_a_once; /* difference-panel GEMM: one sweep over A */ };
 struct wl_curve_ctx { const void* t; const void* data; void* stream; int kind; };
 
 void wl_tanh_linear_f_d(void* vctx, size_t m, size_t n, const double* x, double* y)
@@ -820,7 +987,7 @@ void wl_tanh_linear_fbr_d(void* vctx, size_t m, size_t n, size_t p, const double
 void wl_tanh_linear_fbd_d(void* vctx, size_t m, size_t n, size_t p, const double* X, double* D)
 {
     auto* c = static_cast<wl_tanh_linear_ctx*>(vctx);
-    launch_tanh_linear_batched_diff((const double*)c->A, (const double*)c->b, X, D, m, (int)n, (int)p, (hipStream_t)c->stream);
+    launch_tanh_linear_batched_diff((const double*)c->A, (const double*)c->b, X, D, m, (int)n, (int)p, (hipStream_t)c->stream, c->read_a_once);
 }
 void wl_tanh_linear_f_s(void* vctx, size_t m, size_t n, const float* x, float* y)
 {

@@ -9,7 +9,7 @@ from . import api
 
 
 class _TanhCtx(C.Structure):
-    _fields_ = [("A", C.c_void_p), ("b", C.c_void_p), ("stream", C.c_void_p)]
+    _fields_ = [("A", C.c_void_p), ("b", C.c_void_p), ("stream", C.c_void_p), ("read_a_once", C.c_int)]
 
 
 class _CurveCtx(C.Structure):

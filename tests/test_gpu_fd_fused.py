@@ -210,11 +210,18 @@ def test_user_side_difference_kernel_is_the_pair_kernel_minus(m, n):
     WL = api.workloads_lib()
     ctx = C.c_void_p(C.addressof(prob.ctx))
     WL.wl_tanh_linear_fbr_d(ctx, C.c_size_t(m), C.c_size_t(n), C.c_size_t(p), C.c_void_p(dX.ptr), C.c_void_p(dY.ptr))
-    WL.wl_tanh_linear_fbd_d(ctx, C.c_size_t(m), C.c_size_t(n), C.c_size_t(p), C.c_void_p(dX.ptr), C.c_void_p(dD.ptr))
     prob.stream.synchronize()
-    Y, D = dY.download(), dD.download()
-    assert np.array_equal(D, Y[:, 0::2] - Y[:, 1::2])
-    assert np.abs(D).max() > 0
+    Y = dY.download()
+    for once in (0, 1):
+        # read_a_once = 1: the stage-outer variant (one sweep over A, operands of the k-steps selected from the base point's
+        # fragments and the one perturbed coordinate per point): the same operands, the same bits
+        prob.ctx.read_a_once = once
+        dD.upload(np.zeros((m, n)))
+        WL.wl_tanh_linear_fbd_d(ctx, C.c_size_t(m), C.c_size_t(n), C.c_size_t(p), C.c_void_p(dX.ptr), C.c_void_p(dD.ptr))
+        prob.stream.synchronize()
+        D = dD.download()
+        assert np.array_equal(D, Y[:, 0::2] - Y[:, 1::2]), once
+        assert np.abs(D).max() > 0
 
 
 @pytest.mark.parametrize("m,n", [(60000, 128), (30000, 64), (20001, 32), (9000, 100), (30000, 256), (10001, 192)])
