@@ -570,7 +570,8 @@ def main():
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": dt / K * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": f"cfg3 tanh-linear NLS m_total={m_total} x n={n} fp64, FD Jacobian ({args.fd} residual callback), "
+                "workload": f"cfg3 tanh-linear NLS m_total={m_total} x n={n} fp64, FD Jacobian (central differences, 2n residual evaluations per refresh through the "
+                            f"{ {'batched': 'batched difference-panel', 'rowmajor': 'batched pair-panel', 'pointmajor': 'batched point-major', 'serial': 'single-point'}[args.fd] } callback), "
                             f"absTolerance={args.abs_tolerance:g}, whole solves x0 -> termination, {args.scaling} scaling "
                             f"({m} rows on rank 0)",
                 "m_total": m_total, "m_per_gpu": m, "n": n, "scaling": args.scaling,
