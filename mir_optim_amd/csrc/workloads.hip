@@ -739,7 +739,8 @@ __global__ __launch_bounds__(TlbCfg<NK>::THREADS) void k_tanh_linear_batched_dma
     const int nchunks = (P + C::CHUNK - 1) / C::CHUNK;
     // the finite-difference points of fbRowMajorDiff, on request: A is read once (2.1 instead of 3.1 GB per call at n = 128,
     // and 3 % SLOWER: the kernel is MFMA-bound and the operand selects are extra VALU work -- not the default)
-    const bool once = DIFF && read_a_once && P == 2 * C::N;
+    // (n = 256: six chunks of per-chunk state next to 128 VGPRs of fragments spill -- measured 2x slower; not offered there)
+    const bool once = DIFF && read_a_once && NK <= 32 && P == 2 * C::N;
     const size_t F = once ? S : S * (size_t)nchunks;            // flat (chunk, stage) sequence: the ring never drains
     if (S == 0) return;
     if (wave == C::COMPUTE_WAVES) tlb_loader<NK, 0>(A, b, m, tlb_smem, lane, S, F);
