@@ -471,20 +471,25 @@ __device__ __forceinline__ void lds_residual(int n, T* smem, T bi, T xi, T& ri, 
     for (int ps = 0; ps < PASSES; ++ps) {
         const int i = (ps * kSolveThreads + tid) >> 1, h = tid & 1;
         const int I = i >> 4, r = i & 15;
-        T ra = 0, wa = 0;
+        T ra = 0, wa = 0, ra1 = 0, wa1 = 0;                    // two chains each: 64 dependent FMAs were the critical path
         if (i < 16 * nbl) {
             for (int J = h; J < nbl; J += 2) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const T a = J <= I ? A[blk_off(I, J, r, c)] : A[blk_off(J, I, c, r)];
-                    const T xc = xv[16 * J + c];
-                    ra += a * xc;
-                    wa += dabs(a) * dabs(xc);
+                for (int c = 0; c < 16; c += 2) {
+                    const T a0 = J <= I ? A[blk_off(I, J, r, c)] : A[blk_off(J, I, c, r)];
+                    const T a1 = J <= I ? A[blk_off(I, J, r, c + 1)] : A[blk_off(J, I, c + 1, r)];
+                    const T x0 = xv[16 * J + c], x1 = xv[16 * J + c + 1];
+                    ra += a0 * x0;
+                    ra1 += a1 * x1;
+                    wa += dabs(a0) * dabs(x0);
+                    wa1 += dabs(a1) * dabs(x1);
                 }
             }
         }
-        ra += wave_shfl_xor(ra, 1);
-        wa += wave_shfl_xor(wa, 1);
+        ra += ra1;
+        wa += wa1;
+        ra += dpp_quad<0xB1>(ra);                              // the row's other half: the neighbouring lane (DPP, no LDS permute)
+        wa += dpp_quad<0xB1>(wa);
         rk[ps] = ra; wk[ps] = wa;
     }
     __syncthreads();                                         // every read of xv is done: zv / xv may be rewritten
