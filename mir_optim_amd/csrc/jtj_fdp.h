@@ -20,6 +20,10 @@
 //     while the producers convert stage t + 1 into the other slot; consumer roles 2 and 3 also write the J rows to
 //     HBM from their fragments (128-byte segments), so the producers' vmcnt stream contains loads only.
 //
+// Three sources, one consumer side: the (+h, -h) pair panel (FD = true; the description above), J itself (FD = false: plain J^T J,
+// nothing written back), and the m x n DIFFERENCE panel the caller's kernel has already subtracted (FD = false, DIFF = true:
+// mir_lsq_gpu_options.fbRowMajorDiff -- the plain producer applies scal(1 / twh), the consumers write J): half the panel bytes.
+//
 // Slabs are laid out exactly like k_jtj2's, so k_jtj_slab_reduce finishes the job. Rows past m are clamped on the
 // load side and written as zeros to LDS.
 #pragma once
