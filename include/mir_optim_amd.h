@@ -201,6 +201,12 @@ enum {
     MIR_LSQ_VARIANT_PIPELINE = 1u << 11,         /* enqueue the library part of the next Broyden round behind a device-side
                                                     guard before the current decision is known (bit-identical results;
                                                     measured: no gain on one GPU, so it is not the default) */
+    MIR_LSQ_VARIANT_NO_TAIL_FUSION = 1u << 12,   /* the reductions and the decision as kernels of their own (k_lr_reduce,
+                                                    k_lr_finish, k_unpack_grad, k_sumsq_*, k_decide_chain) instead of in the
+                                                    tail of the sweep that produces their input; bit-identical results */
+    MIR_LSQ_VARIANT_FD_HOST_COLUMNS = 1u << 13,  /* host-callback finite differences column by column (per-slot staging vectors,
+                                                    a strided column write and a stream synchronisation per task, under a
+                                                    lock) instead of through the pinned point-major panel */
     MIR_LSQ_VARIANT_LR_CAP_SHIFT = 16            /* bits 16..20: fold the pending Broyden terms into J after this many
                                                     updates (1..16; 0 = 16) */
 };
@@ -237,7 +243,25 @@ typedef struct mir_lsq_stats {
     uint64_t fd_callback_calls, fd_callback_points;
     double trial_callback_ms;
     uint64_t trial_callback_calls, trial_callback_points;
+    /* ---- everything below: written only when mir_lsq_gpu_options.stats_size says the caller's struct has it ----
+     * kernels the LIBRARY launched (the caller's callbacks and memory copies are not counted), by the kind of round they
+     * belong to: [0] rounds that start with a full Jacobian refresh (LS:1008-1050), [1] rounds that start with a Broyden
+     * update (LS:999-1007), [2] rounds that re-solve with a larger lambda after a rejection (J unchanged); rounds[k] counts
+     * the rounds of each kind (a round = update, solve(s), trial residual(s), decision). library_launches also counts what
+     * belongs to no round (entry, flushes). */
+    uint64_t library_launches;
+    uint64_t round_launches[3];
+    uint64_t rounds[3];
+    /* host-callback finite differences (the reference ABI, LS:1018-1049): wall time of the refreshes (thread manager
+     * included), time spent inside the caller's f summed over the manager's threads, columns refreshed */
+    double fd_host_wall_ms, fd_host_f_ms;
+    uint64_t fd_host_columns;
 } mir_lsq_stats;
+/* Versioning of mir_lsq_stats: the library writes min(stats_size, sizeof(mir_lsq_stats)) bytes. A caller whose options
+ * struct has no stats_size member (struct_size < 96), or leaves it 0, gets the layout of its era: 120 bytes (through
+ * qp_active_set_passes) below struct_size 80, 144 (through jtj_fd_launches) below 88, 264 (through trial_callback_points)
+ * from 88 on. Changelog: fd_ms is 0 in device-callback mode since the fd_callback_* fields exist (the refresh is only
+ * enqueued there); *_callback_calls / *_callback_points are always counted, the *_ms next to them need MIR_LSQ_TIME_KERNELS. */
 
 /* Optional per-pass trace (not in the reference; a parity-pinning aid: tests compare it event by event with the
  * oracle's trace). One record per Jacobian update and per executed loop pass, in the reference's order -- passes
@@ -286,6 +310,9 @@ typedef struct mir_lsq_gpu_options {
                                         the library's is then m x n instead of m x 2n: 2 GB less HBM traffic per refresh at
                                         m = 1e6, n = 128 (1 GB not written, 1 GB not read), bitwise the same Jacobian.
                                         Preferred over fbRowMajor when both are given. Read only when struct_size covers it */
+    uint32_t stats_size;             /* sizeof(mir_lsq_stats) as the CALLER compiled it: the library never writes past it
+                                        (0 or not covered by struct_size: see "Versioning of mir_lsq_stats") */
+    uint32_t reserved0;
 } mir_lsq_gpu_options;
 
 /* Same algorithm and result contract as mir_optimize_least_squares_{d,s}; x/l/u stay host
@@ -379,12 +406,18 @@ mir_lsq_comm* mir_lsq_comm_create_callback(int nranks, int rank, mir_lsq_allredu
  * shards on one GPU: the single-device emulation of SURVEY.md section 7 step 7) or on different devices (one process
  * driving several GPUs without RCCL). An all-reduce copies each rank's buffer to pinned host memory, the ranks meet at a
  * barrier, every rank sums the nranks contributions in rank order (bitwise identical totals on all ranks) and copies the
- * total back. out_comms receives nranks handles (rank r at out_comms[r]); destroy each with mir_lsq_comm_destroy.
+ * total back. out_comms receives nranks handles (rank r at out_comms[r]); destroy each with mir_lsq_comm_destroy -- in any
+ * order and from any thread, also while other ranks are still solving: the shared slots live until the last handle goes.
  * A rank that waits longer than 120 s at the barrier gives up (the solve then returns numericError). Returns 0. */
 int mir_lsq_comm_create_local_group(int nranks, mir_lsq_comm** out_comms);
 void mir_lsq_comm_destroy(mir_lsq_comm* comm);
 /* ranks of the communicator as its transport reports them (RCCL: ncclCommCount); -1 on error */
 int mir_lsq_comm_ranks(const mir_lsq_comm* comm);
+/* One line about the transport, for logs: "rccl path=<shared object ncclAllReduce was bound from> version=<ncclGetVersion>
+ * preloaded=<1: the host program had it mapped already> ranks=<ncclCommCount> rank=<r>", or "callback ..." / "local-group ...".
+ * snprintf semantics (returns the length it needs). bench.py puts it into its JSON line: the library binds an RCCL the
+ * host program has already loaded (PyTorch's) in preference to /opt/rocm's, and a version skew should be visible. */
+int mir_lsq_comm_describe(const mir_lsq_comm* comm, char* buf, size_t len);
 /* Sum `count` doubles (floats) of the DEVICE buffer `buf` over the communicator's ranks, in place, ordered on `stream` -- the
  * collective the solver issues for the three exchanges of a pass (least_squares.d:1052, 1065, 1115), exposed so that a caller
  * can check a communicator before the first solve (bench.py does). Returns 0 on success. */

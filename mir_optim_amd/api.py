@@ -34,7 +34,7 @@ __all__ = [
     "fit_spline_residuals", "variant_lr_cap",
     "VARIANT_BROYDEN_REWRITE", "VARIANT_FD_SEPARATE_FILL", "VARIANT_JTJ_RING", "VARIANT_JTJ_STREAM",
     "VARIANT_NO_SPECULATION", "VARIANT_NO_NULL_SKIP", "VARIANT_SOLVE_BOUNDED", "VARIANT_DEBUG_SOLVE",
-    "VARIANT_HOST_PROFILE", "VARIANT_NO_RESYNC", "VARIANT_SOLVE_GENERIC", "VARIANT_PIPELINE",
+    "VARIANT_HOST_PROFILE", "VARIANT_NO_RESYNC", "VARIANT_SOLVE_GENERIC", "VARIANT_PIPELINE", "VARIANT_NO_TAIL_FUSION", "VARIANT_FD_HOST_COLUMNS",
 ]
 
 MODEL_EXP_DECAY = 0      # n = 3: p0 exp(-t p1) + p2
@@ -57,6 +57,8 @@ VARIANT_HOST_PROFILE = 1 << 8
 VARIANT_NO_RESYNC = 1 << 9
 VARIANT_SOLVE_GENERIC = 1 << 10
 VARIANT_PIPELINE = 1 << 11
+VARIANT_NO_TAIL_FUSION = 1 << 12
+VARIANT_FD_HOST_COLUMNS = 1 << 13
 
 
 def variant_lr_cap(k):
@@ -150,10 +152,12 @@ class Stats(C.Structure):
                 ("broyden_flushes", C.c_uint64), ("jtj_resyncs", C.c_uint64),
                 ("fd_callback_ms", C.c_double), ("fd_callback_calls", C.c_uint64), ("fd_callback_points", C.c_uint64),
                 ("trial_callback_ms", C.c_double), ("trial_callback_calls", C.c_uint64),
-                ("trial_callback_points", C.c_uint64)]
+                ("trial_callback_points", C.c_uint64),
+                ("library_launches", C.c_uint64), ("round_launches", C.c_uint64 * 3), ("rounds", C.c_uint64 * 3),
+                ("fd_host_wall_ms", C.c_double), ("fd_host_f_ms", C.c_double), ("fd_host_columns", C.c_uint64)]
 
     def as_dict(self):
-        return {k: (list(getattr(self, k)) if k.startswith("allreduce_") else getattr(self, k)) for k, _ in self._fields_}
+        return {k: (list(getattr(self, k)) if isinstance(getattr(self, k), C.Array) else getattr(self, k)) for k, _ in self._fields_}
 
 
 class TraceRecord(C.Structure):
@@ -187,11 +191,13 @@ class GpuOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("flags", C.c_uint32), ("stream", C.c_void_p), ("comm", C.c_void_p),
                 ("workspace", C.c_void_p), ("fbContext", C.c_void_p), ("fb", C.c_void_p), ("fd_batch", C.c_uint32),
                 ("variant", C.c_uint32), ("stats", C.POINTER(Stats)), ("trace", C.POINTER(_TraceHeader)),
-                ("fbRowMajor", C.c_void_p), ("fbRowMajorDiff", C.c_void_p)]
+                ("fbRowMajor", C.c_void_p), ("fbRowMajorDiff", C.c_void_p), ("stats_size", C.c_uint32),
+                ("reserved0", C.c_uint32)]
 
     def __init__(self, **kw):
         super().__init__(**kw)
         self.struct_size = C.sizeof(GpuOptions)
+        self.stats_size = C.sizeof(Stats)
 
 
 TASK_FN = C.CFUNCTYPE(None, _Task, C.c_uint32, C.c_uint32, C.c_uint32)
@@ -269,6 +275,8 @@ def lib():
         L.mir_lsq_batched_kernel_s.restype = C.c_int
         L.mir_lsq_batched_kernel_s.argtypes = [C.POINTER(_Ss), sz, sz, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p, sz, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mir_lsq_comm_describe.restype = C.c_int
+        L.mir_lsq_comm_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         L.mir_lsq_workspace_create.restype = C.c_void_p
         L.mir_lsq_workspace_create.argtypes = [sz, sz, sz]
         L.mir_lsq_workspace_destroy.argtypes = [C.c_void_p]

@@ -50,7 +50,121 @@ struct LrArgs {
     int n;
     int k;
     const int32_t* guard;   // optional: the kernel does nothing when *guard == 0 (rounds enqueued ahead of time)
+    // ---- fused tail (tail_counters != nullptr): the reduction of k_lr_reduce and, without an all-reduce behind it, the
+    //      n x n work of k_lr_finish run inside the sweep, in the workgroups that arrive last (see lr_tail below)
+    uint32_t* tail_counters;   // kReduceRanges group counters + 1 top counter: zero before the launch, reset by the tail
+    T* range_sums;             // kReduceRanges x lr_len(n)
+    T* out;                    // the reduced sweep vector (lr_len(n))
+    int finish;                // 1: also apply k_lr_finish (single GPU); 0: an all-reduce of `out` follows
+    T* Dw;                     // finish: D (writable: row k receives dx)
+    T* JJ; T* Jy; LmState<T>* st;
 };
+
+constexpr int kReduceRanges = 32;
+
+// one entry of the symmetric rank-two update J_k^T J_k = J_{k-1}^T J_{k-1} + v dx^T + dx v^T + uu dx dx^T, r >= c: ONE
+// function for k_lr_finish and the fused tail, so that both round the same way
+template <typename T>
+__device__ __forceinline__ T lr_jj_term(T vr, T vc, T dr, T dc, T uu) { return (vr * dc + dr * vc) + uu * dr * dc; }
+
+// ---- the tail of the sweep. Workgroup b belongs to range r = b / per (per = ceil(nblk / 32): the ranges of k_lr_reduce).
+// Every workgroup publishes its partial vector and counts itself into its range; the LAST arrival of a range sums the
+// range's partials in index order into range_sums[r] and counts the range in; the last range to arrive sums the 32 range
+// vectors in index order. Same partition and same order as k_lr_reduce whichever workgroups happen to come last: bitwise
+// reproducible and bit-identical to the two-kernel path. With `finish` the final workgroup goes on with k_lr_finish's
+// work (v = v0 + D w, the rank-two update of J^T J, J^T y, |J^T y|_inf, D_k = dx) from the vector it holds in LDS.
+template <typename T>
+__device__ inline void lr_tail(const LrArgs<T>& a, T (*red)[lr_len(kLrMaxN)])
+{
+    __shared__ int role_s;
+    const int len = lr_len(a.n), nblk = (int)gridDim.x, tid = threadIdx.x;
+    const int per = (nblk + kReduceRanges - 1) / kReduceRanges;
+    const int r = (int)blockIdx.x / per;
+    const int b0 = r * per, b1 = (b0 + per < nblk) ? b0 + per : nblk;
+    const int ngroups = (nblk + per - 1) / per;
+    __threadfence();                                       // release: this workgroup's partial vector ...
+    __syncthreads();
+    if (tid == 0) role_s = atomicAdd(&a.tail_counters[r], 1u) == (uint32_t)(b1 - b0 - 1);   // ... before its count
+    __syncthreads();
+    if (!role_s) return;
+    __threadfence();                                       // acquire: the partials of the whole range
+    if (tid == 0) a.tail_counters[r] = 0;
+    constexpr int kInFlight = 8;                           // loads in flight per thread: the tail must fit the registers of the main loop
+#pragma unroll 1
+    for (int e = tid; e < len; e += blockDim.x) {
+        T p[kInFlight];
+        T s = 0;
+#pragma unroll 1
+        for (int c0 = b0; c0 < b1; c0 += kInFlight) {
+            const T* src = a.partials + (size_t)c0 * len + e;
+#pragma unroll
+            for (int u = 0; u < kInFlight; ++u) p[u] = (c0 + u < b1) ? src[(size_t)u * len] : T(0);
+#pragma unroll
+            for (int u = 0; u < kInFlight; ++u) if (c0 + u < b1) s += p[u];
+        }
+        a.range_sums[(size_t)r * len + e] = s;
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) role_s = atomicAdd(&a.tail_counters[kReduceRanges], 1u) == (uint32_t)(ngroups - 1);
+    __syncthreads();
+    if (!role_s) return;
+    __threadfence();
+    if (tid == 0) a.tail_counters[kReduceRanges] = 0;
+    T* lrs = red[0];                                       // the reduced vector, kept in LDS for the finish
+#pragma unroll 1
+    for (int e = tid; e < len; e += blockDim.x) {
+        T p[kInFlight];
+        T tot = 0;
+#pragma unroll 1
+        for (int c0 = 0; c0 < kReduceRanges; c0 += kInFlight) {
+#pragma unroll
+            for (int u = 0; u < kInFlight; ++u) p[u] = (c0 + u < ngroups) ? a.range_sums[(size_t)(c0 + u) * len + e] : T(0);
+#pragma unroll
+            for (int u = 0; u < kInFlight; ++u) tot = (c0 + u == 0) ? p[0] : tot + p[u];     // k_lr_reduce's order: part[0] + part[1] + ...
+        }
+        a.out[e] = tot;
+        lrs[e] = tot;
+    }
+    if (!a.finish) return;
+    __syncthreads();
+    const int n = a.n, k = a.k;
+    T* v = red[1];
+    T* dxs = red[2];
+    const T* w = lrs + 2 * n;
+    const T* h = w + kLrMax;
+    const T uu = lrs[2 * n + 2 * kLrMax], uy = lrs[2 * n + 2 * kLrMax + 1];
+    T mx = 0;
+    for (int j = tid; j < n; j += blockDim.x) {
+        const T dj = a.dx[j];
+        T s = lrs[j];
+        for (int l = 0; l < k; ++l) s += a.Dw[(size_t)l * n + j] * w[l];
+        v[j] = s;
+        dxs[j] = dj;
+        T g = lrs[n + j];
+        for (int l = 0; l < k; ++l) g += a.Dw[(size_t)l * n + j] * h[l];
+        g += dj * uy;
+        a.Jy[j] = g;
+        const T av = dabs(g);
+        if (av > mx) mx = av;
+    }
+    __syncthreads();                                       // also: every read of D rows < k is done before row k is written
+    for (int j = tid; j < n; j += blockDim.x) a.Dw[(size_t)k * n + j] = dxs[j];
+    for (int idx = tid; idx < n * n; idx += blockDim.x) {
+        const int i = idx / n, j = idx - i * n;
+        const int rr = i >= j ? i : j, cc = i >= j ? j : i;
+        a.JJ[idx] += lr_jj_term(v[rr], v[cc], dxs[rr], dxs[cc], uu);
+    }
+    mx = wave_max(mx);
+    __shared__ T mred[4];
+    if ((tid & 63) == 0) mred[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        T m2 = mred[0];
+        for (int wv = 1; wv < (int)(blockDim.x >> 6); ++wv) m2 = mred[wv] > m2 ? mred[wv] : m2;
+        a.st->jy_inf = m2;
+    }
+}
 
 template <typename T, int NCP, bool VEC>
 __global__ __launch_bounds__(256) void k_broyden_lr(const LrArgs<T> a)
@@ -159,13 +273,13 @@ __global__ __launch_bounds__(256) void k_broyden_lr(const LrArgs<T> a)
     }
     __syncthreads();
     const int len = lr_len(n);
-    T* __restrict__ out = a.partials + (size_t)blockIdx.x * len;
+    T* out = a.partials + (size_t)blockIdx.x * len;
     for (int e = threadIdx.x; e < len; e += blockDim.x) out[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    if (a.tail_counters) lr_tail<T>(a, red);
 }
 
 // sum the per-block partial vectors in a fixed order: blockDim = 1024 = 32 entries x 32 block ranges (a thread walks
 // nparts / 32 partials with 8 loads in flight: the 8-range version spent 9 us on 16 dependent L2 round trips per thread)
-constexpr int kReduceRanges = 32;
 template <typename T>
 __global__ __launch_bounds__(32 * kReduceRanges) void k_lr_reduce(const T* __restrict__ partials, int nparts, int len, T* __restrict__ out,
                                                                   const int32_t* guard = nullptr)
@@ -214,7 +328,7 @@ __global__ __launch_bounds__(256) void k_lr_finish(const T* __restrict__ lr, T* 
         __syncthreads();
         for (int j = threadIdx.x; j < n; j += blockDim.x) {
             const int r = i >= j ? i : j, c = i >= j ? j : i;      // one expression for (i, j) and (j, i): exactly symmetric
-            JJ[(size_t)i * n + j] += (v[r] * dx[c] + dx[r] * v[c]) + uu * dx[r] * dx[c];
+            JJ[(size_t)i * n + j] += lr_jj_term(v[r], v[c], dx[r], dx[c], uu);
         }
         return;
     }
@@ -310,8 +424,8 @@ __global__ __launch_bounds__(256) void k_lr_flush(T* __restrict__ J, const T* __
 template <typename T, int NCP>
 hipError_t lr_sweep_ncp(const LrArgs<T>& a, int nblk, bool vec, hipStream_t s)
 {
-    if (vec) hipLaunchKernelGGL((k_broyden_lr<T, NCP, true>), dim3(nblk), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_broyden_lr<T, NCP, false>), dim3(nblk), dim3(256), 0, s, a);
+    if (vec) MIRLSQ_LAUNCH((k_broyden_lr<T, NCP, true>), dim3(nblk), dim3(256), 0, s, a);
+    else MIRLSQ_LAUNCH((k_broyden_lr<T, NCP, false>), dim3(nblk), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 template <typename T>
@@ -330,8 +444,8 @@ template <typename T, int NCP>
 hipError_t lr_flush_ncp(T* J, const T* U, const T* D, int k, size_t m, int n, int nblk, bool vec, hipStream_t s)
 {
     const size_t lds = (size_t)k * n * sizeof(T);
-    if (vec) hipLaunchKernelGGL((k_lr_flush<T, NCP, true>), dim3(nblk), dim3(256), lds, s, J, U, D, k, m, n);
-    else hipLaunchKernelGGL((k_lr_flush<T, NCP, false>), dim3(nblk), dim3(256), lds, s, J, U, D, k, m, n);
+    if (vec) MIRLSQ_LAUNCH((k_lr_flush<T, NCP, true>), dim3(nblk), dim3(256), lds, s, J, U, D, k, m, n);
+    else MIRLSQ_LAUNCH((k_lr_flush<T, NCP, false>), dim3(nblk), dim3(256), lds, s, J, U, D, k, m, n);
     return hipGetLastError();
 }
 template <typename T>

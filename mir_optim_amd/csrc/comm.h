@@ -57,6 +57,9 @@ struct mir_lsq_comm {
     // rccl
     void* lib = nullptr;
     void* nccl_comm = nullptr;
+    char lib_path[256] = {0};     // the shared object ncclAllReduce was bound from (dladdr)
+    int lib_version = 0;          // ncclGetVersion: major * 10000 + minor * 100 + patch
+    int lib_preloaded = 0;        // 1: the host program had an RCCL mapped already (e.g. PyTorch's) and that one was bound
     int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*destroy_fn)(void*) = nullptr;
     // callback
@@ -70,12 +73,14 @@ namespace mirlsq {
 
 struct NcclUniqueId { char internal[128]; };
 
-inline void* rccl_open()
+inline void* rccl_open(int* preloaded = nullptr)
 {
     // prefer an RCCL that the host program has already loaded (e.g. the one bundled with PyTorch): two
-    // RCCL instances in one process work but double the IPC/bootstrap state
+    // RCCL instances in one process work but double the IPC/bootstrap state. Which one was bound, and its version, is
+    // recorded in the communicator (mir_lsq_comm_describe) so that a version skew shows up in the first log line.
     void* h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (preloaded) *preloaded = h != nullptr;
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);

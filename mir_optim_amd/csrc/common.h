@@ -23,6 +23,11 @@ constexpr int kWave = 64;  // CDNA wavefront
         }                                                                                       \
     } while (0)
 
+// Every kernel the LIBRARY launches on behalf of a solve goes through MIRLSQ_LAUNCH: the per-thread counter is what
+// mir_lsq_stats.library_launches reports (the caller's callbacks and memory copies are not counted).
+inline thread_local uint64_t tl_launches = 0;
+#define MIRLSQ_LAUNCH(...) do { ++::mirlsq::tl_launches; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 template <typename T> struct Lim;
 template <> struct Lim<double> {
     static constexpr double eps = DBL_EPSILON, max = DBL_MAX, min_normal = DBL_MIN;

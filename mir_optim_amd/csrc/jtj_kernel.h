@@ -255,8 +255,13 @@ void k_jtj(JtjArgs<T> a)
 // blockDim = 1024 = 32 slab elements x 32 slab ranges (8 loads in flight per thread, at most two dependent round trips).
 template <typename T>
 __global__ __launch_bounds__(1024) void k_jtj_slab_reduce(const T* __restrict__ slabs, int nslabs, int slab_len,
-                                                          int ncb, int n, T* __restrict__ packed)
+                                                          int ncb, int n, T* __restrict__ packed,
+                                                          T* JJ = nullptr, T* Jy = nullptr, T* jy_inf = nullptr,
+                                                          uint32_t* counter = nullptr)
 {
+    // JJ != nullptr (single GPU: no all-reduce of `packed` follows): the work of k_unpack_grad is done here -- both
+    // triangles of J^T J and J^T y are written directly, and the workgroup that arrives last (counter: zero before the
+    // launch, reset here) takes max |J^T y| (LS:1053; a maximum does not depend on the order)
     constexpr int RANGES = 32;                               // blockDim = 1024 = 32 entries x 32 slab ranges
     __shared__ T part[RANGES][33];
     const int es = threadIdx.x & 31, sp = threadIdx.x >> 5;
@@ -283,12 +288,38 @@ __global__ __launch_bounds__(1024) void k_jtj_slab_reduce(const T* __restrict__ 
             const int Jb = blk - I * (I + 1) / 2;
             const int row = 16 * I + Mma<T>::row(lane, r);
             const int col = 16 * Jb + (lane & 15);
-            if (row < n && col <= row) packed[(size_t)row * (row + 1) / 2 + col] = tot;
+            if (row < n && col <= row) {
+                packed[(size_t)row * (row + 1) / 2 + col] = tot;
+                if (JJ) { JJ[(size_t)row * n + col] = tot; JJ[(size_t)col * n + row] = tot; }
+            }
         } else {
             const int c = reg - nacc * 4;
             const int col = 16 * c + lane;
-            if (lane < 16 && col < n) packed[(size_t)n * (n + 1) / 2 + col] = tot;
+            if (lane < 16 && col < n) {
+                packed[(size_t)n * (n + 1) / 2 + col] = tot;
+                if (JJ) Jy[col] = tot;
+            }
         }
+    }
+    if (!JJ) return;
+    __shared__ int last_s;
+    __shared__ T mred[16];
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last_s = atomicAdd(counter, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!last_s) return;
+    __threadfence();
+    if (threadIdx.x == 0) *counter = 0;
+    T mx = 0;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) { const T av = dabs(Jy[j]); if (av > mx) mx = av; }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) mred[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T r = mred[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = mred[w] > r ? mred[w] : r;
+        *jy_inf = r;
     }
 }
 

@@ -41,6 +41,13 @@ inline hipError_t ensure_dyn_lds(const void* fn, size_t bytes, std::atomic<uint6
         if (e_ != hipSuccess) return e_;                                                          \
     } while (0)
 
+// Where the slab reduction may put its result besides `packed`: the full symmetric J^T J, J^T y and max |J^T y| (the work
+// of k_unpack_grad), when no all-reduce of `packed` sits in between. All null: `packed` only.
+template <typename T>
+struct JtjUnpack {
+    T* JJ = nullptr; T* Jy = nullptr; T* jy_inf = nullptr; uint32_t* counter = nullptr;
+};
+
 struct JtjPlan {
     int ncb = 0;
     int nblk = 0;
@@ -154,12 +161,17 @@ JtjPlan jtj_plan(size_t m, int n, int num_cu, uint32_t variant = 0)
 
 // ---- slab reduction shared by every one-job kernel: -> packed[ n(n+1)/2 + n ]
 template <typename T>
-inline hipError_t jtj_reduce_slabs(const JtjPlan& p, const JtjArgs<T>& a, T* packed, hipStream_t s)
+inline hipError_t jtj_reduce_slabs(const JtjPlan& p, const JtjArgs<T>& a, T* packed, hipStream_t s, const JtjUnpack<T>& u = {},
+                                   int nslabs = -1, int slab_len = -1)
 {
-    const int rb = (p.slab_len + 31) / 32;
-    hipLaunchKernelGGL(k_jtj_slab_reduce<T>, dim3(rb), dim3(1024), 0, s, a.slabs, p.nblk, p.slab_len, p.ncb, a.n, packed);
+    if (nslabs < 0) { nslabs = p.nblk; slab_len = p.slab_len; }
+    const int rb = (slab_len + 31) / 32;
+    MIRLSQ_LAUNCH(k_jtj_slab_reduce<T>, dim3(rb), dim3(1024), 0, s, a.slabs, nslabs, slab_len, p.ncb, a.n, packed,
+                  u.JJ, u.Jy, u.jy_inf, u.counter);
     return hipGetLastError();
 }
+// does jtj_run honour a JtjUnpack for this plan? (the tile-pair jobs have a reduction of their own; jtj_run_fd* always do)
+inline bool jtj_plain_unpacks(const JtjPlan& p) { return !p.wide; }
 
 // ---- k_jtj: register streaming (f32, odd n; MIR_LSQ_VARIANT_JTJ_STREAM)
 template <typename T, int NCB, bool BR>
@@ -167,7 +179,7 @@ hipError_t jtj_stream_one(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
 {
     auto kern = k_jtj<T, NCB, BR>;
     MIRLSQ_ENSURE_LDS(kern, p.lds);
-    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(256), p.lds, s, a);
+    MIRLSQ_LAUNCH(kern, dim3(p.nblk), dim3(256), p.lds, s, a);
     return hipGetLastError();
 }
 template <typename T, bool BR>
@@ -192,7 +204,7 @@ hipError_t jtj_fdp_one(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t s
 {
     using FC = JtjFdpCfg<NCB, FD>;
     MIRLSQ_ENSURE_LDS((k_jtj_fdp<NCB, FD, DIFF>), (size_t)FC::LDS_BYTES);
-    hipLaunchKernelGGL((k_jtj_fdp<NCB, FD, DIFF>), dim3(p.nblk), dim3(FC::THREADS), FC::LDS_BYTES, s, a);
+    MIRLSQ_LAUNCH((k_jtj_fdp<NCB, FD, DIFF>), dim3(p.nblk), dim3(FC::THREADS), FC::LDS_BYTES, s, a);
     return hipGetLastError();
 }
 template <typename T, bool FD, bool DIFF = false>
@@ -220,7 +232,7 @@ hipError_t jtj2_one(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t s)
     auto kern = k_jtj2<NCB, BR>;
     constexpr size_t lds = Jtj2Cfg<NCB, BR>::LDS_BYTES;
     MIRLSQ_ENSURE_LDS(kern, lds);
-    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(kJtj2Threads), lds, s, a);
+    MIRLSQ_LAUNCH(kern, dim3(p.nblk), dim3(kJtj2Threads), lds, s, a);
     return hipGetLastError();
 }
 template <typename T, bool BR>
@@ -248,7 +260,7 @@ hipError_t jtj8_one(const JtjPlan& p, const JtjArgs<double>& a, bool broyden, hi
     auto kern = k_jtj8<NCB>;
     constexpr size_t lds = Jtj8Cfg<NCB>::LDS_BYTES;
     MIRLSQ_ENSURE_LDS(kern, lds);
-    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(kJtj8Threads), lds, s, a, broyden ? 1 : 0);
+    MIRLSQ_LAUNCH(kern, dim3(p.nblk), dim3(kJtj8Threads), lds, s, a, broyden ? 1 : 0);
     return hipGetLastError();
 }
 template <typename T>
@@ -278,22 +290,23 @@ hipError_t jtj_run_wide(const JtjPlan& p, const JtjArgs<T>& a, bool broyden, T* 
         size_t blocks = (G + 3) / 4;
         if (blocks > 2048) blocks = 2048;
         if (a.n <= 256)
-            hipLaunchKernelGGL(k_broyden_wide<T>, dim3((unsigned)blocks), dim3(256), 0, s, a.Jout, a.y, a.y_old, a.dx, a.dx_dot, a.m, a.n);
+            MIRLSQ_LAUNCH(k_broyden_wide<T>, dim3((unsigned)blocks), dim3(256), 0, s, a.Jout, a.y, a.y_old, a.dx, a.dx_dot, a.m, a.n);
         else
-            hipLaunchKernelGGL(k_broyden_rows<T>, dim3((unsigned)blocks), dim3(256), 0, s, a.Jout, a.y, a.y_old, a.dx, a.dx_dot, a.m, a.n);
+            MIRLSQ_LAUNCH(k_broyden_rows<T>, dim3((unsigned)blocks), dim3(256), 0, s, a.Jout, a.y, a.y_old, a.dx, a.dx_dot, a.m, a.n);
     }
     JtjWideArgs<T> w{};
     w.J = a.J; w.y = a.y; w.slabs = a.slabs; w.m = a.m; w.n = a.n;
     w.nt = ((a.n + 15) / 16 + kWideTile - 1) / kWideTile;
     MIRLSQ_ENSURE_LDS(k_jtj_wide<T>, p.lds);
-    hipLaunchKernelGGL(k_jtj_wide<T>, dim3(p.nblk, p.njobs), dim3(256), p.lds, s, w);
-    hipLaunchKernelGGL(k_jtj_wide_reduce<T>, dim3((kWideSlabLen + 31) / 32, p.njobs), dim3(256), 0, s, a.slabs, p.nblk, a.n, packed);
+    MIRLSQ_LAUNCH(k_jtj_wide<T>, dim3(p.nblk, p.njobs), dim3(256), p.lds, s, w);
+    MIRLSQ_LAUNCH(k_jtj_wide_reduce<T>, dim3((kWideSlabLen + 31) / 32, p.njobs), dim3(256), 0, s, a.slabs, p.nblk, a.n, packed);
     return hipGetLastError();
 }
 
 // ---- [Broyden rewrite] + J^T J + J^T y -> packed[ n(n+1)/2 + n ]
 template <typename T>
-hipError_t jtj_run(const JtjPlan& p, const JtjArgs<T>& a, bool broyden, T* packed, hipStream_t s, uint32_t variant = 0)
+hipError_t jtj_run(const JtjPlan& p, const JtjArgs<T>& a, bool broyden, T* packed, hipStream_t s, uint32_t variant = 0,
+                   const JtjUnpack<T>& u = {})
 {
     hipError_t e;
     if (p.ring8) e = jtj8_launch<T>(p, a, broyden, s);
@@ -303,7 +316,7 @@ hipError_t jtj_run(const JtjPlan& p, const JtjArgs<T>& a, bool broyden, T* packe
     else if (p.v2) e = jtj2_launch<T, false>(p, a, s);
     else e = jtj_stream<T, false>(p, a, s);
     if (e != hipSuccess) return e;
-    return jtj_reduce_slabs<T>(p, a, packed, s);
+    return jtj_reduce_slabs<T>(p, a, packed, s, u);
 }
 
 // ---- k_jtj_fdp8: the finite-difference J^T J for 128 < n <= 256 (jtj_fdp8.h)
@@ -312,7 +325,7 @@ hipError_t jtj_fdp8_one(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t 
 {
     using FC = JtjFdp8Cfg<NCB>;
     MIRLSQ_ENSURE_LDS((k_jtj_fdp8<NCB, DIFF>), (size_t)FC::LDS_BYTES);
-    hipLaunchKernelGGL((k_jtj_fdp8<NCB, DIFF>), dim3(p.fdp8_nblk), dim3(FC::THREADS), FC::LDS_BYTES, s, a);
+    MIRLSQ_LAUNCH((k_jtj_fdp8<NCB, DIFF>), dim3(p.fdp8_nblk), dim3(FC::THREADS), FC::LDS_BYTES, s, a);
     return hipGetLastError();
 }
 template <typename T, bool DIFF = false>
@@ -338,38 +351,34 @@ hipError_t jtj_fdp8_launch(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
 
 // ---- finite-difference panel (a.J: m x 2n row-major, a.twh) -> a.Jout, packed
 template <typename T>
-hipError_t jtj_run_fd(const JtjPlan& p, const JtjArgs<T>& a, T* packed, hipStream_t s)
+hipError_t jtj_run_fd(const JtjPlan& p, const JtjArgs<T>& a, T* packed, hipStream_t s, const JtjUnpack<T>& u = {})
 {
     if (p.fdp8) {
         const hipError_t e = jtj_fdp8_launch<T>(p, a, s);
         if (e != hipSuccess) return e;
-        const int rb = (p.fdp8_slab_len + 31) / 32;
-        hipLaunchKernelGGL(k_jtj_slab_reduce<T>, dim3(rb), dim3(1024), 0, s, a.slabs, p.fdp8_nblk, p.fdp8_slab_len, p.ncb, a.n, packed);
-        return hipGetLastError();
+        return jtj_reduce_slabs<T>(p, a, packed, s, u, p.fdp8_nblk, p.fdp8_slab_len);
     }
     if (!p.fdp) return hipErrorInvalidValue;
     const hipError_t e = jtj_fdp_launch<T, true>(p, a, s);
     if (e != hipSuccess) return e;
-    return jtj_reduce_slabs<T>(p, a, packed, s);
+    return jtj_reduce_slabs<T>(p, a, packed, s, u);
 }
 
 // ---- finite-difference DIFFERENCE panel (a.J: m x n row-major, D_ij = f(x + h e_j)_i - f(x - h e_j)_i; a.twh) -> a.Jout, packed
 //      (f64; n <= 128, n even: JtjPlan::fdp_plain; n = 192, 256: k_jtj_fdp8)
 inline bool jtj_fd_diff_ok(const JtjPlan& p, int n) { return p.fdp_plain || (p.fdp8 && n % 64 == 0); }
 template <typename T>
-hipError_t jtj_run_fd_diff(const JtjPlan& p, const JtjArgs<T>& a, T* packed, hipStream_t s)
+hipError_t jtj_run_fd_diff(const JtjPlan& p, const JtjArgs<T>& a, T* packed, hipStream_t s, const JtjUnpack<T>& u = {})
 {
     if (p.fdp8 && a.n % 64 == 0) {
         const hipError_t e = jtj_fdp8_launch<T, true>(p, a, s);
         if (e != hipSuccess) return e;
-        const int rb = (p.fdp8_slab_len + 31) / 32;
-        hipLaunchKernelGGL(k_jtj_slab_reduce<T>, dim3(rb), dim3(1024), 0, s, a.slabs, p.fdp8_nblk, p.fdp8_slab_len, p.ncb, a.n, packed);
-        return hipGetLastError();
+        return jtj_reduce_slabs<T>(p, a, packed, s, u, p.fdp8_nblk, p.fdp8_slab_len);
     }
     if (!p.fdp_plain) return hipErrorInvalidValue;
     const hipError_t e = jtj_fdp_launch<T, false, true>(p, a, s);
     if (e != hipSuccess) return e;
-    return jtj_reduce_slabs<T>(p, a, packed, s);
+    return jtj_reduce_slabs<T>(p, a, packed, s, u);
 }
 
 }  // namespace mirlsq

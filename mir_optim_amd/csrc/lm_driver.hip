@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/mir_optim_amd.h"
@@ -60,6 +61,14 @@ struct mir_lsq_workspace {
     void* pinned_dev = nullptr;   // ... its device address (the decision kernels write the state mirror directly)
     void* pinned_y = nullptr;  // m-vector staging (host-callback mode), lazily allocated
     void* pinned_J = nullptr;  // m*n staging for host analytic Jacobians, lazily allocated
+    // host-callback finite differences (fd_host): the 2n residual vectors of a refresh are written by the caller's f straight
+    // into this pinned, point-major panel and copied to the device panel by the copy streams while other columns are
+    // still being evaluated; lazily allocated
+    void* pinned_panel = nullptr;
+    size_t pinned_panel_bytes = 0;
+    static constexpr int kCopyStreams = 4;
+    hipStream_t copy_stream[kCopyStreams] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t copy_event[kCopyStreams] = {nullptr, nullptr, nullptr, nullptr};
     int num_cu = 256;
 };
 
@@ -82,6 +91,18 @@ template <> struct Abi<float> {
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// polite busy-wait step: the architecture's spin hint where there is one
+inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::atomic_signal_fence(std::memory_order_seq_cst);
+#endif
+}
 
 bool device_available()
 {
@@ -106,11 +127,16 @@ struct Buffers {
     ChainRec<T>* rec;
     T* slabs;
     T *lrD, *lrvec, *lrpart;   // pending Broyden steps (kLrMax x n), reduced sweep vector, per-workgroup partials
+    T* lrranges;               // kReduceRanges x lr_len(n): range sums of the sweep's fused reduction (broyden_lr.h, lr_tail)
+    uint32_t* counters;        // kCounters arrival counters of the "last workgroup finishes" tails; zero between launches
     SolveScratch<T> sc[kChainMax];
     size_t bytes;
 };
 
 constexpr int kPartials = 1024;
+// arrival counters: [0, kReduceRanges] the Broyden sweep's ranges + top, then one each for the sum of squares and the slab reduction
+constexpr int kCounters = 64, kCounterSumsq = 40, kCounterSlabs = 41;
+static_assert(kReduceRanges + 1 <= kCounterSumsq, "counter block layout");
 
 // slab elements the J^T J kernels may need for this shape: the larger of the product plan and the streaming variant's
 template <typename T>
@@ -157,6 +183,8 @@ Buffers<T> carve(void* base, size_t m, size_t n, int num_cu)
     b.lrD = (T*)take((size_t)kLrMax * n, sizeof(T));
     b.lrvec = (T*)take((size_t)lr_len((int)n) + 6, sizeof(T));
     b.lrpart = (T*)take((size_t)lr_blocks(m, num_cu) * lr_len((int)n), sizeof(T));
+    b.lrranges = (T*)take((size_t)kReduceRanges * lr_len((int)n), sizeof(T));
+    b.counters = (uint32_t*)take(kCounters, sizeof(uint32_t));
     for (int k = 0; k < kChainMax; ++k) {
         b.sc[k].Pm = (T*)take(n * n, sizeof(T));
         b.sc[k].A = (T*)take(n * n, sizeof(T));
@@ -220,6 +248,11 @@ void workspace_destroy(mir_lsq_workspace* ws)
     if (ws->pinned) (void)hipHostFree(ws->pinned);
     if (ws->pinned_y) (void)hipHostFree(ws->pinned_y);
     if (ws->pinned_J) (void)hipHostFree(ws->pinned_J);
+    if (ws->pinned_panel) (void)hipHostFree(ws->pinned_panel);
+    for (int k = 0; k < mir_lsq_workspace::kCopyStreams; ++k) {
+        if (ws->copy_event[k]) (void)hipEventDestroy(ws->copy_event[k]);
+        if (ws->copy_stream[k]) (void)hipStreamDestroy(ws->copy_stream[k]);
+    }
     delete ws;
 }
 
@@ -268,6 +301,24 @@ struct Solver {
     // (k_jtj2<., true> / k_jtj8 / k_broyden_wide); bits 16..20 the number of pending terms after which they are folded into J
     uint32_t variant = 0;
     bool dbg_solve = false, no_speculation = false, lowrank = true, no_null_skip = false, host_profile = false;
+    bool fuse_tails = true;    // reductions / decision in the tail of the sweep that feeds them (MIR_LSQ_VARIANT_NO_TAIL_FUSION: separate kernels)
+    mir_lsq_stats stats_local{};      // the solve works on this image; stats_bytes of it go back to the caller's struct
+    mir_lsq_stats* stats_user = nullptr;
+    size_t stats_bytes = 0;
+    uint64_t launches_mark = 0;       // tl_launches at the start of the round being accounted (mir_lsq_stats.round_launches)
+    int round_kind = -1;
+    uint64_t launches_excluded = 0;   // of the launches since the mark: those that belong to no round (flush + resynchronisation)
+    void close_round()
+    {
+        const uint64_t now = tl_launches;
+        if (stats) {
+            stats->library_launches += now - launches_mark;
+            if (round_kind >= 0) { stats->round_launches[round_kind] += now - launches_mark - launches_excluded; stats->rounds[round_kind]++; }
+        }
+        launches_mark = now;
+        launches_excluded = 0;
+        round_kind = -1;
+    }
     int lr_cap = kLrMax;
     int lr_k = 0;
     int device = 0, caller_device = -1;
@@ -311,6 +362,10 @@ struct Solver {
     std::vector<int> slot_count;
     std::mutex fd_mutex;
     std::atomic<bool> fd_failed{false};
+    bool fd_panel_mode = false;        // this refresh stages through the pinned point-major panel (fd_host)
+    std::atomic<uint32_t> fd_streams_used{0};   // bit k: copy stream k carries copies of this refresh
+    std::atomic<uint64_t> fd_f_ns{0};  // wall time inside the caller's f, summed over the tasks (statistics)
+    std::atomic<uint32_t> fd_tasks_run{0};   // tasks the manager has run in this refresh: every i in [0, n) exactly once (LS:575-578)
 
     // MIR_LSQ_HOST_PROFILE=1: host wall time per category of runtime call, printed at teardown (diagnostic)
     double hp_ms[6] = {0, 0, 0, 0, 0, 0};   // 0 events, 1 all-reduce calls, 2 callbacks, 3 sync/readback, 4 launches (solve), 5 max single
@@ -401,6 +456,7 @@ struct Solver {
         no_speculation = (variant & MIR_LSQ_VARIANT_NO_SPECULATION) != 0;
         lowrank = (variant & MIR_LSQ_VARIANT_BROYDEN_REWRITE) == 0;
         no_null_skip = (variant & MIR_LSQ_VARIANT_NO_NULL_SKIP) != 0;
+        fuse_tails = (variant & MIR_LSQ_VARIANT_NO_TAIL_FUSION) == 0;
         host_profile = (variant & MIR_LSQ_VARIANT_HOST_PROFILE) != 0;
         {
             const int v = (int)((variant >> MIR_LSQ_VARIANT_LR_CAP_SHIFT) & 31u);
@@ -419,6 +475,8 @@ struct Solver {
         f_in_lds = solve_nb_ > 0;
         solve_lds = solve_lds_bytes((int)n, (int)sizeof(T));
         twh_h.resize(n);
+        // arrival counters of the fused tails: every tail leaves its counter at zero, but a solve that died half way may not have
+        if (!ok(hipMemsetAsync(B.counters, 0, kCounters * sizeof(uint32_t), stream), "memset counters")) return false;
         // x, lower, upper sit back to back in the workspace: one copy from the pinned block instead of three from pageable
         // memory (each of those is a staged blit kernel, ~18 us apart on the stream)
         {
@@ -448,8 +506,8 @@ struct Solver {
                 else if (e.kind == 1) { stats->jtj_ms += ms; stats->jtj_launches++; stats->jtj_broyden_ms += ms; stats->jtj_broyden_launches++; }
                 else if (e.kind == 2) { stats->solve_ms += ms; stats->solve_launches++; }
                 else if (e.kind == 3) { stats->jtj_ms += ms; stats->jtj_launches++; stats->jtj_fd_ms += ms; stats->jtj_fd_launches++; }
-                else if (e.kind == 4) { stats->fd_callback_ms += ms; stats->fd_callback_calls++; }
-                else if (e.kind == 5) { stats->trial_callback_ms += ms; stats->trial_callback_calls++; }
+                else if (e.kind == 4) stats->fd_callback_ms += ms;          // the calls themselves are counted where they are made
+                else if (e.kind == 5) stats->trial_callback_ms += ms;
             }
         }
         events.clear();                                  // the events themselves stay in the workspace's pool
@@ -483,7 +541,7 @@ struct Solver {
     {
         auto kern = k_lm_solve<T, NB, BOUNDED>;
         if (solve_lds > 48 * 1024) MIRLSQ_ENSURE_LDS(kern, (size_t)(160 * 1024 - 256));
-        hipLaunchKernelGGL(kern, dim3(ks), dim3(kSolveThreads), solve_lds, stream, a);
+        MIRLSQ_LAUNCH(kern, dim3(ks), dim3(kSolveThreads), solve_lds, stream, a);
         return hipGetLastError();
     }
     template <int NB>
@@ -498,7 +556,7 @@ struct Solver {
             // any n: one 512-thread workgroup per ladder entry, matrices in global memory (solve_big.h)
             auto kern = k_lm_solve_big<T>;
             MIRLSQ_ENSURE_LDS(kern, sizeof(BigLds<T>));
-            hipLaunchKernelGGL(kern, dim3(ks), dim3(kBigThreads), sizeof(BigLds<T>), stream, a);
+            MIRLSQ_LAUNCH(kern, dim3(ks), dim3(kBigThreads), sizeof(BigLds<T>), stream, a);
             return hipGetLastError();
         }
         switch (solve_nb_) {
@@ -512,14 +570,31 @@ struct Solver {
 
     // ---- ||v_k||^2 for k < count vectors (stride vstride) -> B.sum[slot + k] on device (all-reduced over row shards)
     //      defer_final (single GPU, trial sums): stage 2 is left to k_decide_chain (sums_pending = the partial count)
-    bool sumsq(const T* v, int slot, int count = 1, size_t vstride = 0, bool defer_final = false)
+    int sumsq_blocks() const
     {
         int nb = (int)((m + 4095) / 4096);
         if (nb > kPartials) nb = kPartials;
-        if (nb < 1) nb = 1;
-        hipLaunchKernelGGL(k_sumsq_partial<T>, dim3(nb, count), dim3(256), 0, stream, v, m, B.partials, vstride, kPartials);
+        return nb < 1 ? 1 : nb;
+    }
+    SumsqTailArgs<T> sumsq_tail_args(const T* v, int slot, size_t vstride)
+    {
+        SumsqTailArgs<T> t{};
+        t.v = v; t.m = m; t.vstride = vstride; t.partials = B.partials; t.pstride = kPartials;
+        t.counter = B.counters + kCounterSumsq; t.out = B.sum + slot;
+        return t;
+    }
+    bool sumsq(const T* v, int slot, int count = 1, size_t vstride = 0, bool defer_final = false)
+    {
+        const int nb = sumsq_blocks();
+        if (fuse_tails) {
+            // stage 2 in the last workgroup of stage 1 (same fixed order): one launch
+            MIRLSQ_LAUNCH((k_sumsq_tail<T, kSumsqTailFinal>), dim3(nb, count), dim3(kSolveThreads), 0, stream, sumsq_tail_args(v, slot, vstride));
+            if (comm && !allreduce(B.sum + slot, (size_t)count, 2)) return false;
+            return ok(hipGetLastError(), "sumsq");
+        }
+        MIRLSQ_LAUNCH(k_sumsq_partial<T>, dim3(nb, count), dim3(256), 0, stream, v, m, B.partials, vstride, kPartials);
         if (defer_final && !comm) { sums_pending = nb; return ok(hipGetLastError(), "sumsq"); }
-        hipLaunchKernelGGL(k_sumsq_final<T>, dim3(count), dim3(256), 0, stream, B.partials, nb, B.sum + slot, kPartials);
+        MIRLSQ_LAUNCH(k_sumsq_final<T>, dim3(count), dim3(256), 0, stream, B.partials, nb, B.sum + slot, kPartials);
         if (comm && !allreduce(B.sum + slot, (size_t)count, 2)) return false;
         return ok(hipGetLastError(), "sumsq");
     }
@@ -574,6 +649,11 @@ struct Solver {
         st_h = st_slot[expect & 1];
         x_h = x_slot[expect & 1];
         volatile uint32_t* sq = &st_h->seq;
+        // Spin briefly (a decision point is normally microseconds away), then yield the core between polls: R solver threads
+        // of an in-process group, the caller's thread manager and OpenMP workers share the host. A stream that stops making
+        // progress ends the wait after kWaitBoundSeconds with numericError instead of hanging the caller.
+        constexpr double kWaitBoundSeconds = 600.0;
+        std::chrono::steady_clock::time_point t_wait{};
         for (uint64_t spins = 0;; ++spins) {
             if (*sq == expect) break;
             if ((spins & 0xfff) == 0xfff) {
@@ -584,8 +664,14 @@ struct Solver {
                     return false;
                 }
                 if (q != hipErrorNotReady) return ok(q, "stream query");
+                const auto now = std::chrono::steady_clock::now();
+                if (t_wait == std::chrono::steady_clock::time_point{}) t_wait = now;
+                else if (std::chrono::duration<double>(now - t_wait).count() > kWaitBoundSeconds) {
+                    std::fprintf(stderr, "[mir_optim_amd] decision point %u: no progress for %.0f s, giving up\n", expect, kWaitBoundSeconds);
+                    return false;
+                }
             }
-            __builtin_ia32_pause();
+            if (spins < 20000) cpu_relax(); else std::this_thread::yield();
         }
         std::atomic_thread_fence(std::memory_order_acquire);
         return true;
@@ -604,6 +690,8 @@ struct Solver {
     {
         T* U = static_cast<T*>(ws->ulr);
         if (lr_k >= lr_cap) {
+            const uint64_t launches_before = tl_launches;
+            struct Excl { Solver* s; uint64_t l0; ~Excl() { s->launches_excluded += tl_launches - l0; } } excl{this, launches_before};
             // fold the pending rank-one terms into J (the reference's successive `ger`s, LS:1006) ...
             if (!ok(lr_flush<T>(B.J, U, B.lrD, lr_k, m, (int)n, ws->num_cu, stream), "broyden flush")) return false;
             lr_k = 0;
@@ -625,12 +713,18 @@ struct Solver {
         a.J = B.J; a.U = U; a.D = B.lrD; a.dx = B.dx_acc; a.dx_dot = &B.st->dx_dot; a.y = y_dev; a.y_old = yold_dev;
         a.partials = B.lrpart; a.m = m; a.n = (int)n; a.k = lr_k; a.guard = guard;
         const int nblk = lr_blocks(m, ws->num_cu), len = lr_len((int)n);
+        if (fuse_tails) {
+            // the reduction -- and, with no all-reduce behind it, the n x n finish -- run in the sweep's last workgroups
+            a.tail_counters = B.counters; a.range_sums = B.lrranges; a.out = B.lrvec; a.finish = comm ? 0 : 1;
+            a.Dw = B.lrD; a.JJ = B.JJ; a.Jy = B.Jy; a.st = B.st;
+        }
         ev_begin(1);
         if (!ok(lr_sweep<T>(a, nblk, stream), "broyden sweep")) return false;
         ev_end();
-        hipLaunchKernelGGL(k_lr_reduce<T>, dim3((len + 31) / 32), dim3(32 * kReduceRanges), 0, stream, B.lrpart, nblk, len, B.lrvec, guard);
+        if (!fuse_tails) MIRLSQ_LAUNCH(k_lr_reduce<T>, dim3((len + 31) / 32), dim3(32 * kReduceRanges), 0, stream, B.lrpart, nblk, len, B.lrvec, guard);
         if (comm && !allreduce(B.lrvec, (size_t)len, 1)) return false;
-        hipLaunchKernelGGL(k_lr_finish<T>, dim3(n + 1), dim3(256), 0, stream, B.lrvec, B.lrD, B.dx_acc, lr_k, (int)n, B.JJ, B.Jy, B.st, guard);
+        if (!fuse_tails || comm)
+            MIRLSQ_LAUNCH(k_lr_finish<T>, dim3(n + 1), dim3(256), 0, stream, B.lrvec, B.lrD, B.dx_acc, lr_k, (int)n, B.JJ, B.Jy, B.st, guard);
         if (!spec_enqueue) {
             if (stats) stats->broyden_lr_columns += (uint64_t)lr_k;
             ++lr_k;
@@ -644,11 +738,26 @@ struct Solver {
         JtjArgs<T> a{};
         a.J = B.J; a.Jout = B.J; a.y = y_vec; a.y_old = y_vec; a.dx = B.dx_acc; a.dx_dot = &B.st->dx_dot;
         a.slabs = B.slabs; a.m = m; a.n = (int)n;
+        const bool direct = unpack_in_reduce(false);
         ev_begin(0);
-        if (!ok(jtj_run<T>(plan, a, false, B.packed, stream, variant), "jtj kernel")) return false;
+        if (!ok(jtj_run<T>(plan, a, false, B.packed, stream, variant, direct ? unpack_target() : JtjUnpack<T>{}), "jtj kernel")) return false;
         ev_end();
+        return finish_products(direct);
+    }
+    // Single GPU: the slab reduction writes J^T J (both triangles), J^T y and |J^T y|_inf itself; with a communicator the
+    // packed buffer is all-reduced first and k_unpack_grad expands it
+    bool unpack_in_reduce(bool fd) const { return fuse_tails && !comm && (fd || jtj_plain_unpacks(plan)); }
+    JtjUnpack<T> unpack_target()
+    {
+        JtjUnpack<T> u;
+        u.JJ = B.JJ; u.Jy = B.Jy; u.jy_inf = &B.st->jy_inf; u.counter = B.counters + kCounterSlabs;
+        return u;
+    }
+    bool finish_products(bool direct)
+    {
+        if (direct) return ok(hipGetLastError(), "jtj reduce");
         if (comm && !allreduce(B.packed, (size_t)n * (n + 1) / 2 + n, 0)) return false;
-        hipLaunchKernelGGL(k_unpack_grad<T>, dim3(n + 1), dim3(128), 0, stream, B.packed, (int)n, B.JJ, B.Jy, B.st);
+        MIRLSQ_LAUNCH(k_unpack_grad<T>, dim3(n + 1), dim3(128), 0, stream, B.packed, (int)n, B.JJ, B.Jy, B.st);
         return ok(hipGetLastError(), "unpack");
     }
 
@@ -665,17 +774,18 @@ struct Solver {
             const bool diff = fd_fused == 2;
             fd_fused = 0;
             a.J = static_cast<const T*>(ws->ypanel); a.twh = B.twh;
+            const bool direct = unpack_in_reduce(true);
+            const JtjUnpack<T> u = direct ? unpack_target() : JtjUnpack<T>{};
             ev_begin(3);
-            if (!ok(diff ? jtj_run_fd_diff<T>(plan, a, B.packed, stream) : jtj_run_fd<T>(plan, a, B.packed, stream), "fd + jtj kernel")) return false;
+            if (!ok(diff ? jtj_run_fd_diff<T>(plan, a, B.packed, stream, u) : jtj_run_fd<T>(plan, a, B.packed, stream, u), "fd + jtj kernel")) return false;
             ev_end();
-        } else {
-            ev_begin(broyden ? 1 : 0);
-            if (!ok(jtj_run<T>(plan, a, broyden, B.packed, stream, variant), "jtj kernel")) return false;
-            ev_end();
+            return finish_products(direct);
         }
-        if (comm && !allreduce(B.packed, (size_t)n * (n + 1) / 2 + n, 0)) return false;
-        hipLaunchKernelGGL(k_unpack_grad<T>, dim3(n + 1), dim3(128), 0, stream, B.packed, (int)n, B.JJ, B.Jy, B.st);
-        return ok(hipGetLastError(), "unpack");
+        const bool direct = unpack_in_reduce(false);
+        ev_begin(broyden ? 1 : 0);
+        if (!ok(jtj_run<T>(plan, a, broyden, B.packed, stream, variant, direct ? unpack_target() : JtjUnpack<T>{}), "jtj kernel")) return false;
+        ev_end();
+        return finish_products(direct);
     }
 
     // ---- finite-difference Jacobian, device callbacks (LS:1016-1050 restructured: all perturbed
@@ -683,7 +793,7 @@ struct Solver {
     //      coalesced column panels)
     bool fd_device()
     {
-        hipLaunchKernelGGL(k_fd_points<T>, dim3(n), dim3(64), 0, stream, B.x, B.lower, B.upper, sd.jacobianEpsilon, (int)n, B.X, B.twh);
+        MIRLSQ_LAUNCH(k_fd_points<T>, dim3(n), dim3(64), 0, stream, B.x, B.lower, B.upper, sd.jacobianEpsilon, (int)n, B.X, B.twh);
         for (uint32_t j = 0; j < n; ++j) {   // same arithmetic on the host, to skip collapsed intervals like LS:1033
             const T save = xh[j];
             T xmh = save - S->jacobianEpsilon, xph = save + S->jacobianEpsilon;
@@ -725,7 +835,7 @@ struct Solver {
             ev_begin(4);
             fbd(fbctx, m, n, 2 * (size_t)n, B.X, Y);
             ev_end();
-            if (stats) stats->fd_callback_points += 2 * (uint64_t)n;
+            if (stats) { stats->fd_callback_points += 2 * (uint64_t)n; stats->fd_callback_calls++; }
             fd_fused = 2;
             ret.fCalls += n;
             return ok(hipGetLastError(), "fd batched callback");
@@ -736,7 +846,7 @@ struct Solver {
             ev_begin(4);
             fbr(fbctx, m, n, 2 * (size_t)n, B.X, Y);
             ev_end();
-            if (stats) stats->fd_callback_points += 2 * (uint64_t)n;
+            if (stats) { stats->fd_callback_points += 2 * (uint64_t)n; stats->fd_callback_calls++; }
             fd_fused = 1;
             ret.fCalls += n;
             return ok(hipGetLastError(), "fd batched callback");
@@ -756,8 +866,9 @@ struct Solver {
                 }
             }
             ev_end();
+            if (stats) stats->fd_callback_calls++;       // one timed bracket per panel (as the events count them)
             dim3 grid((unsigned)((m + 63) / 64), (unsigned)((pc + 31) / 32));
-            hipLaunchKernelGGL(k_fd_fill<T>, grid, dim3(256), 0, stream, Y, m, B.twh, B.J, m, (int)n, (int)j0, (int)pc);
+            MIRLSQ_LAUNCH(k_fd_fill<T>, grid, dim3(256), 0, stream, Y, m, B.twh, B.J, m, (int)n, (int)j0, (int)pc);
         }
         ret.fCalls += n;    // LS:1024, LS:1049 (quirk Q5: +n although 2n evaluations are made)
         return ok(hipGetLastError(), "fd fill");
@@ -772,6 +883,7 @@ struct Solver {
     {
         const uint32_t idx = totalThreads >= n ? j : threadId;       // LS:1022
         if (idx >= n || j >= n) { fd_failed = true; return; }
+        ++fd_tasks_run;
         // the manager's worker threads start on device 0: select the solver's device before any runtime call
         if (hipSetDevice(device) != hipSuccess) { fd_failed = true; return; }
         Slot* s;
@@ -780,8 +892,11 @@ struct Solver {
             s = &slots[idx];
             if (!s->p) {
                 s->p = static_cast<T*>(std::malloc(n * sizeof(T)));
+                if (!s->p) { fd_failed = true; return; }
+            }
+            if (!fd_panel_mode && !s->yp) {
                 if (hipHostMalloc((void**)&s->yp, m * sizeof(T), hipHostMallocDefault) != hipSuccess
-                    || hipHostMalloc((void**)&s->ym, m * sizeof(T), hipHostMallocDefault) != hipSuccess || !s->p) {
+                    || hipHostMalloc((void**)&s->ym, m * sizeof(T), hipHostMallocDefault) != hipSuccess) {
                     fd_failed = true;
                     return;
                 }
@@ -794,6 +909,29 @@ struct Solver {
         xmh = std::fmax(xmh, lh[j]);
         xph = std::fmin(xph, uh[j]);
         const T twh = xph - xmh;
+        if (fd_panel_mode) {
+            // The caller's f writes f(x + h e_j), f(x - h e_j) straight into rows 2j, 2j + 1 of the pinned point-major panel;
+            // ONE asynchronous copy takes the pair to the device panel on a copy stream while this thread -- and the
+            // manager's other threads -- go on with the next column. No lock, no synchronisation: fd_host() makes the
+            // solver's stream wait for the copy streams once, at the end. (A collapsed interval, LS:1033, evaluates and
+            // copies nothing: k_fd_fill writes the zero column without reading the panel.)
+            if (twh != 0) {
+                T* hp = static_cast<T*>(ws->pinned_panel) + (size_t)(2 * j) * m;
+                const auto t0 = std::chrono::steady_clock::now();
+                p[j] = xph;
+                f(fctx, m, n, p, hp);                                // LS:1035-1036
+                p[j] = xmh;
+                f(fctx, m, n, p, hp + m);                            // LS:1038-1039
+                p[j] = save;                                         // LS:1040
+                fd_f_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+                const int k = (int)(idx % mir_lsq_workspace::kCopyStreams);
+                fd_streams_used |= 1u << k;
+                if (hipMemcpyAsync(static_cast<T*>(ws->ypanel) + (size_t)(2 * j) * m, hp, 2 * m * sizeof(T), hipMemcpyHostToDevice,
+                                   ws->copy_stream[k]) != hipSuccess)
+                    fd_failed = true;
+            }
+            return;
+        }
         if (twh != 0) {                                              // LS:1033-1043
             p[j] = xph;
             f(fctx, m, n, p, s->yp);
@@ -812,21 +950,84 @@ struct Solver {
                 return;
             }
         }
-        hipLaunchKernelGGL(k_fd_fill_col<T>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream,
+        MIRLSQ_LAUNCH(k_fd_fill_col<T>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream,
                            mB, fr, twh, B.J, m, (int)n, (int)j);
         if (hipStreamSynchronize(stream) != hipSuccess) fd_failed = true;
+    }
+    // Can this refresh stage through the pinned point-major panel? Needs the whole 2n x m panel on both sides: device (the
+    // budget fd_device() uses: half of the free HBM, at most 64 GiB) and pinned host memory (at most 16 GiB). Otherwise the
+    // column-at-a-time path below (per-slot staging vectors, one strided column write per task) serves any size.
+    bool fd_host_prepare_panel()
+    {
+        if (variant & MIR_LSQ_VARIANT_FD_HOST_COLUMNS) return false;
+        const size_t need = 2 * (size_t)n * m * sizeof(T);
+        if (need > ((size_t)16 << 30)) return false;
+        if (ws->ypanel_bytes < need) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+            size_t cap = (ws->ypanel_bytes + free_b) / 2;
+            if (cap > ((size_t)64 << 30)) cap = (size_t)64 << 30;
+            if (need > cap) return false;
+            if (ws->ypanel) (void)hipFree(ws->ypanel);
+            ws->ypanel = nullptr; ws->ypanel_bytes = 0;
+            if (hipMalloc(&ws->ypanel, need) != hipSuccess) return false;
+            ws->ypanel_bytes = need;
+        }
+        if (ws->pinned_panel_bytes < need) {
+            if (ws->pinned_panel) (void)hipHostFree(ws->pinned_panel);
+            ws->pinned_panel = nullptr; ws->pinned_panel_bytes = 0;
+            if (hipHostMalloc(&ws->pinned_panel, need, hipHostMallocDefault) != hipSuccess) return false;
+            ws->pinned_panel_bytes = need;
+        }
+        for (int k = 0; k < mir_lsq_workspace::kCopyStreams; ++k) {
+            if (!ws->copy_stream[k] && hipStreamCreateWithFlags(&ws->copy_stream[k], hipStreamNonBlocking) != hipSuccess) return false;
+            if (!ws->copy_event[k] && hipEventCreateWithFlags(&ws->copy_event[k], hipEventDisableTiming) != hipSuccess) return false;
+        }
+        return true;
     }
     bool fd_host()
     {
         slots.resize(n);
         slot_count.assign(n, 0);                                     // LS:1018
+        fd_panel_mode = fd_host_prepare_panel();
+        fd_streams_used = 0;
+        fd_tasks_run = 0;
+        if (fd_panel_mode) {
+            // twh (and the points, unused here) on the device with the arithmetic of LS:1027-1031: k_fd_fill needs the widths
+            MIRLSQ_LAUNCH(k_fd_points<T>, dim3(n), dim3(64), 0, stream, B.x, B.lower, B.upper, sd.jacobianEpsilon, (int)n, B.X, B.twh);
+        }
         mir_least_squares_task task{this, nullptr};
+        const auto t0 = std::chrono::steady_clock::now();
         if (tm) tm(tmctx, n, task, &fd_task_trampoline);             // LS:1019
         else for (uint32_t j = 0; j < n; ++j) fd_task(1, 0, j);      // LS:947-951
         uint32_t calls = 0;
         for (uint32_t k = 0; k < n; ++k) calls += (uint32_t)slot_count[k];
         ret.fCalls += calls;                                         // LS:1049
-        return !fd_failed;
+        if (stats) {
+            stats->fd_host_wall_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            stats->fd_host_f_ms += (double)fd_f_ns.exchange(0) * 1e-6;
+            stats->fd_host_columns += n;
+        }
+        if (fd_tasks_run.load() != n) {
+            // a manager that stops half way (an exception in a binding, a cancelled pool) leaves columns of J stale: fail loudly
+            std::fprintf(stderr, "[mir_optim_amd] thread manager ran %u of %u finite-difference tasks\n", fd_tasks_run.load(), n);
+            return false;
+        }
+        if (fd_failed) return false;
+        if (fd_panel_mode) {
+            // the solver's stream waits for the copy streams (no host synchronisation), then ONE coalesced conversion of the
+            // whole panel: pairs of m-vectors -> column panels of J through an LDS transpose (LS:1041-1047)
+            const uint32_t used = fd_streams_used.load();
+            for (int k = 0; k < mir_lsq_workspace::kCopyStreams; ++k) {
+                if (!(used & (1u << k))) continue;
+                if (!ok(hipEventRecord(ws->copy_event[k], ws->copy_stream[k]), "copy event")
+                    || !ok(hipStreamWaitEvent(stream, ws->copy_event[k], 0), "wait for the panel copies")) return false;
+            }
+            dim3 grid((unsigned)((m + 63) / 64), (unsigned)((n + 31) / 32));
+            MIRLSQ_LAUNCH(k_fd_fill<T>, grid, dim3(256), 0, stream, static_cast<const T*>(ws->ypanel), m, B.twh, B.J, m, (int)n, 0, (int)n);
+            return ok(hipGetLastError(), "fd fill");
+        }
+        return true;
     }
 
     bool analytic_jacobian()
@@ -867,8 +1068,12 @@ struct Solver {
     }
 
     // the decision of a round (LS:1080-1161) for ks trials whose sums of squares are in B.sum + 1; publishes decision point ++seq
-    bool enqueue_decide(int ks, bool check_grad, bool lambda_from_state, bool next_round_enqueued_ahead)
+    //      sum_v != nullptr: the ks trial residual vectors at sum_v + k m still have to be summed -- on a single GPU the sweep
+    //      and the decision are one launch (k_sumsq_tail<., kSumsqTailDecide>), otherwise sumsq() runs first
+    bool enqueue_decide(int ks, bool check_grad, bool lambda_from_state, bool next_round_enqueued_ahead, const T* sum_v = nullptr)
     {
+        const bool one_launch = sum_v && fuse_tails && !comm;
+        if (sum_v && !one_launch && !sumsq(sum_v, 1, ks, m, true)) return false;
         DecideArgs<T> d{};
         d.sums = B.sum + 1; d.rec = B.rec; d.st = B.st; d.set = sd; d.x = B.x; d.trial = B.trial; d.dx_chain = B.dx;
         d.dx_acc = B.dx_acc; d.n = (int)n; d.ks = ks; d.check_grad = check_grad ? 1 : 0;
@@ -880,7 +1085,13 @@ struct Solver {
         d.maxIterations = S->maxIterations;
         d.partials = B.partials; d.nparts = sums_pending; d.pstride = kPartials;
         sums_pending = 0;
-        hipLaunchKernelGGL(k_decide_chain<T>, dim3(1), dim3(kSolveThreads), 0, stream, d);
+        if (one_launch) {
+            SumsqTailArgs<T> t = sumsq_tail_args(sum_v, 1, m);
+            t.dec = d;
+            MIRLSQ_LAUNCH((k_sumsq_tail<T, kSumsqTailDecide>), dim3(sumsq_blocks(), ks), dim3(kSolveThreads), 0, stream, t);
+        } else {
+            MIRLSQ_LAUNCH(k_decide_chain<T>, dim3(1), dim3(kSolveThreads), 0, stream, d);
+        }
         return ok(hipGetLastError(), "decide kernel");
     }
 
@@ -920,6 +1131,7 @@ struct Solver {
         ret.status = mir_ls_numericError; ret.iterations = 0; ret.fCalls = 0; ret.gCalls = 0;   // LS:132-142
         ret.residual = Lim<T>::inf(); ret.lambda = 0;
         const auto t_start = std::chrono::steady_clock::now();
+        launches_mark = tl_launches;
 
         // validation, LS:930-943 (quirk Q9) -- needs no device
         {
@@ -945,9 +1157,15 @@ struct Solver {
         do {   // single-exit block for device errors
             if (!eval_f(B.x, xh, y)) { fail = true; break; }                 // LS:953
             ++ret.fCalls;
-            if (!sumsq(y, 0)) { fail = true; break; }                        // LS:955
             ++seq;
-            hipLaunchKernelGGL(k_init_state<T>, dim3(1), dim3(1), 0, stream, B.sum, B.st, st_slot_d[seq & 1], seq);
+            if (fuse_tails && !comm) {                                       // LS:955 + the state at entry, one launch
+                SumsqTailArgs<T> t = sumsq_tail_args(y, 0, 0);
+                t.st = B.st; t.host_st = st_slot_d[seq & 1]; t.seq = seq;
+                MIRLSQ_LAUNCH((k_sumsq_tail<T, kSumsqTailInit>), dim3(sumsq_blocks(), 1), dim3(kSolveThreads), 0, stream, t);
+            } else {
+                if (!sumsq(y, 0)) { fail = true; break; }                    // LS:955
+                MIRLSQ_LAUNCH(k_init_state<T>, dim3(1), dim3(1), 0, stream, B.sum, B.st, st_slot_d[seq & 1], seq);
+            }
             if (!ok(hipGetLastError(), "init state") || !wait_state(seq)) { fail = true; break; }
         } while (false);
         if (fail) { teardown(); ret.status = mir_ls_numericError; return ret; }
@@ -966,6 +1184,7 @@ struct Solver {
         ret.status = mir_ls_maxIterations;                                   // LS:971
 
         do {
+            close_round();
             if (stats) stats->passes++;
             if (fConverged) { ret.status = mir_ls_fConverged; break; }       // LS:974-978
             if (!(ret.lambda <= S->maxLambda)) { ret.status = mir_ls_furtherImprovement; break; }   // LS:979-983
@@ -973,7 +1192,7 @@ struct Solver {
                 needJacobian = true;
                 age = maxAge;
                 mu = 1;
-                hipLaunchKernelGGL(k_reset_mu<T>, dim3(1), dim3(1), 0, stream, B.st);
+                MIRLSQ_LAUNCH(k_reset_mu<T>, dim3(1), dim3(1), 0, stream, B.st);
             }
             {                                                                // LS:990-995
                 bool nan = false;
@@ -1000,10 +1219,12 @@ struct Solver {
                 commit_spec_round();
                 solve_enqueued = true;
             }
+            round_kind = solve_enqueued ? 1 : 2;
             if (needJacobian) {                                              // LS:996-1063
                 needJacobian = false;
                 newJacobian = true;
                 last_rejected = false;
+                round_kind = age < maxAge ? 1 : 0;
                 if (age < maxAge) {                                          // Broyden, LS:999-1007
                     age++;
                     if (stats) stats->jacobian_broyden++;
@@ -1082,7 +1303,7 @@ struct Solver {
                 if (ks > 1 && fb) fb(fbctx, m, n, (size_t)ks, B.trial, ytr);
                 else for (int k = 0; k < ks; ++k) f(fctx, m, n, B.trial + (size_t)k * n, ytr + (size_t)k * m);
                 ev_end();
-                if (stats) stats->trial_callback_points += (uint64_t)ks;
+                if (stats) { stats->trial_callback_points += (uint64_t)ks; stats->trial_callback_calls++; }
             } else {
                 // reference contract: the callback needs the trial point on the host
                 ChainRec<T> r0;
@@ -1093,13 +1314,12 @@ struct Solver {
                     || (r0.flags & (kFlagDxNaN | kFlagStepTooLong)) || null_step;
                 if (!no_f && !eval_f(B.trial, trial_h, ytr)) { fail = true; break; }
             }
-            if (!skip_eval && !sumsq(ytr, 1, ks, m, true)) { fail = true; break; }
 
             // Can the round after this one be enqueued before this one's decision is known? Only the common case is covered:
             // one trial now, and -- if it is accepted and no exit test fires (decided on the device, k_decide_chain) -- a
             // Broyden pass next that needs neither a full refresh (age) nor a flush of the pending terms (lr_k).
             const bool decide_static = pipeline && spec_predict && ks == 1 && !skip_eval && age < maxAge && lr_k < lr_cap;
-            if (!enqueue_decide(ks, newJacobian, lambda_from_state, decide_static)) { fail = true; break; }
+            if (!enqueue_decide(ks, newJacobian, lambda_from_state, decide_static, skip_eval ? nullptr : ytr)) { fail = true; break; }
             const uint32_t round_seq = seq;
             if (decide_static && !enqueue_spec_round()) { fail = true; break; }
             if (!wait_state(round_seq)) { fail = true; break; }
@@ -1152,6 +1372,7 @@ struct Solver {
             }
         } while (ret.iterations < S->maxIterations);                         // LS:1175
 
+        close_round();
         if (fail) ret.status = mir_ls_numericError;
         if (stats) stats->total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
         teardown();
@@ -1177,7 +1398,22 @@ typename Abi<T>::Result solve_entry(const typename Abi<T>::Settings* settings, s
         s.fb = s.device_cb ? reinterpret_cast<typename Abi<T>::FB>(opt->fb) : nullptr;
         s.fd_batch = opt->fd_batch;
         s.variant = opt->variant;
-        s.stats = opt->stats;
+        if (opt->stats) {
+            // mir_lsq_stats is versioned by size (header: "Versioning of mir_lsq_stats"): work on a full local image, hand back
+            // only what the caller's struct holds
+            size_t bytes = opt->struct_size >= offsetof(mir_lsq_gpu_options, fbRowMajorDiff) + sizeof(void*)
+                ? offsetof(mir_lsq_stats, trial_callback_points) + sizeof(uint64_t)
+                : (opt->struct_size >= offsetof(mir_lsq_gpu_options, fbRowMajor) + sizeof(void*)
+                       ? offsetof(mir_lsq_stats, jtj_fd_launches) + sizeof(uint64_t)
+                       : offsetof(mir_lsq_stats, qp_active_set_passes) + sizeof(uint64_t));
+            if (opt->struct_size >= offsetof(mir_lsq_gpu_options, stats_size) + sizeof(uint32_t) && opt->stats_size)
+                bytes = opt->stats_size;
+            if (bytes > sizeof(mir_lsq_stats)) bytes = sizeof(mir_lsq_stats);
+            s.stats_user = opt->stats;
+            s.stats_bytes = bytes;
+            std::memcpy(&s.stats_local, opt->stats, bytes);          // the counters accumulate over calls
+            s.stats = &s.stats_local;
+        }
         if (opt->struct_size >= offsetof(mir_lsq_gpu_options, trace) + sizeof(void*)) s.trace = opt->trace;
         if (opt->struct_size >= offsetof(mir_lsq_gpu_options, fbRowMajor) + sizeof(void*) && s.device_cb)
             s.fbr = reinterpret_cast<typename Abi<T>::FB>(opt->fbRowMajor);
@@ -1185,7 +1421,9 @@ typename Abi<T>::Result solve_entry(const typename Abi<T>::Settings* settings, s
             s.fbd = reinterpret_cast<typename Abi<T>::FB>(opt->fbRowMajorDiff);
         if (s.trace) s.trace->count = 0;
     }
-    return s.run();
+    const typename Abi<T>::Result r = s.run();
+    if (s.stats_user) std::memcpy(s.stats_user, &s.stats_local, s.stats_bytes);
+    return r;
 }
 
 }  // namespace
@@ -1647,7 +1885,8 @@ int mir_lsq_rccl_unique_id(void* out)
 
 mir_lsq_comm* mir_lsq_comm_create_rccl(int nranks, int rank, const void* unique_id)
 {
-    void* h = rccl_open();
+    int preloaded = 0;
+    void* h = rccl_open(&preloaded);
     if (!h) { std::fprintf(stderr, "[mir_optim_amd] librccl not found\n"); return nullptr; }
     auto init = reinterpret_cast<int (*)(void**, int, NcclUniqueId, int)>(dlsym(h, "ncclCommInitRank"));
     auto ar = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(h, "ncclAllReduce"));
@@ -1661,6 +1900,16 @@ mir_lsq_comm* mir_lsq_comm_create_rccl(int nranks, int rank, const void* unique_
     auto* comm = new mir_lsq_comm();
     comm->nranks = nranks; comm->rank = rank; comm->kind = 1; comm->lib = h; comm->nccl_comm = c;
     comm->allreduce_fn = ar; comm->destroy_fn = destroy;
+    comm->lib_preloaded = preloaded;
+    {
+        Dl_info info{};
+        if (dladdr(reinterpret_cast<void*>(ar), &info) && info.dli_fname) std::snprintf(comm->lib_path, sizeof comm->lib_path, "%s", info.dli_fname);
+        auto ver = reinterpret_cast<int (*)(int*)>(dlsym(h, "ncclGetVersion"));
+        if (ver) (void)ver(&comm->lib_version);
+        if (rank == 0)
+            std::fprintf(stderr, "[mir_optim_amd] RCCL bound from %s (version %d, %s), %d ranks\n", comm->lib_path, comm->lib_version,
+                         preloaded ? "already mapped by the host program" : "loaded by this library", nranks);
+    }
     {
         // RCCL loads its kernels and connects its channels at the first collective of each size class: do that here
         // (creation is collective anyway), with the three payload sizes of a solve -- one scalar, the Broyden sweep
@@ -1721,26 +1970,35 @@ int mir_lsq_comm_ranks(const mir_lsq_comm* comm)
     return comm->nranks;
 }
 
+int mir_lsq_comm_describe(const mir_lsq_comm* comm, char* buf, size_t len)
+{
+    if (!comm || !buf || len == 0) return -1;
+    if (comm->kind == 1)
+        return std::snprintf(buf, len, "rccl path=%s version=%d preloaded=%d ranks=%d rank=%d", comm->lib_path, comm->lib_version,
+                             comm->lib_preloaded, mir_lsq_comm_ranks(comm), comm->rank);
+    return std::snprintf(buf, len, "%s ranks=%d rank=%d", comm->kind == 2 ? "callback" : "local-group", comm->nranks, comm->rank);
+}
+
 void mir_lsq_comm_destroy(mir_lsq_comm* comm)
 {
     if (!comm) return;
     if (comm->kind == 1 && comm->destroy_fn && comm->nccl_comm) comm->destroy_fn(comm->nccl_comm);
     if (comm->kind == 3 && comm->group) {
+        // The handles of a group may be destroyed independently, each by its own rank's thread as soon as that rank is done:
+        // a slower peer may still be summing this rank's slot of the last all-reduce (the sum runs outside the lock, after
+        // the barrier), so every slot stays allocated until the LAST handle goes.
         LocalGroup* g = comm->group;
         bool last;
         {
             std::lock_guard<std::mutex> lk(g->mu);
-            for (int par = 0; par < 2; ++par) {
-                auto& sl = g->slots[par][comm->rank];
-                if (sl.host) (void)hipHostFree(sl.host);
-                sl.host = nullptr; sl.bytes = 0;
-            }
-            auto& t = g->total[comm->rank];
-            if (t.host) (void)hipHostFree(t.host);
-            t.host = nullptr; t.bytes = 0;
             last = --g->refs == 0;
         }
-        if (last) delete g;
+        if (last) {
+            for (int par = 0; par < 2; ++par)
+                for (auto& sl : g->slots[par]) if (sl.host) (void)hipHostFree(sl.host);
+            for (auto& t : g->total) if (t.host) (void)hipHostFree(t.host);
+            delete g;
+        }
     }
     delete comm;
 }

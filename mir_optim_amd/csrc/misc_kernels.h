@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_sumsq_partial(const T* __restrict__ v0,
 // Stage 2: one block of 256 threads sums the partials in a fixed order. Collective; thread 0 returns the sum. Also run by
 // k_decide_chain itself when there is no all-reduce between the two stages: same order, same bits.
 template <typename T>
-__device__ inline T sumsq_final_block(const T* __restrict__ partials, int nparts, T* red /* 4 */)
+__device__ inline T sumsq_final_block(const T* partials, int nparts, T* red /* 4 */)
 {
     T s = 0;
     for (int i = threadIdx.x; i < nparts; i += 256) s += partials[i];
@@ -209,8 +209,11 @@ struct DecideArgs {
     int nparts, pstride;  // sits between the stages: single GPU) -- this kernel runs stage 2 itself, one launch less per round
 };
 
+// The body is a device function: k_decide_chain runs it as a kernel of its own (a communicator's all-reduce sits between
+// the trial sums and the decision, or no residual was evaluated at all), k_sumsq_tail<., kSumsqTailDecide> runs it in the
+// last workgroup of the sum-of-squares sweep (single GPU: one launch per round instead of two).
 template <typename T>
-__global__ __launch_bounds__(kSolveThreads) void k_decide_chain(DecideArgs<T> a)
+__device__ inline void decide_chain_body(const DecideArgs<T>& a)
 {
     __shared__ int acc_s;
     __shared__ LmState<T> s_pub;
@@ -313,6 +316,81 @@ __global__ __launch_bounds__(kSolveThreads) void k_decide_chain(DecideArgs<T> a)
         __threadfence_system();          // the accepted point is in host memory before the state that announces it
         __syncthreads();
         if (threadIdx.x == 0) publish_state(s_pub, a.host_st, a.seq);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kSolveThreads) void k_decide_chain(DecideArgs<T> a)
+{
+    decide_chain_body(a);
+}
+
+// ---- sum of squares with the NEXT step of the pass fused into its tail ("last workgroup finishes"): every workgroup
+//      writes its stage-1 partial, makes it visible device-wide (__threadfence: the eight XCDs have separate L2s) and
+//      counts itself in; the workgroup that arrives last runs stage 2 -- the same fixed-order sum as k_sumsq_final,
+//      whichever workgroup that is, so the bits do not depend on the arrival order -- and then
+//        kSumsqTailFinal   writes the sums (an all-reduce over the row shards follows),
+//        kSumsqTailDecide  walks the lambda ladder and publishes the decision (decide_chain_body; LS:1117-1161),
+//        kSumsqTailInit    sets up the state at entry (LS:953-971).
+//      grid = (stage-1 workgroups, vectors). The counter is zero before the launch and is reset by the last workgroup.
+enum { kSumsqTailFinal = 0, kSumsqTailDecide = 1, kSumsqTailInit = 2 };
+template <typename T>
+struct SumsqTailArgs {
+    const T* v; size_t m, vstride;
+    T* partials; int pstride;
+    uint32_t* counter;
+    T* out;                  // Final / Init: the sums (vector k at out[k])
+    DecideArgs<T> dec;       // Decide (dec.partials / nparts / pstride are filled in here)
+    LmState<T>* st;          // Init
+    LmState<T>* host_st;
+    uint32_t seq;
+};
+
+template <typename T, int TAIL>
+__global__ __launch_bounds__(kSolveThreads) void k_sumsq_tail(SumsqTailArgs<T> a)
+{
+    __shared__ T red[4];
+    __shared__ int last_s;
+    {
+        const T* __restrict__ v = a.v + (size_t)blockIdx.y * a.vstride;
+        T s = 0;
+        const size_t per = (a.m + gridDim.x - 1) / gridDim.x;
+        const size_t b0 = (size_t)blockIdx.x * per;
+        const size_t b1 = b0 + per < a.m ? b0 + per : a.m;
+        for (size_t i = b0 + threadIdx.x; i < b1; i += blockDim.x) { const T t = v[i]; s += t * t; }
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            a.partials[(size_t)blockIdx.y * a.pstride + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+            __threadfence();                                             // release: the partial before the count
+            const uint32_t total = gridDim.x * gridDim.y;
+            last_s = atomicAdd(a.counter, 1u) == total - 1;
+        }
+        __syncthreads();
+        if (!last_s) return;
+        __threadfence();                                                 // acquire: every other workgroup's partial
+        if (threadIdx.x == 0) *a.counter = 0;                            // the next launch on the stream finds it zero
+    }
+    if constexpr (TAIL == kSumsqTailDecide) {
+        DecideArgs<T> d = a.dec;
+        d.partials = a.partials; d.nparts = (int)gridDim.x; d.pstride = a.pstride;
+        decide_chain_body(d);
+    } else {
+        for (int k = 0; k < (int)gridDim.y; ++k) {
+            const T tot = sumsq_final_block(a.partials + (size_t)k * a.pstride, (int)gridDim.x, red);
+            if (threadIdx.x == 0) a.out[k] = tot;
+            if constexpr (TAIL == kSumsqTailInit) {
+                if (threadIdx.x == 0 && k == 0) {
+                    LmState<T> s{};
+                    s.lambda = 0;            // LS:966 (no warm start, quirk Q11)
+                    s.mu = 1;                // LS:969
+                    s.residual = tot;        // LS:955
+                    *a.st = s;
+                    publish_state(s, a.host_st, a.seq);
+                }
+            }
+        }
     }
 }
 

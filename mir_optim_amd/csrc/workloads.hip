@@ -7,6 +7,7 @@
 // Also holds the host-side counter RNG u(k) = (splitmix64(seed + k) >> 11) * 2^-53 used to build
 // bit-identical inputs for the GPU run and the CPU baseline.
 #include <hip/hip_runtime.h>
+#include <omp.h>
 
 #include <cmath>
 #include <cstddef>
@@ -1013,6 +1014,35 @@ void wl_tanh_linear_f_host_d(void* vctx, size_t m, size_t n, const double* x, do
         double s = 0;
         for (size_t j = 0; j < n; ++j) s += a[j] * x[j];
         y[i] = std::tanh(s) - c->b[i];
+    }
+}
+
+// The same residual on ONE host thread: what the tasks of a thread manager call (the manager supplies the parallelism,
+// LS:184-215: one finite-difference column per task).
+void wl_tanh_linear_f_host_serial_d(void* vctx, size_t m, size_t n, const double* x, double* y)
+{
+    auto* c = static_cast<wl_tanh_linear_host_ctx*>(vctx);
+    for (size_t i = 0; i < m; ++i) {
+        const double* a = c->A + i * n;
+        double s = 0;
+        for (size_t j = 0; j < n; ++j) s += a[j] * x[j];
+        y[i] = std::tanh(s) - c->b[i];
+    }
+}
+
+// A native thread manager with the reference's contract (mir_least_squares_thread_manager, LS:672-678; what the D tier
+// builds from a TaskPool, LS:184-215): task(taskContext, totalThreads, threadId, i) for every i in [0, count), threadId <
+// totalThreads, a thread runs one task at a time. ctx: optional int* with the number of threads (0 / null: OpenMP's default).
+struct wl_task { void* context; void* fn; };          // the 16-byte D delegate, passed by value
+typedef void (*wl_task_fn)(wl_task, uint32_t, uint32_t, uint32_t);
+void wl_omp_thread_manager(void* ctx, uint32_t count, wl_task task, wl_task_fn fn)
+{
+    const int want = ctx ? *static_cast<const int*>(ctx) : 0;
+#pragma omp parallel num_threads(want > 0 ? want : omp_get_max_threads())
+    {
+        const uint32_t total = (uint32_t)omp_get_num_threads(), tid = (uint32_t)omp_get_thread_num();
+#pragma omp for schedule(dynamic, 1)
+        for (ptrdiff_t i = 0; i < (ptrdiff_t)count; ++i) fn(task, total, tid, (uint32_t)i);
     }
 }
 

@@ -48,7 +48,7 @@ class DeviceProblem:
         o.flags = api.DEVICE_CALLBACKS | flags
         o.variant = variant
         o.stream = self.stream.handle
-        o.comm = comm
+        o.comm = getattr(comm, "handle", comm)       # a raw handle or a parallel.HostAllreduceComm
         o.workspace = workspace
         if batched and self.fb is not None:
             o.fbContext = C.addressof(self.ctx)
@@ -66,9 +66,13 @@ class DeviceProblem:
 
     def solve(self, x0, l=None, u=None, settings=None, analytic=False, **opt_kw):
         opts = self.options(**opt_kw)
-        return api.optimizeLeastSquares(self.f, self.m, np.array(x0, dtype=self.dtype), l, u,
-                                        g=self.g if analytic else None, settings=settings, dtype=self.dtype,
-                                        fContext=C.addressof(self.ctx), gContext=C.addressof(self.ctx), options=opts)
+        out = api.optimizeLeastSquares(self.f, self.m, np.array(x0, dtype=self.dtype), l, u,
+                                       g=self.g if analytic else None, settings=settings, dtype=self.dtype,
+                                       fContext=C.addressof(self.ctx), gContext=C.addressof(self.ctx), options=opts)
+        comm = opt_kw.get("comm")
+        if hasattr(comm, "check"):
+            comm.check()         # an exception inside the all-reduce callback: the solve ended with numericError, raise the cause
+        return out
 
 
 class TanhLinear(DeviceProblem):

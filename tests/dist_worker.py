@@ -35,7 +35,7 @@ def main():
         comm = PAR.HostAllreduceComm(world, rank, ar)
         prob = W.TanhLinear(w["A"], w["b"])
         s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
-        res, x = prob.solve(w["x0"], settings=s, comm=comm.handle)
+        res, x = prob.solve(w["x0"], settings=s, comm=comm)      # the object: solve() re-raises what its callback recorded
         comm.close()
         status, iters, residual = res.status.name, res.iterations, res.residual
     with open(f"{out_path}.{rank}", "w") as f:
