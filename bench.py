@@ -90,6 +90,9 @@ def parse():
                          "panel (n <= 128; the caller's kernel subtracts the (+h, -h) pair, the library's fused kernel scales, writes J "
                          "and forms J^T J); rowmajor: the m x 2n row-major pair panel, same fused kernel; pointmajor: the point-major "
                          "batched callback + k_fd_fill -- or one call per point (serial)")
+    ap.add_argument("--fd-windows", type=int, default=0,
+                    help="--fd batched: two-stream finite-difference refresh in this many row windows (fbRowMajorDiffWindow: the caller's "
+                         "GEMM of window k + 1 on a side stream while the library's fused kernel consumes window k); 0 = one sweep")
     ap.add_argument("--gemm-read-a-once", action="store_true",
                     help="caller side, --fd batched: the difference-panel GEMM sweeps A once (stage-outer variant: 2.1 instead of "
                          "3.1 GB per call at cfg 3, ~3 %% slower -- the kernel is MFMA-bound; A/B only)")
@@ -116,6 +119,9 @@ def parse():
                     help="bracket the kernels with HIP events in every k-th step of the timed region (an event record costs a "
                          "few microseconds on the stream: ~0.2 ms per cfg-3 solve when every step is instrumented)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-callback", action="store_true",
+                    help="skip the reference-ABI leg (host residual callback + native thread manager, PCIe inclusive; rank 0, N = 1): "
+                         "one untimed + one timed solve, a few seconds of host work")
     ap.add_argument("--no-cpu-1thread", action="store_true")
     ap.add_argument("--cpu-iterations", type=int, default=6, help="accepted iterations of the CPU sample")
     return ap.parse_args()
@@ -288,6 +294,19 @@ def main_cfg2(args):
     print(json.dumps(out), flush=True)
 
 
+def describe_comm(api, comm):
+    if not comm:
+        return None
+    buf = C.create_string_buffer(512)
+    api.lib().mir_lsq_comm_describe(comm, buf, 512)
+    return buf.value.decode()
+
+
+def step_stats(ms):
+    import statistics
+    return [min(ms), statistics.median(ms), max(ms)] if ms else None
+
+
 def main():
     args = parse()
     if args.config == "cfg5":
@@ -388,7 +407,8 @@ def main():
         torch.cuda.synchronize()
 
     def solve(stats=None, flags=0, s=settings):
-        return prob.solve(data["x0"], settings=s, stats=stats, flags=flags, comm=comm, workspace=ws, variant=args.variant,
+        return prob.solve(data["x0"], settings=s, stats=stats, flags=flags, comm=comm_obj or comm, workspace=ws, variant=args.variant,
+                          fd_windows=args.fd_windows,
                           batched={"batched": True, "rowmajor": "rowmajor", "pointmajor": "pointmajor", "serial": False}[args.fd])
 
     # RCCL finishes part of its initialisation asynchronously: a few seconds after ncclCommInitRank every HIP launch of the
@@ -428,14 +448,21 @@ def main():
         st, st_plain = M.Stats(), M.Stats()
         iters = 0
         every = max(1, args.timing_every)
+        step_ms, step_timed = [], []                         # host wall time of every step (a solve ends with a host wait)
         barrier()
         t0 = time.perf_counter()
+        tp = t0
         for i in range(count):
             timed_step = not args.no_kernel_timing and i % every == 0
             r, xx = solve(stats=st if timed_step else st_plain, flags=M.TIME_KERNELS if timed_step else 0, s=s)
             iters += r.iterations
+            tn = time.perf_counter()
+            step_ms.append((tn - tp) * 1e3)
+            step_timed.append(timed_step)
+            tp = tn
         barrier()
         dt = time.perf_counter() - t0
+        timed.last_steps = (step_ms, step_timed)
         if distributed:
             tt = torch.tensor([dt], dtype=torch.float64, device=ctl_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -445,6 +472,7 @@ def main():
         return d, iters, dt, r, xx
 
     st, iters, dt, res, x = timed(args.steps, settings)
+    main_steps = timed.last_steps
     sta = st["all"]
     timed_steps = len(range(0, args.steps, max(1, args.timing_every))) if not args.no_kernel_timing else 0
     if res.status < 0:
@@ -455,9 +483,14 @@ def main():
         s9.absTolerance = 1e-9
         solve(s=s9)
         st9, it9, dt9, r9, _ = timed(args.survey_steps, s9)
+        p9 = st9["all"]["passes"] / args.survey_steps
         survey = {"abs_tolerance": 1e-9, "value": it9 / dt9, "unit": "iterations/s", "steps": args.survey_steps,
                   "ms_per_solve": dt9 / args.survey_steps * 1e3, "iterations_per_solve": it9 / args.survey_steps,
-                  "passes_per_solve": st9["all"]["passes"] / args.survey_steps, "status": r9.status.name, "residual": r9.residual}
+                  "passes_per_solve": p9, "status": r9.status.name, "residual": r9.residual,
+                  # which of the two branches the noise-decided last acceptance took
+                  "branch": ("xConverged after the confirming step (short: ~12-22 passes)" if r9.status.name == "xConverged"
+                             else "the confirming step was rejected: the reference's lambda ladder runs to maxLambda (~45 more rejected passes)"),
+                  "ms_per_step_min_median_max": step_stats(timed.last_steps[0])}
 
     out = None
     if rank == 0:
@@ -524,7 +557,7 @@ def main():
 
         # ---- the caller-side kernels (the synthetic workload's residual callbacks), timed by the solver on its stream
         user = {}
-        if st["fd_callback_calls"]:
+        if st["fd_callback_calls"] and st["fd_callback_ms"] > 0:    # (two-stream window refreshes overlap the caller's kernels with the library's: not timed apart)
             ms = st["fd_callback_ms"] / st["fd_callback_calls"]
             pts = st["fd_callback_points"] / st["fd_callback_calls"]
             if args.fd == "serial":
@@ -568,6 +601,9 @@ def main():
         out = {
             "metric": "LM iterations/sec", "value": value, "unit": "iterations/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": dt / K * 1e3,
+            # host wall time per step on rank 0 (min, median, max): all K steps, and the steps without kernel events only
+            "ms_per_step_min_median_max": step_stats(main_steps[0]),
+            "ms_per_step_uninstrumented_min_median_max": step_stats([t for t, e in zip(*main_steps) if not e]),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": f"cfg3 tanh-linear NLS m_total={m_total} x n={n} fp64, FD Jacobian (central differences, 2n residual evaluations per refresh through the "
@@ -579,6 +615,11 @@ def main():
                                                                  "gloo callback all-reduce (" + ("FALLBACK: RCCL unusable" if comm_fallback else "rehearsal") + ")"),
                 "rccl_ranks": api.lib().mir_lsq_comm_ranks(comm) if (comm and args.comm == "rccl") else None,
                 "rccl_fallback_reason": comm_fallback,
+                "comm": describe_comm(api, comm),     # transport, the shared object RCCL was bound from, its version, ncclCommCount
+                # library kernel launches per round, by the kind of round (refresh / Broyden / re-solve after a rejection)
+                "library_launches_per_round": {k: (sta["round_launches"][i] / sta["rounds"][i] if sta["rounds"][i] else None)
+                                               for i, k in enumerate(("refresh", "broyden", "resolve"))},
+                "rounds_per_solve": {k: sta["rounds"][i] / K for i, k in enumerate(("refresh", "broyden", "resolve"))},
                 "allreduce_per_solve": {"packed_calls": sta["allreduce_calls"][0] / K, "packed_elems": sta["allreduce_elems"][0] / max(1, sta["allreduce_calls"][0]),
                                         "sweep_calls": sta["allreduce_calls"][1] / K, "sweep_elems": sta["allreduce_elems"][1] / max(1, sta["allreduce_calls"][1]),
                                         "scalar_calls": sta["allreduce_calls"][2] / K},
@@ -590,6 +631,7 @@ def main():
                 "iterations_per_solve": iters / K, "status": res.status.name,
                 "passes_per_solve": sta["passes"] / K, "fcalls_per_solve": res.fCalls,
                 "jacobian_full_per_solve": sta["jacobian_full"] / K, "residual": res.residual,
+                "fd_windows": args.fd_windows, "fd_window_refreshes_per_solve": sta["fd_window_refreshes"] / K,
                 "kernel_timing": f"HIP events on the solver's stream in {timed_steps} of the {K} timed steps (every {max(1, args.timing_every)}th)",
                 "time_split_ms_per_solve": {
                     "caller_fd_callbacks": st["fd_callback_ms"] / KT, "caller_trial_callbacks": st["trial_callback_ms"] / KT,
@@ -602,6 +644,14 @@ def main():
             **user,
             "solve_kernel": solve_k,
         }
+        if world == 1 and not args.no_host_callback and (m, n) == (1_000_000, 128):
+            # the path a caller of the UNMODIFIED reference API gets: host residual callback, native thread manager, PCIe inclusive
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            import bench_host_callback as BH
+            hc = BH.run(m, n, abs_tolerance=args.abs_tolerance, data=data, solves=1)
+            xh = hc.pop("x")
+            hc["parity_x_max_abs_diff_vs_device_callback_solve"] = float(np.abs(np.asarray(xh) - np.asarray(x)).max())
+            out["host_callback_mode"] = hc
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data, m, n, args.cpu_iterations, args.abs_tolerance, min(os.cpu_count() or 1, 64), x, res)
             if not args.no_cpu_1thread:

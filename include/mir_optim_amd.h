@@ -175,6 +175,10 @@ typedef struct mir_lsq_workspace mir_lsq_workspace;  /* reusable device workspac
  * 2n perturbed points together instead of one at a time. */
 typedef void (*mir_lsq_batched_function_d)(void* context, size_t m, size_t n, size_t p, const double* X, double* Y);
 typedef void (*mir_lsq_batched_function_s)(void* context, size_t m, size_t n, size_t p, const float* X, float* Y);
+/* Row-window form of fbRowMajorDiff (mir_lsq_gpu_options.fbRowMajorDiffWindow): D is the WHOLE m x n panel (write rows
+ * row0 .. row0 + rows - 1 only), `stream` the HIP stream to enqueue on. */
+typedef void (*mir_lsq_window_function_d)(void* context, size_t m, size_t n, size_t p, const double* X, double* D,
+                                          size_t row0, size_t rows, void* stream);
 
 enum {
     MIR_LSQ_DEVICE_CALLBACKS = 1u,   /* f/g/fb receive DEVICE pointers and enqueue on `stream` (no host staging) */
@@ -201,9 +205,15 @@ enum {
     MIR_LSQ_VARIANT_PIPELINE = 1u << 11,         /* enqueue the library part of the next Broyden round behind a device-side
                                                     guard before the current decision is known (bit-identical results;
                                                     measured: no gain on one GPU, so it is not the default) */
-    MIR_LSQ_VARIANT_NO_TAIL_FUSION = 1u << 12,   /* the reductions and the decision as kernels of their own (k_lr_reduce,
-                                                    k_lr_finish, k_unpack_grad, k_sumsq_*, k_decide_chain) instead of in the
-                                                    tail of the sweep that produces their input; bit-identical results */
+    MIR_LSQ_VARIANT_NO_TAIL_FUSION = 1u << 12,   /* round 2's launch sequence: k_lr_finish and k_unpack_grad as kernels of
+                                                    their own instead of inside the solve kernel's prologue / the slab
+                                                    reduction; bit-identical results */
+    MIR_LSQ_VARIANT_SWEEP_TAIL = 1u << 14,       /* the Broyden sweep reduces its partials (and, single GPU, applies the n x n
+                                                    finish) in its last-arriving workgroups instead of k_lr_reduce: one launch
+                                                    less, bit-identical -- and measured slower on MI355X (cross-workgroup hops
+                                                    through memory cost more than the launch they save): not the default */
+    MIR_LSQ_VARIANT_SUMSQ_TAIL = 1u << 15,       /* ||f||^2 and the decision of a round (and the state at entry) in ONE launch:
+                                                    the last-arriving workgroup of the sum-of-squares sweep finishes; same */
     MIR_LSQ_VARIANT_FD_HOST_COLUMNS = 1u << 13,  /* host-callback finite differences column by column (per-slot staging vectors,
                                                     a strided column write and a stream synchronisation per task, under a
                                                     lock) instead of through the pinned point-major panel */
@@ -256,6 +266,10 @@ typedef struct mir_lsq_stats {
      * included), time spent inside the caller's f summed over the manager's threads, columns refreshed */
     double fd_host_wall_ms, fd_host_f_ms;
     uint64_t fd_host_columns;
+    double host_f_ms;                /* host-callback mode: wall time inside the caller's f for the entry and trial evaluations */
+    uint64_t host_f_calls;
+    uint64_t fd_window_refreshes;    /* refreshes that ran as the two-stream window pipeline (their time is in jtj_fd_ms: the
+                                        caller's kernels overlap the library's there, fd_callback_ms does not see them) */
 } mir_lsq_stats;
 /* Versioning of mir_lsq_stats: the library writes min(stats_size, sizeof(mir_lsq_stats)) bytes. A caller whose options
  * struct has no stats_size member (struct_size < 96), or leaves it 0, gets the layout of its era: 120 bytes (through
@@ -312,7 +326,15 @@ typedef struct mir_lsq_gpu_options {
                                         Preferred over fbRowMajor when both are given. Read only when struct_size covers it */
     uint32_t stats_size;             /* sizeof(mir_lsq_stats) as the CALLER compiled it: the library never writes past it
                                         (0 or not covered by struct_size: see "Versioning of mir_lsq_stats") */
-    uint32_t reserved0;
+    uint32_t fd_windows;             /* row windows of the two-stream finite-difference refresh (fbRowMajorDiffWindow):
+                                        0 or 1 = off, 2..16 = that many windows */
+    void* fbRowMajorDiffWindow;      /* optional mir_lsq_window_function_d (f64, even n <= 128), context fbContext: fbRowMajorDiff
+                                        restricted to the rows [row0, row0 + rows) of the problem and enqueued on the stream it
+                                        is HANDED (not the options' stream): with fd_windows >= 2 the library runs the caller's
+                                        kernel for window k + 1 on a side stream while its fused finite-difference kernel
+                                        consumes window k on the solver's stream -- an MFMA-bound and an HBM-bound kernel
+                                        sharing the chip. Results differ from the one-window refresh by the summation order of
+                                        J^T J / J^T y only (J is bit-identical). Read only when struct_size covers it */
 } mir_lsq_gpu_options;
 
 /* Same algorithm and result contract as mir_optimize_least_squares_{d,s}; x/l/u stay host

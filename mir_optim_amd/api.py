@@ -34,7 +34,7 @@ __all__ = [
     "fit_spline_residuals", "variant_lr_cap",
     "VARIANT_BROYDEN_REWRITE", "VARIANT_FD_SEPARATE_FILL", "VARIANT_JTJ_RING", "VARIANT_JTJ_STREAM",
     "VARIANT_NO_SPECULATION", "VARIANT_NO_NULL_SKIP", "VARIANT_SOLVE_BOUNDED", "VARIANT_DEBUG_SOLVE",
-    "VARIANT_HOST_PROFILE", "VARIANT_NO_RESYNC", "VARIANT_SOLVE_GENERIC", "VARIANT_PIPELINE", "VARIANT_NO_TAIL_FUSION", "VARIANT_FD_HOST_COLUMNS",
+    "VARIANT_HOST_PROFILE", "VARIANT_NO_RESYNC", "VARIANT_SOLVE_GENERIC", "VARIANT_PIPELINE", "VARIANT_NO_TAIL_FUSION", "VARIANT_FD_HOST_COLUMNS", "VARIANT_SWEEP_TAIL", "VARIANT_SUMSQ_TAIL",
 ]
 
 MODEL_EXP_DECAY = 0      # n = 3: p0 exp(-t p1) + p2
@@ -59,6 +59,8 @@ VARIANT_SOLVE_GENERIC = 1 << 10
 VARIANT_PIPELINE = 1 << 11
 VARIANT_NO_TAIL_FUSION = 1 << 12
 VARIANT_FD_HOST_COLUMNS = 1 << 13
+VARIANT_SWEEP_TAIL = 1 << 14
+VARIANT_SUMSQ_TAIL = 1 << 15
 
 
 def variant_lr_cap(k):
@@ -154,7 +156,8 @@ class Stats(C.Structure):
                 ("trial_callback_ms", C.c_double), ("trial_callback_calls", C.c_uint64),
                 ("trial_callback_points", C.c_uint64),
                 ("library_launches", C.c_uint64), ("round_launches", C.c_uint64 * 3), ("rounds", C.c_uint64 * 3),
-                ("fd_host_wall_ms", C.c_double), ("fd_host_f_ms", C.c_double), ("fd_host_columns", C.c_uint64)]
+                ("fd_host_wall_ms", C.c_double), ("fd_host_f_ms", C.c_double), ("fd_host_columns", C.c_uint64),
+                ("host_f_ms", C.c_double), ("host_f_calls", C.c_uint64), ("fd_window_refreshes", C.c_uint64)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if isinstance(getattr(self, k), C.Array) else getattr(self, k)) for k, _ in self._fields_}
@@ -192,7 +195,7 @@ class GpuOptions(C.Structure):
                 ("workspace", C.c_void_p), ("fbContext", C.c_void_p), ("fb", C.c_void_p), ("fd_batch", C.c_uint32),
                 ("variant", C.c_uint32), ("stats", C.POINTER(Stats)), ("trace", C.POINTER(_TraceHeader)),
                 ("fbRowMajor", C.c_void_p), ("fbRowMajorDiff", C.c_void_p), ("stats_size", C.c_uint32),
-                ("reserved0", C.c_uint32)]
+                ("fd_windows", C.c_uint32), ("fbRowMajorDiffWindow", C.c_void_p)]
 
     def __init__(self, **kw):
         super().__init__(**kw)

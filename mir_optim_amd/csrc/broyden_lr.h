@@ -27,10 +27,6 @@
 
 namespace mirlsq {
 
-constexpr int kLrMax = 16;
-// [ v0 (n) | g0 (n) | w (kLrMax) | h (kLrMax) | uu | uy ]
-__host__ __device__ constexpr int lr_len(int n) { return 2 * n + 2 * kLrMax + 2; }
-constexpr int kLrMaxN = 256;
 
 template <typename T> struct LrPair;
 template <> struct LrPair<double> { using type = double2; };
@@ -60,12 +56,6 @@ struct LrArgs {
     T* JJ; T* Jy; LmState<T>* st;
 };
 
-constexpr int kReduceRanges = 32;
-
-// one entry of the symmetric rank-two update J_k^T J_k = J_{k-1}^T J_{k-1} + v dx^T + dx v^T + uu dx dx^T, r >= c: ONE
-// function for k_lr_finish and the fused tail, so that both round the same way
-template <typename T>
-__device__ __forceinline__ T lr_jj_term(T vr, T vc, T dr, T dc, T uu) { return (vr * dc + dr * vc) + uu * dr * dc; }
 
 // ---- the tail of the sweep. Workgroup b belongs to range r = b / per (per = ceil(nblk / 32): the ranges of k_lr_reduce).
 // Every workgroup publishes its partial vector and counts itself into its range; the LAST arrival of a range sums the
@@ -76,19 +66,12 @@ __device__ __forceinline__ T lr_jj_term(T vr, T vc, T dr, T dc, T uu) { return (
 template <typename T>
 __device__ inline void lr_tail(const LrArgs<T>& a, T (*red)[lr_len(kLrMaxN)])
 {
-    __shared__ int role_s;
     const int len = lr_len(a.n), nblk = (int)gridDim.x, tid = threadIdx.x;
     const int per = (nblk + kReduceRanges - 1) / kReduceRanges;
     const int r = (int)blockIdx.x / per;
     const int b0 = r * per, b1 = (b0 + per < nblk) ? b0 + per : nblk;
     const int ngroups = (nblk + per - 1) / per;
-    __threadfence();                                       // release: this workgroup's partial vector ...
-    __syncthreads();
-    if (tid == 0) role_s = atomicAdd(&a.tail_counters[r], 1u) == (uint32_t)(b1 - b0 - 1);   // ... before its count
-    __syncthreads();
-    if (!role_s) return;
-    __threadfence();                                       // acquire: the partials of the whole range
-    if (tid == 0) a.tail_counters[r] = 0;
+    if (!arrive_last(&a.tail_counters[r], (uint32_t)(b1 - b0))) return;
     constexpr int kInFlight = 8;                           // loads in flight per thread: the tail must fit the registers of the main loop
 #pragma unroll 1
     for (int e = tid; e < len; e += blockDim.x) {
@@ -98,19 +81,13 @@ __device__ inline void lr_tail(const LrArgs<T>& a, T (*red)[lr_len(kLrMaxN)])
         for (int c0 = b0; c0 < b1; c0 += kInFlight) {
             const T* src = a.partials + (size_t)c0 * len + e;
 #pragma unroll
-            for (int u = 0; u < kInFlight; ++u) p[u] = (c0 + u < b1) ? src[(size_t)u * len] : T(0);
+            for (int u = 0; u < kInFlight; ++u) p[u] = (c0 + u < b1) ? load_agent(src + (size_t)u * len) : T(0);
 #pragma unroll
             for (int u = 0; u < kInFlight; ++u) if (c0 + u < b1) s += p[u];
         }
-        a.range_sums[(size_t)r * len + e] = s;
+        store_agent(&a.range_sums[(size_t)r * len + e], s);
     }
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) role_s = atomicAdd(&a.tail_counters[kReduceRanges], 1u) == (uint32_t)(ngroups - 1);
-    __syncthreads();
-    if (!role_s) return;
-    __threadfence();
-    if (tid == 0) a.tail_counters[kReduceRanges] = 0;
+    if (!arrive_last(&a.tail_counters[kReduceRanges], (uint32_t)ngroups)) return;
     T* lrs = red[0];                                       // the reduced vector, kept in LDS for the finish
 #pragma unroll 1
     for (int e = tid; e < len; e += blockDim.x) {
@@ -119,7 +96,7 @@ __device__ inline void lr_tail(const LrArgs<T>& a, T (*red)[lr_len(kLrMaxN)])
 #pragma unroll 1
         for (int c0 = 0; c0 < kReduceRanges; c0 += kInFlight) {
 #pragma unroll
-            for (int u = 0; u < kInFlight; ++u) p[u] = (c0 + u < ngroups) ? a.range_sums[(size_t)(c0 + u) * len + e] : T(0);
+            for (int u = 0; u < kInFlight; ++u) p[u] = (c0 + u < ngroups) ? load_agent(&a.range_sums[(size_t)(c0 + u) * len + e]) : T(0);
 #pragma unroll
             for (int u = 0; u < kInFlight; ++u) tot = (c0 + u == 0) ? p[0] : tot + p[u];     // k_lr_reduce's order: part[0] + part[1] + ...
         }
@@ -150,10 +127,20 @@ __device__ inline void lr_tail(const LrArgs<T>& a, T (*red)[lr_len(kLrMaxN)])
     }
     __syncthreads();                                       // also: every read of D rows < k is done before row k is written
     for (int j = tid; j < n; j += blockDim.x) a.Dw[(size_t)k * n + j] = dxs[j];
-    for (int idx = tid; idx < n * n; idx += blockDim.x) {
-        const int i = idx / n, j = idx - i * n;
-        const int rr = i >= j ? i : j, cc = i >= j ? j : i;
-        a.JJ[idx] += lr_jj_term(v[rr], v[cc], dxs[rr], dxs[cc], uu);
+    const int nn = n * n;
+    for (int base = tid; base < nn; base += 8 * (int)blockDim.x) {         // loads in flight: see lr_finish_block
+        T old[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int idx = base + u * (int)blockDim.x; old[u] = a.JJ[idx < nn ? idx : nn - 1]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * (int)blockDim.x;
+            if (idx < nn) {
+                const int i = idx / n, j = idx - i * n;
+                const int rr = i >= j ? i : j, cc = i >= j ? j : i;
+                a.JJ[idx] = old[u] + lr_jj_term(v[rr], v[cc], dxs[rr], dxs[cc], uu);
+            }
+        }
     }
     mx = wave_max(mx);
     __shared__ T mred[4];
@@ -274,8 +261,13 @@ __global__ __launch_bounds__(256) void k_broyden_lr(const LrArgs<T> a)
     __syncthreads();
     const int len = lr_len(n);
     T* out = a.partials + (size_t)blockIdx.x * len;
-    for (int e = threadIdx.x; e < len; e += blockDim.x) out[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-    if (a.tail_counters) lr_tail<T>(a, red);
+    if (a.tail_counters) {
+        // the partial vector crosses to another workgroup inside this kernel: agent-scope stores (common.h)
+        for (int e = threadIdx.x; e < len; e += blockDim.x) store_agent(&out[e], (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]));
+        lr_tail<T>(a, red);
+    } else {
+        for (int e = threadIdx.x; e < len; e += blockDim.x) out[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    }
 }
 
 // sum the per-block partial vectors in a fixed order: blockDim = 1024 = 32 entries x 32 block ranges (a thread walks

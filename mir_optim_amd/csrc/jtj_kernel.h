@@ -256,12 +256,10 @@ void k_jtj(JtjArgs<T> a)
 template <typename T>
 __global__ __launch_bounds__(1024) void k_jtj_slab_reduce(const T* __restrict__ slabs, int nslabs, int slab_len,
                                                           int ncb, int n, T* __restrict__ packed,
-                                                          T* JJ = nullptr, T* Jy = nullptr, T* jy_inf = nullptr,
-                                                          uint32_t* counter = nullptr)
+                                                          T* JJ = nullptr, T* Jy = nullptr)
 {
-    // JJ != nullptr (single GPU: no all-reduce of `packed` follows): the work of k_unpack_grad is done here -- both
-    // triangles of J^T J and J^T y are written directly, and the workgroup that arrives last (counter: zero before the
-    // launch, reset here) takes max |J^T y| (LS:1053; a maximum does not depend on the order)
+    // JJ != nullptr (single GPU: no all-reduce of `packed` follows): the expansion k_unpack_grad would do happens here -- both
+    // triangles of J^T J and J^T y are written directly (the solve kernel takes max |J^T y| itself, LS:1053)
     constexpr int RANGES = 32;                               // blockDim = 1024 = 32 entries x 32 slab ranges
     __shared__ T part[RANGES][33];
     const int es = threadIdx.x & 31, sp = threadIdx.x >> 5;
@@ -300,26 +298,6 @@ __global__ __launch_bounds__(1024) void k_jtj_slab_reduce(const T* __restrict__ 
                 if (JJ) Jy[col] = tot;
             }
         }
-    }
-    if (!JJ) return;
-    __shared__ int last_s;
-    __shared__ T mred[16];
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) last_s = atomicAdd(counter, 1u) == gridDim.x - 1;
-    __syncthreads();
-    if (!last_s) return;
-    __threadfence();
-    if (threadIdx.x == 0) *counter = 0;
-    T mx = 0;
-    for (int j = threadIdx.x; j < n; j += blockDim.x) { const T av = dabs(Jy[j]); if (av > mx) mx = av; }
-    mx = wave_max(mx);
-    if ((threadIdx.x & 63) == 0) mred[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        T r = mred[0];
-        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = mred[w] > r ? mred[w] : r;
-        *jy_inf = r;
     }
 }
 

@@ -41,11 +41,11 @@ inline hipError_t ensure_dyn_lds(const void* fn, size_t bytes, std::atomic<uint6
         if (e_ != hipSuccess) return e_;                                                          \
     } while (0)
 
-// Where the slab reduction may put its result besides `packed`: the full symmetric J^T J, J^T y and max |J^T y| (the work
-// of k_unpack_grad), when no all-reduce of `packed` sits in between. All null: `packed` only.
+// Where the slab reduction may put its result besides `packed`: the full symmetric J^T J and J^T y (the work of
+// k_unpack_grad; max |J^T y| is taken by the solve kernel), when no all-reduce of `packed` sits in between. All null: `packed` only.
 template <typename T>
 struct JtjUnpack {
-    T* JJ = nullptr; T* Jy = nullptr; T* jy_inf = nullptr; uint32_t* counter = nullptr;
+    T* JJ = nullptr; T* Jy = nullptr;
 };
 
 struct JtjPlan {
@@ -167,7 +167,7 @@ inline hipError_t jtj_reduce_slabs(const JtjPlan& p, const JtjArgs<T>& a, T* pac
     if (nslabs < 0) { nslabs = p.nblk; slab_len = p.slab_len; }
     const int rb = (slab_len + 31) / 32;
     MIRLSQ_LAUNCH(k_jtj_slab_reduce<T>, dim3(rb), dim3(1024), 0, s, a.slabs, nslabs, slab_len, p.ncb, a.n, packed,
-                  u.JJ, u.Jy, u.jy_inf, u.counter);
+                  u.JJ, u.Jy);
     return hipGetLastError();
 }
 // does jtj_run honour a JtjUnpack for this plan? (the tile-pair jobs have a reduction of their own; jtj_run_fd* always do)

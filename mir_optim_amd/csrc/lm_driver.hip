@@ -66,6 +66,13 @@ struct mir_lsq_workspace {
     // still being evaluated; lazily allocated
     void* pinned_panel = nullptr;
     size_t pinned_panel_bytes = 0;
+    // two-stream finite-difference refresh (fbRowMajorDiffWindow): the side stream the caller's window kernels run on, one
+    // event per window (+ one that releases the side stream), per-window slab sets; all lazily created
+    static constexpr int kMaxWindows = 16;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t win_event[kMaxWindows + 1] = {};
+    void* win_slabs = nullptr;
+    size_t win_slab_bytes = 0;
     static constexpr int kCopyStreams = 4;
     hipStream_t copy_stream[kCopyStreams] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t copy_event[kCopyStreams] = {nullptr, nullptr, nullptr, nullptr};
@@ -134,8 +141,8 @@ struct Buffers {
 };
 
 constexpr int kPartials = 1024;
-// arrival counters: [0, kReduceRanges] the Broyden sweep's ranges + top, then one each for the sum of squares and the slab reduction
-constexpr int kCounters = 64, kCounterSumsq = 40, kCounterSlabs = 41;
+// arrival counters: [0, kReduceRanges] the Broyden sweep's ranges + top, then the one of the sum of squares
+constexpr int kCounters = 64, kCounterSumsq = 40;
 static_assert(kReduceRanges + 1 <= kCounterSumsq, "counter block layout");
 
 // slab elements the J^T J kernels may need for this shape: the larger of the product plan and the streaming variant's
@@ -249,6 +256,9 @@ void workspace_destroy(mir_lsq_workspace* ws)
     if (ws->pinned_y) (void)hipHostFree(ws->pinned_y);
     if (ws->pinned_J) (void)hipHostFree(ws->pinned_J);
     if (ws->pinned_panel) (void)hipHostFree(ws->pinned_panel);
+    if (ws->win_slabs) (void)hipFree(ws->win_slabs);
+    for (hipEvent_t e : ws->win_event) if (e) (void)hipEventDestroy(e);
+    if (ws->side_stream) (void)hipStreamDestroy(ws->side_stream);
     for (int k = 0; k < mir_lsq_workspace::kCopyStreams; ++k) {
         if (ws->copy_event[k]) (void)hipEventDestroy(ws->copy_event[k]);
         if (ws->copy_stream[k]) (void)hipStreamDestroy(ws->copy_stream[k]);
@@ -280,6 +290,8 @@ struct Solver {
     void* fbctx; FB fb;
     FB fbr = nullptr;          // batched residual callback writing Y row-major (m x p): finite differences fused into k_jtj2
     FB fbd = nullptr;          // batched residual callback writing the m x n row-major DIFFERENCE panel (fbRowMajorDiff)
+    mir_lsq_window_function_d fbdw = nullptr;   // ... its row-window form, for the two-stream refresh (f64)
+    uint32_t fd_windows = 0;
     int fd_fused = 0;          // 1: the (+h, -h) pair panel, 2: the difference panel of this refresh is in ws->ypanel and J has not been filled yet
     int sums_pending = 0;      // > 0: the trial sums of this round are still stage-1 partials (k_decide_chain finishes them)
     uint32_t fd_batch;
@@ -301,7 +313,13 @@ struct Solver {
     // (k_jtj2<., true> / k_jtj8 / k_broyden_wide); bits 16..20 the number of pending terms after which they are folded into J
     uint32_t variant = 0;
     bool dbg_solve = false, no_speculation = false, lowrank = true, no_null_skip = false, host_profile = false;
-    bool fuse_tails = true;    // reductions / decision in the tail of the sweep that feeds them (MIR_LSQ_VARIANT_NO_TAIL_FUSION: separate kernels)
+    // Fewer launches per pass. merge_small (default; MIR_LSQ_VARIANT_NO_TAIL_FUSION = round 2's sequence):
+    // the slab reduction writes J^T J / J^T y itself and the solve kernel applies the n x n finish of a Broyden pass and takes
+    // |J^T y|_inf in its prologue. sweep_tail / sumsq_tail (opt-in, MIR_LSQ_VARIANT_SWEEP_TAIL / SUMSQ_TAIL): "last workgroup
+    // finishes" tails inside the Broyden sweep and the sum-of-squares sweep.
+    bool merge_small = true, sweep_tail = false, sumsq_tail = false;
+    bool finish_pending = false;   // a Broyden sweep's reduced vector waits in B.lrvec for the solve kernel's prologue
+    int finish_k = 0;              // ... with this many pending terms before it
     mir_lsq_stats stats_local{};      // the solve works on this image; stats_bytes of it go back to the caller's struct
     mir_lsq_stats* stats_user = nullptr;
     size_t stats_bytes = 0;
@@ -456,7 +474,10 @@ struct Solver {
         no_speculation = (variant & MIR_LSQ_VARIANT_NO_SPECULATION) != 0;
         lowrank = (variant & MIR_LSQ_VARIANT_BROYDEN_REWRITE) == 0;
         no_null_skip = (variant & MIR_LSQ_VARIANT_NO_NULL_SKIP) != 0;
-        fuse_tails = (variant & MIR_LSQ_VARIANT_NO_TAIL_FUSION) == 0;
+        merge_small = (variant & MIR_LSQ_VARIANT_NO_TAIL_FUSION) == 0;
+        sweep_tail = merge_small && (variant & MIR_LSQ_VARIANT_SWEEP_TAIL) != 0;
+        sumsq_tail = merge_small && (variant & MIR_LSQ_VARIANT_SUMSQ_TAIL) != 0;
+        finish_pending = false;
         host_profile = (variant & MIR_LSQ_VARIANT_HOST_PROFILE) != 0;
         {
             const int v = (int)((variant >> MIR_LSQ_VARIANT_LR_CAP_SHIFT) & 31u);
@@ -531,7 +552,9 @@ struct Solver {
         }
         if (!ws->pinned_y && !ok(hipHostMalloc(&ws->pinned_y, m * sizeof(T), hipHostMallocDefault), "hipHostMalloc(y)")) return false;
         T* yh = static_cast<T*>(ws->pinned_y);
+        const auto t0 = std::chrono::steady_clock::now();
         f(fctx, m, n, x_host, yh);
+        if (stats) { stats->host_f_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); stats->host_f_calls++; }
         return ok(hipMemcpyAsync(y_dev, yh, m * sizeof(T), hipMemcpyHostToDevice, stream), "H2D y")
             && ok(hipStreamSynchronize(stream), "sync");
     }
@@ -586,7 +609,7 @@ struct Solver {
     bool sumsq(const T* v, int slot, int count = 1, size_t vstride = 0, bool defer_final = false)
     {
         const int nb = sumsq_blocks();
-        if (fuse_tails) {
+        if (sumsq_tail) {
             // stage 2 in the last workgroup of stage 1 (same fixed order): one launch
             MIRLSQ_LAUNCH((k_sumsq_tail<T, kSumsqTailFinal>), dim3(nb, count), dim3(kSolveThreads), 0, stream, sumsq_tail_args(v, slot, vstride));
             if (comm && !allreduce(B.sum + slot, (size_t)count, 2)) return false;
@@ -713,7 +736,7 @@ struct Solver {
         a.J = B.J; a.U = U; a.D = B.lrD; a.dx = B.dx_acc; a.dx_dot = &B.st->dx_dot; a.y = y_dev; a.y_old = yold_dev;
         a.partials = B.lrpart; a.m = m; a.n = (int)n; a.k = lr_k; a.guard = guard;
         const int nblk = lr_blocks(m, ws->num_cu), len = lr_len((int)n);
-        if (fuse_tails) {
+        if (sweep_tail) {
             // the reduction -- and, with no all-reduce behind it, the n x n finish -- run in the sweep's last workgroups
             a.tail_counters = B.counters; a.range_sums = B.lrranges; a.out = B.lrvec; a.finish = comm ? 0 : 1;
             a.Dw = B.lrD; a.JJ = B.JJ; a.Jy = B.Jy; a.st = B.st;
@@ -721,10 +744,16 @@ struct Solver {
         ev_begin(1);
         if (!ok(lr_sweep<T>(a, nblk, stream), "broyden sweep")) return false;
         ev_end();
-        if (!fuse_tails) MIRLSQ_LAUNCH(k_lr_reduce<T>, dim3((len + 31) / 32), dim3(32 * kReduceRanges), 0, stream, B.lrpart, nblk, len, B.lrvec, guard);
+        if (!sweep_tail) MIRLSQ_LAUNCH(k_lr_reduce<T>, dim3((len + 31) / 32), dim3(32 * kReduceRanges), 0, stream, B.lrpart, nblk, len, B.lrvec, guard);
         if (comm && !allreduce(B.lrvec, (size_t)len, 1)) return false;
-        if (!fuse_tails || comm)
+        if (sweep_tail && !comm) {
+            // finished inside the sweep
+        } else if (merge_small) {
+            finish_pending = true;       // the solve kernel that follows applies it in its prologue (enqueue_solve)
+            finish_k = lr_k;
+        } else {
             MIRLSQ_LAUNCH(k_lr_finish<T>, dim3(n + 1), dim3(256), 0, stream, B.lrvec, B.lrD, B.dx_acc, lr_k, (int)n, B.JJ, B.Jy, B.st, guard);
+        }
         if (!spec_enqueue) {
             if (stats) stats->broyden_lr_columns += (uint64_t)lr_k;
             ++lr_k;
@@ -744,13 +773,13 @@ struct Solver {
         ev_end();
         return finish_products(direct);
     }
-    // Single GPU: the slab reduction writes J^T J (both triangles), J^T y and |J^T y|_inf itself; with a communicator the
-    // packed buffer is all-reduced first and k_unpack_grad expands it
-    bool unpack_in_reduce(bool fd) const { return fuse_tails && !comm && (fd || jtj_plain_unpacks(plan)); }
+    // Single GPU: the slab reduction writes J^T J (both triangles) and J^T y itself (the solve kernel takes |J^T y|_inf); with a
+    // communicator the packed buffer is all-reduced first and k_unpack_grad expands it
+    bool unpack_in_reduce(bool fd) const { return merge_small && !comm && (fd || jtj_plain_unpacks(plan)); }
     JtjUnpack<T> unpack_target()
     {
         JtjUnpack<T> u;
-        u.JJ = B.JJ; u.Jy = B.Jy; u.jy_inf = &B.st->jy_inf; u.counter = B.counters + kCounterSlabs;
+        u.JJ = B.JJ; u.Jy = B.Jy;
         return u;
     }
     bool finish_products(bool direct)
@@ -768,6 +797,10 @@ struct Solver {
         JtjArgs<T> a{};
         a.J = B.J; a.Jout = B.J; a.y = y_dev; a.y_old = yold_dev; a.dx = B.dx_acc; a.dx_dot = &B.st->dx_dot;
         a.slabs = B.slabs; a.m = m; a.n = (int)n;
+        if (!broyden && fd_fused == 3) {
+            fd_fused = 0;
+            return fd_window_pipeline(y_dev);
+        }
         if (!broyden && fd_fused) {
             // the row-major FD panel is still in ws->ypanel: one kernel forms the Jacobian rows (LS:1041-1047), writes
             // them to J and accumulates J^T J / J^T y from the same registers
@@ -786,6 +819,53 @@ struct Solver {
         if (!ok(jtj_run<T>(plan, a, broyden, B.packed, stream, variant, direct ? unpack_target() : JtjUnpack<T>{}), "jtj kernel")) return false;
         ev_end();
         return finish_products(direct);
+    }
+
+    // ---- two-stream finite-difference refresh (LS:1018-1049, 1052, 1065): the caller's batched residual kernel is MFMA-bound,
+    //      the library's fused finite-difference kernel HBM-bound; in W row windows the caller's kernel for window k + 1 runs on
+    //      a side stream while k_jtj_fdp consumes window k on the solver's stream (its own slab set per window: no
+    //      read-modify-write of partial sums), one slab reduction over all W sets at the end.
+    bool fd_window_pipeline(const T* y_dev)
+    {
+        if constexpr (sizeof(T) != 8) { return false; } else {
+        const int W = (int)(fd_windows < (uint32_t)mir_lsq_workspace::kMaxWindows ? fd_windows : (uint32_t)mir_lsq_workspace::kMaxWindows);
+        const size_t set = (size_t)plan.nblk * plan.slab_len;
+        if (ws->win_slab_bytes < (size_t)W * set * sizeof(T)) {
+            if (ws->win_slabs) (void)hipFree(ws->win_slabs);
+            ws->win_slabs = nullptr; ws->win_slab_bytes = 0;
+            if (!ok(hipMalloc(&ws->win_slabs, (size_t)W * set * sizeof(T)), "hipMalloc(window slabs)")) return false;
+            ws->win_slab_bytes = (size_t)W * set * sizeof(T);
+        }
+        if (!ws->side_stream && !ok(hipStreamCreateWithFlags(&ws->side_stream, hipStreamNonBlocking), "side stream")) return false;
+        for (int k = 0; k <= W; ++k)
+            if (!ws->win_event[k] && !ok(hipEventCreateWithFlags(&ws->win_event[k], hipEventDisableTiming), "window event")) return false;
+        size_t rows = (m + W - 1) / W;
+        rows = (rows + 31) / 32 * 32;                    // whole 32-row stages of both kernels
+        T* D = static_cast<T*>(ws->ypanel);
+        ev_begin(3);
+        // the side stream starts once the points X (k_fd_points) are there
+        if (!ok(hipEventRecord(ws->win_event[W], stream), "event") || !ok(hipStreamWaitEvent(ws->side_stream, ws->win_event[W], 0), "wait")) return false;
+        int used = 0;
+        for (int k = 0; k < W; ++k) {
+            const size_t r0 = (size_t)k * rows;
+            if (r0 >= m) break;
+            const size_t rc = r0 + rows <= m ? rows : m - r0;
+            fbdw(fbctx, m, n, 2 * (size_t)n, B.X, D, r0, rc, ws->side_stream);
+            if (!ok(hipEventRecord(ws->win_event[k], ws->side_stream), "event") || !ok(hipStreamWaitEvent(stream, ws->win_event[k], 0), "wait")) return false;
+            JtjArgs<T> a{};
+            a.J = D + r0 * n; a.Jout = B.J + r0 * n; a.y = y_dev + r0; a.y_old = a.y; a.dx = B.dx_acc; a.dx_dot = &B.st->dx_dot;
+            a.slabs = static_cast<T*>(ws->win_slabs) + (size_t)k * set; a.m = rc; a.n = (int)n; a.twh = B.twh;
+            if (!ok(jtj_fdp_launch<T, false, true>(plan, a, stream), "fd window kernel")) return false;
+            ++used;
+        }
+        if (stats) { stats->fd_callback_points += 2 * (uint64_t)n; stats->fd_callback_calls += (uint64_t)used; stats->fd_window_refreshes++; }
+        JtjArgs<T> r{};
+        r.slabs = static_cast<T*>(ws->win_slabs); r.n = (int)n;
+        const bool direct = unpack_in_reduce(true);
+        if (!ok(jtj_reduce_slabs<T>(plan, r, B.packed, stream, direct ? unpack_target() : JtjUnpack<T>{}, used * plan.nblk, plan.slab_len), "slab reduce")) return false;
+        ev_end();
+        return finish_products(direct);
+        }
     }
 
     // ---- finite-difference Jacobian, device callbacks (LS:1016-1050 restructured: all perturbed
@@ -829,6 +909,13 @@ struct Solver {
             ws->ypanel_bytes = need;
         }
         T* Y = static_cast<T*>(ws->ypanel);
+        if (use_diff && fbdw && fd_windows >= 2 && plan.fdp_plain && m >= (size_t)fd_windows * 4096) {
+            // two streams (jacobian_products runs the pipeline: caller's window kernels on the side stream, the fused
+            // finite-difference kernel window by window on this one)
+            fd_fused = 3;
+            ret.fCalls += n;
+            return true;
+        }
         if (use_diff) {
             // all 2n points in one sweep, the caller's kernel hands over D[i][j] = f(x + h e_j)_i - f(x - h e_j)_i (LS:1041, 1045);
             // k_jtj_fdp<., false, true> (jacobian_products) scales the columns (LS:1047), writes J and accumulates J^T J / J^T y
@@ -1057,6 +1144,11 @@ struct Solver {
         a.lambda_from_state = lambda_from_state ? 1 : 0;
         a.lambda_from_device = spec_enqueue ? 1 : 0;
         a.guard = spec_enqueue ? &B.st->spec_ok : nullptr;
+        if (finish_pending) {
+            if (ks != 1) { std::fprintf(stderr, "[mir_optim_amd] internal error: a Broyden finish is pending for a ladder of %d\n", ks); return false; }
+            a.lr = B.lrvec; a.lrD = B.lrD; a.lr_dx = B.dx_acc; a.lr_k = finish_k; a.JJw = B.JJ; a.Jyw = B.Jy;
+            finish_pending = false;
+        }
         if (!dbg_solve) a.sc[0].dbg = nullptr;
         ev_begin(2);
         {
@@ -1072,7 +1164,7 @@ struct Solver {
     //      and the decision are one launch (k_sumsq_tail<., kSumsqTailDecide>), otherwise sumsq() runs first
     bool enqueue_decide(int ks, bool check_grad, bool lambda_from_state, bool next_round_enqueued_ahead, const T* sum_v = nullptr)
     {
-        const bool one_launch = sum_v && fuse_tails && !comm;
+        const bool one_launch = sum_v && sumsq_tail && !comm;
         if (sum_v && !one_launch && !sumsq(sum_v, 1, ks, m, true)) return false;
         DecideArgs<T> d{};
         d.sums = B.sum + 1; d.rec = B.rec; d.st = B.st; d.set = sd; d.x = B.x; d.trial = B.trial; d.dx_chain = B.dx;
@@ -1158,7 +1250,7 @@ struct Solver {
             if (!eval_f(B.x, xh, y)) { fail = true; break; }                 // LS:953
             ++ret.fCalls;
             ++seq;
-            if (fuse_tails && !comm) {                                       // LS:955 + the state at entry, one launch
+            if (sumsq_tail && !comm) {                                       // LS:955 + the state at entry, one launch
                 SumsqTailArgs<T> t = sumsq_tail_args(y, 0, 0);
                 t.st = B.st; t.host_st = st_slot_d[seq & 1]; t.seq = seq;
                 MIRLSQ_LAUNCH((k_sumsq_tail<T, kSumsqTailInit>), dim3(sumsq_blocks(), 1), dim3(kSolveThreads), 0, stream, t);
@@ -1419,6 +1511,10 @@ typename Abi<T>::Result solve_entry(const typename Abi<T>::Settings* settings, s
             s.fbr = reinterpret_cast<typename Abi<T>::FB>(opt->fbRowMajor);
         if (opt->struct_size >= offsetof(mir_lsq_gpu_options, fbRowMajorDiff) + sizeof(void*) && s.device_cb)
             s.fbd = reinterpret_cast<typename Abi<T>::FB>(opt->fbRowMajorDiff);
+        if (opt->struct_size >= offsetof(mir_lsq_gpu_options, fbRowMajorDiffWindow) + sizeof(void*) && s.device_cb && sizeof(T) == 8) {
+            s.fbdw = reinterpret_cast<mir_lsq_window_function_d>(opt->fbRowMajorDiffWindow);
+            s.fd_windows = opt->fd_windows;
+        }
         if (s.trace) s.trace->count = 0;
     }
     const typename Abi<T>::Result r = s.run();

@@ -42,7 +42,8 @@ template <typename T>
 __device__ inline T sumsq_final_block(const T* partials, int nparts, T* red /* 4 */)
 {
     T s = 0;
-    for (int i = threadIdx.x; i < nparts; i += 256) s += partials[i];
+    for (int i = threadIdx.x; i < nparts; i += 256) s += load_agent(&partials[i]);   // (coherent read: the fused tails run this
+                                                                                     //  in the kernel that wrote the partials)
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -326,8 +327,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_decide_chain(DecideArgs<T> a)
 }
 
 // ---- sum of squares with the NEXT step of the pass fused into its tail ("last workgroup finishes"): every workgroup
-//      writes its stage-1 partial, makes it visible device-wide (__threadfence: the eight XCDs have separate L2s) and
-//      counts itself in; the workgroup that arrives last runs stage 2 -- the same fixed-order sum as k_sumsq_final,
+//      writes its stage-1 partial with an agent-scope store (common.h: the eight XCDs have separate L2s) and counts itself
+//      in; the workgroup that arrives last runs stage 2 -- the same fixed-order sum as k_sumsq_final,
 //      whichever workgroup that is, so the bits do not depend on the arrival order -- and then
 //        kSumsqTailFinal   writes the sums (an all-reduce over the row shards follows),
 //        kSumsqTailDecide  walks the lambda ladder and publishes the decision (decide_chain_body; LS:1117-1161),
@@ -350,7 +351,6 @@ template <typename T, int TAIL>
 __global__ __launch_bounds__(kSolveThreads) void k_sumsq_tail(SumsqTailArgs<T> a)
 {
     __shared__ T red[4];
-    __shared__ int last_s;
     {
         const T* __restrict__ v = a.v + (size_t)blockIdx.y * a.vstride;
         T s = 0;
@@ -361,16 +361,9 @@ __global__ __launch_bounds__(kSolveThreads) void k_sumsq_tail(SumsqTailArgs<T> a
         s = wave_sum(s);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            a.partials[(size_t)blockIdx.y * a.pstride + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-            __threadfence();                                             // release: the partial before the count
-            const uint32_t total = gridDim.x * gridDim.y;
-            last_s = atomicAdd(a.counter, 1u) == total - 1;
-        }
-        __syncthreads();
-        if (!last_s) return;
-        __threadfence();                                                 // acquire: every other workgroup's partial
-        if (threadIdx.x == 0) *a.counter = 0;                            // the next launch on the stream finds it zero
+        if (threadIdx.x == 0)                                            // crosses to the finishing workgroup: agent-scope store
+            store_agent(&a.partials[(size_t)blockIdx.y * a.pstride + blockIdx.x], (red[0] + red[1]) + (red[2] + red[3]));
+        if (!arrive_last(a.counter, gridDim.x * gridDim.y)) return;
     }
     if constexpr (TAIL == kSumsqTailDecide) {
         DecideArgs<T> d = a.dec;

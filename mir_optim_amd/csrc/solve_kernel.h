@@ -648,7 +648,68 @@ struct LmSolveArgs {
     int lambda_from_state; // step 0 takes st->lambda and applies the lambda_0 rule LS:1067-1072
     int lambda_from_device; // step 0 takes st->lambda as it is (a round enqueued before the host has seen the previous decision)
     const int32_t* guard;  // optional: the kernel does nothing when *guard == 0 (rounds enqueued ahead of time)
+    // ---- the n x n finish of a Broyden pass (k_lr_finish), applied by workgroup 0 before anything else when lr != nullptr:
+    //      one launch less per Broyden pass. lr: the reduced (and all-reduced) sweep vector; the ladder has one entry then.
+    const T* lr; T* lrD; const T* lr_dx; int lr_k;
+    T* JJw; T* Jyw;        // writable aliases of JJ / Jy
 };
+
+// k_lr_finish's work by ONE workgroup (any size): v = v0 + D w; JJ += v dx^T + dx v^T + uu dx dx^T (lr_jj_term: the same
+// rounding as k_lr_finish); Jy = g0 + D h + dx uy; D_k = dx. Returns |Jy|_inf (LS:1053) to every thread.
+// scratch: 4 n + 2 kLrMax + 2 elements of LDS; red: one element per wave.
+template <typename T>
+__device__ inline T lr_finish_block(const T* lr, T* D, const T* dx, int k, int n, T* JJ, T* Jy, T* scratch, T* red)
+{
+    const int tid = threadIdx.x, nthr = blockDim.x, len = lr_len(n);
+    T* v = scratch;
+    T* dxs = scratch + n;
+    T* lrs = scratch + 2 * n;
+    for (int e = tid; e < len; e += nthr) lrs[e] = lr[e];
+    __syncthreads();
+    const T* w = lrs + 2 * n;
+    const T* h = w + kLrMax;
+    const T uu = lrs[2 * n + 2 * kLrMax], uy = lrs[2 * n + 2 * kLrMax + 1];
+    T mx = 0;
+    for (int j = tid; j < n; j += nthr) {
+        const T dj = dx[j];
+        T sv = lrs[j];
+        for (int l = 0; l < k; ++l) sv += D[(size_t)l * n + j] * w[l];
+        v[j] = sv;
+        dxs[j] = dj;
+        T g = lrs[n + j];
+        for (int l = 0; l < k; ++l) g += D[(size_t)l * n + j] * h[l];
+        g += dj * uy;
+        Jy[j] = g;
+        const T av = dabs(g);
+        if (av > mx) mx = av;
+    }
+    __syncthreads();                                       // also: every read of the D rows < k is done before row k is written
+    for (int j = tid; j < n; j += nthr) D[(size_t)k * n + j] = dxs[j];
+    // 16 loads in flight per thread: a plain read-modify-write loop serialises on may-alias load / store ordering (one L2
+    // round trip per element: 64 of them at n = 128)
+    const int nn = n * n;
+    for (int base = tid; base < nn; base += 16 * nthr) {
+        T old[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int idx = base + u * nthr; old[u] = JJ[idx < nn ? idx : nn - 1]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = base + u * nthr;
+            if (idx < nn) {
+                const int i = idx / n, j = idx - i * n;
+                const int rr = i >= j ? i : j, cc = i >= j ? j : i;
+                JJ[idx] = old[u] + lr_jj_term(v[rr], v[cc], dxs[rr], dxs[cc], uu);
+            }
+        }
+    }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();                                       // also: the updated JJ / Jy are visible to the whole workgroup
+    T m2 = red[0];
+    for (int wv = 1; wv < (nthr >> 6); ++wv) m2 = red[wv] > m2 ? red[wv] : m2;
+    __syncthreads();                                       // red may be reused
+    return m2;
+}
 
 template <typename T, int NB, bool BOUNDED = true>
 __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
@@ -671,8 +732,20 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
     if (a.guard && *a.guard == 0) return;
     MIRLSQ_STAMP(sc.dbg, 0);
     if (sc.dbg && threadIdx.x == 0) sc.dbg[9] = clock64();
+    // the n x n finish of a Broyden pass first (one workgroup: the ladder has one entry whenever J has just changed)
+    __shared__ T fin_s[NB == 0 ? 4 * kLrMaxN + 2 * kLrMax + 2 : 1];
+    T jy_inf = 0;
+    if (a.lr) {
+        T* scratch;
+        if constexpr (NB > 0) scratch = F; else scratch = fin_s;         // the solve's LDS is still free
+        jy_inf = lr_finish_block<T>(a.lr, a.lrD, a.lr_dx, a.lr_k, n, a.JJw, a.Jyw, scratch, red);
+    } else if (a.check_grad) {
+        jy_inf = block_max(tid < n ? dabs(a.Jy[tid]) : T(0), red);       // |Jy[iamax(Jy)]|, LS:1053
+        __syncthreads();
+    }
+    if ((a.lr || a.check_grad) && tid == 0 && kc == 0) a.st->jy_inf = jy_inf;
     // gradient test, LS:1053: stop before touching lambda when ||Jy||_inf <= gradTolerance
-    if (a.check_grad && !(a.st->jy_inf > a.set.gradTolerance)) {
+    if (a.check_grad && !(jy_inf > a.set.gradTolerance)) {
         if (tid == 0) { ChainRec<T> r{}; r.flags = kFlagGradSmall; a.rec[kc] = r; }
         return;
     }

@@ -64,7 +64,7 @@ def run(m=1000000, n=128, threads=0, abs_tolerance=1e-5, columns=False, data=Non
     fd_calls = 2 * st.fd_host_columns                              # residual evaluations inside the refreshes
     trial_calls = res.fCalls - st.fd_host_columns                  # fCalls counts n per refresh (quirk Q5) + 1 per trial / entry
     fd_wall = st.fd_host_wall_ms * 1e-3
-    trial_f_s = trial_calls * tf
+    trial_f_s = st.host_f_ms * 1e-3                                # measured inside the library around each call of f
     library_s = dt - fd_wall - trial_f_s                           # everything that is not the caller's residual work
     return {
         "entry": "mir_optimize_least_squares_gpu_d, host callbacks (the reference contract LS:78-80), native OpenMP thread manager",

@@ -123,11 +123,11 @@ def test_gpu_options_trace_field_is_appended():
     the library falls back to are the historic ones (tests/test_gpu_tail_fusion.py checks the writes with a canary)."""
     import ctypes as C
     from mir_optim_amd import api
-    assert C.sizeof(api.GpuOptions) == 96 and api.GpuOptions.stats.offset == 56 and api.GpuOptions.trace.offset == 64
+    assert C.sizeof(api.GpuOptions) == 104 and api.GpuOptions.fbRowMajorDiffWindow.offset == 96 and api.GpuOptions.stats.offset == 56 and api.GpuOptions.trace.offset == 64
     assert api.GpuOptions.fbRowMajor.offset == 72 and api.GpuOptions.fbRowMajorDiff.offset == 80
     assert api.GpuOptions.stats_size.offset == 88 and api.GpuOptions().stats_size == C.sizeof(api.Stats)
     assert api.Stats.qp_active_set_passes.offset + 8 == 120 and api.Stats.jtj_fd_launches.offset + 8 == 144
-    assert api.Stats.trial_callback_points.offset + 8 == 264 and C.sizeof(api.Stats) == 264 + 10 * 8
+    assert api.Stats.trial_callback_points.offset + 8 == 264 and C.sizeof(api.Stats) == 264 + 13 * 8
     assert C.sizeof(api.TraceRecord) == 40
     t = api.Trace(8)
     assert t.count == 0 and t.records() == []

@@ -20,7 +20,8 @@ EXE = os.path.join(ROOT, "tests", "c_harness", "harness")
 @pytest.fixture(scope="module")
 def harness():
     libdir = os.path.dirname(hipbuild.SOLVER_LIB)
-    if (not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(SRC), os.path.getmtime(hipbuild.SOLVER_LIB))):
+    if (not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(SRC), os.path.getmtime(hipbuild.SOLVER_LIB),
+                                                                     os.path.getmtime(os.path.join(ROOT, "include", "mir_optim_amd.h")))):
         subprocess.check_call(["gcc", "-O1", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), SRC,
                                "-o", EXE, "-L", libdir, "-lmir_optim_amd", "-lm", "-Wl,-rpath," + libdir,
                                "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"])

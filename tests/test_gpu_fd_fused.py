@@ -238,3 +238,26 @@ def test_solve_through_the_difference_panel_equals_the_pair_panel_solve(oracle, 
     else:
         assert np.allclose(xd, xp, rtol=1e-9, atol=1e-12) and np.isclose(rd.residual, rp.residual, rtol=1e-12)
     assert sd.jacobian_full == sp.jacobian_full >= 1
+
+
+@pytest.mark.parametrize("m,n,windows", [(200000, 128, 4), (70001, 64, 3), (40000, 32, 8), (150000, 128, 16)])
+def test_two_stream_window_refresh_matches_the_one_sweep_refresh(m, n, windows):
+    """fbRowMajorDiffWindow (round 3): the caller's difference-panel kernel in row windows on a side stream,
+    k_jtj_fdp window by window on the solver's stream, one slab reduction over all windows' slab sets. J is the same matrix;
+    J^T J / J^T y differ by the summation order only: same counters, x and residual to rounding, trace to 1e-9."""
+    import mir_optim_amd as M
+    from mir_optim_amd import workloads as W
+    import problems as P
+    w = P.tanh_linear(m, n)
+    prob = W.TanhLinear(w["A"], w["b"])
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-5      # every accept / reject decision has margin (DESIGN.md section 5)
+    st0, st1, t0, t1 = M.Stats(), M.Stats(), M.Trace(), M.Trace()
+    r0, x0 = prob.solve(w["x0"], settings=s, batched=True, stats=st0, trace=t0)
+    r1, x1 = prob.solve(w["x0"], settings=s, batched=True, stats=st1, trace=t1, fd_windows=windows)
+    assert st1.fd_window_refreshes == st1.jacobian_full >= 2 and st0.fd_window_refreshes == 0
+    assert (int(r1.status), r1.iterations, r1.fCalls) == (int(r0.status), r0.iterations, r0.fCalls)
+    assert np.allclose(x1, x0, rtol=1e-9, atol=1e-11) and np.isclose(r1.residual, r0.residual, rtol=1e-12)
+    a, b = t0.records(), t1.records()
+    assert len(a) == len(b)
+    for ra, rb in zip(a, b):
+        assert ra[:2] == rb[:2] and np.allclose(ra[2:5], rb[2:5], rtol=1e-9, atol=1e-300) and np.isclose(ra[5], rb[5], rtol=1e-5)   # dx.dx of a 5e-6 step

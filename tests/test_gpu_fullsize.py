@@ -34,12 +34,12 @@ class OracleResult:
     pass
 
 
-def oracle_run(tmp_path, abs_tolerance, max_iterations):
+def oracle_run(tmp_path, abs_tolerance, max_iterations, m=M_ROWS, n=N):
     """The oracle in a process of its own (tests/oracle_fullsize_worker.py), same inputs (counter RNG)."""
     threads = min(os.cpu_count() or 1, 32)
     out = str(tmp_path / "oracle.npz")
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_fullsize_worker.py")
-    p = subprocess.run([sys.executable, worker, str(M_ROWS), str(N), repr(abs_tolerance), str(max_iterations), str(threads), out],
+    p = subprocess.run([sys.executable, worker, str(m), str(n), repr(abs_tolerance), str(max_iterations), str(threads), out],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     z = np.load(out)
@@ -86,3 +86,28 @@ def test_cfg3_full_size_survey_setting_matches_oracle(cfg3, tmp_path):
     assert np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max(), np.abs(x - xo).max()
     assert np.isclose(res.residual, ro.residual, rtol=1e-9, atol=0)
     assert 10 <= res.iterations <= 14
+
+
+def test_cfg4_shape_quarter_million_rows_first_iterations_match_oracle(tmp_path):
+    """cfg 4's per-GPU kernels (n = 256: k_jtj_fdp8, the eight-column-pair sweep, the global-memory-factor solve) against the
+    ORACLE above the m = 40 004 the sharded tests reach (round-2 verdict, "what's weak" 3): m = 250 000 x n = 256, the first
+    three accepted iterations (maxIterations = 3 on both sides: one FD refresh of 512 residual evaluations + Broyden passes),
+    pass by pass and at the end. Tolerances as for cfg 3 at full size."""
+    m, n = 250_000, 256
+    data = W.tanh_linear_data(m, n)
+    prob = W.TanhLinear(data["A"], data["b"])
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-9; s.maxIterations = 3
+    tr = M.Trace(64)
+    res, x = prob.solve(data["x0"], settings=s, batched=True, trace=tr)
+    prob.dA.free(); prob.db.free()
+    ro, xo = oracle_run(tmp_path, 1e-9, 3, m, n)
+    assert int(res.status) == ro.status == M.LeastSquaresStatus.maxIterations
+    assert (res.iterations, res.fCalls) == (ro.iterations, ro.fCalls) == (3, ro.fCalls)
+    got = tr.records()
+    assert [(int(g[0]), int(g[1])) for g in got] == [(int(e[0]), int(e[1])) for e in ro.trace], (got, ro.trace)
+    for g, e in zip(got, ro.trace):
+        assert np.isclose(g[2], e[2], rtol=1e-6), (g, e)
+        assert np.allclose(g[3:5], e[3:5], rtol=1e-9), (g, e)
+        assert np.isclose(g[5], e[5], rtol=1e-5), (g, e)
+    assert np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max(), np.abs(x - xo).max()
+    assert np.isclose(res.residual, ro.residual, rtol=1e-9, atol=0)

@@ -323,19 +323,69 @@ def test_batched_residual_callback_matches_pointwise(m, n):
         assert np.max(np.abs(Yb - ref)) < 1e-13 and np.max(np.abs(Y1 - ref)) < 1e-13
 
 
+def assert_traces_agree_until_noise(got, ref, min_passes):
+    """Pass-by-pass comparison of mir_lsq_trace with the oracle's trace up to the first pass whose accept / reject decision
+    compares rounding noise (first_noisy_pass): same events and iteration counters, lambda to 1e-6, residuals to 1e-9."""
+    k_end = min(first_noisy_pass(got), first_noisy_pass(ref), len(got), len(ref))
+    assert k_end >= min_passes, (k_end, len(got), len(ref))
+    for k in range(k_end):
+        g, e = got[k], ref[k]
+        assert (int(g[0]), int(g[1])) == (int(e[0]), int(e[1])), (k, g, e)
+        assert np.isclose(g[2], e[2], rtol=1e-6), (k, g, e)
+        assert np.allclose(g[3:5], e[3:5], rtol=1e-9, atol=1e-300), (k, g, e)
+    return k_end
+
+
 def test_cfg2_gauss_sum_full_size(oracle):
-    """BASELINE cfg 2: Gaussian-sum curve fit, m = 1e5 residuals x n = 16 parameters, fp64, width bounds, FD Jacobian."""
+    """BASELINE cfg 2: Gaussian-sum curve fit, m = 1e5 residuals x n = 16 parameters, fp64, width bounds, FD Jacobian.
+    The two sides end in different ways (the GPU: furtherImprovement after the reference's lambda ladder, the oracle:
+    xConverged -- the last acceptance compares rounding noise, quirk Q3 / DESIGN.md section 5), so besides the minimiser
+    (x rtol 1e-6, residual rtol 1e-9: BASELINE.md section 2) the TRAJECTORIES are compared pass by pass up to the first
+    noise-decided pass (round-2 verdict, "what's weak" 1)."""
     import ctypes as C
     g = P.gauss_sum(100000, K=5)
     assert g["n"] == 16
     prob = W.Curve("gauss_sum", g["t"], g["data"])
-    res, x = prob.solve(g["x0"], g["lower"], g["upper"])
+    tr = M.Trace(4096)
+    res, x = prob.solve(g["x0"], g["lower"], g["upper"], trace=tr)
     ctx = oracle.GaussSumCtx(g["t"].ctypes.data, g["data"].ctypes.data)
+    ev = []
     ro, xo = oracle.optimize(oracle.native_fn("wlc_gauss_sum_f"), g["m"], g["x0"], lower=g["lower"], upper=g["upper"],
-                             fctx=C.addressof(ctx))
+                             fctx=C.addressof(ctx), trace=lambda *a: ev.append(a))
     assert res.status >= 0 and ro.status >= 0
-    assert np.allclose(x, xo, rtol=1e-6, atol=1e-9) and np.isclose(res.residual, ro.residual, rtol=1e-8)
+    assert np.allclose(x, xo, rtol=1e-6, atol=1e-9) and np.isclose(res.residual, ro.residual, rtol=1e-9)
     assert np.allclose(x, g["truth"], rtol=5e-3, atol=1e-3)
+    k_end = assert_traces_agree_until_noise(tr.records(), ev, min_passes=30)
+    accepted = sum(1 for r in tr.records()[:k_end] if r[0] == 3)
+    assert accepted >= 12                                              # most of the 22-23 accepted steps are compared one by one
+
+
+def test_cfg2_gauss_sum_full_size_with_binding_width_bounds(oracle):
+    """cfg 2's width bounds w_k >= 1e-3 never bind on the SURVEY inputs (qp_active_set_passes = 0 in round 2's bench line), so
+    "bounded cfg 2" did not exercise BOXCQP. Here two widths are boxed in ABOVE their true value and the amplitudes from above:
+    the minimiser sits on those bounds, the active-set loop runs (QP:234-376) at m = 1e5 x n = 16, and the result is the
+    oracle's: same active set, x rtol 1e-6, residual rtol 1e-9, traces equal up to the first noise-decided pass."""
+    import ctypes as C
+    g = P.gauss_sum(100000, K=5)
+    K = g["K"]
+    lower, upper = g["lower"].copy(), g["upper"].copy()
+    lower[2 * K] = 0.045; lower[2 * K + 3] = 0.05                      # true widths are 0.04
+    upper[0] = 0.95; upper[3] = 0.85                                   # true amplitudes 1.0 and 0.9
+    x0 = np.clip(g["x0"], lower, upper)
+    prob = W.Curve("gauss_sum", g["t"], g["data"])
+    st, tr = M.Stats(), M.Trace(4096)
+    res, x = prob.solve(x0, lower, upper, stats=st, trace=tr)
+    ctx = oracle.GaussSumCtx(g["t"].ctypes.data, g["data"].ctypes.data)
+    ev = []
+    ro, xo = oracle.optimize(oracle.native_fn("wlc_gauss_sum_f"), g["m"], x0, lower=lower, upper=upper, fctx=C.addressof(ctx),
+                             trace=lambda *a: ev.append(a))
+    assert res.status >= 0 and ro.status >= 0
+    assert st.qp_active_set_passes >= 3                                # BOXCQP's active-set loop really ran on the device
+    on_gpu = (x == lower) | (x == upper)
+    on_cpu = (xo == lower) | (xo == upper)
+    assert on_gpu.sum() >= 4 and np.array_equal(on_gpu, on_cpu)
+    assert np.allclose(x, xo, rtol=1e-6, atol=1e-9) and np.isclose(res.residual, ro.residual, rtol=1e-9)
+    assert_traces_agree_until_noise(tr.records(), ev, min_passes=8)
 
 
 def test_gauss_sum_batched_callback_equals_pointwise(oracle):

@@ -1,16 +1,20 @@
-"""The per-pass serial tail (round 3): reductions and the decision run in the LAST workgroups of the sweep that feeds them
-instead of as kernels of their own --
+"""The per-pass serial tail (round 3): fewer launches per pass, bit for bit the same solve.
 
-    k_broyden_lr -> k_lr_reduce -> k_lr_finish            =>  k_broyden_lr (ranges summed by their last arrivals, the
-                                                              last range sums the ranges and applies the n x n finish)
-    k_jtj_* -> k_jtj_slab_reduce -> k_unpack_grad         =>  k_jtj_* -> k_jtj_slab_reduce (writes J^T J, J^T y, |J^T y|_inf)
-    f(trial) -> k_sumsq_partial -> k_decide_chain         =>  f(trial) -> k_sumsq_tail<decide>
-    f(x0) -> k_sumsq_partial -> k_sumsq_final -> k_init   =>  f(x0) -> k_sumsq_tail<init>
+Default (merges into the CONSUMER's prologue -- no cross-workgroup traffic inside a kernel):
+    k_jtj_* -> k_jtj_slab_reduce -> k_unpack_grad -> solve   =>  k_jtj_* -> k_jtj_slab_reduce (writes J^T J, J^T y) -> solve
+    k_broyden_lr -> k_lr_reduce -> k_lr_finish -> solve      =>  k_broyden_lr -> k_lr_reduce -> solve (n x n finish and
+                                                                 |J^T y|_inf in the solve kernel's prologue)
+Opt-in ("last workgroup finishes" tails; MIR_LSQ_VARIANT_SWEEP_TAIL / SUMSQ_TAIL -- measured no faster on MI355X, kept as
+A/B: profiles/r03/tail_fusion_ab.md):
+    k_broyden_lr -> k_lr_reduce (-> finish)                  =>  k_broyden_lr (ranges summed by their last arrivals, the
+                                                                 last range sums the ranges and applies the finish)
+    f(trial) -> k_sumsq_partial -> k_decide_chain            =>  f(trial) -> k_sumsq_tail<decide>
+    f(x0) -> k_sumsq_partial -> k_sumsq_final -> k_init      =>  f(x0) -> k_sumsq_tail<init>
 
-Every fused tail sums the same partials in the same fixed order as the kernel it replaces, whichever workgroup arrives
-last, so the solves must be BIT-IDENTICAL to MIR_LSQ_VARIANT_NO_TAIL_FUSION (the round-2 launch sequence, kept as the
-literal restatement), and the launch counts per round (mir_lsq_stats.round_launches / rounds) must be what DESIGN.md
-section 4 says. Reference loop: least_squares.d:972-1175 (the reductions are LS:1052, 1065, 1115)."""
+Every variant sums the same partials in the same fixed order and applies the same expressions, so the solves must be
+BIT-IDENTICAL to MIR_LSQ_VARIANT_NO_TAIL_FUSION (the round-2 launch sequence, kept as the literal restatement), and the
+launch counts per round (mir_lsq_stats.round_launches / rounds) must be what DESIGN.md section 4 says.
+Reference loop: least_squares.d:972-1175 (the reductions are LS:1052, 1065, 1115)."""
 import ctypes as C
 import threading
 
@@ -48,15 +52,21 @@ def test_fused_tails_are_bit_identical_to_separate_kernels(m, n, dtype, tol):
     s = M.LeastSquaresSettings(dtype) if dtype == np.float32 else M.LeastSquaresSettings()
     s.absTolerance = tol
     out = []
-    for variant in (0, M.VARIANT_NO_TAIL_FUSION):
+    for variant in (M.VARIANT_NO_TAIL_FUSION, 0, M.VARIANT_SWEEP_TAIL, M.VARIANT_SUMSQ_TAIL, M.VARIANT_SWEEP_TAIL | M.VARIANT_SUMSQ_TAIL):
         st, tr = M.Stats(), M.Trace(4096)
         r, x = prob.solve(w["x0"].astype(dtype), settings=s, batched=True, stats=st, trace=tr, variant=variant)
         out.append((key(r, x), counters(st), tr.records(), st))
-    (k1, c1, t1, st1), (k0, c0, t0, st0) = out
-    assert k1 == k0
-    assert c1 == c0
-    assert t1 == t0                                          # every pass: lambda, residuals, dx.dx bit for bit
-    assert st1.library_launches < st0.library_launches
+    k0, c0, t0, st0 = out[0]
+    launches = [st0.library_launches]
+    for k1, c1, t1, st1 in out[1:]:
+        assert k1 == k0
+        assert c1 == c0
+        assert t1 == t0                                      # every pass: lambda, residuals, dx.dx bit for bit
+        launches.append(st1.library_launches)
+    if n <= 256:
+        assert launches[1] < launches[0] and launches[4] < launches[2] < launches[1] and launches[4] < launches[3] < launches[1]
+    else:                                                    # no low-rank sweep, tile-pair J^T J: only the sums / decision tail applies
+        assert launches[1] == launches[0] == launches[2] and launches[3] == launches[4] < launches[1]
 
 
 def test_bounded_gauss_sum_bit_identical_and_launch_counts():
@@ -64,22 +74,25 @@ def test_bounded_gauss_sum_bit_identical_and_launch_counts():
     g = P.gauss_sum(100000, K=5)
     prob = W.Curve("gauss_sum", g["t"], g["data"])
     res = []
-    for variant in (0, M.VARIANT_NO_TAIL_FUSION):
+    for variant in (0, M.VARIANT_NO_TAIL_FUSION, M.VARIANT_SWEEP_TAIL | M.VARIANT_SUMSQ_TAIL):
         st = M.Stats()
         r, x = prob.solve(g["x0"], l=g["lower"], u=g["upper"], batched=True, stats=st, variant=variant)
         res.append((key(r, x), counters(st), st))
-    assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
+    assert res[0][0] == res[1][0] == res[2][0] and res[0][1] == res[1][1] == res[2][1]
     st = res[0][2]
     assert st.rounds[0] == st.jacobian_full and st.rounds[1] == st.jacobian_broyden
     # library launches per round, single GPU:
-    #   Broyden round   sweep (+ reduce + finish) | solve | sum of squares + decision                       = 3
-    #   refresh round   FD points | fused FD J^T J | slab reduce (+ unpack) | solve | sums + decision       = 5
-    #   re-solve round  solve | sums + decision (or the decision alone when every trial is a null step)    = 2
-    assert st.round_launches[1] == 3 * st.rounds[1]
-    assert st.round_launches[2] == 2 * st.rounds[2]
-    assert st.round_launches[0] <= 7 * st.rounds[0]          # point-major panel + fill pass here; + k_reset_mu when LS:984 forces the refresh
+    #   Broyden round   sweep | reduce | solve (+ finish) | sum of squares | decision                            = 5
+    #   refresh round   FD points | fused FD J^T J | slab reduce (+ unpack) | solve | sums | decision            = 6
+    #   re-solve round  solve | sums | decision (or solve | decision when every trial is a null step)           <= 3
+    assert st.round_launches[1] == 5 * st.rounds[1]
+    assert st.round_launches[2] <= 3 * st.rounds[2]
+    assert st.round_launches[0] <= 8 * st.rounds[0]          # point-major panel + fill pass here; + k_reset_mu when LS:984 forces the refresh
     st0 = res[1][2]
     assert st0.round_launches[1] == 6 * st0.rounds[1]        # round 2's sequence: sweep, reduce, finish, solve, sumsq, decide
+    st2 = res[2][2]
+    assert st2.round_launches[1] == 3 * st2.rounds[1]        # both tails: sweep (+ reduce + finish) | solve | sums + decision
+    assert st2.round_launches[2] == 2 * st2.rounds[2]
 
 
 def test_launch_budget_cfg3_shape():
@@ -90,9 +103,14 @@ def test_launch_budget_cfg3_shape():
     r, x = prob.solve(w["x0"], settings=s, batched=True, stats=st)
     assert r.status == M.LeastSquaresStatus.xConverged
     assert st.rounds[0] == st.jacobian_full >= 2 and st.rounds[1] == st.jacobian_broyden >= 2
-    assert st.round_launches[1] == 3 * st.rounds[1]          # <= 4 asked for by the round-2 verdict
-    assert st.round_launches[0] == 5 * st.rounds[0]          # FD points, k_jtj_fdp, slab reduce, solve, sums + decision
-    assert st.library_launches == sum(st.round_launches) + 1  # + the sum of squares at entry (LS:955) with the state set-up
+    assert st.round_launches[1] == 5 * st.rounds[1]          # sweep, reduce, solve (+ finish), sums, decision
+    # FD points, k_jtj_fdp, slab reduce, solve, sums, decision (+ k_reset_mu in a refresh that LS:984-989 forces)
+    assert 6 * st.rounds[0] <= st.round_launches[0] <= 6 * st.rounds[0] + 1
+    assert st.library_launches == sum(st.round_launches) + 3  # + the sum of squares at entry (LS:955: two stages) and the state set-up
+    st2 = M.Stats()
+    r2, x2 = prob.solve(w["x0"], settings=s, batched=True, stats=st2, variant=M.VARIANT_SWEEP_TAIL | M.VARIANT_SUMSQ_TAIL)
+    assert key(r2, x2) == key(r, x)
+    assert st2.round_launches[1] == 3 * st2.rounds[1] and 5 * st2.rounds[0] <= st2.round_launches[0] <= 5 * st2.rounds[0] + 1
 
 
 def test_one_rank_communicator_keeps_the_reductions_apart():
@@ -108,15 +126,15 @@ def test_one_rank_communicator_keeps_the_reductions_apart():
     close()
     r0, x0 = prob.solve(w["x0"], settings=s, batched=True)
     assert key(r1, x1) == key(r0, x0)
-    # Broyden round with a communicator: sweep (+ reduce) | AR | finish | solve | sums | AR | decision = 5 launches
-    assert st.round_launches[1] == 5 * st.rounds[1]
+    # Broyden round with a communicator: sweep | reduce | AR | solve (+ finish) | sums x 2 | AR | decision = 6 launches
+    assert st.round_launches[1] == 6 * st.rounds[1]
 
 
 def test_eight_shards_with_fused_tails_agree_bitwise():
     world, m_total, n = 8, 64000, 128
     s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
     outs = []
-    for variant in (0, M.VARIANT_NO_TAIL_FUSION):
+    for variant in (0, M.VARIANT_NO_TAIL_FUSION, M.VARIANT_SWEEP_TAIL | M.VARIANT_SUMSQ_TAIL):
         comms, close = PAR.local_group(world)
         probs = []
         for r in range(world):
@@ -139,10 +157,11 @@ def test_eight_shards_with_fused_tails_agree_bitwise():
         close()
         assert not any(t.is_alive() for t in ts) and not any(err), err
         outs.append([key(r, x) for r, x in res])
-    assert len(set(outs[0])) == 1 and outs[0] == outs[1]
+    assert len(set(outs[0])) == 1 and outs[0] == outs[1] == outs[2]
 
 
-def test_repeated_solves_on_one_workspace_leave_the_counters_clean():
+@pytest.mark.parametrize("variant", [0, M.VARIANT_SWEEP_TAIL | M.VARIANT_SUMSQ_TAIL])
+def test_repeated_solves_on_one_workspace_leave_the_counters_clean(variant):
     """The arrival counters live in the workspace; every tail resets its own. 30 solves back to back on one workspace, all
     bit-identical (a counter left non-zero would make a later tail fire early or never)."""
     w = P.tanh_linear(40000, 64)
@@ -153,7 +172,7 @@ def test_repeated_solves_on_one_workspace_leave_the_counters_clean():
     try:
         ref = None
         for _ in range(30):
-            r, x = prob.solve(w["x0"], settings=s, batched=True, workspace=ws)
+            r, x = prob.solve(w["x0"], settings=s, batched=True, workspace=ws, variant=variant)
             k = key(r, x)
             ref = ref or k
             assert k == ref
