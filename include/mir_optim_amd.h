@@ -208,6 +208,10 @@ enum {
     MIR_LSQ_VARIANT_NO_TAIL_FUSION = 1u << 12,   /* round 2's launch sequence: k_lr_finish and k_unpack_grad as kernels of
                                                     their own instead of inside the solve kernel's prologue / the slab
                                                     reduction; bit-identical results */
+    MIR_LSQ_VARIANT_FD_PANEL_IS_J = 1u << 21,    /* after a difference-panel refresh keep the panel as J (the fused kernel does not
+                                                    write J; the Broyden sweep and the flush apply scal(1 / twh) at load time)
+                                                    instead of materialising J: bit-identical, 8 m n fewer bytes per refresh,
+                                                    measured a wash at cfg 3 (the scaled sweep is 8 % slower): not the default */
     MIR_LSQ_VARIANT_SWEEP_TAIL = 1u << 14,       /* the Broyden sweep reduces its partials (and, single GPU, applies the n x n
                                                     finish) in its last-arriving workgroups instead of k_lr_reduce: one launch
                                                     less, bit-identical -- and measured slower on MI355X (cross-workgroup hops

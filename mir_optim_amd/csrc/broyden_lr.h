@@ -45,6 +45,10 @@ struct LrArgs {
     size_t m;
     int n;
     int k;
+    const T* colscale;      // SCALED kernels: J0 is the finite-difference DIFFERENCE panel D as the caller's kernel wrote it, and
+                            // the Jacobian entry is D_ij (1 / twh_j) (0 for a collapsed interval) -- colscale = twh. The same
+                            // multiplication k_jtj_fdp performs (LS:1046-1047), applied at load time: the values are bit-identical
+                            // to a materialised J, and the refresh does not have to write m x n doubles
     const int32_t* guard;   // optional: the kernel does nothing when *guard == 0 (rounds enqueued ahead of time)
     // ---- fused tail (tail_counters != nullptr): the reduction of k_lr_reduce and, without an all-reduce behind it, the
     //      n x n work of k_lr_finish run inside the sweep, in the workgroups that arrive last (see lr_tail below)
@@ -153,8 +157,9 @@ __device__ inline void lr_tail(const LrArgs<T>& a, T (*red)[lr_len(kLrMaxN)])
     }
 }
 
-template <typename T, int NCP, bool VEC>
-__global__ __launch_bounds__(256) void k_broyden_lr(const LrArgs<T> a)
+// (four workgroups per CU up to n = 128: the scaled variant would otherwise take 130 VGPRs and drop to three)
+template <typename T, int NCP, bool VEC, bool SCALED = false>
+__global__ __launch_bounds__(256, (NCP <= 4 ? 4 : 1)) void k_broyden_lr(const LrArgs<T> a)
 {
     using P2 = typename LrPair<T>::type;
     __shared__ T red[4][lr_len(kLrMaxN)];
@@ -184,6 +189,15 @@ __global__ __launch_bounds__(256) void k_broyden_lr(const LrArgs<T> a)
         const T t0 = a.dx[ok0[c] ? col : 0], t1 = a.dx[ok1[c] ? col + 1 : 0];
         d0[c] = ok0[c] ? t0 : T(0);
         d1[c] = ok1[c] ? t1 : T(0);
+    }
+    T sc0[SCALED ? NCP : 1], sc1[SCALED ? NCP : 1];        // 1 / twh of the lane's columns (0: collapsed interval, zero column)
+    if constexpr (SCALED) {
+#pragma unroll
+        for (int c = 0; c < NCP; ++c) {
+            const T t0 = a.colscale[ok0[c] ? coff[c] : 0], t1 = a.colscale[ok1[c] ? coff[c] + 1 : 0];
+            sc0[c] = (t0 == 0 || !ok0[c]) ? T(0) : T(1) / t0;
+            sc1[c] = (t1 == 0 || !ok1[c]) ? T(0) : T(1) / t1;
+        }
     }
     __syncthreads();
     const bool own = p < k;
@@ -218,6 +232,10 @@ __global__ __launch_bounds__(256) void k_broyden_lr(const LrArgs<T> a)
             } else {
                 v0[c] = rp[coff[c]];
                 v1[c] = rp[ok1[c] ? coff[c] + 1 : 0];
+            }
+            if constexpr (SCALED) {
+                v0[c] = sc0[c] == 0 ? T(0) : v0[c] * sc0[c];              // scal(1 / twh, Jj), LS:1047 (LS:1046: zero column)
+                v1[c] = sc1[c] == 0 ? T(0) : v1[c] * sc1[c];
             }
         }
         T yn = a.y[rr];
@@ -345,10 +363,12 @@ __global__ __launch_bounds__(256) void k_lr_finish(const T* __restrict__ lr, T* 
 }
 
 // fold the k pending terms into J: J[i,:] += u_0[i] dx_0 + ... + u_{k-1}[i] dx_{k-1}, in update order
-template <typename T, int NCP, bool VEC>
-__global__ __launch_bounds__(256) void k_lr_flush(T* __restrict__ J, const T* __restrict__ U, const T* __restrict__ D,
-                                                  int k, size_t m, int n)
+// src: what J is read from -- J itself (in place), or the unscaled difference panel with colscale = twh (SCALED, see LrArgs)
+template <typename T, int NCP, bool VEC, bool SCALED = false>
+__global__ __launch_bounds__(256) void k_lr_flush(T* J, const T* __restrict__ U, const T* __restrict__ D,
+                                                  int k, size_t m, int n, const T* src = nullptr, const T* colscale = nullptr)
 {
+    if (!src) src = J;
     using P2 = typename LrPair<T>::type;
     extern __shared__ unsigned char lr_smem[];
     T* Ds = reinterpret_cast<T*>(lr_smem);                 // k x n
@@ -365,6 +385,15 @@ __global__ __launch_bounds__(256) void k_lr_flush(T* __restrict__ J, const T* __
         ok1[c] = col + 1 < n;
         coff[c] = ok0[c] ? col : 0;
     }
+    T sc0[SCALED ? NCP : 1], sc1[SCALED ? NCP : 1];
+    if constexpr (SCALED) {
+#pragma unroll
+        for (int c = 0; c < NCP; ++c) {
+            const T t0 = colscale[ok0[c] ? coff[c] : 0], t1 = colscale[ok1[c] ? coff[c] + 1 : 0];
+            sc0[c] = (t0 == 0 || !ok0[c]) ? T(0) : T(1) / t0;
+            sc1[c] = (t1 == 0 || !ok1[c]) ? T(0) : T(1) / t1;
+        }
+    }
     const size_t G = (m + 3) / 4;
     const size_t wave_id = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
@@ -372,18 +401,23 @@ __global__ __launch_bounds__(256) void k_lr_flush(T* __restrict__ J, const T* __
         const size_t row = 4 * g + q;
         const bool rok = row < m;
         const size_t rr = rok ? row : m - 1;
-        T* __restrict__ rp = J + rr * (size_t)n;
+        T* rp = J + rr * (size_t)n;
+        const T* sp = src + rr * (size_t)n;
         T v0[NCP], v1[NCP];
 #pragma unroll
         for (int c = 0; c < NCP; ++c) {
             if constexpr (VEC) {
                 typedef T lr_v2 __attribute__((ext_vector_type(2)));
-                const lr_v2 t = __builtin_nontemporal_load(reinterpret_cast<const lr_v2*>(rp + coff[c]));
+                const lr_v2 t = __builtin_nontemporal_load(reinterpret_cast<const lr_v2*>(sp + coff[c]));
                 v0[c] = t.x;
                 v1[c] = t.y;
             } else {
-                v0[c] = rp[coff[c]];
-                v1[c] = rp[ok1[c] ? coff[c] + 1 : 0];
+                v0[c] = sp[coff[c]];
+                v1[c] = sp[ok1[c] ? coff[c] + 1 : 0];
+            }
+            if constexpr (SCALED) {
+                v0[c] = sc0[c] == 0 ? T(0) : v0[c] * sc0[c];
+                v1[c] = sc1[c] == 0 ? T(0) : v1[c] * sc1[c];
             }
         }
         for (int l = 0; l < k; ++l) {
@@ -416,6 +450,16 @@ __global__ __launch_bounds__(256) void k_lr_flush(T* __restrict__ J, const T* __
 template <typename T, int NCP>
 hipError_t lr_sweep_ncp(const LrArgs<T>& a, int nblk, bool vec, hipStream_t s)
 {
+    if (a.colscale) {
+        // only the f64, even-n shapes of the difference panel reach here (16-byte loads)
+        if constexpr (sizeof(T) == 8) {
+            if (!vec) return hipErrorInvalidValue;
+            MIRLSQ_LAUNCH((k_broyden_lr<T, NCP, true, true>), dim3(nblk), dim3(256), 0, s, a);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     if (vec) MIRLSQ_LAUNCH((k_broyden_lr<T, NCP, true>), dim3(nblk), dim3(256), 0, s, a);
     else MIRLSQ_LAUNCH((k_broyden_lr<T, NCP, false>), dim3(nblk), dim3(256), 0, s, a);
     return hipGetLastError();
@@ -433,28 +477,41 @@ hipError_t lr_sweep(const LrArgs<T>& a, int nblk, hipStream_t s)
 }
 
 template <typename T, int NCP>
-hipError_t lr_flush_ncp(T* J, const T* U, const T* D, int k, size_t m, int n, int nblk, bool vec, hipStream_t s)
+hipError_t lr_flush_ncp(T* J, const T* U, const T* D, int k, size_t m, int n, int nblk, bool vec, hipStream_t s, const T* src, const T* colscale)
 {
     const size_t lds = (size_t)k * n * sizeof(T);
-    if (vec) MIRLSQ_LAUNCH((k_lr_flush<T, NCP, true>), dim3(nblk), dim3(256), lds, s, J, U, D, k, m, n);
-    else MIRLSQ_LAUNCH((k_lr_flush<T, NCP, false>), dim3(nblk), dim3(256), lds, s, J, U, D, k, m, n);
+    if (colscale) {
+        if constexpr (sizeof(T) == 8) {
+            if (!vec) return hipErrorInvalidValue;
+            MIRLSQ_LAUNCH((k_lr_flush<T, NCP, true, true>), dim3(nblk), dim3(256), lds, s, J, U, D, k, m, n, src, colscale);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
+    if (vec) MIRLSQ_LAUNCH((k_lr_flush<T, NCP, true>), dim3(nblk), dim3(256), lds, s, J, U, D, k, m, n, src, colscale);
+    else MIRLSQ_LAUNCH((k_lr_flush<T, NCP, false>), dim3(nblk), dim3(256), lds, s, J, U, D, k, m, n, src, colscale);
     return hipGetLastError();
 }
+// J <- src (scaled by 1 / colscale when given) + the k pending terms; src == nullptr: J in place. With k == 0 and a scaled
+// source this just materialises J.
 template <typename T>
-hipError_t lr_flush(T* J, const T* U, const T* D, int k, size_t m, int n, int num_cu, hipStream_t s)
+hipError_t lr_flush(T* J, const T* U, const T* D, int k, size_t m, int n, int num_cu, hipStream_t s, const T* src = nullptr,
+                    const T* colscale = nullptr)
 {
-    if (k <= 0) return hipSuccess;
+    if (k <= 0 && !colscale) return hipSuccess;
     if (n > kLrMaxN || k > kLrMax) return hipErrorInvalidValue;
     const size_t G = (m + 3) / 4;
     size_t blocks = (G + 3) / 4;
     if (blocks > (size_t)num_cu * 8) blocks = (size_t)num_cu * 8;
     if (blocks < 1) blocks = 1;
-    const bool vec = (n % 2 == 0) && (reinterpret_cast<uintptr_t>(J) % (2 * sizeof(T)) == 0);
+    const bool vec = (n % 2 == 0) && (reinterpret_cast<uintptr_t>(J) % (2 * sizeof(T)) == 0)
+        && (reinterpret_cast<uintptr_t>(src) % (2 * sizeof(T)) == 0);
     const int ncp = (n + 31) / 32;
-    if (ncp <= 1) return lr_flush_ncp<T, 1>(J, U, D, k, m, n, (int)blocks, vec, s);
-    if (ncp <= 2) return lr_flush_ncp<T, 2>(J, U, D, k, m, n, (int)blocks, vec, s);
-    if (ncp <= 4) return lr_flush_ncp<T, 4>(J, U, D, k, m, n, (int)blocks, vec, s);
-    return lr_flush_ncp<T, 8>(J, U, D, k, m, n, (int)blocks, vec, s);
+    if (ncp <= 1) return lr_flush_ncp<T, 1>(J, U, D, k, m, n, (int)blocks, vec, s, src, colscale);
+    if (ncp <= 2) return lr_flush_ncp<T, 2>(J, U, D, k, m, n, (int)blocks, vec, s, src, colscale);
+    if (ncp <= 4) return lr_flush_ncp<T, 4>(J, U, D, k, m, n, (int)blocks, vec, s, src, colscale);
+    return lr_flush_ncp<T, 8>(J, U, D, k, m, n, (int)blocks, vec, s, src, colscale);
 }
 
 // workgroups of the sweep: 4 per CU, at least ~8 row steps per wave

@@ -236,7 +236,7 @@ __device__ __forceinline__ void fdp_consumer(const JtjArgs<double>& a, const dou
             if constexpr ((FD || DIFF) && ROLE >= 2) {
                 // the Jacobian rows leave through roles 2 and 3 (column blocks c = ROLE (mod 2))
                 const size_t row = row0 + 4 * gi + q;
-                if (row < m) {
+                if (row < m && a.Jout) {                   // Jout == nullptr: the caller keeps the panel itself as J (unscaled)
                     T* wp = a.Jout + row * (size_t)a.n;    // the problem's n: row stride of J; padding columns stay in LDS
 #pragma unroll
                     for (int c = 0; c < NCB; ++c)

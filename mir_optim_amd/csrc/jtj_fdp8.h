@@ -101,7 +101,7 @@ __device__ __forceinline__ void jtj_fdp8_body(const JtjArgs<double>& a, double* 
                 v.x = (zc[i] || !rok) ? 0.0 : b[i].x * inv[i];
                 v.y = (inv1[i] == 0 || !rok) ? 0.0 : b[i].y * inv1[i];
                 *reinterpret_cast<fdp_v2d*>(slot + (C::RP * ROLE + prow[i]) * C::LDJ + 2 * pcol[i]) = v;
-                if (rok) __builtin_nontemporal_store(v, reinterpret_cast<fdp_v2d*>(a.Jout + row * (size_t)N + 2 * pcol[i]));
+                if (rok && a.Jout) __builtin_nontemporal_store(v, reinterpret_cast<fdp_v2d*>(a.Jout + row * (size_t)N + 2 * pcol[i]));   // nullptr: the panel stays J
             } else {
                 T d = b[i].x;                              // copy(mBuffer, Jj)       LS:1041
                 d += -1.0 * b[i].y;                        // axpy(-1, mBuffer, Jj)   LS:1045

@@ -318,6 +318,12 @@ struct Solver {
     // |J^T y|_inf in its prologue. sweep_tail / sumsq_tail (opt-in, MIR_LSQ_VARIANT_SWEEP_TAIL / SUMSQ_TAIL): "last workgroup
     // finishes" tails inside the Broyden sweep and the sum-of-squares sweep.
     bool merge_small = true, sweep_tail = false, sumsq_tail = false;
+    // The Jacobian the Broyden sweeps read: B.J, or -- MIR_LSQ_VARIANT_FD_PANEL_IS_J, after a refresh through the difference
+    // panel -- the PANEL ITSELF with the column widths twh (broyden_lr.h, LrArgs::colscale): the fused finite-difference kernel
+    // then does not write J at all (1 GB less HBM traffic per refresh at cfg 3); J is materialised only when the pending
+    // terms are folded into it.
+    const T* Jcur = nullptr;
+    const T* Jscale = nullptr;
     bool finish_pending = false;   // a Broyden sweep's reduced vector waits in B.lrvec for the solve kernel's prologue
     int finish_k = 0;              // ... with this many pending terms before it
     mir_lsq_stats stats_local{};      // the solve works on this image; stats_bytes of it go back to the caller's struct
@@ -486,6 +492,8 @@ struct Solver {
         y = B.y;
         mB = B.mB;
         fr = B.ytmp;
+        Jcur = B.J;
+        Jscale = nullptr;
         big_solve = n > (uint32_t)kSolveMaxN || (variant & MIR_LSQ_VARIANT_SOLVE_GENERIC) != 0;
         if (n > (uint32_t)kLrMaxN) lowrank = false;    // the read-only Broyden sweep keeps n <= 256; above, J is rewritten
         // opt-in (MIR_LSQ_VARIANT_PIPELINE): measured on one MI355X it does not pay -- cfg 3 7.08 ms per solve with it, 7.02
@@ -716,7 +724,9 @@ struct Solver {
             const uint64_t launches_before = tl_launches;
             struct Excl { Solver* s; uint64_t l0; ~Excl() { s->launches_excluded += tl_launches - l0; } } excl{this, launches_before};
             // fold the pending rank-one terms into J (the reference's successive `ger`s, LS:1006) ...
-            if (!ok(lr_flush<T>(B.J, U, B.lrD, lr_k, m, (int)n, ws->num_cu, stream), "broyden flush")) return false;
+            if (!ok(lr_flush<T>(B.J, U, B.lrD, lr_k, m, (int)n, ws->num_cu, stream, Jcur == B.J ? nullptr : Jcur, Jscale), "broyden flush")) return false;
+            Jcur = B.J;                          // J is materialised now
+            Jscale = nullptr;
             lr_k = 0;
             if (stats) stats->broyden_flushes++;
             // ... and resynchronise: J^T J and J^T y_old recomputed from the flushed J, as the reference's syrk / gemv do
@@ -733,7 +743,7 @@ struct Solver {
         // host-side bookkeeping (lr_k, statistics) is done when the round is committed (commit_spec_round)
         const int32_t* guard = spec_enqueue ? &B.st->spec_ok : nullptr;
         LrArgs<T> a{};
-        a.J = B.J; a.U = U; a.D = B.lrD; a.dx = B.dx_acc; a.dx_dot = &B.st->dx_dot; a.y = y_dev; a.y_old = yold_dev;
+        a.J = Jcur; a.colscale = Jscale; a.U = U; a.D = B.lrD; a.dx = B.dx_acc; a.dx_dot = &B.st->dx_dot; a.y = y_dev; a.y_old = yold_dev;
         a.partials = B.lrpart; a.m = m; a.n = (int)n; a.k = lr_k; a.guard = guard;
         const int nblk = lr_blocks(m, ws->num_cu), len = lr_len((int)n);
         if (sweep_tail) {
@@ -773,6 +783,10 @@ struct Solver {
         ev_end();
         return finish_products(direct);
     }
+    // MIR_LSQ_VARIANT_FD_PANEL_IS_J (opt-in): after a difference-panel refresh the panel stays the Jacobian (unscaled); the later
+    // readers -- the read-only Broyden sweep and the flush -- scale on the fly. Bit-identical; measured at cfg 3: the fused
+    // kernel 0.40 -> 0.37 ms without the 1 GB write, the four scaled sweeps 0.167 -> 0.182 ms each: a wash, so J is written.
+    bool panel_is_J() const { return lowrank && sizeof(T) == 8 && n % 2 == 0 && (variant & MIR_LSQ_VARIANT_FD_PANEL_IS_J) != 0; }
     // Single GPU: the slab reduction writes J^T J (both triangles) and J^T y itself (the solve kernel takes |J^T y|_inf); with a
     // communicator the packed buffer is all-reduced first and k_unpack_grad expands it
     bool unpack_in_reduce(bool fd) const { return merge_small && !comm && (fd || jtj_plain_unpacks(plan)); }
@@ -793,7 +807,7 @@ struct Solver {
     bool jacobian_products(bool broyden, const T* y_dev, const T* yold_dev)
     {
         if (broyden && lowrank) return broyden_lowrank(y_dev, yold_dev);
-        if (!broyden) lr_k = 0;                  // J was refreshed in full: nothing is pending any more
+        if (!broyden) { lr_k = 0; Jcur = B.J; Jscale = nullptr; }   // J was refreshed in full: nothing is pending any more
         JtjArgs<T> a{};
         a.J = B.J; a.Jout = B.J; a.y = y_dev; a.y_old = yold_dev; a.dx = B.dx_acc; a.dx_dot = &B.st->dx_dot;
         a.slabs = B.slabs; a.m = m; a.n = (int)n;
@@ -807,6 +821,7 @@ struct Solver {
             const bool diff = fd_fused == 2;
             fd_fused = 0;
             a.J = static_cast<const T*>(ws->ypanel); a.twh = B.twh;
+            if (diff && panel_is_J()) { a.Jout = nullptr; Jcur = static_cast<const T*>(ws->ypanel); Jscale = B.twh; }
             const bool direct = unpack_in_reduce(true);
             const JtjUnpack<T> u = direct ? unpack_target() : JtjUnpack<T>{};
             ev_begin(3);
@@ -842,6 +857,7 @@ struct Solver {
         size_t rows = (m + W - 1) / W;
         rows = (rows + 31) / 32 * 32;                    // whole 32-row stages of both kernels
         T* D = static_cast<T*>(ws->ypanel);
+        if (panel_is_J()) { Jcur = D; Jscale = B.twh; }
         ev_begin(3);
         // the side stream starts once the points X (k_fd_points) are there
         if (!ok(hipEventRecord(ws->win_event[W], stream), "event") || !ok(hipStreamWaitEvent(ws->side_stream, ws->win_event[W], 0), "wait")) return false;
@@ -853,7 +869,7 @@ struct Solver {
             fbdw(fbctx, m, n, 2 * (size_t)n, B.X, D, r0, rc, ws->side_stream);
             if (!ok(hipEventRecord(ws->win_event[k], ws->side_stream), "event") || !ok(hipStreamWaitEvent(stream, ws->win_event[k], 0), "wait")) return false;
             JtjArgs<T> a{};
-            a.J = D + r0 * n; a.Jout = B.J + r0 * n; a.y = y_dev + r0; a.y_old = a.y; a.dx = B.dx_acc; a.dx_dot = &B.st->dx_dot;
+            a.J = D + r0 * n; a.Jout = panel_is_J() ? nullptr : B.J + r0 * n; a.y = y_dev + r0; a.y_old = a.y; a.dx = B.dx_acc; a.dx_dot = &B.st->dx_dot;
             a.slabs = static_cast<T*>(ws->win_slabs) + (size_t)k * set; a.m = rc; a.n = (int)n; a.twh = B.twh;
             if (!ok(jtj_fdp_launch<T, false, true>(plan, a, stream), "fd window kernel")) return false;
             ++used;

@@ -87,6 +87,39 @@ def test_cfg5_full_size_4096_problems(oracle):
     assert gfail <= ofail and worse == 0
 
 
+def test_cfg5_exp3_every_problem_both_sides_solve_is_compared(oracle):
+    """EXP3_AFFINE, all 4096 problems, per problem (round-2 verdict, "what's weak" 2: the test above only looks at a 32-problem
+    sample). The model is ill-conditioned in fp32 -- the float oracle ends 72 % of the problems with numericError (the damped
+    Cholesky fails near the noise floor, LS:1080-1085), the wave kernel 7 % -- so the comparison runs over the problems BOTH
+    sides solve (about 1100). There, per problem: the objective agrees to 2e-2 (98 % to 3e-3), and the FITTED CURVES agree to
+    1e-3 = half the noise amplitude of the data (measured: <= 3.8e-4; scripts/cfg5_exp3_parity.py prints the distribution).
+    The parameters themselves are not comparable: three exponentials are not identifiable at this noise level (two runs
+    that reach the same curve differ by up to 0.6 relative in a rate)."""
+    count = 4096
+    t, data, truth, x0 = make_exp3(count)
+    res, x = M.optimizeLeastSquaresBatched(M.MODEL_EXP3_AFFINE, x0, t, data)
+    st = np.array([int(r.status) for r in res])
+    rg = np.array([r.residual for r in res])
+    so = np.empty(count, dtype=int); ro_res = np.empty(count); xo = np.empty_like(x)
+    with np.errstate(over="ignore", invalid="ignore"):
+        for k in range(count):
+            r, xk = oracle.optimize(oracle_f(M.MODEL_EXP3_AFFINE, t, data[k]), 512, x0[k], dtype=np.float32)
+            so[k], ro_res[k], xo[k] = r.status, r.residual, xk
+    both = (st >= 0) & (so >= 0)
+    assert both.sum() >= 800 and (st >= 0).sum() >= (so >= 0).sum()
+    ratio = rg[both] / ro_res[both]
+    assert np.all(np.abs(ratio - 1) <= 2e-2), (ratio.min(), ratio.max())
+    assert np.mean(np.abs(ratio - 1) <= 3e-3) >= 0.98
+    td = t.astype(np.float64)
+
+    def curve(p):
+        p = p.astype(np.float64)
+        return (p[:, 0:1] * np.exp(-td * p[:, 1:2]) + p[:, 2:3] * np.exp(-td * p[:, 3:4]) + p[:, 4:5] * np.exp(-td * p[:, 5:6])
+                + p[:, 6:7] + p[:, 7:8] * td)
+    cd = np.abs(curve(x[both]) - curve(xo[both])).max(axis=1)
+    assert cd.max() <= 1e-3 and np.median(cd) <= 1e-4, (cd.max(), np.median(cd))
+
+
 def oracle_eval(p, t, d):
     return p[0] * np.exp(-t * p[1]) + p[2] * np.exp(-t * p[3]) + p[4] * np.exp(-t * p[5]) + p[6] + p[7] * t - d
 

@@ -261,3 +261,27 @@ def test_two_stream_window_refresh_matches_the_one_sweep_refresh(m, n, windows):
     assert len(a) == len(b)
     for ra, rb in zip(a, b):
         assert ra[:2] == rb[:2] and np.allclose(ra[2:5], rb[2:5], rtol=1e-9, atol=1e-300) and np.isclose(ra[5], rb[5], rtol=1e-5)   # dx.dx of a 5e-6 step
+
+
+@pytest.mark.parametrize("m,n,tol,lrcap", [(60000, 128, 1e-9, 0), (30000, 256, 1e-9, 0), (40000, 64, 1e-12, 3), (20001, 34, 0.0, 2),
+                                           (25000, 192, 1e-9, 5)])
+def test_panel_kept_as_jacobian_is_bit_identical_to_writing_J(m, n, tol, lrcap):
+    """Round 3, MIR_LSQ_VARIANT_FD_PANEL_IS_J: after a difference-panel refresh the fused kernel does not write J -- the PANEL
+    stays the Jacobian, the Broyden sweeps (and the flush that folds the pending terms in) apply scal(1 / twh) (LS:1046-1047)
+    at load time: the same multiplication on the same operands, so every pass must be bit-identical to the default
+    (materialised J), including runs whose pending terms are flushed several times (small caps) and the long rejection tail."""
+    import mir_optim_amd as M
+    from mir_optim_amd import workloads as W
+    import problems as P
+    w = P.tanh_linear(m, n)
+    prob = W.TanhLinear(w["A"], w["b"])
+    s = M.LeastSquaresSettings(); s.absTolerance = tol
+    cap = M.variant_lr_cap(lrcap) if lrcap else 0
+    out = []
+    for v in (0, M.VARIANT_FD_PANEL_IS_J):
+        st, tr = M.Stats(), M.Trace(4096)
+        r, x = prob.solve(w["x0"], settings=s, batched=True, stats=st, trace=tr, variant=v | cap)
+        out.append(((int(r.status), r.iterations, r.fCalls, r.residual, r.lambda_, x.tobytes()), tr.records(), st))
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    if lrcap:
+        assert out[0][2].broyden_flushes >= 1 and out[0][2].broyden_flushes == out[1][2].broyden_flushes
