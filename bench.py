@@ -59,8 +59,11 @@ def pmc_field(kernel, m, n, field):
     if (m, n) != (1_000_000, 128) or f is None:
         return None
     try:
-        return json.load(open(f))["kernels"][kernel][field]
-    except (KeyError, ValueError):
+        ks = json.load(open(f))["kernels"]
+        if kernel not in ks:            # template arguments appended since (k_broyden_lr<double, 4, true> -> <..., true, false>)
+            kernel = next(k for k in ks if k.startswith(kernel[:-1] + ","))
+        return ks[kernel][field]
+    except (KeyError, ValueError, StopIteration):
         return None
 
 
@@ -191,13 +194,7 @@ def main_cfg5(args):
                    "fits_per_s": count / (ms * 1e-3), "iterations_per_fit": iters / count, "fcalls_per_fit": fcalls / count,
                    "status_counts": {str(int(k)): int(v) for k, v in zip(*np.unique(raw["status"], return_counts=True))},
                    "mean_residual": float(raw["residual"].mean()), "parallelism": "replicas only (independent problems)"},
-        "roofline": {"kernel": "mirlsq::k_lm_batched<2> (one wavefront per problem: J, y in the wave's LDS slice, FD + Broyden + J^T J + "
-                               "posvx + acceptance in registers; no barrier, no host round trip)",
-                     "bound": "valu", "achieved": evals / (ms * 1e-3) / 1e9, "peak": None, "unit": "G model evaluations/s (upper bound)",
-                     "frac": None, "avg_launch_ms": ms, "launches": args.steps,
-                     "traffic": None, "algorithmic_bytes_per_launch": float(count * (m * 4 + 2 * n * 4 + 24) + m * 4),
-                     "note": "neither HBM- nor MFMA-bound: 8.4 MB of inputs per launch (read once, < 1 % of the launch time at "
-                             "HBM rate); the time is exp/sin/cos evaluations and dependent per-wave chains (latency-bound)"},
+        "roofline": cfg5_roofline(ms, evals, args.steps, count, m, n),
     }
     if not args.no_cpu_baseline:
         from oracle import oracle as O
@@ -292,6 +289,40 @@ def main_cfg2(args):
                                "parity_residual_rel_diff": abs(res.residual - ro.residual) / abs(ro.residual)}
     api.lib().mir_lsq_workspace_destroy(ws)
     print(json.dumps(out), flush=True)
+
+
+def cfg5_roofline(ms, evals, steps, count, m, n):
+    """k_lm_batched is neither HBM- nor MFMA-bound (8.4 MB of inputs per launch): its bound is the VALU issue rate -- one wave64
+    instruction per 4 cycles per SIMD, 1024 SIMDs at 2.4 GHz = 614.4 G wave-instructions/s. `achieved` = the VALU instructions
+    one launch executes (SQ_INSTS_VALU of the committed rocprofv3 pass, profiles/r03/cfg5_pmc.json: the instruction count of a
+    launch does not depend on the box) over this run's launch time; `valu_busy_pmc` is the hardware's own figure
+    (4 x SQ_ACTIVE_INST_VALU over GRBM_GUI_ACTIVE x 1024 SIMDs) from the same pass."""
+    import glob
+    peak = 1024 * 2.4e9 / 4.0 / 1e9
+    pm = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "cfg5_pmc.json"))):
+        try:
+            pm = next(v for k, v in json.load(open(f))["kernels"].items() if "k_lm_batched" in k)
+            src = os.path.relpath(f, ROOT)
+        except (StopIteration, KeyError, ValueError):
+            pass
+    out = {"kernel": "mirlsq::k_lm_batched<2> (one wavefront per problem: J, y in the wave's LDS slice, FD + Broyden + J^T J + "
+                     "posvx + acceptance in registers; no barrier, no host round trip)",
+           "bound": "valu", "achieved": None, "peak": peak, "unit": "G wave64 VALU instructions/s", "frac": None,
+           "avg_launch_ms": ms, "launches": steps, "traffic": None,
+           "algorithmic_bytes_per_launch": float(count * (m * 4 + 2 * n * 4 + 24) + m * 4),
+           "model_evaluations_per_s_upper_bound": evals / (ms * 1e-3),
+           "note": "neither HBM- nor MFMA-bound: 8.4 MB of inputs per launch (< 1 % of the launch time at HBM rate). Two waves per "
+                   "SIMD (each problem's J, y, trial residual take 20 KB of LDS), dependent per-wave chains: the VALU pipes are busy "
+                   "40 % of the time, the rest is instruction latency that two waves cannot hide"}
+    if pm and pm.get("SQ_INSTS_VALU"):
+        out["achieved"] = pm["SQ_INSTS_VALU"] / (ms * 1e-3) / 1e9
+        out["frac"] = out["achieved"] / peak
+        out["valu_instructions_per_launch"] = pm["SQ_INSTS_VALU"]
+        out["transcendental_instructions_per_launch"] = pm.get("SQ_INSTS_VALU_TRANS_F32")
+        out["valu_busy_pmc"] = pm.get("valu_util")
+        out["counters_source"] = src + " (committed rocprofv3 --pmc passes of this command; not measured in this run)"
+    return out
 
 
 def describe_comm(api, comm):
@@ -528,11 +559,17 @@ def main():
             # read the panel (m x n differences, or m x 2n pairs) and y, write J
             fd_bytes = 8.0 * ((2.0 if diff_panel else 3.0) * m * n + m)
             fd_rate = fd_bytes / (fd_ms * 1e-3) / 1e9
+            fd_tf = (jtj_flops + 2.0 * m * n) / (fd_ms * 1e-3) / 1e12
+            # which roofline bounds it: n (n + 1) flop against 16 (or 24) bytes per row element -- at n = 128 the HBM time at
+            # 8 TB/s (0.26 ms) exceeds the MFMA time at 78.6 TF (0.21 ms), at n = 256 it is the other way round (0.51 vs 0.84 ms)
+            mfma_bound = (jtj_flops / (F64_MFMA_PEAK_TF * 1e12)) > (fd_bytes / (HBM_PEAK_GBS * 1e9))
             fresh = {
                 "kernel": fd_name + (" (finite-difference rows from the m x n DIFFERENCE panel" if diff_panel else
                                      " (finite-difference rows from the (+h, -h) pair panel")
                                   + " -> J, J^T J + J^T y on f64 MFMA 16x16x4, register-staged producer waves + MFMA consumer waves)",
-                "bound": "hbm", "achieved": fd_rate, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fd_rate / HBM_PEAK_GBS,
+                **({"bound": "mfma", "achieved": fd_tf, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": fd_tf / F64_MFMA_PEAK_TF,
+                    "hbm_GBs": fd_rate, "hbm_frac": fd_rate / HBM_PEAK_GBS} if mfma_bound else
+                   {"bound": "hbm", "achieved": fd_rate, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fd_rate / HBM_PEAK_GBS}),
                 "traffic": pmc_field(fd_name, m, n, "hbm_bytes_per_launch"), "traffic_source": traffic_source(m, n),
                 "algorithmic_bytes_per_launch": fd_bytes, "avg_launch_ms": fd_ms,
                 "launches": nfd, "mfma_tflops": (jtj_flops + 2.0 * m * n) / (fd_ms * 1e-3) / 1e12,

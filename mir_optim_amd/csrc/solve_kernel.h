@@ -122,6 +122,16 @@ __device__ inline int block_or(int v, int* red)
 #include "solve_lds.h"
 namespace mirlsq {
 
+// The out-of-line routines below receive generic pointers; dereferenced as such they become FLAT loads, which count on both
+// memory counters -- every "wait for my LDS operations" before a barrier then also waits for global loads that were issued
+// ahead on purpose. as_global / as_lds name the address space again (the callers only pass global scratch / __shared__ arrays).
+template <typename T> using gbl_cptr = const __attribute__((address_space(1))) T*;
+template <typename T> using gbl_ptr = __attribute__((address_space(1))) T*;
+template <typename T> using lds_ptr = __attribute__((address_space(3))) T*;
+template <typename T> __device__ __forceinline__ gbl_cptr<T> as_global(const T* p) { return (gbl_cptr<T>)p; }
+template <typename T> __device__ __forceinline__ gbl_ptr<T> as_global_w(T* p) { return (gbl_ptr<T>)p; }
+template <typename T> __device__ __forceinline__ lds_ptr<T> as_lds(T* p) { return (lds_ptr<T>)p; }
+
 // ---------------------------------------------------------------- generic path helpers (factor in global memory)
 // Inverses of the 16 x 16 diagonal blocks of L (lower triangular), one thread per (block, column):
 // column c of inv(L_kk) is the forward substitution L_kk x = e_c. Dinv block k at Dinv + k * 272,
@@ -170,9 +180,12 @@ __device__ __forceinline__ void invert_diag_blocks(int n, const T* F, int ldf, T
 // unrolled code that box_qp_device would otherwise instantiate four times per kernel; as out-of-line functions their
 // pointer arguments are generic (flat loads), which this path can afford.
 template <typename T>
-__device__ __noinline__ int potrf_panel(int n, const T* A, int lda, T* F, int ldf, T* blk, T* rd, int* info_s, T* spanel)
+__device__ __noinline__ int potrf_panel(int n, const T* A_, int lda, T* F_, int ldf, T* blk_, T* rd_, int* info_s, T* spanel_)
 {
     using Acc = typename Mma<T>::Acc;
+    const gbl_cptr<T> A = as_global(A_);
+    const gbl_ptr<T> F = as_global_w(F_);
+    const lds_ptr<T> blk = as_lds(blk_), rd = as_lds(rd_), spanel = as_lds(spanel_);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = tid;
     const int nblk = (n + 15) / 16;
@@ -181,14 +194,27 @@ __device__ __noinline__ int potrf_panel(int n, const T* A, int lda, T* F, int ld
     __syncthreads();
     for (int k = 0; k < nblk; ++k) {
         const int c0 = 16 * k;
-        // ---- 1. S for this wave's row blocks rb = 4 wave + u that reach into the panel (rb >= k)
-        if (k > 0 && 4 * wave + 3 >= k) {
+        // the panel's entries of A (row i, 16 columns) do not depend on step 1: their loads fly while the matrix cores work
+        const int ic = i < n ? i : n - 1;
+        T pa[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) pa[c] = A[ic + (size_t)(c0 + c < n ? c0 + c : n - 1) * lda];
+        // ---- 1. S for this wave's row blocks rb = wave + 4 u that reach into the panel (rb >= k). Dealt CYCLICALLY: the
+        //      blocks below the panel are the ones that have work, and with contiguous blocks per wave the last wave carried
+        //      16 k MFMAs per panel while the first had none (51 us of a 220 us factorisation on one SIMD)
+        if (k > 0) {
             Acc acc[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc[u] = Acc{0, 0, 0, 0};
             int rowa[4];
+            bool live[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int r = 64 * wave + 16 * u + lr; rowa[u] = r < n ? r : n - 1; }
+            for (int u = 0; u < 4; ++u) {
+                const int rb = wave + 4 * u;
+                const int r = 16 * rb + lr;
+                rowa[u] = r < n ? r : n - 1;
+                live[u] = rb >= k && 16 * rb < n;               // wave-uniform
+            }
             const int rowb = c0 + lr < n ? c0 + lr : n - 1;
             T fa[2][4][4], fb[2][4];                            // [buffer][k-step][row block]
             auto load = [&](int j, int buf) {
@@ -197,39 +223,41 @@ __device__ __noinline__ int potrf_panel(int n, const T* A, int lda, T* F, int ld
                     const size_t col = (size_t)(16 * j + 4 * s4 + lk) * ldf;
                     fb[buf][s4] = F[rowb + col];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) fa[buf][s4][u] = F[rowa[u] + col];
+                    for (int u = 0; u < 4; ++u) if (live[u]) fa[buf][s4][u] = F[rowa[u] + col];
                 }
             };
-            load(0, 0);
-            for (int j = 0; j < k; j += 2) {
-                if (j + 1 < k) load(j + 1, 1);
+            auto mmas = [&](int buf) {
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) acc[u] = Mma<T>::mma(fa[0][s4][u], fb[0][s4], acc[u]);
-                if (j + 1 < k) {
-                    if (j + 2 < k) load(j + 2, 0);
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) acc[u] = Mma<T>::mma(fa[1][s4][u], fb[1][s4], acc[u]);
+                    for (int u = 0; u < 4; ++u) if (live[u]) acc[u] = Mma<T>::mma(fa[buf][s4][u], fb[buf][s4], acc[u]);
+            };
+            if (live[0] || live[1] || live[2] || live[3]) {
+                load(0, 0);
+                for (int j = 0; j < k; j += 2) {
+                    if (j + 1 < k) load(j + 1, 1);
+                    mmas(0);
+                    if (j + 1 < k) {
+                        if (j + 2 < k) load(j + 2, 0);
+                        mmas(1);
+                    }
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (live[u]) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            spanel[(16 * (wave + 4 * u) + Mma<T>::row(lane, r)) * 17 + lr] = acc[u][r];   // D: row, col = lane & 15
+                    }
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    spanel[(64 * wave + 16 * u + Mma<T>::row(lane, r)) * 17 + lr] = acc[u][r];   // D: row, col = lane & 15
         }
         __syncthreads();
         // ---- 2. row per thread
         const bool active = i < n && i >= c0;
-        const int ic = i < n ? i : n - 1;
         T p[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-            const int col = c0 + c < n ? c0 + c : n - 1;
-            const T v = A[ic + (size_t)col * lda];
+            const T v = pa[c];
             const T sv = k > 0 ? spanel[i * 17 + c] : T(0);
             p[c] = (active && c0 + c < n) ? v - sv : ((i == c0 + c) ? T(1) : T(0));   // identity padding past n
         }
@@ -289,19 +317,36 @@ __device__ __noinline__ void invert_diag_blocks_generic(int n, const T* F, int l
 // the solution, so their loads (global, L2) are issued before the barrier. Replaces the one-wave blocked solve here
 // (105 us per call at n = 256: 32 dependent block steps, each a round trip to L2).
 template <typename T>
-__device__ __noinline__ void potrs_rows(int n, const T* F, int ldf, const T* Dinv, T* xv, T* xk)
+__device__ __noinline__ void potrs_rows(int n, const T* F_, int ldf, const T* Dinv_, T* xv_, T* xk_)
 {
+    const gbl_cptr<T> F = as_global(F_);
+    const lds_ptr<T> Dinv = as_lds(const_cast<T*>(Dinv_)), xk = as_lds(xk_);
+    const gbl_ptr<T> xv = as_global_w(xv_);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = tid, ic = i < n ? i : n - 1;
     const int nb = (n + 15) / 16;
     __syncthreads();
     T z = i < n ? xv[i] : T(0);
+    // The factor entries a row needs in block step kb do not depend on the solution: the loads of step kb + 1 are issued
+    // before step kb's barrier, so a step costs the diagonal solve + one barrier instead of an L2 round trip (45 -> ~15 us
+    // per call at n = 256).
+    T lnext[16];
+    auto load_row = [&](int kb) {                              // L[i][16 kb .. 16 kb + 15]
+#pragma unroll
+        for (int c = 0; c < 16; ++c) lnext[c] = F[ic + (size_t)(16 * kb + c < n ? 16 * kb + c : n - 1) * ldf];
+    };
+    auto load_col = [&](int kb) {                              // L[16 kb .. 16 kb + 15][i]
+#pragma unroll
+        for (int c = 0; c < 16; ++c) lnext[c] = F[(16 * kb + c < n ? 16 * kb + c : n - 1) + (size_t)ic * ldf];
+    };
     // ---- forward: L z = b
+    load_row(0);
     for (int kb = 0; kb < nb; ++kb) {
         const int c0 = 16 * kb;
         T lrow[16];                                             // L[i][c0 .. c0 + 15], needed when i >= c0 + 16
 #pragma unroll
-        for (int c = 0; c < 16; ++c) lrow[c] = F[ic + (size_t)(c0 + c < n ? c0 + c : n - 1) * ldf];
+        for (int c = 0; c < 16; ++c) lrow[c] = lnext[c];
+        if (kb + 1 < nb) load_row(kb + 1); else load_col(nb - 1);
         if (wave == (c0 >> 6)) {
             const int l0 = c0 & 63, r = (lane - l0) & 15;
             T xn = 0;
@@ -322,7 +367,8 @@ __device__ __noinline__ void potrs_rows(int n, const T* F, int ldf, const T* Din
         const int c0 = 16 * kb;
         T lcol[16];                                             // L[c0 .. c0 + 15][i], needed when i < c0
 #pragma unroll
-        for (int c = 0; c < 16; ++c) lcol[c] = F[(c0 + c < n ? c0 + c : n - 1) + (size_t)ic * ldf];
+        for (int c = 0; c < 16; ++c) lcol[c] = lnext[c];
+        if (kb > 0) load_col(kb - 1);
         if (wave == (c0 >> 6)) {
             const int l0 = c0 & 63, r = (lane - l0) & 15;
             T xn = 0;
@@ -778,17 +824,45 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
         T* __restrict__ dp = sc.Pm;
         T* __restrict__ da = sc.A;
         const int nn = n * n;
-        for (int base = tid; base < nn; base += 16 * kSolveThreads) {
-            T v[16];
+        // Pm is what the BOXCQP loop reads: an unbounded problem (BOUNDED = false) never gets there
+        constexpr bool kNeedPm = BOUNDED;
+        if (nn % 2 == 0) {
+            // 16-byte accesses, 16 in flight per thread: one workgroup has to move 3 n^2 elements here (60 us at n = 256 with
+            // 8-byte accesses and both copies)
+            typedef T v2 __attribute__((ext_vector_type(2)));
+            const v2* __restrict__ s2 = reinterpret_cast<const v2*>(src);
+            v2* __restrict__ p2 = reinterpret_cast<v2*>(dp);
+            v2* __restrict__ a2 = reinterpret_cast<v2*>(da);
+            const int np = nn / 2;
+            for (int base = tid; base < np; base += 16 * kSolveThreads) {
+                v2 v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) { const int idx = base + u * kSolveThreads; v[u] = src[idx < nn ? idx : nn - 1]; }
+                for (int u = 0; u < 16; ++u) { const int idx = base + u * kSolveThreads; v[u] = s2[idx < np ? idx : np - 1]; }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int idx = base + u * kSolveThreads;
-                if (idx < nn) {
-                    const T t = (idx % (n + 1) == 0) ? v[u] + lambda : v[u];
-                    dp[idx] = t;
-                    da[idx] = t;
+                for (int u = 0; u < 16; ++u) {
+                    const int idx = base + u * kSolveThreads;
+                    if (idx < np) {
+                        v2 t = v[u];
+                        if ((2 * idx) % (n + 1) == 0) t.x += lambda;
+                        if ((2 * idx + 1) % (n + 1) == 0) t.y += lambda;
+                        if constexpr (kNeedPm) p2[idx] = t;
+                        a2[idx] = t;
+                    }
+                }
+            }
+        } else {
+            for (int base = tid; base < nn; base += 16 * kSolveThreads) {
+                T v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { const int idx = base + u * kSolveThreads; v[u] = src[idx < nn ? idx : nn - 1]; }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int idx = base + u * kSolveThreads;
+                    if (idx < nn) {
+                        const T t = (idx % (n + 1) == 0) ? v[u] + lambda : v[u];
+                        if constexpr (kNeedPm) dp[idx] = t;
+                        da[idx] = t;
+                    }
                 }
             }
         }
