@@ -16,6 +16,7 @@
 #include "jtj_fdp.h"
 #include "jtj_fdp8.h"
 #include "jtj_kernel.h"
+#include "jtj_pc32.h"
 #include "jtj_ring8.h"
 #include "jtj_wide.h"
 
@@ -60,6 +61,8 @@ struct JtjPlan {
     bool fdp_plain = false; // ... and, n even, for the plain J^T J
     bool fdp8 = false;      // f64, 128 < n <= 256, n % 32 == 0, any m: eight producer + consumer waves (jtj_fdp8.h), FD J^T J only
     int fdp8_nblk = 0, fdp8_slab_len = 0;
+    bool pc32 = false;      // f32, n <= 128, n % 4 == 0, any m: producer / consumer kernel on v_mfma_f32_16x16x4 (jtj_pc32.h), plain J^T J
+    int pc32_nblk = 0;
     int njobs = 1;
 };
 
@@ -131,6 +134,13 @@ JtjPlan jtj_plan(size_t m, int n, int num_cu, uint32_t variant = 0)
         if (cap < 1) cap = 1;
         p.nblk = (int)(want < cap ? (want ? want : 1) : cap);
         return p;
+    }
+    if (sizeof(T) == 4 && n <= 128 && n % 4 == 0 && !stream) {
+        p.pc32 = true;
+        const size_t stot = (m + 63) / 64;                     // 64-row stages
+        const size_t want = (stot + 3) / 4;                    // at least ~4 stages per workgroup
+        const size_t cap = (size_t)num_cu * 2;
+        p.pc32_nblk = (int)(want < cap ? (want ? want : 1) : cap);
     }
     p.fdp = sizeof(T) == 8 && n <= 128 && !stream;
     p.fdp_plain = p.fdp && n % 2 == 0;
@@ -225,6 +235,33 @@ hipError_t jtj_fdp_launch(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
     return hipErrorInvalidValue;
 }
 
+// ---- k_jtj_pc32: the f32 producer / consumer kernel (jtj_pc32.h)
+template <int NCB>
+hipError_t jtj_pc32_one(const JtjPlan& p, const JtjArgs<float>& a, hipStream_t s)
+{
+    using C = JtjPc32Cfg<NCB>;
+    MIRLSQ_ENSURE_LDS((k_jtj_pc32<NCB>), (size_t)C::LDS_BYTES);
+    MIRLSQ_LAUNCH((k_jtj_pc32<NCB>), dim3(p.pc32_nblk), dim3(C::THREADS), C::LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+template <typename T>
+hipError_t jtj_pc32_launch(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
+{
+    if constexpr (sizeof(T) == 4) {
+        switch (p.ncb) {
+        case 1: return jtj_pc32_one<1>(p, a, s);
+        case 2: return jtj_pc32_one<2>(p, a, s);
+        case 3: return jtj_pc32_one<3>(p, a, s);
+        case 4: return jtj_pc32_one<4>(p, a, s);
+        case 5: return jtj_pc32_one<5>(p, a, s);
+        case 6: return jtj_pc32_one<6>(p, a, s);
+        case 7: return jtj_pc32_one<7>(p, a, s);
+        case 8: return jtj_pc32_one<8>(p, a, s);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
 // ---- k_jtj2: LDS-DMA ring; BR = Broyden update fused in, J rewritten (the literal restatement of LS:1003-1006)
 template <int NCB, bool BR>
 hipError_t jtj2_one(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t s)
@@ -309,6 +346,11 @@ hipError_t jtj_run(const JtjPlan& p, const JtjArgs<T>& a, bool broyden, T* packe
                    const JtjUnpack<T>& u = {})
 {
     hipError_t e;
+    if (p.pc32 && !broyden) {
+        e = jtj_pc32_launch<T>(p, a, s);
+        if (e != hipSuccess) return e;
+        return jtj_reduce_slabs<T>(p, a, packed, s, u, p.pc32_nblk, p.slab_len);
+    }
     if (p.ring8) e = jtj8_launch<T>(p, a, broyden, s);
     else if (p.wide) return jtj_run_wide<T>(p, a, broyden, packed, s);
     else if (broyden) e = p.v2 ? jtj2_launch<T, true>(p, a, s) : jtj_stream<T, true>(p, a, s);

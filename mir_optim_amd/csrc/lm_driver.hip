@@ -152,8 +152,10 @@ size_t slab_elems(size_t m, size_t n, int num_cu)
     const JtjPlan a = jtj_plan<T>(m, (int)n, num_cu, 0), b = jtj_plan<T>(m, (int)n, num_cu, MIR_LSQ_VARIANT_JTJ_STREAM);
     const size_t ea = (size_t)a.nblk * a.njobs * a.slab_len, eb = (size_t)b.nblk * b.njobs * b.slab_len;
     const size_t ec = (size_t)a.fdp8_nblk * a.fdp8_slab_len;
-    const size_t e = ea > eb ? ea : eb;
-    return e > ec ? e : ec;
+    const size_t ed = (size_t)a.pc32_nblk * a.slab_len;
+    size_t e = ea > eb ? ea : eb;
+    e = e > ec ? e : ec;
+    return e > ed ? e : ed;
 }
 
 template <typename T>
@@ -1725,7 +1727,9 @@ int jtj_entry(size_t m, size_t n, T* J, const T* y, const T* y_old, const T* dx,
     const size_t packed_len = n * (n + 1) / 2 + n + 8;
     T *slabs = nullptr, *packed = nullptr, *dxdot = nullptr;
     LmState<T>* st = nullptr;
-    if (hipMalloc((void**)&slabs, sizeof(T) * (size_t)plan.nblk * plan.njobs * plan.slab_len) != hipSuccess) return -3;
+    size_t slab_count = (size_t)plan.nblk * plan.njobs * plan.slab_len;
+    if ((size_t)plan.pc32_nblk * plan.slab_len > slab_count) slab_count = (size_t)plan.pc32_nblk * plan.slab_len;
+    if (hipMalloc((void**)&slabs, sizeof(T) * slab_count) != hipSuccess) return -3;
     if (hipMalloc((void**)&packed, sizeof(T) * packed_len) != hipSuccess) { (void)hipFree(slabs); return -3; }
     if (hipMalloc((void**)&st, sizeof(LmState<T>) + sizeof(T) * 8) != hipSuccess) { (void)hipFree(slabs); (void)hipFree(packed); return -3; }
     dxdot = reinterpret_cast<T*>(st + 1);

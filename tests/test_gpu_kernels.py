@@ -107,6 +107,32 @@ def test_jtj_float32():
     assert np.array_equal(JJ, Ji.T @ Ji) and np.array_equal(Jy, Ji.T @ yi)
 
 
+@pytest.mark.parametrize("m,n", [(70001, 128), (64, 4), (63, 8), (5000, 100), (20000, 36), (4097, 64), (1, 16), (300000, 128),
+                                 (9000, 126), (9000, 33)])
+def test_jtj_float32_producer_consumer_kernel(m, n):
+    """k_jtj_pc32 (jtj_pc32.h, round 3): the f32 J^T J on v_mfma_f32_16x16x4 with producer / consumer waves, n % 4 == 0; the
+    other n (126, 33) still take the register-streaming kernel. Small integers: every partial sum is exact in f32, so the result
+    is bit-exact; random data: against float64 numpy at the f32 summation tolerance; and symmetric, J untouched."""
+    rng = np.random.default_rng(m + n)
+    Ji = rng.integers(-3, 4, size=(m, n)).astype(np.float32)
+    Ji[:, 0] = (np.arange(m) % 5 - 2).astype(np.float32)        # asymmetric column: catches a transposed accumulator map
+    yi = rng.integers(-3, 4, size=m).astype(np.float32)
+    JJ, Jy, J_after, _ = M.jtj(Ji, yi, dtype=np.float32)
+    ref = Ji.astype(np.float64).T @ Ji.astype(np.float64)
+    if np.abs(ref).max() < 2 ** 24:                                 # every partial sum representable
+        assert np.array_equal(JJ, ref.astype(np.float32)) and np.array_equal(Jy, (Ji.astype(np.float64).T @ yi).astype(np.float32))
+    assert np.array_equal(J_after, Ji) and np.array_equal(JJ, JJ.T)
+    J = rng.standard_normal((m, n)).astype(np.float32)
+    y = rng.standard_normal(m).astype(np.float32)
+    JJ, Jy, _, _ = M.jtj(J, y, dtype=np.float32)
+    JJr = J.astype(np.float64).T @ J.astype(np.float64)
+    Jyr = J.astype(np.float64).T @ y.astype(np.float64)
+    scale = np.sqrt(np.outer(np.diag(JJr), np.diag(JJr)))
+    assert np.max(np.abs(JJ - JJr) / scale) < 3e-6                  # ~ sqrt(m) eps_f32 relative to ||col_i|| ||col_j||
+    assert np.max(np.abs(Jy - Jyr)) < 3e-6 * np.sqrt(m) * np.linalg.norm(J.astype(np.float64), axis=0).max() * np.abs(y).max() + 1e-6
+    assert np.array_equal(JJ, JJ.T)
+
+
 @pytest.mark.parametrize("m", [100003, 100000])     # odd m: register-streaming kernel; even m: LDS-DMA ring kernel
 def test_jtj_determinism(m):
     rng = np.random.default_rng(1)
