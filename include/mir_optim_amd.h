@@ -204,10 +204,12 @@ enum {
     MIR_LSQ_VARIANT_SOLVE_GENERIC = 1u << 10,    /* the any-n solve path (biglinalg.h) also for n <= 256 */
     MIR_LSQ_VARIANT_PIPELINE = 1u << 11,         /* enqueue the library part of the next Broyden round behind a device-side
                                                     guard before the current decision is known (bit-identical results;
-                                                    measured: no gain on one GPU, so it is not the default) */
+                                                    measured: no gain at cfg 3, 3 % at cfg 2 -- on by default only for small
+                                                    problems, J up to 32 MB; this bit forces it for any size) */
     MIR_LSQ_VARIANT_NO_TAIL_FUSION = 1u << 12,   /* round 2's launch sequence: k_lr_finish and k_unpack_grad as kernels of
                                                     their own instead of inside the solve kernel's prologue / the slab
                                                     reduction; bit-identical results */
+    MIR_LSQ_VARIANT_NO_PIPELINE = 1u << 22,      /* never enqueue a round ahead of time (small problems -- J up to 32 MB -- do by default) */
     MIR_LSQ_VARIANT_FD_PANEL_IS_J = 1u << 21,    /* after a difference-panel refresh keep the panel as J (the fused kernel does not
                                                     write J; the Broyden sweep and the flush apply scal(1 / twh) at load time)
                                                     instead of materialising J: bit-identical, 8 m n fewer bytes per refresh,

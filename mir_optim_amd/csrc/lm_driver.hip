@@ -500,7 +500,12 @@ struct Solver {
         if (n > (uint32_t)kLrMaxN) lowrank = false;    // the read-only Broyden sweep keeps n <= 256; above, J is rewritten
         // opt-in (MIR_LSQ_VARIANT_PIPELINE): measured on one MI355X it does not pay -- cfg 3 7.08 ms per solve with it, 7.02
         // without; cfg 2 2.92 against 3.00 ms (scripts/ab_bench.sh) -- the stream is already busy > 97 % of a solve
-        pipeline = device_cb && lowrank && !big_solve && !trace && !dbg_solve && (variant & MIR_LSQ_VARIANT_PIPELINE)
+        // ... except for SMALL problems (J up to 32 MB: every kernel of a round is a few microseconds and the host's decision
+        // latency is a visible share of it): cfg 2 63.5 -> 61.8 us per round, so those pipeline by default
+        // (MIR_LSQ_VARIANT_NO_PIPELINE turns it off); at a strong-scaled rank's 125 000 x 128 it changes nothing (2.72 ms either way)
+        const bool small_problem = (double)m * (double)n * sizeof(T) <= 32.0 * 1024 * 1024;
+        pipeline = device_cb && lowrank && !big_solve && !trace && !dbg_solve
+            && ((variant & MIR_LSQ_VARIANT_PIPELINE) || (small_problem && !(variant & MIR_LSQ_VARIANT_NO_PIPELINE)))
             && (!comm || comm->kind == 1);      // host-mediated communicators synchronise the stream inside every exchange
         solve_nb_ = solve_nb((int)n, (int)sizeof(T));
         f_in_lds = solve_nb_ > 0;
@@ -1387,6 +1392,8 @@ struct Solver {
                 if (hipMemcpy(h, B.sc[0].dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
                     std::fprintf(stderr, "[solve dbg] (10ns ticks) build %lld  copy/equil %lld  scale %lld  potrf %lld  potrs %lld  refine %lld  epilogue %lld  total %lld  shader MHz %.0f  [matvec1 %lld berr %lld]\n",
                                  h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[8] - h[7], h[8] - h[0], (double)(h[10] - h[9]) / (double)(h[8] - h[0]) * 100.0, h[11] - h[5], h[12] - h[11]);
+                    if (n > 128 && n <= (uint32_t)kSolveMaxN)
+                        std::fprintf(stderr, "[solve dbg] potrf_panel steps (10ns ticks, summed over the panels): earlier panels on MFMA %lld  diagonal rows %lld  other rows + store %lld\n", h[16], h[17], h[18]);
                 }
             }
 

@@ -180,7 +180,8 @@ __device__ __forceinline__ void invert_diag_blocks(int n, const T* F, int ldf, T
 // unrolled code that box_qp_device would otherwise instantiate four times per kernel; as out-of-line functions their
 // pointer arguments are generic (flat loads), which this path can afford.
 template <typename T>
-__device__ __noinline__ int potrf_panel(int n, const T* A_, int lda, T* F_, int ldf, T* blk_, T* rd_, int* info_s, T* spanel_)
+__device__ __noinline__ int potrf_panel(int n, const T* A_, int lda, T* F_, int ldf, T* blk_, T* rd_, int* info_s, T* spanel_,
+                                        long long* dbg = nullptr)
 {
     using Acc = typename Mma<T>::Acc;
     const gbl_cptr<T> A = as_global(A_);
@@ -192,8 +193,10 @@ __device__ __noinline__ int potrf_panel(int n, const T* A_, int lda, T* F_, int 
     const int lr = lane & 15, lk = lane >> 4;
     if (tid == 0) *info_s = 0;
     __syncthreads();
+    long long ph[4] = {0, 0, 0, 0};       // DEBUG_SOLVE: time in steps 1, 2, 3 summed over the panels (thread 0)
     for (int k = 0; k < nblk; ++k) {
         const int c0 = 16 * k;
+        if (dbg && tid == 0) ph[3] = wall_clock64();
         // the panel's entries of A (row i, 16 columns) do not depend on step 1: their loads fly while the matrix cores work
         const int ic = i < n ? i : n - 1;
         T pa[16];
@@ -252,6 +255,7 @@ __device__ __noinline__ int potrf_panel(int n, const T* A_, int lda, T* F_, int 
             }
         }
         __syncthreads();
+        if (dbg && tid == 0) { const long long t = wall_clock64(); ph[0] += t - ph[3]; ph[3] = t; }
         // ---- 2. row per thread
         const bool active = i < n && i >= c0;
         T p[16];
@@ -286,6 +290,7 @@ __device__ __noinline__ int potrf_panel(int n, const T* A_, int lda, T* F_, int 
             if (bad != 0 && lane == 0) *info_s = bad;
         }
         __syncthreads();
+        if (dbg && tid == 0) { const long long t = wall_clock64(); ph[1] += t - ph[3]; ph[3] = t; }
         const int info = *info_s;
         if (info != 0) return info;                             // uniform
         // ---- 3. the other rows against L_kk, store
@@ -305,7 +310,9 @@ __device__ __noinline__ int potrf_panel(int n, const T* A_, int lda, T* F_, int 
                 if (c0 + c < n && i >= c0 + c) F[i + (size_t)(c0 + c) * ldf] = p[c];
         }
         __syncthreads();                                        // the panel is visible to the later ones; blk / rd / spanel reusable
+        if (dbg && tid == 0) { const long long t = wall_clock64(); ph[2] += t - ph[3]; }
     }
+    if (dbg && tid == 0) { dbg[16] = ph[0]; dbg[17] = ph[1]; dbg[18] = ph[2]; }
     return 0;
 }
 
@@ -436,7 +443,7 @@ __device__ __forceinline__ int posvx_device(int n, T* A, int lda, T* F, int ldf,
     // ?lacpy + ?potrf 'L'
     {
         // factor in global memory, left-looking panels (potrf_panel) + the blocked triangular solves
-        const int info = potrf_panel<T>(n, A, lda, F, ldf, gblk, grd, ginfo, gpanel);
+        const int info = potrf_panel<T>(n, A, lda, F, ldf, gblk, grd, ginfo, gpanel, dbg);
         if (info != 0) return info;
         invert_diag_blocks_generic<T>(n, F, ldf, gDinv);
     }

@@ -526,7 +526,7 @@ def test_rounds_enqueued_ahead_of_time_change_nothing(m, n, bounded):
     for tol in (1e-5, 1e-12):
         s = M.LeastSquaresSettings(); s.absTolerance = tol
         out = []
-        for variant in (M.VARIANT_PIPELINE, 0):
+        for variant in (M.VARIANT_PIPELINE, M.VARIANT_NO_PIPELINE):
             st = M.Stats()
             r, x = prob.solve(x0, l=lo, u=up, settings=s, batched=True, stats=st, flags=M.TIME_KERNELS, variant=variant)
             out.append((r, x, st))
