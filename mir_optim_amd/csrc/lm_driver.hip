@@ -511,8 +511,8 @@ struct Solver {
         f_in_lds = solve_nb_ > 0;
         solve_lds = solve_lds_bytes((int)n, (int)sizeof(T));
         twh_h.resize(n);
-        // arrival counters of the fused tails: every tail leaves its counter at zero, but a solve that died half way may not have
-        if (!ok(hipMemsetAsync(B.counters, 0, kCounters * sizeof(uint32_t), stream), "memset counters")) return false;
+        // arrival counters of the opt-in tails: every tail leaves its counter at zero, but a solve that died half way may not have
+        if ((sweep_tail || sumsq_tail) && !ok(hipMemsetAsync(B.counters, 0, kCounters * sizeof(uint32_t), stream), "memset counters")) return false;
         // x, lower, upper sit back to back in the workspace: one copy from the pinned block instead of three from pageable
         // memory (each of those is a staged blit kernel, ~18 us apart on the stream)
         {

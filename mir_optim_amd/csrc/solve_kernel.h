@@ -265,36 +265,43 @@ __device__ __noinline__ int potrf_panel(int n, const T* A_, int lda, T* F_, int 
             const T sv = k > 0 ? spanel[i * 17 + c] : T(0);
             p[c] = (active && c0 + c < n) ? v - sv : ((i == c0 + c) ? T(1) : T(0));   // identity padding past n
         }
-        // the diagonal rows c0 .. c0 + 15 are lanes l0 .. l0 + 15 of wave wd
+        // the diagonal rows c0 .. c0 + 15 are lanes l0 .. l0 + 15 of wave wd: ONE DPP row (c0 is a multiple of 16). They factor
+        // the block among themselves with row_newbcast moves (VALU; v_readlane with a run-time lane cost an SGPR round trip per
+        // pivot and per multiplier: 4.9 us per panel); the other three rows of that wave execute the same instructions on
+        // values nobody uses and take step 3 like every other row.
         const int wd = c0 >> 6, l0 = c0 & 63;
+        const bool own = wave == wd && lane >= l0 && lane < l0 + 16;
         if (wave == wd) {
+            const int il = lane & 15;
             int bad = 0;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const T piv = lane_bcast(p[c], l0 + c);
+            static_for<16>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                const T piv = dpp_row_bcast<c>(p[c]);
                 if (!(piv > 0)) { if (c0 + c < n && bad == 0) bad = c0 + c + 1; }
                 T rinv, d;
                 rsqrt_sqrt(piv > 0 ? piv : T(1), rinv, d);
-                if (i > c0 + c) p[c] *= rinv; else if (i == c0 + c) p[c] = d;
-                if (lane == l0 + c) rd[c] = rinv;
+                if (own) { if (il > c) p[c] *= rinv; else if (il == c) p[c] = d; }
+                if (own && il == c) rd[c] = rinv;
+                static_for<16>([&](auto c2c) {
+                    constexpr int c2 = decltype(c2c)::value;
+                    if constexpr (c2 > c) {
+                        const T lc = dpp_row_bcast<c2>(p[c]);    // L[c0 + c2][c0 + c]
+                        if (own && il > c) p[c2] -= p[c] * lc;
+                    }
+                });
+            });
+            if (own) {
 #pragma unroll
-                for (int c2 = c + 1; c2 < 16; ++c2) {
-                    const T lc = lane_bcast(p[c], l0 + c2);      // L[c0 + c2][c0 + c]
-                    if (i > c0 + c) p[c2] -= p[c] * lc;
-                }
+                for (int c = 0; c < 16; ++c) blk[il * 17 + c] = p[c];
             }
-            if (lane >= l0 && lane < l0 + 16) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) blk[(lane - l0) * 17 + c] = p[c];
-            }
-            if (bad != 0 && lane == 0) *info_s = bad;
+            if (bad != 0 && lane == l0) *info_s = bad;
         }
         __syncthreads();
         if (dbg && tid == 0) { const long long t = wall_clock64(); ph[1] += t - ph[3]; ph[3] = t; }
         const int info = *info_s;
         if (info != 0) return info;                             // uniform
         // ---- 3. the other rows against L_kk, store
-        if (wave != wd && active) {
+        if (!own && active) {
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 T v = p[c];
@@ -355,10 +362,14 @@ __device__ __noinline__ void potrs_rows(int n, const T* F_, int ldf, const T* Di
         for (int c = 0; c < 16; ++c) lrow[c] = lnext[c];
         if (kb + 1 < nb) load_row(kb + 1); else load_col(nb - 1);
         if (wave == (c0 >> 6)) {
-            const int l0 = c0 & 63, r = (lane - l0) & 15;
-            T xn = 0;
+            // the 16 owners are one DPP row of the wave (c0 is a multiple of 16): the broadcasts of z are row_newbcast moves on
+            // the VALU (no SGPR round trip per term as with v_readlane), the 16 coefficients are loaded in one batch
+            const int l0 = c0 & 63, r = lane & 15;
+            T dv[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) xn += Dinv[kb * 272 + r + 17 * c] * lane_bcast(z, l0 + c);   // entries above the diagonal are 0
+            for (int c = 0; c < 16; ++c) dv[c] = Dinv[kb * 272 + r + 17 * c];                         // entries above the diagonal are 0
+            T xn = 0;
+            static_for<16>([&](auto cc) { constexpr int c = decltype(cc)::value; xn += dv[c] * dpp_row_bcast<c>(z); });
             if (lane >= l0 && lane < l0 + 16) { z = xn; xk[(kb & 1) * 16 + r] = xn; }
         }
         __syncthreads();
@@ -377,10 +388,12 @@ __device__ __noinline__ void potrs_rows(int n, const T* F_, int ldf, const T* Di
         for (int c = 0; c < 16; ++c) lcol[c] = lnext[c];
         if (kb > 0) load_col(kb - 1);
         if (wave == (c0 >> 6)) {
-            const int l0 = c0 & 63, r = (lane - l0) & 15;
-            T xn = 0;
+            const int l0 = c0 & 63, r = lane & 15;
+            T dv[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) xn += Dinv[kb * 272 + c + 17 * r] * lane_bcast(z, l0 + c);   // (inv L_kk)^T (r, c) = inv(c, r)
+            for (int c = 0; c < 16; ++c) dv[c] = Dinv[kb * 272 + c + 17 * r];                         // (inv L_kk)^T (r, c) = inv(c, r)
+            T xn = 0;
+            static_for<16>([&](auto cc) { constexpr int c = decltype(cc)::value; xn += dv[c] * dpp_row_bcast<c>(z); });
             if (lane >= l0 && lane < l0 + 16) { z = xn; xk[(kb & 1) * 16 + r] = xn; }
         }
         __syncthreads();
