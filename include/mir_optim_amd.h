@@ -206,9 +206,12 @@ enum {
                                                     guard before the current decision is known (bit-identical results;
                                                     measured: no gain at cfg 3, 3 % at cfg 2 -- on by default only for small
                                                     problems, J up to 32 MB; this bit forces it for any size) */
-    MIR_LSQ_VARIANT_NO_TAIL_FUSION = 1u << 12,   /* round 2's launch sequence: k_lr_finish and k_unpack_grad as kernels of
-                                                    their own instead of inside the solve kernel's prologue / the slab
-                                                    reduction; bit-identical results */
+    MIR_LSQ_VARIANT_NO_TAIL_FUSION = 1u << 12,   /* round 2's launch sequence: k_unpack_grad as a kernel of its own (with
+                                                    |J^T y|_inf) instead of the slab reduction writing J^T J / J^T y and the
+                                                    solve kernel taking the maximum; bit-identical results */
+    MIR_LSQ_VARIANT_FINISH_IN_SOLVE = 1u << 23,  /* the n x n finish of a Broyden pass in the solve kernel's prologue (one workgroup)
+                                                    instead of the kernel k_lr_finish (n + 1 workgroups): one launch less,
+                                                    bit-identical, measured 1 % slower at cfg 3: not the default */
     MIR_LSQ_VARIANT_NO_PIPELINE = 1u << 22,      /* never enqueue a round ahead of time (small problems -- J up to 32 MB -- do by default) */
     MIR_LSQ_VARIANT_FD_PANEL_IS_J = 1u << 21,    /* after a difference-panel refresh keep the panel as J (the fused kernel does not
                                                     write J; the Broyden sweep and the flush apply scal(1 / twh) at load time)

@@ -34,7 +34,7 @@ __all__ = [
     "fit_spline_residuals", "variant_lr_cap",
     "VARIANT_BROYDEN_REWRITE", "VARIANT_FD_SEPARATE_FILL", "VARIANT_JTJ_RING", "VARIANT_JTJ_STREAM",
     "VARIANT_NO_SPECULATION", "VARIANT_NO_NULL_SKIP", "VARIANT_SOLVE_BOUNDED", "VARIANT_DEBUG_SOLVE",
-    "VARIANT_HOST_PROFILE", "VARIANT_NO_RESYNC", "VARIANT_SOLVE_GENERIC", "VARIANT_PIPELINE", "VARIANT_NO_TAIL_FUSION", "VARIANT_FD_HOST_COLUMNS", "VARIANT_SWEEP_TAIL", "VARIANT_SUMSQ_TAIL", "VARIANT_FD_PANEL_IS_J", "VARIANT_NO_PIPELINE",
+    "VARIANT_HOST_PROFILE", "VARIANT_NO_RESYNC", "VARIANT_SOLVE_GENERIC", "VARIANT_PIPELINE", "VARIANT_NO_TAIL_FUSION", "VARIANT_FD_HOST_COLUMNS", "VARIANT_SWEEP_TAIL", "VARIANT_SUMSQ_TAIL", "VARIANT_FD_PANEL_IS_J", "VARIANT_NO_PIPELINE", "VARIANT_FINISH_IN_SOLVE",
 ]
 
 MODEL_EXP_DECAY = 0      # n = 3: p0 exp(-t p1) + p2
@@ -63,6 +63,7 @@ VARIANT_SWEEP_TAIL = 1 << 14
 VARIANT_SUMSQ_TAIL = 1 << 15
 VARIANT_FD_PANEL_IS_J = 1 << 21
 VARIANT_NO_PIPELINE = 1 << 22
+VARIANT_FINISH_IN_SOLVE = 1 << 23
 
 
 def variant_lr_cap(k):

@@ -316,9 +316,9 @@ struct Solver {
     uint32_t variant = 0;
     bool dbg_solve = false, no_speculation = false, lowrank = true, no_null_skip = false, host_profile = false;
     // Fewer launches per pass. merge_small (default; MIR_LSQ_VARIANT_NO_TAIL_FUSION = round 2's sequence):
-    // the slab reduction writes J^T J / J^T y itself and the solve kernel applies the n x n finish of a Broyden pass and takes
-    // |J^T y|_inf in its prologue. sweep_tail / sumsq_tail (opt-in, MIR_LSQ_VARIANT_SWEEP_TAIL / SUMSQ_TAIL): "last workgroup
-    // finishes" tails inside the Broyden sweep and the sum-of-squares sweep.
+    // the slab reduction writes J^T J / J^T y itself and the solve kernel takes |J^T y|_inf in its prologue (and, opt-in
+    // MIR_LSQ_VARIANT_FINISH_IN_SOLVE, applies the n x n finish of a Broyden pass there). sweep_tail / sumsq_tail (opt-in,
+    // MIR_LSQ_VARIANT_SWEEP_TAIL / SUMSQ_TAIL): "last workgroup finishes" tails inside the Broyden sweep and the sum-of-squares sweep.
     bool merge_small = true, sweep_tail = false, sumsq_tail = false;
     // The Jacobian the Broyden sweeps read: B.J, or -- MIR_LSQ_VARIANT_FD_PANEL_IS_J, after a refresh through the difference
     // panel -- the PANEL ITSELF with the column widths twh (broyden_lr.h, LrArgs::colscale): the fused finite-difference kernel
@@ -765,8 +765,11 @@ struct Solver {
         if (comm && !allreduce(B.lrvec, (size_t)len, 1)) return false;
         if (sweep_tail && !comm) {
             // finished inside the sweep
-        } else if (merge_small) {
-            finish_pending = true;       // the solve kernel that follows applies it in its prologue (enqueue_solve)
+        } else if (merge_small && (variant & MIR_LSQ_VARIANT_FINISH_IN_SOLVE)) {
+            // opt-in: the solve kernel that follows applies the finish in its prologue (enqueue_solve). One launch less, but ONE
+            // workgroup then does the n^2 read-modify-write that k_lr_finish spreads over n + 1: +9-11 us in the solve kernel
+            // against 4.6 + 1.3 us for the kernel and its gap at n = 128 -- cfg 3 6.08 vs 6.01 ms per solve, cfg 2 equal
+            finish_pending = true;
             finish_k = lr_k;
         } else {
             MIRLSQ_LAUNCH(k_lr_finish<T>, dim3(n + 1), dim3(256), 0, stream, B.lrvec, B.lrD, B.dx_acc, lr_k, (int)n, B.JJ, B.Jy, B.st, guard);

@@ -472,6 +472,40 @@ __device__ __forceinline__ int posvx_device(int n, T* A, int lda, T* F, int ldf,
     T lstres = 3;
     for (int count = 1;; ++count) {
         // r = b - A x ; w = |b| + |A| |x|      (two threads per row, 16 loads in flight per thread)
+        if (n % 2 == 0 && lda % 2 == 0) {
+            // row PAIRS with 16-byte loads (A is column-major: rows 2 t, 2 t + 1 of a column are adjacent): twice the bytes per
+            // round trip to L2 -- one workgroup reads the whole n x n matrix here, 28 us at n = 256 with 8-byte loads. Thread
+            // (t = tid >> 1, h = tid & 1) sums the columns of half h for rows 2 t, 2 t + 1 in the same order as below: same bits.
+            typedef T v2 __attribute__((ext_vector_type(2)));
+            const int t = tid >> 1, h = tid & 1;
+            const int i0 = 2 * t < n ? 2 * t : n - 2;
+            const int k0 = h ? n / 2 : 0, k1 = h ? n : n / 2;
+            const T* Ap = A;
+            const T* xp = x;
+            T ra = 0, rb = 0, wa = 0, wb = 0;
+            for (int kb = k0; kb < k1; kb += 16) {
+                v2 av[16];
+                T xv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int k = kb + u < k1 ? kb + u : k1 - 1;
+                    av[u] = *reinterpret_cast<const v2*>(Ap + i0 + (size_t)k * lda);
+                    xv[u] = xp[k];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (kb + u < k1) {
+                        ra -= av[u].x * xv[u]; wa += dabs(av[u].x) * dabs(xv[u]);
+                        rb -= av[u].y * xv[u]; wb += dabs(av[u].y) * dabs(xv[u]);
+                    }
+            }
+            ra += wave_shfl_xor(ra, 1); wa += wave_shfl_xor(wa, 1);
+            rb += wave_shfl_xor(rb, 1); wb += wave_shfl_xor(wb, 1);
+            if (2 * t < n && h == 0) {
+                r[2 * t] = b[2 * t] + ra; w[2 * t] = dabs(b[2 * t]) + wa;
+                r[2 * t + 1] = b[2 * t + 1] + rb; w[2 * t + 1] = dabs(b[2 * t + 1]) + wb;
+            }
+        } else
         for (int base = 0; base < n; base += kSolveThreads / 2) {
             const int i = base + (tid >> 1), h = tid & 1;
             const int ic = i < n ? i : n - 1;
@@ -738,12 +772,17 @@ __device__ inline T lr_finish_block(const T* lr, T* D, const T* dx, int k, int n
     T mx = 0;
     for (int j = tid; j < n; j += nthr) {
         const T dj = dx[j];
+        T dl[kLrMax];                                          // the k pending steps' entry j: one batch of loads, then the sums
+#pragma unroll
+        for (int l = 0; l < kLrMax; ++l) dl[l] = l < k ? D[(size_t)l * n + j] : T(0);
         T sv = lrs[j];
-        for (int l = 0; l < k; ++l) sv += D[(size_t)l * n + j] * w[l];
+#pragma unroll
+        for (int l = 0; l < kLrMax; ++l) if (l < k) sv += dl[l] * w[l];
         v[j] = sv;
         dxs[j] = dj;
         T g = lrs[n + j];
-        for (int l = 0; l < k; ++l) g += D[(size_t)l * n + j] * h[l];
+#pragma unroll
+        for (int l = 0; l < kLrMax; ++l) if (l < k) g += dl[l] * h[l];
         g += dj * uy;
         Jy[j] = g;
         const T av = dabs(g);
@@ -754,17 +793,39 @@ __device__ inline T lr_finish_block(const T* lr, T* D, const T* dx, int k, int n
     // 16 loads in flight per thread: a plain read-modify-write loop serialises on may-alias load / store ordering (one L2
     // round trip per element: 64 of them at n = 128)
     const int nn = n * n;
-    for (int base = tid; base < nn; base += 16 * nthr) {
-        T old[16];
+    auto term = [&](int idx) {
+        const int i = idx / n, j = idx - i * n;
+        const int rr = i >= j ? i : j, cc = i >= j ? j : i;
+        return lr_jj_term(v[rr], v[cc], dxs[rr], dxs[cc], uu);
+    };
+    if (nn % 2 == 0) {                                         // 16-byte accesses: half the round trips
+        typedef T v2 __attribute__((ext_vector_type(2)));
+        v2* J2 = reinterpret_cast<v2*>(JJ);
+        const int np = nn / 2;
+        for (int base = tid; base < np; base += 16 * nthr) {
+            v2 old[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const int idx = base + u * nthr; old[u] = JJ[idx < nn ? idx : nn - 1]; }
+            for (int u = 0; u < 16; ++u) { const int idx = base + u * nthr; old[u] = J2[idx < np ? idx : np - 1]; }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int idx = base + u * nthr;
-            if (idx < nn) {
-                const int i = idx / n, j = idx - i * n;
-                const int rr = i >= j ? i : j, cc = i >= j ? j : i;
-                JJ[idx] = old[u] + lr_jj_term(v[rr], v[cc], dxs[rr], dxs[cc], uu);
+            for (int u = 0; u < 16; ++u) {
+                const int idx = base + u * nthr;
+                if (idx < np) {
+                    v2 t = old[u];
+                    t.x += term(2 * idx);
+                    t.y += term(2 * idx + 1);
+                    J2[idx] = t;
+                }
+            }
+        }
+    } else {
+        for (int base = tid; base < nn; base += 16 * nthr) {
+            T old[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int idx = base + u * nthr; old[u] = JJ[idx < nn ? idx : nn - 1]; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int idx = base + u * nthr;
+                if (idx < nn) JJ[idx] = old[u] + term(idx);
             }
         }
     }

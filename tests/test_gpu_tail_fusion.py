@@ -1,11 +1,12 @@
 """The per-pass serial tail (round 3): fewer launches per pass, bit for bit the same solve.
 
-Default (merges into the CONSUMER's prologue -- no cross-workgroup traffic inside a kernel):
+Default (a merge into the CONSUMER -- no cross-workgroup traffic inside a kernel):
     k_jtj_* -> k_jtj_slab_reduce -> k_unpack_grad -> solve   =>  k_jtj_* -> k_jtj_slab_reduce (writes J^T J, J^T y) -> solve
-    k_broyden_lr -> k_lr_reduce -> k_lr_finish -> solve      =>  k_broyden_lr -> k_lr_reduce -> solve (n x n finish and
-                                                                 |J^T y|_inf in the solve kernel's prologue)
+                                                                 (|J^T y|_inf in the solve kernel's prologue)
+Opt-in, MIR_LSQ_VARIANT_FINISH_IN_SOLVE (measured 1 % slower at cfg 3: one workgroup does the n^2 update):
+    k_broyden_lr -> k_lr_reduce -> k_lr_finish -> solve      =>  k_broyden_lr -> k_lr_reduce -> solve (n x n finish in the prologue)
 Opt-in ("last workgroup finishes" tails; MIR_LSQ_VARIANT_SWEEP_TAIL / SUMSQ_TAIL -- measured no faster on MI355X, kept as
-A/B: profiles/r03/tail_fusion_ab.md):
+A/B: profiles/r03/ab_tails.txt):
     k_broyden_lr -> k_lr_reduce (-> finish)                  =>  k_broyden_lr (ranges summed by their last arrivals, the
                                                                  last range sums the ranges and applies the finish)
     f(trial) -> k_sumsq_partial -> k_decide_chain            =>  f(trial) -> k_sumsq_tail<decide>
@@ -52,7 +53,8 @@ def test_fused_tails_are_bit_identical_to_separate_kernels(m, n, dtype, tol):
     s = M.LeastSquaresSettings(dtype) if dtype == np.float32 else M.LeastSquaresSettings()
     s.absTolerance = tol
     out = []
-    for variant in (M.VARIANT_NO_TAIL_FUSION, 0, M.VARIANT_SWEEP_TAIL, M.VARIANT_SUMSQ_TAIL, M.VARIANT_SWEEP_TAIL | M.VARIANT_SUMSQ_TAIL):
+    for variant in (M.VARIANT_NO_TAIL_FUSION, M.VARIANT_FINISH_IN_SOLVE, M.VARIANT_SWEEP_TAIL, M.VARIANT_SUMSQ_TAIL,
+                    M.VARIANT_SWEEP_TAIL | M.VARIANT_SUMSQ_TAIL, 0):
         st, tr = M.Stats(), M.Trace(4096)
         r, x = prob.solve(w["x0"].astype(dtype), settings=s, batched=True, stats=st, trace=tr, variant=variant)
         out.append((key(r, x), counters(st), tr.records(), st))
@@ -64,9 +66,9 @@ def test_fused_tails_are_bit_identical_to_separate_kernels(m, n, dtype, tol):
         assert t1 == t0                                      # every pass: lambda, residuals, dx.dx bit for bit
         launches.append(st1.library_launches)
     if n <= 256:
-        assert launches[1] < launches[0] and launches[4] < launches[2] < launches[1] and launches[4] < launches[3] < launches[1]
+        assert launches[1] < launches[5] < launches[0] and launches[4] < launches[2] < launches[5] and launches[4] < launches[3] < launches[5]
     else:                                                    # no low-rank sweep, tile-pair J^T J: only the sums / decision tail applies
-        assert launches[1] == launches[0] == launches[2] and launches[3] == launches[4] < launches[1]
+        assert launches[1] == launches[0] == launches[2] == launches[5] and launches[3] == launches[4] < launches[1]
 
 
 def test_bounded_gauss_sum_bit_identical_and_launch_counts():
@@ -84,10 +86,10 @@ def test_bounded_gauss_sum_bit_identical_and_launch_counts():
     st = res[0][2]
     assert st.rounds[0] == st.jacobian_full and st.rounds[1] == st.jacobian_broyden
     # library launches per round, single GPU:
-    #   Broyden round   sweep | reduce | solve (+ finish) | sum of squares | decision                            = 5
+    #   Broyden round   sweep | reduce | finish | solve | sum of squares | decision                              = 6
     #   refresh round   FD points | fused FD J^T J | slab reduce (+ unpack) | solve | sums | decision            = 6
     #   re-solve round  solve | sums | decision (or solve | decision when every trial is a null step)           <= 3
-    assert st.round_launches[1] == 5 * st.rounds[1]
+    assert st.round_launches[1] == 6 * st.rounds[1]
     assert st.round_launches[2] <= 3 * st.rounds[2]
     assert st.round_launches[0] <= 8 * st.rounds[0]          # point-major panel + fill pass here; + k_reset_mu when LS:984 forces the refresh
     st0 = res[1][2]
@@ -105,7 +107,7 @@ def test_launch_budget_cfg3_shape():
     r, x = prob.solve(w["x0"], settings=s, batched=True, stats=st)
     assert r.status == M.LeastSquaresStatus.xConverged
     assert st.rounds[0] == st.jacobian_full >= 2 and st.rounds[1] == st.jacobian_broyden >= 2
-    assert st.round_launches[1] == 5 * st.rounds[1]          # sweep, reduce, solve (+ finish), sums, decision
+    assert st.round_launches[1] == 6 * st.rounds[1]          # sweep, reduce, finish, solve, sums, decision
     # FD points, k_jtj_fdp, slab reduce, solve, sums, decision (+ k_reset_mu in a refresh that LS:984-989 forces)
     assert 6 * st.rounds[0] <= st.round_launches[0] <= 6 * st.rounds[0] + 1
     assert st.library_launches == sum(st.round_launches) + 3  # + the sum of squares at entry (LS:955: two stages) and the state set-up
@@ -128,8 +130,8 @@ def test_one_rank_communicator_keeps_the_reductions_apart():
     close()
     r0, x0 = prob.solve(w["x0"], settings=s, batched=True)
     assert key(r1, x1) == key(r0, x0)
-    # Broyden round with a communicator: sweep | reduce | AR | solve (+ finish) | sums x 2 | AR | decision = 6 launches
-    assert st.round_launches[1] == 6 * st.rounds[1]
+    # Broyden round with a communicator: sweep | reduce | AR | finish | solve | sums x 2 | AR | decision = 7 launches
+    assert st.round_launches[1] == 7 * st.rounds[1]
 
 
 def test_eight_shards_with_fused_tails_agree_bitwise():
