@@ -683,12 +683,15 @@ def main():
         }
         if world == 1 and not args.no_host_callback and (m, n) == (1_000_000, 128):
             # the path a caller of the UNMODIFIED reference API gets: host residual callback, native thread manager, PCIe inclusive
-            sys.path.insert(0, os.path.join(ROOT, "scripts"))
-            import bench_host_callback as BH
-            hc = BH.run(m, n, abs_tolerance=args.abs_tolerance, data=data, solves=1)
-            xh = hc.pop("x")
-            hc["parity_x_max_abs_diff_vs_device_callback_solve"] = float(np.abs(np.asarray(xh) - np.asarray(x)).max())
-            out["host_callback_mode"] = hc
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "scripts"))
+                import bench_host_callback as BH
+                hc = BH.run(m, n, abs_tolerance=args.abs_tolerance, data=data, solves=1)
+                xh = hc.pop("x")
+                hc["parity_x_max_abs_diff_vs_device_callback_solve"] = float(np.abs(np.asarray(xh) - np.asarray(x)).max())
+                out["host_callback_mode"] = hc
+            except Exception as e:      # noqa: BLE001 -- an auxiliary leg must not take the headline line down with it
+                out["host_callback_mode"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data, m, n, args.cpu_iterations, args.abs_tolerance, min(os.cpu_count() or 1, 64), x, res)
             if not args.no_cpu_1thread:
