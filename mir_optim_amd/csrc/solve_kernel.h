@@ -236,6 +236,7 @@ __device__ __noinline__ int potrf_panel(int n, const T* A_, int lda, T* F_, int 
                     for (int u = 0; u < 4; ++u) if (live[u]) acc[u] = Mma<T>::mma(fa[buf][s4][u], fb[buf][s4], acc[u]);
             };
             if (live[0] || live[1] || live[2] || live[3]) {
+                // (four panels in flight instead of two: 88 -> 118 us for the sixteen panel steps at n = 256 -- not the loads)
                 load(0, 0);
                 for (int j = 0; j < k; j += 2) {
                     if (j + 1 < k) load(j + 1, 1);
