@@ -216,78 +216,49 @@ __global__ __launch_bounds__(256, (NCP <= 4 ? 4 : 1)) void k_broyden_lr(const Lr
     const size_t per = (G + nw - 1) / nw;
     const size_t gb = wid * per;
     const size_t ge = gb + per < G ? gb + per : G;
-    // one row group of the sweep: its loads, then its arithmetic. Small n (NCP <= 2: a handful of registers per group) keeps TWO
-    // groups in flight -- the loads of group g + 1 are issued before group g is summed -- because a small problem's sweep is a few
-    // dependent round trips to memory per wave (m = 1e5, n = 16: 8 groups per wave, 12 us per launch for 13 MB); the wide shapes
-    // are bandwidth-bound with four workgroups per CU and have no registers to spare for it.
-    struct Grp { T v0[NCP], v1[NCP], yn, yo, ul; size_t row; bool rok; };
-    auto load = [&](size_t g, Grp& G_) {
-        G_.row = 4 * g + q;
-        G_.rok = G_.row < m;
-        const size_t rr = G_.rok ? G_.row : m - 1;
+    for (size_t g = gb; g < ge; ++g) {
+        const size_t row = 4 * g + q;
+        const bool rok = row < m;
+        const size_t rr = rok ? row : m - 1;
         const T* __restrict__ rp = a.J + rr * (size_t)n;
+        T v0[NCP], v1[NCP];
 #pragma unroll
         for (int c = 0; c < NCP; ++c) {
             if constexpr (VEC) {
                 typedef T lr_v2 __attribute__((ext_vector_type(2)));
                 const lr_v2 t = __builtin_nontemporal_load(reinterpret_cast<const lr_v2*>(rp + coff[c]));   // J is swept once per pass and is larger than the Infinity Cache
-                G_.v0[c] = t.x;
-                G_.v1[c] = t.y;
+                v0[c] = t.x;
+                v1[c] = t.y;
             } else {
-                G_.v0[c] = rp[coff[c]];
-                G_.v1[c] = rp[ok1[c] ? coff[c] + 1 : 0];
+                v0[c] = rp[coff[c]];
+                v1[c] = rp[ok1[c] ? coff[c] + 1 : 0];
             }
-        }
-        G_.yn = a.y[rr];
-        G_.yo = a.y_old[rr];
-        G_.ul = own ? Up[rr] : T(0);
-    };
-    auto work = [&](Grp& G_) {
-#pragma unroll
-        for (int c = 0; c < NCP; ++c) {
             if constexpr (SCALED) {
-                G_.v0[c] = sc0[c] == 0 ? T(0) : G_.v0[c] * sc0[c];        // scal(1 / twh, Jj), LS:1047 (LS:1046: zero column)
-                G_.v1[c] = sc1[c] == 0 ? T(0) : G_.v1[c] * sc1[c];
+                v0[c] = sc0[c] == 0 ? T(0) : v0[c] * sc0[c];              // scal(1 / twh, Jj), LS:1047 (LS:1046: zero column)
+                v1[c] = sc1[c] == 0 ? T(0) : v1[c] * sc1[c];
             }
         }
-        T yn = G_.yn;
-        T s = G_.ul * cp;
+        T yn = a.y[rr];
+        const T yo = a.y_old[rr];
+        const T ul = own ? Up[rr] : T(0);
+        T s = ul * cp;
 #pragma unroll
-        for (int c = 0; c < NCP; ++c) s += G_.v0[c] * d0[c] + G_.v1[c] * d1[c];
+        for (int c = 0; c < NCP; ++c) s += v0[c] * d0[c] + v1[c] * d1[c];
         s = sum16(s);
-        T u = nd * ((G_.yo - yn) + s);                     // LS:1003-1005: axpy(-1, y, mBuffer); gemv; scal(-d)
-        if (!G_.rok) { u = 0; yn = 0; }
-        if (G_.rok && p == 0) Uk[G_.row] = u;
+        T u = nd * ((yo - yn) + s);                        // LS:1003-1005: axpy(-1, y, mBuffer); gemv; scal(-d)
+        if (!rok) { u = 0; yn = 0; }
+        if (rok && p == 0) Uk[row] = u;
 #pragma unroll
         for (int c = 0; c < NCP; ++c) {
-            va0[c] += G_.v0[c] * u;
-            va1[c] += G_.v1[c] * u;
-            ga0[c] += G_.v0[c] * yn;
-            ga1[c] += G_.v1[c] * yn;
+            va0[c] += v0[c] * u;
+            va1[c] += v1[c] * u;
+            ga0[c] += v0[c] * yn;
+            ga1[c] += v1[c] * yn;
         }
-        wl += G_.ul * u;
-        hl += G_.ul * yn;
+        wl += ul * u;
+        hl += ul * yn;
         uu += u * u;
         uy += u * yn;
-    };
-    if constexpr (NCP <= 2) {
-        Grp ga_, gb_;
-        size_t g = gb;
-        if (g < ge) load(g, ga_);
-        while (g < ge) {
-            if (g + 1 < ge) load(g + 1, gb_);
-            work(ga_);
-            if (++g >= ge) break;
-            if (g + 1 < ge) load(g + 1, ga_);
-            work(gb_);
-            ++g;
-        }
-    } else {
-        for (size_t g = gb; g < ge; ++g) {
-            Grp g_;
-            load(g, g_);
-            work(g_);
-        }
     }
 
     // the four row groups of the wave, then the four waves of the block, in a fixed order
