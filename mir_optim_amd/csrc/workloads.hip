@@ -117,7 +117,12 @@ __global__ __launch_bounds__(256) void k_tanh_linear(const T* __restrict__ A, co
     const size_t G = (m + 3) / 4;
     const size_t wave_id = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
-    for (size_t g = wave_id; g < G; g += nwaves) {
+    // a contiguous range of row groups per wave (like the library's sweep over J: 6.2-6.4 TB/s against 5.9 for the
+    // grid-stride walk this kernel used to do)
+    const size_t per = (G + nwaves - 1) / nwaves;
+    const size_t gb = wave_id * per < G ? wave_id * per : G;
+    const size_t ge = gb + per < G ? gb + per : G;
+    for (size_t g = gb; g < ge; ++g) {
         const size_t row = 4 * g + q;
         const bool rok = row < m;
         const T* rp = A + (rok ? row : m - 1) * (size_t)n;
@@ -192,7 +197,7 @@ void launch_tanh_linear(const T* A, const T* b, const T* x, T* out, size_t m, in
 {
     const size_t G = (m + 3) / 4;
     size_t blocks = (G + 3) / 4;
-    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks > 256 * 4) blocks = 256 * 4;
     if (blocks < 1) blocks = 1;
     const int ncp = (n + 31) / 32;                         // column pairs per lane
     dim3 grid((unsigned)blocks);
