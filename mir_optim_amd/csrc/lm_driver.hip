@@ -1121,12 +1121,17 @@ struct Solver {
             stats->fd_host_f_ms += (double)fd_f_ns.exchange(0) * 1e-6;
             stats->fd_host_columns += n;
         }
-        if (fd_tasks_run.load() != n) {
-            // a manager that stops half way (an exception in a binding, a cancelled pool) leaves columns of J stale: fail loudly
+        const bool incomplete = fd_tasks_run.load() != n;
+        if (incomplete)     // a manager that stops half way (an exception in a binding, a cancelled pool) leaves columns of J stale: fail loudly
             std::fprintf(stderr, "[mir_optim_amd] thread manager ran %u of %u finite-difference tasks\n", fd_tasks_run.load(), n);
+        if (incomplete || fd_failed) {
+            // copies of the columns that did get evaluated may still be reading the pinned panel: let them finish before the
+            // caller (or an owned workspace's teardown) can touch it
+            if (fd_panel_mode)
+                for (int k = 0; k < mir_lsq_workspace::kCopyStreams; ++k)
+                    if (fd_streams_used.load() & (1u << k)) (void)hipStreamSynchronize(ws->copy_stream[k]);
             return false;
         }
-        if (fd_failed) return false;
         if (fd_panel_mode) {
             // the solver's stream waits for the copy streams (no host synchronisation), then ONE coalesced conversion of the
             // whole panel: pairs of m-vectors -> column panels of J through an LDS transpose (LS:1041-1047)
