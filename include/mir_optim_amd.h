@@ -398,6 +398,13 @@ int mir_lsq_batched_kernel_s(const mir_least_squares_settings_s* settings, size_
                              const float* t, size_t t_stride, const float* data,
                              mir_least_squares_result_s* results, void* stream);
 
+/* Unit-level access to the damped solve of that kernel (?posvx('E','L') with one matrix row per lane; what boxcqp.d:194
+ * calls): `count` systems of order n (3 or 8, the orders of the compiled-in models), device pointers; P count x 64 floats,
+ * system p at P + 64 p, row-major with row stride 8, the LOWER triangle is read; rhs and x count x 8 floats (components
+ * >= n ignored / zero); info[p] = 0 or the order of the leading minor that is not positive (x of that system is zero).
+ * Enqueued on `stream`, no synchronisation. */
+int mir_lsq_batched_posvx_s(size_t count, size_t n, const float* P, const float* rhs, float* x, int* info, void* stream);
+
 /* Unit-level access to the hot kernels (parity tests and micro-benchmarks). All pointers are
  * DEVICE pointers; stream may be NULL (default stream; the call synchronises before returning).
  * JJ: n x n row-major, full symmetric on return. broyden != 0 first applies

@@ -29,7 +29,7 @@ __all__ = [
     "LeastSquaresException", "optimize", "optimizeLeastSquares", "solveBoxQP", "leastSquaresStatusString",
     "mir_least_squares_work_length", "mir_least_squares_iwork_length", "mir_box_qp_work_length",
     "mir_box_qp_iwork_length", "GpuOptions", "Stats", "lib", "workloads_lib", "device_count",
-    "DeviceBuffer", "Stream", "jtj", "fd_jtj", "DEVICE_CALLBACKS", "TIME_KERNELS", "optimizeLeastSquaresBatched",
+    "DeviceBuffer", "Stream", "jtj", "fd_jtj", "DEVICE_CALLBACKS", "TIME_KERNELS", "optimizeLeastSquaresBatched", "batchedPosvx",
     "MODEL_EXP_DECAY", "MODEL_EXP3_AFFINE", "MODEL_EXP_DECAY_PAD8", "ResultS", "Trace", "TraceRecord", "Spline", "FitSplineResult", "fitSpline",
     "fit_spline_residuals", "variant_lr_cap",
     "VARIANT_BROYDEN_REWRITE", "VARIANT_FD_SEPARATE_FILL", "VARIANT_JTJ_RING", "VARIANT_JTJ_STREAM",
@@ -281,6 +281,8 @@ def lib():
         L.mir_lsq_batched_kernel_s.restype = C.c_int
         L.mir_lsq_batched_kernel_s.argtypes = [C.POINTER(_Ss), sz, sz, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p, sz, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mir_lsq_batched_posvx_s.restype = C.c_int
+        L.mir_lsq_batched_posvx_s.argtypes = [sz, sz, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mir_lsq_comm_describe.restype = C.c_int
         L.mir_lsq_comm_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         L.mir_lsq_workspace_create.restype = C.c_void_p
@@ -588,6 +590,28 @@ def optimizeLeastSquaresBatched(model, x, t, data, l=None, u=None, settings=None
     if rc != 0:
         raise RuntimeError(f"mir_optimize_least_squares_batched_s failed: {rc}")
     return [LeastSquaresResult(r) for r in raw], x
+
+
+def batchedPosvx(P, rhs):
+    """The damped solve of the wave-per-problem kernel on its own (mir_lsq_batched_posvx_s): P count x n x n (lower
+    triangles read), rhs count x n, n in (3, 8), fp32. Returns (x count x n, info count)."""
+    L = lib()
+    P = np.asarray(P, dtype=np.float32)
+    count, n = P.shape[0], P.shape[1]
+    Pp = np.zeros((count, 8, 8), dtype=np.float32); Pp[:, :n, :n] = P
+    bp = np.zeros((count, 8), dtype=np.float32); bp[:, :n] = rhs
+    dP, db = DeviceBuffer(Pp), DeviceBuffer(bp)
+    dx = DeviceBuffer(nbytes=count * 32, dtype=np.float32, shape=(count, 8))
+    di = DeviceBuffer(nbytes=count * 4, dtype=np.int32, shape=(count,))
+    st = Stream()
+    rc = L.mir_lsq_batched_posvx_s(count, n, dP.ptr, db.ptr, dx.ptr, di.ptr, st.handle)
+    if rc != 0:
+        raise RuntimeError(f"mir_lsq_batched_posvx_s failed: {rc}")
+    st.synchronize()
+    x, info = dx.download()[:, :n].copy(), di.download().copy()
+    for b in (dP, db, dx, di):
+        b.free()
+    return x, info
 
 
 def solveBoxQP(P, q, l, u, x=None, settings=None, dtype=np.float64, unconstrainedSolution=False):

@@ -1,12 +1,12 @@
 // batched_kernel.h -- many small independent LM fits, ONE WAVEFRONT PER PROBLEM (BASELINE cfg 5:
 // 4096 x (m = 512, n = 8), fp32). The whole loop of optimizeLeastSquaresImplGeneric!T
 // (/root/reference/source/mir/optim/least_squares.d:877-1176) runs inside the kernel:
-//   * a wave owns one problem; its J (m x n), y and the trial residual live in the wave's slice of LDS,
-//     lane l owns rows l, l + 64, ...; x, dx, J^T J, J^T y and all scalars are replicated in registers;
+//   * a wave (= a workgroup) owns one problem; its J (m x n), y and the trial residual live in LDS, lane l owns rows
+//     l, l + 64, ...; x, dx and all scalars are replicated in registers, J^T J and J^T y are held one row per lane;
 //   * the residual model is a compile-time functor (no callback across the FFI in this entry);
 //   * finite-difference Jacobian (LS:1018-1049), Broyden (LS:1002-1006), J^T J / J^T y as per-lane partial sums
-//     + one wave reduction, the n x n damped solve redundantly in every lane (?posvx semantics: equilibrate,
-//     Cholesky, refine), acceptance and the lambda/mu schedule exactly as the reference;
+//     + one wave reduction, the n x n damped solve with one matrix row per lane (?posvx semantics: equilibrate,
+//     Cholesky, refine: posvx_rows), acceptance and the lambda/mu schedule exactly as the reference;
 //   * all control flow is wave-uniform, there is no barrier and no host round trip.
 // Problems whose step hits a finite bound are not finished here (BOXCQP's active-set loop is not part of this
 // kernel): they return status kBatchedNeedsGeneral and the host entry re-solves them with the general solver.
@@ -22,15 +22,19 @@ constexpr int kBatchedNMax = 8;
 
 enum : int { kModelExpDecay = 0, kModelExp3Affine = 1, kModelExpDecayPad8 = 2 };
 
-// residual models: r = model(t, x) - d
+// residual models: r = model(t, x) - d. A model may declare `nb` per-row BASIS values that do not depend on the parameters
+// (basis(t, b)); k_batched_basis tabulates them once per launch (rows x nb floats) and eval() reads the row's values instead
+// of evaluating them again at every trial point and finite-difference point: the same floats enter the same expression.
 template <int MODEL> struct BatchedModel;
 template <> struct BatchedModel<kModelExpDecay> {      // p0 exp(-t p1) + p2            (n = 3; reference unittest T5's family)
-    static constexpr int n = 3;
-    __device__ static inline float eval(float t, const float* x) { return x[0] * __expf(-t * x[1]) + x[2]; }
+    static constexpr int n = 3, nb = 0;
+    __device__ static inline void basis(float, float*) {}
+    __device__ static inline float eval(float t, const float*, const float* x) { return x[0] * __expf(-t * x[1]) + x[2]; }
 };
 template <> struct BatchedModel<kModelExp3Affine> {    // sum_{k<3} p_{2k} exp(-t p_{2k+1}) + p6 + p7 t   (n = 8)
-    static constexpr int n = 8;
-    __device__ static inline float eval(float t, const float* x)
+    static constexpr int n = 8, nb = 0;
+    __device__ static inline void basis(float, float*) {}
+    __device__ static inline float eval(float t, const float*, const float* x)
     {
         return x[0] * __expf(-t * x[1]) + x[2] * __expf(-t * x[3]) + x[4] * __expf(-t * x[5]) + x[6] + x[7] * t;
     }
@@ -39,13 +43,16 @@ template <> struct BatchedModel<kModelExp3Affine> {    // sum_{k<3} p_{2k} exp(-
 // BASELINE cfg 5's well-conditioned n = 8 family ("p0 exp(-t p1) + p2 + 5-term variants padded to n = 8"): the
 // exponential decay plus five terms that are LINEAR in their parameters (a two-frequency trigonometric pair and a slope),
 // so the only nonlinearity is the decay and J^T J stays well conditioned in fp32. Precise expf / sinf / cosf (the float
-// oracle evaluates the same expression with libm).
+// oracle evaluates the same expression with libm). The four trigonometric values of a row are its basis.
 template <> struct BatchedModel<kModelExpDecayPad8> {
-    static constexpr int n = 8;
-    __device__ static inline float eval(float t, const float* x)
+    static constexpr int n = 8, nb = 4;
+    __device__ static inline void basis(float t, float* b)
     {
-        return x[0] * expf(-t * x[1]) + x[2] + x[3] * sinf(2.0f * t) + x[4] * cosf(2.0f * t) + x[5] * sinf(5.0f * t)
-             + x[6] * cosf(5.0f * t) + x[7] * t;
+        b[0] = sinf(2.0f * t); b[1] = cosf(2.0f * t); b[2] = sinf(5.0f * t); b[3] = cosf(5.0f * t);
+    }
+    __device__ static inline float eval(float t, const float* b, const float* x)
+    {
+        return x[0] * expf(-t * x[1]) + x[2] + x[3] * b[0] + x[4] * b[1] + x[5] * b[2] + x[6] * b[3] + x[7] * t;
     }
 };
 
@@ -62,106 +69,167 @@ struct BatchedArgs {
     const float* lower;    // n (shared)
     const float* upper;    // n
     BatchedResult* results;
+    const float* basis;    // (t_stride ? count : 1) x m x nb: the model's per-row basis (k_batched_basis), nullptr when nb == 0
 };
 
-// ?posvx('E','L') for n <= NMAX, redundantly in every lane. P: lower triangle meaningful. Returns info.
-template <int NMAX>
-__device__ inline int posvx_small(int n, const float (&P)[NMAX][NMAX], const float (&rhs)[NMAX], float (&x)[NMAX])
-{
-    const float eps = Lim<float>::eps / 2, safmin = Lim<float>::min_normal;
-    float A[NMAX][NMAX], F[NMAX][NMAX], s[NMAX], b[NMAX];
-    float smin = Lim<float>::inf(), amax = -Lim<float>::inf();
+// one row of the basis table: 16-byte loads when the model has four values
+template <int NB> struct BasisRow {
+    float v[NB > 0 ? NB : 1];
+    __device__ inline void load(const float* table, int i)
+    {
+        if constexpr (NB == 4) {
+            const float4 q = reinterpret_cast<const float4*>(table)[i];
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
 #pragma unroll
-    for (int i = 0; i < NMAX; ++i) if (i < n) { smin = fminf(smin, P[i][i]); amax = fmaxf(amax, P[i][i]); }
+            for (int k = 0; k < NB; ++k) v[k] = table[(size_t)i * NB + k];
+        }
+    }
+};
+
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_batched_basis(const float* __restrict__ t, float* __restrict__ table, size_t rows)
+{
+    constexpr int NB = BatchedModel<MODEL>::nb;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < rows; i += (size_t)gridDim.x * blockDim.x) {
+        float b[NB > 0 ? NB : 1];
+        BatchedModel<MODEL>::basis(t[i], b);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) table[i * NB + k] = b[k];
+    }
+}
+
+// ---- the damped n x n solve with ONE ROW PER LANE ------------------------------------------------------------------------
+// ?posvx('E','L') as the oracle restates it (oracle/lm_oracle_impl.inc, lmo_posvx: ?poequ, ?laqsy, ?potf2, ?potrs, ?porfs;
+// the condition estimate is left out: the reference accepts info = n + 1, boxcqp.d:212, and reads no other output of it).
+// Lane r = lane & 7 of every group of eight lanes holds row r of each matrix (eight registers a matrix instead of the 36 of a
+// private copy per lane, which took 256 + 29 registers and ~2000 instructions a solve) and component r of each vector; the
+// eight groups of a wave compute the same thing. A value of another row comes through v_readlane (lanes 0..7 hold every row).
+// Every element sees the operations of the oracle's loops in the oracle's order: the left-looking sums of ?potf2
+// (`s -= F[i][k] F[j][k]`, k ascending) are applied one k at a time to the whole trailing part; the forward sweep of ?potrs
+// runs by columns, its backward sweep (a chain that can only start when z[i + 1] is known) in lane i on column i of the
+// factor. Every multiply-add is ONE fused operation (__builtin_fmaf): the oracle's C rounds the product first, so the
+// two agree to rounding, not bit for bit -- and neither does this file depend on which products the compiler chooses to fuse.
+// Divisions and square roots per solve: 44 + 9 sequences (a copy per lane: 76 + 16).
+__device__ inline float lane_get(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+// a[r], r = lane & 7, as a chain of selects on VALUES: taking the array by reference lets the optimiser turn the chain into one
+// load at a computed address, which pins the whole array in scratch memory
+__device__ inline float row_pick8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, int r)
+{
+    float v = a0;
+    v = (r == 1) ? a1 : v; v = (r == 2) ? a2 : v; v = (r == 3) ? a3 : v; v = (r == 4) ? a4 : v;
+    v = (r == 5) ? a5 : v; v = (r == 6) ? a6 : v; v = (r == 7) ? a7 : v;
+    return v;
+}
+#define MIRLSQ_ROW_PICK(a, r) row_pick8((a)[0], (a)[1], (a)[2], (a)[3], (a)[4], (a)[5], (a)[6], (a)[7], (r))
+// max / min over the eight rows (every lane gets it): the values repeat with period 8 along a 16-lane DPP row, so the
+// rotations by 4, 2, 1 pair each lane with the rows r ^ 4, then r ^ 2, r ^ 1. fmaxf / fminf: a NaN operand is ignored.
+__device__ inline float rows_max(float v)
+{
+    v = fmaxf(v, dpp_row_ror<4>(v)); v = fmaxf(v, dpp_row_ror<2>(v)); v = fmaxf(v, dpp_row_ror<1>(v));
+    return v;
+}
+__device__ inline float rows_min(float v)
+{
+    v = fminf(v, dpp_row_ror<4>(v)); v = fminf(v, dpp_row_ror<2>(v)); v = fminf(v, dpp_row_ror<1>(v));
+    return v;
+}
+
+// ?posvx('E','L'), n = N <= NMAX = 8. Prow: the full symmetric row r of P; rhs_r: component r of the right-hand side.
+// x: the solution, wave-uniform (the caller's acceptance logic is). Returns info (wave-uniform).
+template <int N, int NMAX>
+__device__ inline int posvx_rows(const float (&Prow)[NMAX], float rhs_r, int r, float (&x)[NMAX])
+{
+    static_assert(NMAX == 8, "row r = lane & 7");
+    const float eps = Lim<float>::eps / 2, safmin = Lim<float>::min_normal;
+    const bool live = r < N;
+    const float d_r = MIRLSQ_ROW_PICK(Prow, r);
+    // ?poequ
+    const float smin = lane_get(rows_min(live ? d_r : Lim<float>::inf()), 0);
+    const float amax = lane_get(rows_max(live ? d_r : -Lim<float>::inf()), 0);
     bool rcequ = false;
+    float s_r = 1.0f;
     if (smin > 0) {
         const float scond = sqrtf(smin) / sqrtf(amax);
-#pragma unroll
-        for (int i = 0; i < NMAX; ++i) s[i] = i < n ? 1.0f / sqrtf(P[i][i]) : 1.0f;
+        s_r = live ? 1.0f / sqrtf(d_r) : 1.0f;
         const float small = safmin / Lim<float>::eps, large = 1.0f / small;
         rcequ = !(scond >= 0.1f && amax >= small && amax <= large);
-    } else {
-#pragma unroll
-        for (int i = 0; i < NMAX; ++i) s[i] = 1.0f;
     }
+    // ?laqsy
+    float Arow[NMAX], Frow[NMAX], Fcol[NMAX];                  // Fcol[k] = F[k][r], k > r: column r of the factor, for L^T
 #pragma unroll
-    for (int i = 0; i < NMAX; ++i)
-#pragma unroll
-        for (int j = 0; j < NMAX; ++j) {
-            const float v = (j <= i) ? P[i][j] : P[j][i];
-            A[i][j] = (i < n && j < n) ? (rcequ ? s[j] * s[i] * v : v) : (i == j ? 1.0f : 0.0f);
-        }
-#pragma unroll
-    for (int i = 0; i < NMAX; ++i) b[i] = i < n ? (rcequ ? s[i] * rhs[i] : rhs[i]) : 0.0f;
-    // ?potf2 'L'
-#pragma unroll
-    for (int i = 0; i < NMAX; ++i)
-#pragma unroll
-        for (int j = 0; j < NMAX; ++j) F[i][j] = A[i][j];
+    for (int k = 0; k < NMAX; ++k) {
+        const float sk = lane_get(s_r, k);
+        const float v = Prow[k];
+        Arow[k] = (live && k < N) ? (rcequ ? sk * s_r * v : v) : (r == k ? 1.0f : 0.0f);
+        Frow[k] = Arow[k];
+        Fcol[k] = 0.0f;
+    }
+    const float b_r = live ? (rcequ ? s_r * rhs_r : rhs_r) : 0.0f;
+    // ?potf2 'L': after step j, Frow[jj] (jj > j) of row r >= jj holds A[r][jj] - sum_{k <= j} F[r][k] F[jj][k]
     int info = 0;
 #pragma unroll
     for (int j = 0; j < NMAX; ++j) {
-        if (info == 0 && j < n) {
-            float ajj = F[j][j];
-#pragma unroll
-            for (int k = 0; k < NMAX; ++k) if (k < j) ajj -= F[j][k] * F[j][k];
+        if (info == 0 && j < N) {
+            float ajj = lane_get(Frow[j], j);
             if (!(ajj > 0)) { info = j + 1; }
             else {
                 ajj = sqrtf(ajj);
-                F[j][j] = ajj;
+                const float q = Frow[j] / ajj;
+                Frow[j] = (r == j) ? ajj : q;                  // rows above the diagonal carry values nobody reads
 #pragma unroll
-                for (int i = 0; i < NMAX; ++i) if (i > j && i < n) {
-                    float v = F[i][j];
-#pragma unroll
-                    for (int k = 0; k < NMAX; ++k) if (k < j) v -= F[i][k] * F[j][k];
-                    F[i][j] = v / ajj;
+                for (int jj = j + 1; jj < NMAX; ++jj) if (jj < N) {
+                    const float ljj = lane_get(Frow[j], jj);   // F[jj][j]
+                    Frow[jj] = __builtin_fmaf(-Frow[j], ljj, Frow[jj]);
+                    Fcol[jj] = (r == j) ? ljj : Fcol[jj];
                 }
             }
         }
     }
     if (info != 0) return info;
-    auto potrs = [&](float (&v)[NMAX]) {
+    const float fd_r = MIRLSQ_ROW_PICK(Frow, r);                      // F[r][r]
+    // ?potrs. L y = v by columns: row r takes `t -= F[r][i] y[i]` at step i (ascending i, as in the oracle's row loop).
+    // L^T z = y: row i needs t = y[i] - sum_{k > i} F[k][i] z[k] with k ascending, a chain that can only start when z[i + 1]
+    // is known: lane i runs it on its column of the factor and the wave-uniform z[k].
+    auto potrs = [&](float v_r, float (&z)[NMAX]) {
 #pragma unroll
-        for (int i = 0; i < NMAX; ++i) if (i < n) {
-            float t = v[i];
-#pragma unroll
-            for (int k = 0; k < NMAX; ++k) if (k < i) t -= F[i][k] * v[k];
-            v[i] = t / F[i][i];
+        for (int i = 0; i < NMAX; ++i) if (i < N) {
+            const float yi = lane_get(v_r / fd_r, i);
+            const float upd = __builtin_fmaf(-Frow[i], yi, v_r);
+            v_r = (r == i) ? yi : (r > i ? upd : v_r);
         }
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i) z[i] = 0.0f;
 #pragma unroll
         for (int ii = 0; ii < NMAX; ++ii) {
             const int i = NMAX - 1 - ii;
-            if (i < n) {
-                float t = v[i];
+            if (i < N) {
+                float t = v_r;
 #pragma unroll
-                for (int k = 0; k < NMAX; ++k) if (k > i && k < n) t -= F[k][i] * v[k];
-                v[i] = t / F[i][i];
+                for (int k = 0; k < NMAX; ++k) if (k > i && k < N) t = __builtin_fmaf(-Fcol[k], z[k], t);
+                z[i] = lane_get(t / fd_r, i);
             }
         }
     };
-#pragma unroll
-    for (int i = 0; i < NMAX; ++i) x[i] = b[i];
-    potrs(x);
+    potrs(b_r, x);
     // ?porfs
-    const float safe1 = (float)(n + 1) * safmin, safe2 = safe1 / eps;
+    const float safe1 = (float)(N + 1) * safmin, safe2 = safe1 / eps;
     float lstres = 3;
     for (int count = 1;; ++count) {
-        float r[NMAX], berr = 0;
+        float ri = b_r, wi = fabsf(b_r);
 #pragma unroll
-        for (int i = 0; i < NMAX; ++i) {
-            float ri = b[i], wi = fabsf(b[i]);
-#pragma unroll
-            for (int k = 0; k < NMAX; ++k) if (k < n) { ri -= A[i][k] * x[k]; wi += fabsf(A[i][k]) * fabsf(x[k]); }
-            r[i] = i < n ? ri : 0.0f;
-            if (i < n) {
-                const float q = (wi > safe2) ? fabsf(ri) / wi : (fabsf(ri) + safe1) / (wi + safe1);
-                berr = fmaxf(berr, q);
-            }
+        for (int k = 0; k < NMAX; ++k) if (k < N) {
+            ri = __builtin_fmaf(-Arow[k], x[k], ri);
+            wi = __builtin_fmaf(fabsf(Arow[k]), fabsf(x[k]), wi);
         }
+        const bool big = wi > safe2;
+        const float q = (big ? fabsf(ri) : fabsf(ri) + safe1) / (big ? wi : wi + safe1);
+        const float berr = lane_get(rows_max(live ? q : 0.0f), 0);
         if (berr > eps && 2 * berr <= lstres && count <= 5) {
-            potrs(r);
+            float c[NMAX];
+            potrs(live ? ri : 0.0f, c);
 #pragma unroll
-            for (int i = 0; i < NMAX; ++i) x[i] += r[i];
+            for (int i = 0; i < NMAX; ++i) x[i] += c[i];
             lstres = berr;
             continue;
         }
@@ -169,36 +237,58 @@ __device__ inline int posvx_small(int n, const float (&P)[NMAX][NMAX], const flo
     }
     if (rcequ) {
 #pragma unroll
-        for (int i = 0; i < NMAX; ++i) x[i] = s[i] * x[i];
+        for (int i = 0; i < NMAX; ++i) x[i] = lane_get(s_r, i) * x[i];
     }
     return 0;
 }
 
+// unit-test entry of posvx_rows: one wave per system; P count x 64 (row-major, lower triangle read), rhs and x count x 8
+template <int N>
+__global__ __launch_bounds__(64) void k_posvx_rows(const float* __restrict__ P, const float* __restrict__ rhs, int count,
+                                                   float* __restrict__ x, int* __restrict__ info)
+{
+    const int lane = threadIdx.x, r = lane & 7;
+    for (int p = blockIdx.x; p < count; p += gridDim.x) {
+        float Prow[8], sol[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) Prow[k] = (r < N && k < N) ? P[(size_t)p * 64 + (k <= r ? r * 8 + k : k * 8 + r)] : 0.0f;
+        const int rc = posvx_rows<N, 8>(Prow, r < N ? rhs[(size_t)p * 8 + r] : 0.0f, r, sol);
+        if (lane == 0) {
+            info[p] = rc;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[(size_t)p * 8 + k] = (rc == 0 && k < N) ? sol[k] : 0.0f;
+        }
+    }
+}
+
 template <int MODEL>
-__global__ __launch_bounds__(256) void k_lm_batched(BatchedArgs a)
+__global__ __launch_bounds__(64, BatchedModel<MODEL>::n <= 4 ? 4 : 2) void k_lm_batched(BatchedArgs a)   // waves per SIMD the LDS slices allow at m = 512
 {
     constexpr int N = BatchedModel<MODEL>::n;
     constexpr int NMAX = kBatchedNMax;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int prob = blockIdx.x * 4 + wave;
-    if (prob >= a.count) return;
+    // one problem per (single-wave) workgroup: the dispatcher hands a finished wave's slot to the next problem, so a
+    // long fit delays nobody (four problems per workgroup held three slots until the slowest of the four was done)
+    const int lane = threadIdx.x;
+    const int prob = blockIdx.x;
     const int m = a.m;
-    float* Jl = reinterpret_cast<float*>(smem_b) + (size_t)wave * (N + 2) * m;   // J: m x N row-major
+    float* Jl = reinterpret_cast<float*>(smem_b);                          // J: m x N row-major
     float* yv = Jl + (size_t)N * m;
     float* mB = yv + m;
     const float* tp = a.t + (size_t)(a.t_stride ? prob : 0) * a.t_stride;
     const float* dp = a.data + (size_t)prob * m;
+    constexpr int NB = BatchedModel<MODEL>::nb;
+    const float* bp = NB ? a.basis + (size_t)(a.t_stride ? prob : 0) * a.t_stride * NB : nullptr;
     const LmSettingsDev<float>& S = a.set;
 
-    float x[NMAX], lo[NMAX], up[NMAX];
+    float x[NMAX];
 #pragma unroll
     for (int j = 0; j < NMAX; ++j) {
         x[j] = j < N ? a.x[(size_t)prob * N + j] : 0.0f;
-        lo[j] = j < N ? a.lower[j] : -Lim<float>::inf();
-        up[j] = j < N ? a.upper[j] : Lim<float>::inf();
     }
+    // the bounds are wave-uniform and rarely read: scalar loads where they are used, not sixteen registers for the whole loop
+    auto lo = [&](int j) { return j < N ? a.lower[j] : -Lim<float>::inf(); };
+    auto up = [&](int j) { return j < N ? a.upper[j] : Lim<float>::inf(); };
     BatchedResult ret;
     ret.status = -26;   // numericError, LS:132
     ret.iterations = 0; ret.fCalls = 0; ret.gCalls = 0;
@@ -207,7 +297,9 @@ __global__ __launch_bounds__(256) void k_lm_batched(BatchedArgs a)
     auto feval = [&](const float (&p)[NMAX], float* dst) -> float {      // dst = f(p); returns ||f||^2
         float ss = 0;
         for (int i = lane; i < m; i += kWave) {
-            const float r = BatchedModel<MODEL>::eval(tp[i], p) - dp[i];
+            BasisRow<NB> b;
+            b.load(bp, i);
+            const float r = BatchedModel<MODEL>::eval(tp[i], b.v, p) - dp[i];
             dst[i] = r;
             ss += r * r;
         }
@@ -219,7 +311,7 @@ __global__ __launch_bounds__(256) void k_lm_batched(BatchedArgs a)
 #pragma unroll
     for (int j = 0; j < NMAX; ++j) if (j < N) {
         if (!(-Lim<float>::inf() < x[j] && x[j] < Lim<float>::inf())) finite = false;
-        if (!(lo[j] <= x[j]) || !(x[j] <= up[j])) inb = false;
+        if (!(lo(j) <= x[j]) || !(x[j] <= up(j))) inb = false;
     }
     if (m == 0 || !finite) ret.status = -31;           // badGuess
     else if (!inb) ret.status = -32;                   // badBounds
@@ -230,9 +322,11 @@ __global__ __launch_bounds__(256) void k_lm_batched(BatchedArgs a)
         bool fConverged = ret.residual <= S.maxGoodResidual;
         bool needJacobian = true;
         uint32_t age = maxAge;
-        float dx[NMAX], Jy[NMAX], JJ[NMAX][NMAX];
+        // J^T J and J^T y live one ROW per lane (row r = lane & 7 in every group of eight lanes), as posvx_rows wants them
+        const int r = lane & 7;
+        float dx[NMAX], JJrow[NMAX], Jy_r = 0;
 #pragma unroll
-        for (int j = 0; j < NMAX; ++j) { dx[j] = 0; Jy[j] = 0; }
+        for (int j = 0; j < NMAX; ++j) { dx[j] = 0; JJrow[j] = 0; }
         float dx_dot = 0, mu = 1, lambda = 0;
         ret.status = -1;                                                   // maxIterations, LS:971
         do {
@@ -262,29 +356,32 @@ __global__ __launch_bounds__(256) void k_lm_batched(BatchedArgs a)
                     }
                 } else {                                                   // FD LS:1016-1050
                     age = 0;
+                    // the n central differences of a row share its t, d and basis: rows outside, columns inside
+                    float xph[NMAX], xmh[NMAX], inv[NMAX];
 #pragma unroll
-                    for (int j = 0; j < N; ++j) {
+                    for (int j = 0; j < NMAX; ++j) {
+                        xmh[j] = fmaxf(x[j] - S.jacobianEpsilon, lo(j));
+                        xph[j] = fminf(x[j] + S.jacobianEpsilon, up(j));
+                        const float twh = xph[j] - xmh[j];
+                        inv[j] = twh != 0 ? 1.0f / twh : 0.0f;             // a zero-width interval: the column is zero, LS:1045
+                    }
+                    for (int i = lane; i < m; i += kWave) {
+                        BasisRow<NB> b;
+                        b.load(bp, i);
+                        const float ti = tp[i], di = dp[i];
                         float p[NMAX];
 #pragma unroll
                         for (int k = 0; k < NMAX; ++k) p[k] = x[k];
-                        const float save = x[j];
-                        float xmh = save - S.jacobianEpsilon, xph = save + S.jacobianEpsilon;
-                        xmh = fmaxf(xmh, lo[j]);
-                        xph = fminf(xph, up[j]);
-                        const float twh = xph - xmh;
-                        if (twh != 0) {
-                            const float inv = 1.0f / twh;
-                            for (int i = lane; i < m; i += kWave) {
-                                p[j] = xph;
-                                const float fp = BatchedModel<MODEL>::eval(tp[i], p) - dp[i];
-                                p[j] = xmh;
-                                const float fm = BatchedModel<MODEL>::eval(tp[i], p) - dp[i];
-                                float v = fp;
-                                v += -1.0f * fm;
-                                Jl[(size_t)i * N + j] = v * inv;
-                            }
-                        } else {
-                            for (int i = lane; i < m; i += kWave) Jl[(size_t)i * N + j] = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < N; ++j) {
+                            p[j] = xph[j];
+                            const float fp = BatchedModel<MODEL>::eval(ti, b.v, p) - di;
+                            p[j] = xmh[j];
+                            const float fm = BatchedModel<MODEL>::eval(ti, b.v, p) - di;
+                            p[j] = x[j];
+                            float v = fp;
+                            v += -1.0f * fm;
+                            Jl[(size_t)i * N + j] = inv[j] != 0 ? v * inv[j] : 0.0f;
                         }
                     }
                     ret.fCalls += N;                                       // LS:1049 (quirk Q5)
@@ -309,14 +406,17 @@ __global__ __launch_bounds__(256) void k_lm_batched(BatchedArgs a)
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < NMAX; ++j) {
-                    Jy[j] = j < N ? wave_sum(accy[j]) : 0.0f;
+                for (int j = 0; j < N; ++j) {
+                    const float ty = wave_sum(accy[j]);
+                    Jy_r = (r == j) ? ty : Jy_r;
 #pragma unroll
-                    for (int k = 0; k < NMAX; ++k) JJ[j][k] = (j < N && k <= j) ? wave_sum(accJ[j][k]) : 0.0f;
+                    for (int k = 0; k <= j; ++k) {
+                        const float t = wave_sum(accJ[j][k]);                  // element (j, k) and its mirror (k, j)
+                        JJrow[k] = (r == j) ? t : JJrow[k];
+                        if (k != j) JJrow[j] = (r == k) ? t : JJrow[j];
+                    }
                 }
-                float gmax = 0;
-#pragma unroll
-                for (int j = 0; j < NMAX; ++j) if (j < N) gmax = fmaxf(gmax, fabsf(Jy[j]));
+                const float gmax = lane_get(rows_max(fabsf(Jy_r)), 0);         // rows >= N hold zeros
                 if (!(gmax > S.gradTolerance)) {                           // LS:1053-1062
                     if (age == 0) { ret.status = 2; break; }
                     age = maxAge;
@@ -324,25 +424,21 @@ __global__ __launch_bounds__(256) void k_lm_batched(BatchedArgs a)
                 }
             }
             if (!(lambda >= S.minLambda)) {                                // LS:1067-1072
-                float best = -1, val = 0;
-#pragma unroll
-                for (int j = 0; j < NMAX; ++j) if (j < N && fabsf(JJ[j][j]) > best) { best = fabsf(JJ[j][j]); val = JJ[j][j]; }
+                // the largest diagonal element (a sum of squares: its own absolute value; a NaN is skipped as by `>`)
+                const float best = lane_get(rows_max(r < N ? fabsf(MIRLSQ_ROW_PICK(JJrow, r)) : -1.0f), 0);
+                const float val = best < 0 ? 0.0f : best;
                 lambda = 0.001f * val;
                 if (!(lambda >= S.minLambda)) lambda = 1;
             }
-            float P[NMAX][NMAX], rhs[NMAX], sol[NMAX];
+            float Prow[NMAX], sol[NMAX];
 #pragma unroll
-            for (int j = 0; j < NMAX; ++j) {
-                rhs[j] = -Jy[j];
-#pragma unroll
-                for (int k = 0; k < NMAX; ++k) P[j][k] = JJ[j][k] + ((j == k && j < N) ? lambda : 0.0f);   // LS:1079 (Q1)
-            }
-            const int info = posvx_small<NMAX>(N, P, rhs, sol);            // LS:1080 -> QP:194
+            for (int k = 0; k < NMAX; ++k) Prow[k] = JJrow[k] + ((k == r && r < N) ? lambda : 0.0f);   // LS:1079 (Q1)
+            const int info = posvx_rows<N, NMAX>(Prow, -Jy_r, r, sol);     // LS:1080 -> QP:194
             if (info != 0) { ret.status = -26; break; }
             bool feasible = true, nan = false;
 #pragma unroll
             for (int j = 0; j < NMAX; ++j) if (j < N) {
-                if (!((lo[j] - x[j]) <= sol[j] && sol[j] <= (up[j] - x[j]))) feasible = false;   // QP:216-219
+                if (!((lo(j) - x[j]) <= sol[j] && sol[j] <= (up(j) - x[j]))) feasible = false;   // QP:216-219
                 if (!(sol[j] <= sol[j])) nan = true;
             }
             if (nan) { ret.status = -26; break; }                          // LS:1087
@@ -354,7 +450,7 @@ __global__ __launch_bounds__(256) void k_lm_batched(BatchedArgs a)
                 d = d - x[j];
                 sol[j] = j < N ? d : 0.0f;
                 ndd += sol[j] * sol[j];
-                trial[j] = fmaxf(fminf(sol[j] + x[j], up[j]), lo[j]);      // LS:1108-1110
+                trial[j] = fmaxf(fminf(sol[j] + x[j], up(j)), lo(j));      // LS:1108-1110
             }
             if (!(sqrtf(ndd) < S.maxStep)) { lambda *= S.lambdaIncrease * mu; mu *= 2; continue; }   // LS:1101-1106
             ++ret.fCalls;                                                  // LS:1112-1115
@@ -373,13 +469,13 @@ __global__ __launch_bounds__(256) void k_lm_batched(BatchedArgs a)
             fConverged = ret.residual <= S.maxGoodResidual;
             dx_dot = ndd;
             float pred = 0;                                                // LS:1141-1142 (undamped JJ)
+            {
+                float tj = 0;                                              // row r of J^T J dx + 2 J^T y, then the dot with dx
 #pragma unroll
-            for (int j = 0; j < NMAX; ++j) {
-                float tj = 0;
+                for (int k = 0; k < NMAX; ++k) tj += JJrow[k] * dx[k];
+                tj = tj + 2 * Jy_r;
 #pragma unroll
-                for (int k = 0; k < NMAX; ++k) tj += ((k <= j) ? JJ[j][k] : JJ[k][j]) * dx[k];
-                tj = tj + 2 * Jy[j];
-                pred += tj * dx[j];
+                for (int j = 0; j < NMAX; ++j) pred += lane_get(tj, j) * dx[j];
             }
             pred = -pred;
             if (!(pred > 0)) { ret.status = 0; break; }                    // LS:1144-1148
@@ -410,11 +506,15 @@ template <int MODEL>
 __global__ __launch_bounds__(256) void k_batched_model_eval(const float* __restrict__ t, const float* __restrict__ d,
                                                             const float* __restrict__ x, float* __restrict__ y, int m)
 {
+    constexpr int NB = BatchedModel<MODEL>::nb;
     float p[kBatchedNMax];
 #pragma unroll
     for (int j = 0; j < kBatchedNMax; ++j) p[j] = j < BatchedModel<MODEL>::n ? x[j] : 0.0f;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x)
-        y[i] = BatchedModel<MODEL>::eval(t[i], p) - d[i];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        float b[NB > 0 ? NB : 1];
+        BatchedModel<MODEL>::basis(t[i], b);
+        y[i] = BatchedModel<MODEL>::eval(t[i], b, p) - d[i];
+    }
 }
 
 }  // namespace mirlsq

@@ -1770,6 +1770,33 @@ int jtj_entry(size_t m, size_t n, T* J, const T* y, const T* y_old, const T* dx,
 }
 }  // namespace
 
+namespace {
+// one wavefront = one workgroup per problem; every pointer in `a` is a device pointer. A model with a per-row
+// basis (BatchedModel::nb > 0) gets its table from a stream-ordered allocation filled by k_batched_basis on the same stream.
+template <int MODEL>
+hipError_t batched_launch_model(BatchedArgs a, hipStream_t stream)
+{
+    constexpr int n = BatchedModel<MODEL>::n, nb = BatchedModel<MODEL>::nb;
+    const size_t lds = (size_t)(n + 2) * a.m * sizeof(float);
+    const unsigned blocks = (unsigned)a.count;
+    auto kern = k_lm_batched<MODEL>;
+    MIRLSQ_ENSURE_LDS(kern, lds);
+    float* table = nullptr;
+    if (nb > 0) {
+        const size_t rows = (size_t)(a.t_stride ? a.count : 1) * a.m;
+        hipError_t e = hipMallocAsync((void**)&table, rows * nb * sizeof(float), stream);
+        if (e != hipSuccess) return e;
+        const unsigned bb = (unsigned)std::min<size_t>((rows + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_batched_basis<MODEL>, dim3(bb), dim3(256), 0, stream, a.t, table, rows);
+        a.basis = table;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, stream, a);
+    hipError_t e = hipGetLastError();
+    if (table) { const hipError_t f = hipFreeAsync(table, stream); if (e == hipSuccess) e = f; }
+    return e;
+}
+}  // namespace
+
 extern "C" {
 
 // ---- batched one-wave-per-problem entry (cfg 5) ------------------------------------------------
@@ -1804,20 +1831,11 @@ void batched_settings(BatchedArgs& a, const mir_least_squares_settings_s* S)
     a.maxIterations = S->maxIterations; a.maxAge = S->maxAge;
 }
 
-// one wavefront per problem, four problems per workgroup; every pointer in `a` is a device pointer
 hipError_t batched_launch(const BatchedArgs& a, int model, hipStream_t stream)
 {
-    const int n = batched_model_n(model);
-    const size_t lds = (size_t)4 * (n + 2) * a.m * sizeof(float);
-    const unsigned blocks = (unsigned)((a.count + 3) / 4);
-    auto launch = [&](auto kern) -> hipError_t {
-        MIRLSQ_ENSURE_LDS(kern, lds);
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, a);
-        return hipGetLastError();
-    };
-    if (model == kModelExpDecay) return launch(k_lm_batched<kModelExpDecay>);
-    if (model == kModelExp3Affine) return launch(k_lm_batched<kModelExp3Affine>);
-    return launch(k_lm_batched<kModelExpDecayPad8>);
+    if (model == kModelExpDecay) return batched_launch_model<kModelExpDecay>(a, stream);
+    if (model == kModelExp3Affine) return batched_launch_model<kModelExp3Affine>(a, stream);
+    return batched_launch_model<kModelExpDecayPad8>(a, stream);
 }
 }  // namespace
 
@@ -1829,7 +1847,7 @@ int mir_lsq_batched_kernel_s(const mir_least_squares_settings_s* S, size_t count
     if (!S || !x || !lower || !upper || !t || !data || !results || n == 0 || (t_stride != 0 && t_stride != m)) return -1;
     if (count == 0) return 0;
     if (!device_available()) return -2;
-    if (m == 0 || (size_t)4 * (n + 2) * m * sizeof(float) > 160 * 1024 - 512) return -3;
+    if (m == 0 || (size_t)(n + 2) * m * sizeof(float) > 160 * 1024 - 512) return -3;
     static_assert(sizeof(BatchedResult) == sizeof(mir_least_squares_result_s), "the kernel writes the C result records in place");
     BatchedArgs a{};
     batched_settings(a, S);
@@ -1837,6 +1855,17 @@ int mir_lsq_batched_kernel_s(const mir_least_squares_settings_s* S, size_t count
     a.t = t; a.data = data; a.x = x; a.lower = lower; a.upper = upper;
     a.results = reinterpret_cast<BatchedResult*>(results);
     return batched_launch(a, model, static_cast<hipStream_t>(stream)) == hipSuccess ? 0 : -5;
+}
+
+int mir_lsq_batched_posvx_s(size_t count, size_t n, const float* P, const float* rhs, float* x, int* info, void* stream)
+{
+    if (!P || !rhs || !x || !info || (n != 3 && n != 8)) return -1;
+    if (count == 0) return 0;
+    if (!device_available()) return -2;
+    const unsigned blocks = (unsigned)std::min<size_t>(count, 8192);
+    if (n == 8) hipLaunchKernelGGL(k_posvx_rows<8>, dim3(blocks), dim3(64), 0, static_cast<hipStream_t>(stream), P, rhs, (int)count, x, info);
+    else hipLaunchKernelGGL(k_posvx_rows<3>, dim3(blocks), dim3(64), 0, static_cast<hipStream_t>(stream), P, rhs, (int)count, x, info);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
 int mir_optimize_least_squares_batched_s(const mir_least_squares_settings_s* S, size_t count, size_t m, int model,
@@ -1860,7 +1889,7 @@ int mir_optimize_least_squares_batched_s(const mir_least_squares_settings_s* S, 
     else if (!(1 <= S->lambdaIncrease && S->lambdaIncrease <= std::sqrt(FLT_MAX))) bad = mir_ls_badLambdaParams;
     else if (!(std::sqrt(FLT_MIN) <= S->lambdaDecrease && S->lambdaDecrease <= 1)) bad = mir_ls_badLambdaParams;
     if (!device_available()) return -2;
-    const size_t lds = (size_t)4 * (n + 2) * m * sizeof(float);
+    const size_t lds = (size_t)(n + 2) * m * sizeof(float);
     if (m == 0 || lds > 160 * 1024 - 512) {
         std::fprintf(stderr, "[mir_optim_amd] batched entry: m = %zu does not fit one wave's LDS slice\n", m);
         return -3;

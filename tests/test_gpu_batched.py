@@ -190,3 +190,39 @@ def test_cfg5_pad8_all_4096_problems_match_the_float_oracle(oracle):
     assert abs(np.mean(resid) / noise_floor - 1) < 0.05                    # and both sit on the noise floor of the data
     it = np.array([r.iterations for r in res])
     assert it.min() >= 2 and it.max() < 1000
+
+
+@pytest.mark.parametrize("n", [8, 3])
+def test_batched_solve_rows_against_the_float_oracle_posvx(oracle, n):
+    """posvx_rows (one matrix row per lane, batched_kernel.h) on its own against the oracle's float ?posvx('E','L'), system by
+    system: well-scaled and badly scaled SPD systems (the second half equilibrates: scond < 0.1), and systems whose leading
+    minor of order k is not positive (info = k on both sides). The kernel fuses every multiply-add, the oracle's C does not:
+    the solutions agree to rounding -- both are refined, so to a few ulp of the solution norm times a modest factor."""
+    rng = np.random.default_rng(11 + n)
+    count = 256
+    P = np.zeros((count, n, n), dtype=np.float32)
+    b = rng.standard_normal((count, n)).astype(np.float32)
+    for p in range(count):
+        G = rng.standard_normal((2 * n, n))
+        if p >= count // 2:
+            G = G * np.logspace(-2, 2, n)[None, :]                 # diagonal spread 1e8: ?laqsy scales
+        A = G.T @ G + 1e-3 * np.eye(n)
+        if p % 16 == 5:                                            # not positive definite from minor k on
+            k = 1 + (p // 16) % n
+            A[k - 1, k - 1] = -abs(A[k - 1, k - 1])
+        P[p] = A
+    x, info = M.batchedPosvx(P, b)
+    worst = 0.0
+    for p in range(count):
+        o = oracle.posvx(P[p].astype(np.float64), b[p], dtype=np.float32)
+        oi = 0 if o["info"] == n + 1 else o["info"]                # rcond < eps is accepted by the caller, boxcqp.d:212
+        assert info[p] == oi, (p, info[p], o["info"])
+        if oi != 0:
+            assert not x[p].any()
+            continue
+        assert (o["equed"] == "Y") == (p >= count // 2) or p % 16 == 5
+        err = np.linalg.norm(x[p] - o["x"]) / np.linalg.norm(o["x"])
+        worst = max(worst, err)
+        xr = np.linalg.solve(P[p].astype(np.float64), b[p].astype(np.float64))
+        assert np.linalg.norm(x[p] - xr) <= 4 * np.linalg.norm(o["x"] - xr) + 1e-6 * np.linalg.norm(xr), p
+    assert worst < 2e-4, worst
