@@ -405,6 +405,12 @@ int mir_lsq_batched_kernel_s(const mir_least_squares_settings_s* settings, size_
  * Enqueued on `stream`, no synchronisation. */
 int mir_lsq_batched_posvx_s(size_t count, size_t n, const float* P, const float* rhs, float* x, int* info, void* stream);
 
+/* A/B switch of the two batched entries above (process-wide; 0 = default). MIR_LSQ_BATCHED_NO_LADDER: every damped solve is
+ * made for ONE lambda, as the reference's loop does (boxcqp.d:194 per LS:1080); by default a solve covers lambda and the three
+ * values the rejection rule would give it next (four 16-lane groups of the wave), with the same steps, bit for bit. */
+enum { MIR_LSQ_BATCHED_NO_LADDER = 1 };
+void mir_lsq_batched_set_variant(uint32_t variant);
+
 /* Unit-level access to the hot kernels (parity tests and micro-benchmarks). All pointers are
  * DEVICE pointers; stream may be NULL (default stream; the call synchronises before returning).
  * JJ: n x n row-major, full symmetric on return. broyden != 0 first applies

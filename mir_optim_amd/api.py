@@ -29,7 +29,7 @@ __all__ = [
     "LeastSquaresException", "optimize", "optimizeLeastSquares", "solveBoxQP", "leastSquaresStatusString",
     "mir_least_squares_work_length", "mir_least_squares_iwork_length", "mir_box_qp_work_length",
     "mir_box_qp_iwork_length", "GpuOptions", "Stats", "lib", "workloads_lib", "device_count",
-    "DeviceBuffer", "Stream", "jtj", "fd_jtj", "DEVICE_CALLBACKS", "TIME_KERNELS", "optimizeLeastSquaresBatched", "batchedPosvx",
+    "DeviceBuffer", "Stream", "jtj", "fd_jtj", "DEVICE_CALLBACKS", "TIME_KERNELS", "optimizeLeastSquaresBatched", "batchedPosvx", "BATCHED_NO_LADDER",
     "MODEL_EXP_DECAY", "MODEL_EXP3_AFFINE", "MODEL_EXP_DECAY_PAD8", "ResultS", "Trace", "TraceRecord", "Spline", "FitSplineResult", "fitSpline",
     "fit_spline_residuals", "variant_lr_cap",
     "VARIANT_BROYDEN_REWRITE", "VARIANT_FD_SEPARATE_FILL", "VARIANT_JTJ_RING", "VARIANT_JTJ_STREAM",
@@ -281,6 +281,8 @@ def lib():
         L.mir_lsq_batched_kernel_s.restype = C.c_int
         L.mir_lsq_batched_kernel_s.argtypes = [C.POINTER(_Ss), sz, sz, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p, sz, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mir_lsq_batched_set_variant.restype = None
+        L.mir_lsq_batched_set_variant.argtypes = [C.c_uint32]
         L.mir_lsq_batched_posvx_s.restype = C.c_int
         L.mir_lsq_batched_posvx_s.argtypes = [sz, sz, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mir_lsq_comm_describe.restype = C.c_int
@@ -590,6 +592,9 @@ def optimizeLeastSquaresBatched(model, x, t, data, l=None, u=None, settings=None
     if rc != 0:
         raise RuntimeError(f"mir_optimize_least_squares_batched_s failed: {rc}")
     return [LeastSquaresResult(r) for r in raw], x
+
+
+BATCHED_NO_LADDER = 1
 
 
 def batchedPosvx(P, rhs):

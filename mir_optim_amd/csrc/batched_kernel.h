@@ -70,7 +70,9 @@ struct BatchedArgs {
     const float* upper;    // n
     BatchedResult* results;
     const float* basis;    // (t_stride ? count : 1) x m x nb: the model's per-row basis (k_batched_basis), nullptr when nb == 0
+    uint32_t variant;      // kBatchedNoLadder: one damping value per solve (A/B and the test of the ladder against it)
 };
+constexpr uint32_t kBatchedNoLadder = 1u;
 
 // one row of the basis table: 16-byte loads when the model has four values
 template <int NB> struct BasisRow {
@@ -135,8 +137,11 @@ __device__ inline float rows_min(float v)
     return v;
 }
 
-// ?posvx('E','L'), n = N <= NMAX = 8. Prow: the full symmetric row r of P; rhs_r: component r of the right-hand side.
-// x: the solution, wave-uniform (the caller's acceptance logic is). Returns info (wave-uniform).
+// ?posvx('E','L'), n = N <= NMAX = 8, FOUR SYSTEMS A WAVE: each row of 16 lanes (a DPP row; r = lane & 7, the upper eight lanes
+// repeat the lower eight) solves its own system, so that one call serves a ladder of four damping values (k_lm_batched).
+// Prow: the full symmetric row r of this group's P; rhs_r: component r of its right-hand side. x: the group's solution in every
+// lane of the group. Returns the group's info in every lane of the group. There is no branch on a group's data: a group whose
+// factorization fails keeps computing on values nobody reads.
 template <int N, int NMAX>
 __device__ inline int posvx_rows(const float (&Prow)[NMAX], float rhs_r, int r, float (&x)[NMAX])
 {
@@ -145,76 +150,74 @@ __device__ inline int posvx_rows(const float (&Prow)[NMAX], float rhs_r, int r, 
     const bool live = r < N;
     const float d_r = MIRLSQ_ROW_PICK(Prow, r);
     // ?poequ
-    const float smin = lane_get(rows_min(live ? d_r : Lim<float>::inf()), 0);
-    const float amax = lane_get(rows_max(live ? d_r : -Lim<float>::inf()), 0);
-    bool rcequ = false;
-    float s_r = 1.0f;
-    if (smin > 0) {
-        const float scond = sqrtf(smin) / sqrtf(amax);
-        s_r = live ? 1.0f / sqrtf(d_r) : 1.0f;
-        const float small = safmin / Lim<float>::eps, large = 1.0f / small;
-        rcequ = !(scond >= 0.1f && amax >= small && amax <= large);
-    }
+    const float smin = rows_min(live ? d_r : Lim<float>::inf());
+    const float amax = rows_max(live ? d_r : -Lim<float>::inf());
+    const bool pos = smin > 0;
+    const float scond = sqrtf(smin) / sqrtf(amax);
+    const float s_r = (pos && live) ? 1.0f / sqrtf(d_r) : 1.0f;
+    const float small = safmin / Lim<float>::eps, large = 1.0f / small;
+    const bool rcequ = pos && !(scond >= 0.1f && amax >= small && amax <= large);
     // ?laqsy
-    float Arow[NMAX], Frow[NMAX], Fcol[NMAX];                  // Fcol[k] = F[k][r], k > r: column r of the factor, for L^T
-#pragma unroll
-    for (int k = 0; k < NMAX; ++k) {
-        const float sk = lane_get(s_r, k);
+    float Arow[NMAX], Frow[NMAX], Fcol[NMAX], s[NMAX];           // Fcol[k] = F[k][r], k > r: column r of the factor, for L^T
+    static_for<NMAX>([&](auto K) {
+        constexpr int k = K.value;
+        s[k] = dpp_row_bcast<k>(s_r);
         const float v = Prow[k];
-        Arow[k] = (live && k < N) ? (rcequ ? sk * s_r * v : v) : (r == k ? 1.0f : 0.0f);
+        Arow[k] = (live && k < N) ? (rcequ ? s[k] * s_r * v : v) : (r == k ? 1.0f : 0.0f);
         Frow[k] = Arow[k];
         Fcol[k] = 0.0f;
-    }
+    });
     const float b_r = live ? (rcequ ? s_r * rhs_r : rhs_r) : 0.0f;
     // ?potf2 'L': after step j, Frow[jj] (jj > j) of row r >= jj holds A[r][jj] - sum_{k <= j} F[r][k] F[jj][k]
     int info = 0;
-#pragma unroll
-    for (int j = 0; j < NMAX; ++j) {
-        if (info == 0 && j < N) {
-            float ajj = lane_get(Frow[j], j);
-            if (!(ajj > 0)) { info = j + 1; }
-            else {
-                ajj = sqrtf(ajj);
-                const float q = Frow[j] / ajj;
-                Frow[j] = (r == j) ? ajj : q;                  // rows above the diagonal carry values nobody reads
-#pragma unroll
-                for (int jj = j + 1; jj < NMAX; ++jj) if (jj < N) {
-                    const float ljj = lane_get(Frow[j], jj);   // F[jj][j]
+    static_for<NMAX>([&](auto J) {
+        constexpr int j = J.value;
+        if constexpr (j < N) {
+            float ajj = dpp_row_bcast<j>(Frow[j]);
+            info = (info == 0 && !(ajj > 0)) ? j + 1 : info;
+            ajj = sqrtf(ajj);
+            const float q = Frow[j] / ajj;
+            Frow[j] = (r == j) ? ajj : q;                          // rows above the diagonal carry values nobody reads
+            static_for<NMAX>([&](auto JJ) {
+                constexpr int jj = JJ.value;
+                if constexpr (jj > j && jj < N) {
+                    const float ljj = dpp_row_bcast<jj>(Frow[j]);  // F[jj][j]
                     Frow[jj] = __builtin_fmaf(-Frow[j], ljj, Frow[jj]);
                     Fcol[jj] = (r == j) ? ljj : Fcol[jj];
                 }
-            }
+            });
         }
-    }
-    if (info != 0) return info;
-    const float fd_r = MIRLSQ_ROW_PICK(Frow, r);                      // F[r][r]
+    });
+    const float fd_r = MIRLSQ_ROW_PICK(Frow, r);                  // F[r][r]
     // ?potrs. L y = v by columns: row r takes `t -= F[r][i] y[i]` at step i (ascending i, as in the oracle's row loop).
     // L^T z = y: row i needs t = y[i] - sum_{k > i} F[k][i] z[k] with k ascending, a chain that can only start when z[i + 1]
-    // is known: lane i runs it on its column of the factor and the wave-uniform z[k].
+    // is known: lane i runs it on its column of the factor and the group's z[k].
     auto potrs = [&](float v_r, float (&z)[NMAX]) {
-#pragma unroll
-        for (int i = 0; i < NMAX; ++i) if (i < N) {
-            const float yi = lane_get(v_r / fd_r, i);
-            const float upd = __builtin_fmaf(-Frow[i], yi, v_r);
-            v_r = (r == i) ? yi : (r > i ? upd : v_r);
-        }
+        static_for<NMAX>([&](auto I) {
+            constexpr int i = I.value;
+            if constexpr (i < N) {
+                const float yi = dpp_row_bcast<i>(v_r / fd_r);
+                const float upd = __builtin_fmaf(-Frow[i], yi, v_r);
+                v_r = (r == i) ? yi : (r > i ? upd : v_r);
+            }
+        });
 #pragma unroll
         for (int i = 0; i < NMAX; ++i) z[i] = 0.0f;
-#pragma unroll
-        for (int ii = 0; ii < NMAX; ++ii) {
-            const int i = NMAX - 1 - ii;
-            if (i < N) {
+        static_for<NMAX>([&](auto II) {
+            constexpr int i = NMAX - 1 - II.value;
+            if constexpr (i < N) {
                 float t = v_r;
 #pragma unroll
                 for (int k = 0; k < NMAX; ++k) if (k > i && k < N) t = __builtin_fmaf(-Fcol[k], z[k], t);
-                z[i] = lane_get(t / fd_r, i);
+                z[i] = dpp_row_bcast<i>(t / fd_r);
             }
-        }
+        });
     };
     potrs(b_r, x);
-    // ?porfs
+    // ?porfs: the loop runs while any group refines; a group that has stopped keeps its solution
     const float safe1 = (float)(N + 1) * safmin, safe2 = safe1 / eps;
     float lstres = 3;
+    bool active = true;
     for (int count = 1;; ++count) {
         float ri = b_r, wi = fabsf(b_r);
 #pragma unroll
@@ -224,36 +227,33 @@ __device__ inline int posvx_rows(const float (&Prow)[NMAX], float rhs_r, int r, 
         }
         const bool big = wi > safe2;
         const float q = (big ? fabsf(ri) : fabsf(ri) + safe1) / (big ? wi : wi + safe1);
-        const float berr = lane_get(rows_max(live ? q : 0.0f), 0);
-        if (berr > eps && 2 * berr <= lstres && count <= 5) {
-            float c[NMAX];
-            potrs(live ? ri : 0.0f, c);
+        const float berr = rows_max(live ? q : 0.0f);
+        active = active && berr > eps && 2 * berr <= lstres && count <= 5;
+        if (__builtin_amdgcn_ballot_w64(active) == 0) break;
+        float c[NMAX];
+        potrs(live ? ri : 0.0f, c);
 #pragma unroll
-            for (int i = 0; i < NMAX; ++i) x[i] += c[i];
-            lstres = berr;
-            continue;
-        }
-        break;
+        for (int i = 0; i < NMAX; ++i) x[i] = active ? x[i] + c[i] : x[i];
+        lstres = active ? berr : lstres;
     }
-    if (rcequ) {
 #pragma unroll
-        for (int i = 0; i < NMAX; ++i) x[i] = lane_get(s_r, i) * x[i];
-    }
-    return 0;
+    for (int i = 0; i < NMAX; ++i) x[i] = rcequ ? s[i] * x[i] : x[i];
+    return info;
 }
 
-// unit-test entry of posvx_rows: one wave per system; P count x 64 (row-major, lower triangle read), rhs and x count x 8
+// unit-test entry of posvx_rows: four systems a wave; P count x 64 (row-major, lower triangle read), rhs and x count x 8
 template <int N>
 __global__ __launch_bounds__(64) void k_posvx_rows(const float* __restrict__ P, const float* __restrict__ rhs, int count,
                                                    float* __restrict__ x, int* __restrict__ info)
 {
-    const int lane = threadIdx.x, r = lane & 7;
-    for (int p = blockIdx.x; p < count; p += gridDim.x) {
+    const int lane = threadIdx.x, r = lane & 7, g = lane >> 4;
+    for (int p0 = 4 * blockIdx.x; p0 < count; p0 += 4 * gridDim.x) {
+        const int p = p0 + g < count ? p0 + g : count - 1;            // a short last wave repeats the last system
         float Prow[8], sol[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) Prow[k] = (r < N && k < N) ? P[(size_t)p * 64 + (k <= r ? r * 8 + k : k * 8 + r)] : 0.0f;
         const int rc = posvx_rows<N, 8>(Prow, r < N ? rhs[(size_t)p * 8 + r] : 0.0f, r, sol);
-        if (lane == 0) {
+        if ((lane & 15) == 0 && p0 + g < count) {
             info[p] = rc;
 #pragma unroll
             for (int k = 0; k < 8; ++k) x[(size_t)p * 8 + k] = (rc == 0 && k < N) ? sol[k] : 0.0f;
@@ -327,6 +327,12 @@ __global__ __launch_bounds__(64, BatchedModel<MODEL>::n <= 4 ? 4 : 2) void k_lm_
         float dx[NMAX], JJrow[NMAX], Jy_r = 0;
 #pragma unroll
         for (int j = 0; j < NMAX; ++j) { dx[j] = 0; JJrow[j] = 0; }
+        float lad_x[NMAX], lad_lam[4] = {0, 0, 0, 0};      // the ladder of solutions (group g of the wave: level g), see below
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) lad_x[j] = 0;
+        int lad_info = 0, lad_level = 0;
+        bool lad_valid = false;
+        const int lad_depth = (a.variant & kBatchedNoLadder) ? 1 : 4;
         float dx_dot = 0, mu = 1, lambda = 0;
         ret.status = -1;                                                   // maxIterations, LS:971
         do {
@@ -416,6 +422,7 @@ __global__ __launch_bounds__(64, BatchedModel<MODEL>::n <= 4 ? 4 : 2) void k_lm_
                         if (k != j) JJrow[j] = (r == k) ? t : JJrow[j];
                     }
                 }
+                lad_valid = false;                                             // J^T J has changed
                 const float gmax = lane_get(rows_max(fabsf(Jy_r)), 0);         // rows >= N hold zeros
                 if (!(gmax > S.gradTolerance)) {                           // LS:1053-1062
                     if (age == 0) { ret.status = 2; break; }
@@ -430,10 +437,28 @@ __global__ __launch_bounds__(64, BatchedModel<MODEL>::n <= 4 ? 4 : 2) void k_lm_
                 lambda = 0.001f * val;
                 if (!(lambda >= S.minLambda)) lambda = 1;
             }
-            float Prow[NMAX], sol[NMAX];
+            // LS:1079-1080 (-> QP:194). The four 16-lane groups of the wave solve with lambda and with the three values the
+            // rejection rule (LS:1101-1106, 1125-1130: lambda *= lambdaIncrease mu, mu *= 2) would make of it next, at the
+            // cost of one solve; a rejected step then finds its solution ready. A level is used only while J^T J is the one
+            // the ladder was built on and lambda is bit for bit the ladder's value: the steps are those of the one-by-one loop.
+            if (!(lad_valid && lad_level < lad_depth && lambda == lad_lam[lad_level])) {
+                float l = lambda, mm = mu;
 #pragma unroll
-            for (int k = 0; k < NMAX; ++k) Prow[k] = JJrow[k] + ((k == r && r < N) ? lambda : 0.0f);   // LS:1079 (Q1)
-            const int info = posvx_rows<N, NMAX>(Prow, -Jy_r, r, sol);     // LS:1080 -> QP:194
+                for (int g = 0; g < 4; ++g) { lad_lam[g] = l; l *= S.lambdaIncrease * mm; mm *= 2; }
+                const int g = lane >> 4;
+                const float mine = g == 0 ? lad_lam[0] : (g == 1 ? lad_lam[1] : (g == 2 ? lad_lam[2] : lad_lam[3]));
+                float Prow[NMAX];
+#pragma unroll
+                for (int k = 0; k < NMAX; ++k) Prow[k] = JJrow[k] + ((k == r && r < N) ? mine : 0.0f);   // (Q1)
+                lad_info = posvx_rows<N, NMAX>(Prow, -Jy_r, r, lad_x);
+                lad_level = 0;
+                lad_valid = true;
+            }
+            float sol[NMAX];
+            const int lad_lane = 16 * lad_level++;
+            const int info = __builtin_amdgcn_readlane(lad_info, lad_lane);
+#pragma unroll
+            for (int j = 0; j < NMAX; ++j) sol[j] = lane_get(lad_x[j], lad_lane);
             if (info != 0) { ret.status = -26; break; }
             bool feasible = true, nan = false;
 #pragma unroll

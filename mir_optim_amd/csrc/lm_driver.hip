@@ -1839,6 +1839,9 @@ hipError_t batched_launch(const BatchedArgs& a, int model, hipStream_t stream)
 }
 }  // namespace
 
+namespace { std::atomic<uint32_t> g_batched_variant{0}; }
+void mir_lsq_batched_set_variant(uint32_t variant) { g_batched_variant.store(variant); }
+
 int mir_lsq_batched_kernel_s(const mir_least_squares_settings_s* S, size_t count, size_t m, int model, float* x,
                              const float* lower, const float* upper, const float* t, size_t t_stride, const float* data,
                              mir_least_squares_result_s* results, void* stream)
@@ -1852,6 +1855,7 @@ int mir_lsq_batched_kernel_s(const mir_least_squares_settings_s* S, size_t count
     BatchedArgs a{};
     batched_settings(a, S);
     a.count = (int)count; a.m = (int)m; a.t_stride = (int)t_stride;
+    a.variant = g_batched_variant.load();
     a.t = t; a.data = data; a.x = x; a.lower = lower; a.upper = upper;
     a.results = reinterpret_cast<BatchedResult*>(results);
     return batched_launch(a, model, static_cast<hipStream_t>(stream)) == hipSuccess ? 0 : -5;
@@ -1898,6 +1902,7 @@ int mir_optimize_least_squares_batched_s(const mir_least_squares_settings_s* S, 
     batched_settings(a, S);
     a.count = (int)count; a.m = (int)m;
     a.t_stride = (int)t_stride;
+    a.variant = g_batched_variant.load();
     const size_t tb = (t_stride ? count : 1) * m * sizeof(float), db = count * m * sizeof(float), xb = count * n * sizeof(float);
     char* base = nullptr;
     size_t off = 0;

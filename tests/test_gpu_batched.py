@@ -226,3 +226,25 @@ def test_batched_solve_rows_against_the_float_oracle_posvx(oracle, n):
         xr = np.linalg.solve(P[p].astype(np.float64), b[p].astype(np.float64))
         assert np.linalg.norm(x[p] - xr) <= 4 * np.linalg.norm(o["x"] - xr) + 1e-6 * np.linalg.norm(xr), p
     assert worst < 2e-4, worst
+
+
+@pytest.mark.parametrize("model,maker", [(M.MODEL_EXP_DECAY_PAD8, "pad8"), (M.MODEL_EXP3_AFFINE, "exp3"), (M.MODEL_EXP_DECAY, "decay")])
+def test_lambda_ladder_takes_the_steps_of_the_one_by_one_loop(model, maker):
+    """By default one damped solve serves lambda and the three values the rejection rule (LS:1101-1106, 1125-1130) would give
+    it next; with MIR_LSQ_BATCHED_NO_LADDER every solve is for one lambda, as the reference's loop. Same x bits, iterations,
+    fCalls, status, residual and lambda on every problem."""
+    count = 1024
+    t, data, truth, x0 = {"pad8": P.cfg5_pad8, "exp3": make_exp3, "decay": make_exp_decay}[maker](count, 512)
+    L = M.lib()
+    out = []
+    for variant in (0, M.BATCHED_NO_LADDER):
+        L.mir_lsq_batched_set_variant(variant)
+        try:
+            res, x = M.optimizeLeastSquaresBatched(model, x0, t, data, settings=M.LeastSquaresSettings(np.float32))
+        finally:
+            L.mir_lsq_batched_set_variant(0)
+        out.append((x.view(np.uint32).copy(), [(int(r.status), r.iterations, r.fCalls, np.float32(r.residual).view(np.uint32),
+                                               np.float32(r.lambda_).view(np.uint32)) for r in res]))
+    assert (out[0][0] == out[1][0]).all()
+    assert out[0][1] == out[1][1]
+    assert sum(r[1] for r in out[0][1]) > 4 * count            # the fits did iterate
