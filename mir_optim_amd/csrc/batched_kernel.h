@@ -70,6 +70,7 @@ struct BatchedArgs {
     const float* upper;    // n
     BatchedResult* results;
     const float* basis;    // (t_stride ? count : 1) x m x nb: the model's per-row basis (k_batched_basis), nullptr when nb == 0
+    uint64_t* timing;      // profiling builds (MIRLSQ_BATCHED_TIMING): 6 x count cycle counters, else unused
     uint32_t variant;      // kBatchedNoLadder: one damping value per solve (A/B and the test of the ladder against it)
 };
 constexpr uint32_t kBatchedNoLadder = 1u;
@@ -261,6 +262,17 @@ __global__ __launch_bounds__(64) void k_posvx_rows(const float* __restrict__ P, 
     }
 }
 
+// -DMIRLSQ_BATCHED_TIMING: per problem, the shader-clock cycles (s_memtime) spent in [0] residual evaluations, [1] Jacobian
+// refreshes (FD or Broyden), [2] J^T J / J^T y with its reductions, [3] damped solves, [4] the whole fit, and [5] the number of
+// solve calls, [6] a trial's preparation, [7] an accepted step's bookkeeping, written to BatchedArgs::timing (10 x uint64 a problem). A profiling build only (scripts/probes/cfg5_phases.py).
+#ifdef MIRLSQ_BATCHED_TIMING
+#define MIRLSQ_T0() const uint64_t t0_ = __builtin_readcyclecounter()
+#define MIRLSQ_T1(k) tacc[k] += __builtin_readcyclecounter() - t0_
+#else
+#define MIRLSQ_T0() ((void)0)
+#define MIRLSQ_T1(k) ((void)0)
+#endif
+
 template <int MODEL>
 __global__ __launch_bounds__(64, BatchedModel<MODEL>::n <= 4 ? 4 : 2) void k_lm_batched(BatchedArgs a)   // waves per SIMD the LDS slices allow at m = 512
 {
@@ -281,27 +293,45 @@ __global__ __launch_bounds__(64, BatchedModel<MODEL>::n <= 4 ? 4 : 2) void k_lm_
     const float* bp = NB ? a.basis + (size_t)(a.t_stride ? prob : 0) * a.t_stride * NB : nullptr;
     const LmSettingsDev<float>& S = a.set;
 
-    float x[NMAX];
+    float x[NMAX], lo[NMAX], up[NMAX];
 #pragma unroll
     for (int j = 0; j < NMAX; ++j) {
         x[j] = j < N ? a.x[(size_t)prob * N + j] : 0.0f;
+        lo[j] = j < N ? a.lower[j] : -Lim<float>::inf();
+        up[j] = j < N ? a.upper[j] : Lim<float>::inf();
     }
-    // the bounds are wave-uniform and rarely read: scalar loads where they are used, not sixteen registers for the whole loop
-    auto lo = [&](int j) { return j < N ? a.lower[j] : -Lim<float>::inf(); };
-    auto up = [&](int j) { return j < N ? a.upper[j] : Lim<float>::inf(); };
+#ifdef MIRLSQ_BATCHED_TIMING
+    uint64_t tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const uint64_t tstart = __builtin_readcyclecounter();
+#endif
     BatchedResult ret;
     ret.status = -26;   // numericError, LS:132
     ret.iterations = 0; ret.fCalls = 0; ret.gCalls = 0;
     ret.residual = Lim<float>::inf(); ret.lambda = 0;
 
+    // The lane's rows (lane, lane + 64, ...) are taken in chunks of UNR: the loads of a chunk are issued together (index clamped
+    // to the last row: always a valid address), then the rows are used in order, so a wave does not pay one memory latency a
+    // row. The sum of squares is accumulated in the order of the plain loop.
     auto feval = [&](const float (&p)[NMAX], float* dst) -> float {      // dst = f(p); returns ||f||^2
+        constexpr int UNR = 8;
         float ss = 0;
-        for (int i = lane; i < m; i += kWave) {
-            BasisRow<NB> b;
-            b.load(bp, i);
-            const float r = BatchedModel<MODEL>::eval(tp[i], b.v, p) - dp[i];
-            dst[i] = r;
-            ss += r * r;
+        for (int base = lane; base - lane < m; base += kWave * UNR) {
+            float tv[UNR], dv[UNR], rv[UNR];
+            BasisRow<NB> bv[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int i = min(base + kWave * u, m - 1);
+                tv[u] = tp[i]; dv[u] = dp[i];
+                bv[u].load(bp, i);
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) rv[u] = BatchedModel<MODEL>::eval(tv[u], bv[u].v, p) - dv[u];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int i = base + kWave * u;
+                if (i < m) dst[i] = rv[u];
+                ss = i < m ? __builtin_fmaf(rv[u], rv[u], ss) : ss;
+            }
         }
         return wave_sum(ss);
     };
@@ -311,13 +341,13 @@ __global__ __launch_bounds__(64, BatchedModel<MODEL>::n <= 4 ? 4 : 2) void k_lm_
 #pragma unroll
     for (int j = 0; j < NMAX; ++j) if (j < N) {
         if (!(-Lim<float>::inf() < x[j] && x[j] < Lim<float>::inf())) finite = false;
-        if (!(lo(j) <= x[j]) || !(x[j] <= up(j))) inb = false;
+        if (!(lo[j] <= x[j]) || !(x[j] <= up[j])) inb = false;
     }
     if (m == 0 || !finite) ret.status = -31;           // badGuess
     else if (!inb) ret.status = -32;                   // badBounds
     else {
         const uint32_t maxAge = a.maxAge ? a.maxAge : 2 * N;               // LS:945 (no analytic Jacobian here)
-        ret.residual = feval(x, yv);                                       // LS:953-955
+        { MIRLSQ_T0(); ret.residual = feval(x, yv); MIRLSQ_T1(0); }       // LS:953-955
         ++ret.fCalls;
         bool fConverged = ret.residual <= S.maxGoodResidual;
         bool needJacobian = true;
@@ -347,6 +377,7 @@ __global__ __launch_bounds__(64, BatchedModel<MODEL>::n <= 4 ? 4 : 2) void k_lm_
             }
             if (needJacobian) {                                            // LS:996
                 needJacobian = false;
+                MIRLSQ_T0();
                 if (age < maxAge) {                                        // Broyden LS:999-1007
                     age++;
                     const float d = 1.0f / dx_dot;
@@ -366,8 +397,8 @@ __global__ __launch_bounds__(64, BatchedModel<MODEL>::n <= 4 ? 4 : 2) void k_lm_
                     float xph[NMAX], xmh[NMAX], inv[NMAX];
 #pragma unroll
                     for (int j = 0; j < NMAX; ++j) {
-                        xmh[j] = fmaxf(x[j] - S.jacobianEpsilon, lo(j));
-                        xph[j] = fminf(x[j] + S.jacobianEpsilon, up(j));
+                        xmh[j] = fmaxf(x[j] - S.jacobianEpsilon, lo[j]);
+                        xph[j] = fminf(x[j] + S.jacobianEpsilon, up[j]);
                         const float twh = xph[j] - xmh[j];
                         inv[j] = twh != 0 ? 1.0f / twh : 0.0f;             // a zero-width interval: the column is zero, LS:1045
                     }
@@ -392,6 +423,10 @@ __global__ __launch_bounds__(64, BatchedModel<MODEL>::n <= 4 ? 4 : 2) void k_lm_
                     }
                     ret.fCalls += N;                                       // LS:1049 (quirk Q5)
                 }
+#ifdef MIRLSQ_BATCHED_TIMING
+                const uint64_t t1_ = __builtin_readcyclecounter();
+                tacc[1] += t1_ - t0_;
+#endif
                 // Jy = J^T y (LS:1052) and JJ = J^T J lower (LS:1065) in one sweep over the lane's rows
                 float accJ[NMAX][NMAX], accy[NMAX];
 #pragma unroll
@@ -423,6 +458,9 @@ __global__ __launch_bounds__(64, BatchedModel<MODEL>::n <= 4 ? 4 : 2) void k_lm_
                     }
                 }
                 lad_valid = false;                                             // J^T J has changed
+#ifdef MIRLSQ_BATCHED_TIMING
+                tacc[2] += __builtin_readcyclecounter() - t1_;
+#endif
                 const float gmax = lane_get(rows_max(fabsf(Jy_r)), 0);         // rows >= N hold zeros
                 if (!(gmax > S.gradTolerance)) {                           // LS:1053-1062
                     if (age == 0) { ret.status = 2; break; }
@@ -450,10 +488,18 @@ __global__ __launch_bounds__(64, BatchedModel<MODEL>::n <= 4 ? 4 : 2) void k_lm_
                 float Prow[NMAX];
 #pragma unroll
                 for (int k = 0; k < NMAX; ++k) Prow[k] = JJrow[k] + ((k == r && r < N) ? mine : 0.0f);   // (Q1)
+                MIRLSQ_T0();
                 lad_info = posvx_rows<N, NMAX>(Prow, -Jy_r, r, lad_x);
+                MIRLSQ_T1(3);
+#ifdef MIRLSQ_BATCHED_TIMING
+                ++tacc[5];
+#endif
                 lad_level = 0;
                 lad_valid = true;
             }
+#ifdef MIRLSQ_BATCHED_TIMING
+            const uint64_t t6_ = __builtin_readcyclecounter();
+#endif
             float sol[NMAX];
             const int lad_lane = 16 * lad_level++;
             const int info = __builtin_amdgcn_readlane(lad_info, lad_lane);
@@ -463,7 +509,7 @@ __global__ __launch_bounds__(64, BatchedModel<MODEL>::n <= 4 ? 4 : 2) void k_lm_
             bool feasible = true, nan = false;
 #pragma unroll
             for (int j = 0; j < NMAX; ++j) if (j < N) {
-                if (!((lo(j) - x[j]) <= sol[j] && sol[j] <= (up(j) - x[j]))) feasible = false;   // QP:216-219
+                if (!((lo[j] - x[j]) <= sol[j] && sol[j] <= (up[j] - x[j]))) feasible = false;   // QP:216-219
                 if (!(sol[j] <= sol[j])) nan = true;
             }
             if (nan) { ret.status = -26; break; }                          // LS:1087
@@ -475,14 +521,21 @@ __global__ __launch_bounds__(64, BatchedModel<MODEL>::n <= 4 ? 4 : 2) void k_lm_
                 d = d - x[j];
                 sol[j] = j < N ? d : 0.0f;
                 ndd += sol[j] * sol[j];
-                trial[j] = fmaxf(fminf(sol[j] + x[j], up(j)), lo(j));      // LS:1108-1110
+                trial[j] = fmaxf(fminf(sol[j] + x[j], up[j]), lo[j]);      // LS:1108-1110
             }
             if (!(sqrtf(ndd) < S.maxStep)) { lambda *= S.lambdaIncrease * mu; mu *= 2; continue; }   // LS:1101-1106
             ++ret.fCalls;                                                  // LS:1112-1115
+#ifdef MIRLSQ_BATCHED_TIMING
+            tacc[6] += __builtin_readcyclecounter() - t6_;
+#endif
             // the trial residual goes to the buffer that is NOT the current y
-            const float trialResidual = feval(trial, mB);
+            float trialResidual;
+            { MIRLSQ_T0(); trialResidual = feval(trial, mB); MIRLSQ_T1(0); }
             if (!(trialResidual <= Lim<float>::inf())) { ret.status = -26; break; }   // LS:1117
             const float improvement = ret.residual - trialResidual;
+#ifdef MIRLSQ_BATCHED_TIMING
+            const uint64_t t7_ = __builtin_readcyclecounter();
+#endif
             if (!(improvement > 0)) { lambda *= S.lambdaIncrease * mu; mu *= 2; continue; }   // LS:1125-1130
             needJacobian = true;                                           // LS:1132-1139
             mu = 1;
@@ -510,6 +563,9 @@ __global__ __launch_bounds__(64, BatchedModel<MODEL>::n <= 4 ? 4 : 2) void k_lm_
             float xn = 0;
 #pragma unroll
             for (int j = 0; j < NMAX; ++j) xn += x[j] * x[j];
+#ifdef MIRLSQ_BATCHED_TIMING
+            tacc[7] += __builtin_readcyclecounter() - t7_;
+#endif
             if (!(sqrtf(dx_dot) > S.absTolerance && sqrtf(xn) > sqrtf(dx_dot) * S.relTolerance)) {   // LS:1164-1173 (Q6)
                 if (age == 0) { ret.status = 1; break; }
                 age = maxAge;
@@ -518,6 +574,10 @@ __global__ __launch_bounds__(64, BatchedModel<MODEL>::n <= 4 ? 4 : 2) void k_lm_
         } while (ret.iterations < a.maxIterations);                        // LS:1175
         ret.lambda = lambda;
     }
+#ifdef MIRLSQ_BATCHED_TIMING
+    tacc[4] = __builtin_readcyclecounter() - tstart;
+    if (lane == 0 && a.timing) for (int k = 0; k < 10; ++k) a.timing[(size_t)prob * 10 + k] = tacc[k];
+#endif
     if (lane == 0) {
         a.results[prob] = ret;
 #pragma unroll

@@ -222,6 +222,17 @@ template <typename T> __device__ inline T wave_sum(T v) {
     v += wave_shfl_xor(v, 32);
     return v;
 }
+// float: the last two levels as the classic gfx9 DPP reduction -- row_bcast:15 adds the last lane of rows 0 and 2 into rows 1
+// and 3, row_bcast:31 the last lane of row 1 into rows 2 and 3 -- and lane 63, which then holds the total, is read back through
+// v_readlane: a wave-uniform result in a scalar register, no trip through the LDS crossbar (ds_bpermute). The pairs of partial
+// sums are those of the butterfly: same bits. (The v_permlane16/32_swap instructions do the exchange in one operation each, but
+// a build with them gave wrong sums now and then, in some processes and not in others: not used here.)
+template <> __device__ inline float wave_sum<float>(float v) {
+    v = sum16(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 template <typename T> __device__ inline T max16(T v) {
     T o = dpp_row_ror<8>(v); v = o > v ? o : v;
     o = dpp_row_ror<4>(v); v = o > v ? o : v;

@@ -1839,6 +1839,15 @@ hipError_t batched_launch(const BatchedArgs& a, int model, hipStream_t stream)
 }
 }  // namespace
 
+#ifdef MIRLSQ_BATCHED_TIMING
+namespace { uint64_t* g_batched_timing = nullptr; size_t g_batched_timing_count = 0; }
+// profiling builds: the cycle counters of the last mir_lsq_batched_kernel_s launch (6 per problem), after a synchronisation
+int mir_lsq_batched_timing(uint64_t* host, size_t count)
+{
+    if (!g_batched_timing || count > g_batched_timing_count) return -1;
+    return hipMemcpy(host, g_batched_timing, count * 10 * sizeof(uint64_t), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif
 namespace { std::atomic<uint32_t> g_batched_variant{0}; }
 void mir_lsq_batched_set_variant(uint32_t variant) { g_batched_variant.store(variant); }
 
@@ -1856,6 +1865,15 @@ int mir_lsq_batched_kernel_s(const mir_least_squares_settings_s* S, size_t count
     batched_settings(a, S);
     a.count = (int)count; a.m = (int)m; a.t_stride = (int)t_stride;
     a.variant = g_batched_variant.load();
+#ifdef MIRLSQ_BATCHED_TIMING
+    if (g_batched_timing_count < count) {
+        if (g_batched_timing) (void)hipFree(g_batched_timing);
+        g_batched_timing_count = 0;
+        if (hipMalloc((void**)&g_batched_timing, count * 10 * sizeof(uint64_t)) != hipSuccess) return -4;
+        g_batched_timing_count = count;
+    }
+    a.timing = g_batched_timing;
+#endif
     a.t = t; a.data = data; a.x = x; a.lower = lower; a.upper = upper;
     a.results = reinterpret_cast<BatchedResult*>(results);
     return batched_launch(a, model, static_cast<hipStream_t>(stream)) == hipSuccess ? 0 : -5;
