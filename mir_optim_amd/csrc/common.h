@@ -233,6 +233,20 @@ template <> __device__ inline float wave_sum<float>(float v) {
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+template <> __device__ inline double wave_sum<double>(double v) {
+    v = sum16(v);
+    {
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x142, 0xA, 0xF, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x142, 0xA, 0xF, false);
+        v += __hiloint2double(hi, lo);
+    }
+    {
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x143, 0xC, 0xF, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x143, 0xC, 0xF, false);
+        v += __hiloint2double(hi, lo);
+    }
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
 template <typename T> __device__ inline T max16(T v) {
     T o = dpp_row_ror<8>(v); v = o > v ? o : v;
     o = dpp_row_ror<4>(v); v = o > v ? o : v;

@@ -35,7 +35,7 @@ assert L.mir_lsq_batched_timing(tm.ctypes.data, count) == 0
 tm = tm.astype(np.float64)
 names = ["residual evaluations", "Jacobian refresh (FD / Broyden)", "J^T J, J^T y + reductions", "damped solves", "whole fit"]
 tot = tm[:, 4]
-print("s_memtime ticks (100 MHz constant clock on gfx9: 1 tick = 10 ns); mean per fit, share of the fit")
+print("s_memtime ticks (shader clock); mean per fit, share of the fit")
 for k in range(4):
     print(f"  {names[k]:34s} {tm[:, k].mean():10.0f}  {tm[:, k].sum() / tot.sum():6.1%}")
 for k, nm in ((6, "a trial's preparation"), (7, "an accepted step's bookkeeping")):
