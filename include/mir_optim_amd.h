@@ -475,6 +475,12 @@ void mir_lsq_device_free(void* p);
 int mir_lsq_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes, void* stream);
 int mir_lsq_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes, void* stream);
 int mir_lsq_memcpy_d2d(void* dst_device, const void* src_device, size_t bytes, void* stream);   /* asynchronous */
+
+/* Self-test of the wave reductions every kernel ends with (csrc/common.h: wave_sum / wave_max on DPP row operations and
+ * v_readlane): 2048 x 256 threads compare them, bit for bit, with the plain butterfly on `rounds` pseudo-random inputs a lane.
+ * mismatches[0..3] = lanes that differ for sum<float>, sum<double>, max<float>, max<double> (all 0 on a healthy device).
+ * Returns 0 when the test ran. */
+int mir_lsq_selftest_reductions(int rounds, int mismatches[4]);
 void* mir_lsq_stream_create(void);
 void mir_lsq_stream_destroy(void* stream);
 int mir_lsq_stream_synchronize(void* stream);

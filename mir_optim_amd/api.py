@@ -281,6 +281,8 @@ def lib():
         L.mir_lsq_batched_kernel_s.restype = C.c_int
         L.mir_lsq_batched_kernel_s.argtypes = [C.POINTER(_Ss), sz, sz, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p, sz, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mir_lsq_selftest_reductions.restype = C.c_int
+        L.mir_lsq_selftest_reductions.argtypes = [C.c_int, C.POINTER(C.c_int * 4)]
         L.mir_lsq_batched_set_variant.restype = None
         L.mir_lsq_batched_set_variant.argtypes = [C.c_uint32]
         L.mir_lsq_batched_posvx_s.restype = C.c_int

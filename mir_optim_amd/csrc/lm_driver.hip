@@ -2212,6 +2212,21 @@ int mir_lsq_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream)
     if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
     return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;
 }
+int mir_lsq_selftest_reductions(int rounds, int mismatches[4])
+{
+    if (!mismatches || rounds <= 0) return -1;
+    if (!device_available()) return -2;
+    int* d = nullptr;
+    if (hipMalloc((void**)&d, 4 * sizeof(int)) != hipSuccess) return -3;
+    bool ok = hipMemset(d, 0, 4 * sizeof(int)) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_selftest_reductions, dim3(2048), dim3(256), 0, nullptr, rounds, 12345u, d);
+        ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess
+          && hipMemcpy(mismatches, d, 4 * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(d);
+    return ok ? 0 : -4;
+}
 int mir_lsq_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream)
 {
     return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)) == hipSuccess ? 0 : -1;

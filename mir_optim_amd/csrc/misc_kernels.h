@@ -391,4 +391,37 @@ __global__ __launch_bounds__(kSolveThreads) void k_sumsq_tail(SumsqTailArgs<T> a
 template <typename T>
 __global__ void k_reset_mu(LmState<T>* st) { st->mu = 1; }
 
+// Self-test of the wave reductions (mir_lsq_selftest_reductions): every wave_sum / wave_max of common.h against the plain
+// butterfly on __shfl_xor (16, 32 last: the order whose pairs the DPP forms reproduce), bit for bit, on `rounds` pseudo-random
+// inputs a lane. out[0..3] += mismatching lanes of sum<float>, sum<double>, max<float>, max<double>.
+__global__ __launch_bounds__(256) void k_selftest_reductions(int rounds, uint32_t seed, int* out)
+{
+    // no contraction here: the multiplication that makes an input would be fused into the FIRST addition of whichever form
+    // consumes it (one rounding less on one operand of one form), and the two forms would differ by construction
+#pragma clang fp contract(off)
+    uint32_t sr = seed ^ (0x9E3779B9u * (blockIdx.x * blockDim.x + threadIdx.x + 1));
+    auto rnd = [&]() { sr ^= sr << 13; sr ^= sr >> 17; sr ^= sr << 5; return sr; };
+    int bad[4] = {0, 0, 0, 0};
+    for (int it = 0; it < rounds; ++it) {
+        const float f = (float)(int32_t)rnd() * (1.0f / 65536.0f) * ((it & 7) == 0 ? 1e-20f : 1.0f);
+        const double d = ((double)(int32_t)rnd() + (double)rnd() * 2.3283064365386963e-10) * ((it & 3) == 0 ? 1e-200 : 1.0);
+        auto ref_sum = [](auto v) {
+            v += __shfl_xor(v, 8, kWave); v += __shfl_xor(v, 4, kWave); v += __shfl_xor(v, 2, kWave); v += __shfl_xor(v, 1, kWave);
+            v += __shfl_xor(v, 16, kWave); v += __shfl_xor(v, 32, kWave);
+            return v;
+        };
+        auto ref_max = [](auto v) {
+            for (int m : {8, 4, 2, 1, 16, 32}) { const auto o = __shfl_xor(v, m, kWave); v = o > v ? o : v; }
+            return v;
+        };
+        const float sf = wave_sum(f), rf = ref_sum(f);
+        const double sd = wave_sum(d), rdd = ref_sum(d);
+        bad[0] += __float_as_uint(sf) != __float_as_uint(rf);
+        bad[1] += __double_as_longlong(sd) != __double_as_longlong(rdd);
+        bad[2] += __float_as_uint(wave_max(f)) != __float_as_uint(ref_max(f));
+        bad[3] += __double_as_longlong(wave_max(d)) != __double_as_longlong(ref_max(d));
+    }
+    for (int k = 0; k < 4; ++k) if (bad[k]) atomicAdd(out + k, bad[k]);
+}
+
 }  // namespace mirlsq

@@ -242,3 +242,15 @@ def test_singular_matrix_reports_numeric_error_on_both_paths(oracle):
         st, _, _ = M.solveBoxQP(np.tril(A), q, -inf, inf)
         so = oracle.solve_box_qp(np.tril(A), q, -inf, inf)[0]
         assert st == M.BoxQPStatus.numericError and so == int(M.BoxQPStatus.numericError)
+
+
+def test_wave_reductions_match_the_plain_butterfly_bit_for_bit():
+    """wave_sum / wave_max (DPP row operations + v_readlane; every reduction kernel and the batched kernel end with them) against
+    the butterfly on __shfl_xor: same pairs of partial results, so the same bits, on 2048 x 256 lanes x 200 random inputs each
+    (a fifth of them denormal-scaled). Run twice: a variant on the permlane swap instructions was right in one process and wrong
+    in the next."""
+    import ctypes as C
+    for _ in range(2):
+        bad = (C.c_int * 4)()
+        assert M.lib().mir_lsq_selftest_reductions(200, C.byref(bad)) == 0
+        assert list(bad) == [0, 0, 0, 0], list(bad)
