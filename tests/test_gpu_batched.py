@@ -248,3 +248,23 @@ def test_lambda_ladder_takes_the_steps_of_the_one_by_one_loop(model, maker):
     assert (out[0][0] == out[1][0]).all()
     assert out[0][1] == out[1][1]
     assert sum(r[1] for r in out[0][1]) > 4 * count            # the fits did iterate
+
+
+@pytest.mark.parametrize("model,maker", [(M.MODEL_EXP_DECAY_PAD8, "pad8"), (M.MODEL_EXP_DECAY, "decay")])
+def test_per_problem_abscissae_give_the_bits_of_shared_ones(model, maker):
+    """t may be one vector for all problems (t_stride = 0) or count x m (t_stride = m: the basis table of a model is then
+    count x m rows): the same numbers either way must give the same fits, bit for bit -- and a problem whose abscissae differ
+    gets ITS basis (its fit changes, the others' do not)."""
+    count = 256
+    t, data, truth, x0 = {"pad8": P.cfg5_pad8, "decay": make_exp_decay}[maker](count, 512)
+    s = M.LeastSquaresSettings(np.float32)
+    res0, xa = M.optimizeLeastSquaresBatched(model, x0, t, data, settings=s)
+    t2 = np.tile(t, (count, 1))
+    res1, xb = M.optimizeLeastSquaresBatched(model, x0, t2, data, settings=s)
+    assert (xa.view(np.uint32) == xb.view(np.uint32)).all()
+    assert [(int(r.status), r.iterations, r.fCalls) for r in res0] == [(int(r.status), r.iterations, r.fCalls) for r in res1]
+    t3 = t2.copy()
+    t3[7] = t3[7] * np.float32(1.01)                                  # problem 7 sees other abscissae
+    res2, xc = M.optimizeLeastSquaresBatched(model, x0, t3, data, settings=s)
+    same = (xa.view(np.uint32) == xc.view(np.uint32)).all(axis=1)
+    assert same[np.arange(count) != 7].all() and not same[7]
