@@ -268,3 +268,19 @@ def test_per_problem_abscissae_give_the_bits_of_shared_ones(model, maker):
     res2, xc = M.optimizeLeastSquaresBatched(model, x0, t3, data, settings=s)
     same = (xa.view(np.uint32) == xc.view(np.uint32)).all(axis=1)
     assert same[np.arange(count) != 7].all() and not same[7]
+
+
+@pytest.mark.parametrize("m", [1, 37, 200, 1000])
+def test_ragged_and_long_problems_match_the_float_oracle(oracle, m):
+    """Rows per lane that are not a whole number of 64-row sweeps, fewer rows than lanes, more than one eight-row chunk a lane
+    (m = 1000), and m = 1 < n (J^T J singular: the damping carries the solve): every problem against the float oracle."""
+    count = 8
+    t, data, truth, x0 = make_exp_decay(count, m)
+    res, x = M.optimizeLeastSquaresBatched(M.MODEL_EXP_DECAY, x0, t, data, settings=M.LeastSquaresSettings(np.float32))
+    for k in range(count):
+        ro, xo = oracle.optimize(oracle_f(M.MODEL_EXP_DECAY, t, data[k]), m, x0[k], dtype=np.float32)
+        assert (res[k].status >= 0) == (ro.status >= 0), (k, res[k], ro.status)
+        if ro.status >= 0:
+            assert np.isclose(res[k].residual, ro.residual, rtol=5e-3, atol=1e-7), (k, res[k].residual, ro.residual)
+            if m >= 37:
+                assert np.allclose(x[k], xo, rtol=1e-2, atol=2e-3), (k, x[k], xo)
