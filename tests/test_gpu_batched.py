@@ -284,3 +284,26 @@ def test_ragged_and_long_problems_match_the_float_oracle(oracle, m):
             assert np.isclose(res[k].residual, ro.residual, rtol=5e-3, atol=1e-7), (k, res[k].residual, ro.residual)
             if m >= 37:
                 assert np.allclose(x[k], xo, rtol=1e-2, atol=2e-3), (k, x[k], xo)
+
+
+def test_largest_row_count_of_the_n8_models(oracle):
+    """A problem's J, y and trial residual live in its workgroup's LDS: (n + 2) m floats <= 160 KB - 512, m <= 4083 at n = 8
+    (the four-problem workgroups of round 2 stopped at 1011). m = 4000 against the float oracle; m = 4200 is refused (-3)."""
+    import ctypes as C
+
+    class Ctx(C.Structure):
+        _fields_ = [("t", C.c_void_p), ("data", C.c_void_p)]
+    count, m = 6, 4000
+    t, data, truth, x0 = P.cfg5_pad8(count, m)
+    res, x = M.optimizeLeastSquaresBatched(M.MODEL_EXP_DECAY_PAD8, x0, t, data)
+    f = oracle.native_fn("wlc_exp_pad8_f_s")
+    for k in range(count):
+        d = np.ascontiguousarray(data[k])
+        ctx = Ctx(t.ctypes.data, d.ctypes.data)
+        ro, xk = oracle.optimize(f, m, x0[k], dtype=np.float32, fctx=C.addressof(ctx))
+        assert res[k].status >= 0 and ro.status >= 0
+        assert np.isclose(res[k].residual, ro.residual, rtol=1e-3), (k, res[k].residual, ro.residual)
+        assert (np.abs(x[k] - xk) / np.maximum(1.0, np.abs(xk))).max() <= 5e-2
+    t2, data2, _, x02 = P.cfg5_pad8(2, 4200)
+    with pytest.raises(RuntimeError, match="-3"):
+        M.optimizeLeastSquaresBatched(M.MODEL_EXP_DECAY_PAD8, x02, t2, data2)
