@@ -378,7 +378,9 @@ int mir_solve_box_qp_gpu_s(const mir_box_qp_settings_s* settings, size_t n, cons
  * x: count x n (in/out), lower/upper: n (shared), t: m values shared by all problems (t_stride = 0) or count x m
  * (t_stride = m), data: count x m, results: count. All HOST pointers. The LM algorithm, statuses and counters are
  * those of mir_optimize_least_squares_s; problems whose step reaches a finite bound are completed by the general
- * solver (BOXCQP active set) transparently. Returns 0, or a negative value when no device / bad arguments. */
+ * solver (BOXCQP active set) transparently. Returns 0, or a negative value: -1 bad arguments, -2 no device, -3 a problem
+ * does not fit its workgroup's LDS ((n + 2) m floats <= 160 KB - 512: m <= 4083 at n = 8, 8166 at n = 3), -4 / -5 a failed
+ * allocation / launch. */
 enum { MIR_LSQ_MODEL_EXP_DECAY = 0, MIR_LSQ_MODEL_EXP3_AFFINE = 1,
        MIR_LSQ_MODEL_EXP_DECAY_PAD8 = 2 };   /* n = 8: p0 exp(-t p1) + p2 + p3 sin 2t + p4 cos 2t + p5 sin 5t + p6 cos 5t + p7 t
                                                 (BASELINE cfg 5: the exponential decay padded to n = 8 with terms linear in
