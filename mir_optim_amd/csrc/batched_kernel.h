@@ -111,8 +111,9 @@ __global__ __launch_bounds__(256) void k_batched_basis(const float* __restrict__
 // Every element sees the operations of the oracle's loops in the oracle's order: the left-looking sums of ?potf2
 // (`s -= F[i][k] F[j][k]`, k ascending) are applied one k at a time to the whole trailing part; the forward sweep of ?potrs
 // runs by columns, its backward sweep (a chain that can only start when z[i + 1] is known) in lane i on column i of the
-// factor. Every multiply-add is ONE fused operation (__builtin_fmaf): the oracle's C rounds the product first, so the
-// two agree to rounding, not bit for bit -- and neither does this file depend on which products the compiler chooses to fuse.
+// factor. Every multiply-add is ONE fused operation (__builtin_fmaf), division and square root are the IEEE ones: the result
+// equals, bit for bit, the oracle's float ?posvx written with fmaf in the same loops (oracle/lm_oracle.c, lmo_posvx_fused_s;
+// tests/test_gpu_batched.py) -- and this file does not depend on which products the compiler chooses to fuse.
 // Divisions and square roots per solve: 44 + 9 sequences (a copy per lane: 76 + 16).
 __device__ inline float lane_get(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
 // a[r], r = lane & 7, as a chain of selects on VALUES: taking the array by reference lets the optimiser turn the chain into one

@@ -142,3 +142,79 @@ const char* lmo_status_string(int st)                                           
 #define T_FMIN fminf
 #define LMO_IS_DOUBLE 0
 #include "lm_oracle_impl.inc"
+
+/* ---- ?posvx('E','L'), float, fused multiply-adds (see lm_oracle.h): the loops of lmo_posvx_s / potrf_lower / potrs_lower with
+ *      `s -= a * b` written as fmaf(-a, b, s) and `w += |a| |x|` as fmaf(|a|, |x|, w) ---- */
+int lmo_posvx_fused_s(int n, const float* a_in, int lda, const float* b_in, float* x, int* equilibrated)
+{
+    enum { NMAXF = 16 };
+    if (n <= 0 || n > NMAXF) return -1;
+    const float eps = FLT_EPSILON / 2, safmin = FLT_MIN;
+    float a[NMAXF][NMAXF], f[NMAXF][NMAXF], s[NMAXF], b[NMAXF], r[NMAXF];
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) a[i][j] = (j <= i) ? a_in[i + (size_t)j * lda] : a_in[j + (size_t)i * lda];
+    float smin = a[0][0], amax = a[0][0];
+    for (int i = 0; i < n; ++i) { s[i] = a[i][i]; if (s[i] < smin) smin = s[i]; if (s[i] > amax) amax = s[i]; }
+    int rcequ = 0;
+    if (smin > 0) {
+        const float scond = sqrtf(smin) / sqrtf(amax);
+        for (int i = 0; i < n; ++i) s[i] = 1.0f / sqrtf(s[i]);
+        const float small = safmin / FLT_EPSILON, large = 1.0f / small;
+        rcequ = !(scond >= 0.1f && amax >= small && amax <= large);
+    } else {
+        for (int i = 0; i < n; ++i) s[i] = 1.0f;
+    }
+    if (equilibrated) *equilibrated = rcequ;
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < n; ++j) { if (rcequ) a[i][j] = s[j] * s[i] * a[i][j]; f[i][j] = a[i][j]; }
+        b[i] = rcequ ? s[i] * b_in[i] : b_in[i];
+    }
+    for (int j = 0; j < n; ++j) {                                    /* ?potf2 'L' */
+        float ajj = f[j][j];
+        for (int k = 0; k < j; ++k) ajj = fmaf(-f[j][k], f[j][k], ajj);
+        if (!(ajj > 0)) return j + 1;
+        ajj = sqrtf(ajj);
+        f[j][j] = ajj;
+        for (int i = j + 1; i < n; ++i) {
+            float v = f[i][j];
+            for (int k = 0; k < j; ++k) v = fmaf(-f[i][k], f[j][k], v);
+            f[i][j] = v / ajj;
+        }
+    }
+#define LMO_POTRS_FUSED(v)                                                                        \
+    do {                                                                                          \
+        for (int i = 0; i < n; ++i) {                                                             \
+            float t = (v)[i];                                                                     \
+            for (int k = 0; k < i; ++k) t = fmaf(-f[i][k], (v)[k], t);                            \
+            (v)[i] = t / f[i][i];                                                                 \
+        }                                                                                         \
+        for (int i = n - 1; i >= 0; --i) {                                                        \
+            float t = (v)[i];                                                                     \
+            for (int k = i + 1; k < n; ++k) t = fmaf(-f[k][i], (v)[k], t);                        \
+            (v)[i] = t / f[i][i];                                                                 \
+        }                                                                                         \
+    } while (0)
+    for (int i = 0; i < n; ++i) x[i] = b[i];
+    LMO_POTRS_FUSED(x);
+    const float safe1 = (float)(n + 1) * safmin, safe2 = safe1 / eps;
+    float lstres = 3;
+    for (int count = 1;; ++count) {                                  /* ?porfs */
+        float berr = 0;
+        for (int i = 0; i < n; ++i) {
+            float ri = b[i], wi = fabsf(b[i]);
+            for (int k = 0; k < n; ++k) { ri = fmaf(-a[i][k], x[k], ri); wi = fmaf(fabsf(a[i][k]), fabsf(x[k]), wi); }
+            r[i] = ri;
+            const float q = (wi > safe2) ? fabsf(ri) / wi : (fabsf(ri) + safe1) / (wi + safe1);
+            if (q > berr) berr = q;
+        }
+        if (berr > eps && 2 * berr <= lstres && count <= 5) {
+            LMO_POTRS_FUSED(r);
+            for (int i = 0; i < n; ++i) x[i] += r[i];
+            lstres = berr;
+            continue;
+        }
+        break;
+    }
+#undef LMO_POTRS_FUSED
+    if (rcequ) for (int i = 0; i < n; ++i) x[i] = s[i] * x[i];
+    return 0;
+}

@@ -146,6 +146,12 @@ int lmo_posvx_s(int n, float* a, int lda, float* af, int ldaf, char* equed, floa
                 float* b, float* x, float* rcond, float* ferr, float* berr,
                 float* work, int32_t* iwork);
 
+/* The same ?posvx('E','L') in float with every multiply-add FUSED (fmaf), loop for loop as lmo_posvx_s (no condition estimate):
+ * the arithmetic of the device's one-row-per-lane solve (csrc/batched_kernel.h, posvx_rows), which is tested against this bit
+ * for bit. a: n x n column-major, lower triangle referenced (not overwritten); n <= 16. Returns info (0, or the order of the
+ * leading minor that is not positive); *equilibrated reports ?laqsy's decision. */
+int lmo_posvx_fused_s(int n, const float* a, int lda, const float* b, float* x, int* equilibrated);
+
 void lmo_apply_bounds_d(size_t n, double* x, const double* l, const double* u);
 void lmo_apply_bounds_s(size_t n, float* x, const float* l, const float* u);
 

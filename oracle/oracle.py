@@ -258,6 +258,21 @@ def posvx(A, b, dtype=np.float64):
                 a_s=a, af=af)
 
 
+def posvx_fused_s(A, b):
+    """lmo_posvx_fused_s: float ?posvx('E','L') with fused multiply-adds (the device's posvx_rows arithmetic).
+    A symmetric (full or lower); returns (info, x, equilibrated)."""
+    L = lib()
+    a = np.array(A, dtype=np.float32, order="F").copy()
+    n = a.shape[0]
+    bb = np.array(b, dtype=np.float32).copy()
+    x = np.zeros(n, dtype=np.float32)
+    eq = C.c_int(0)
+    L.lmo_posvx_fused_s.restype = C.c_int
+    L.lmo_posvx_fused_s.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+    info = L.lmo_posvx_fused_s(n, a.ctypes.data, n, bb.ctypes.data, x.ctypes.data, C.byref(eq))
+    return info, x, bool(eq.value)
+
+
 def openblas_path():
     import scipy
     cands = glob.glob(os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs", "libscipy_openblas*.so"))

@@ -307,3 +307,33 @@ def test_largest_row_count_of_the_n8_models(oracle):
     t2, data2, _, x02 = P.cfg5_pad8(2, 4200)
     with pytest.raises(RuntimeError, match="-3"):
         M.optimizeLeastSquaresBatched(M.MODEL_EXP_DECAY_PAD8, x02, t2, data2)
+
+
+@pytest.mark.parametrize("n", [8, 3])
+def test_batched_solve_is_bit_identical_with_the_fused_float_posvx(oracle, n):
+    """posvx_rows states ?posvx('E','L') with every multiply-add fused and IEEE division / square root; the oracle's
+    lmo_posvx_fused_s is the oracle's float ?posvx with fmaf in the same loops. Same operations in the same order on both sides:
+    the solutions are equal BIT FOR BIT -- well-scaled systems, systems that ?laqsy equilibrates, and the info of systems whose
+    leading minor of order k is not positive."""
+    rng = np.random.default_rng(23 + n)
+    count = 512
+    Pm = np.zeros((count, n, n), dtype=np.float32)
+    b = rng.standard_normal((count, n)).astype(np.float32)
+    for p in range(count):
+        G = rng.standard_normal((2 * n, n))
+        if p % 2:
+            G = G * np.logspace(-2, 2, n)[None, :]
+        A = G.T @ G + 1e-3 * np.eye(n)
+        if p % 32 == 9:
+            k = 1 + (p // 32) % n
+            A[k - 1, k - 1] = -abs(A[k - 1, k - 1])
+        Pm[p] = A
+    x, info = M.batchedPosvx(Pm, b)
+    scaled = 0
+    for p in range(count):
+        oi, xo, eq = oracle.posvx_fused_s(Pm[p], b[p])
+        assert info[p] == oi, (p, info[p], oi)
+        scaled += int(eq)
+        if oi == 0:
+            assert (x[p].view(np.uint32) == xo.view(np.uint32)).all(), (p, x[p], xo)
+    assert scaled > count // 3                                       # the equilibration branch was exercised

@@ -183,3 +183,24 @@ def test_native_workload_callbacks(oracle):
     r3, x3 = oracle.optimize(oracle.native_fn("wlc_gauss_sum_f"), 500, gs["x0"], lower=gs["lower"], upper=gs["upper"],
                              fctx=C.addressof(gctx))
     assert r3.status >= 0 and np.allclose(x3, gs["truth"], rtol=2e-2, atol=2e-3)
+
+
+@pytest.mark.parametrize("n,badscale", [(3, False), (8, False), (8, True), (16, True)])
+def test_fused_float_posvx_is_the_float_posvx_up_to_rounding(oracle, n, badscale):
+    """lmo_posvx_fused_s (the bit-for-bit reference of the device's posvx_rows) against the oracle's float ?posvx: same info,
+    same ?laqsy decision, solutions within a few float roundings of each other relative to the refined double solution."""
+    rng = np.random.default_rng(5 + n)
+    for trial in range(20):
+        G = rng.standard_normal((2 * n, n))
+        if badscale:
+            G = G * np.logspace(-2, 2, n)[None, :]
+        A = (G.T @ G + 1e-3 * np.eye(n)).astype(np.float32)
+        b = rng.standard_normal(n).astype(np.float32)
+        info, x, eq = oracle.posvx_fused_s(A, b)
+        o = oracle.posvx(A.astype(np.float64), b, dtype=np.float32)
+        assert info == 0 and o["info"] in (0, n + 1) and eq == (o["equed"] == "Y")
+        xr = np.linalg.solve(A.astype(np.float64), b.astype(np.float64))
+        scale = np.linalg.norm(xr)
+        assert np.linalg.norm(x - xr) <= 4 * np.linalg.norm(o["x"] - xr) + 4e-7 * scale
+    A = np.diag([1.0, -2.0, 3.0]).astype(np.float32)
+    assert oracle.posvx_fused_s(A, np.ones(3, dtype=np.float32))[0] == 2      # the second leading minor is not positive
