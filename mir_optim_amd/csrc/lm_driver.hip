@@ -1782,17 +1782,28 @@ hipError_t batched_launch_model(BatchedArgs a, hipStream_t stream)
     auto kern = k_lm_batched<MODEL>;
     MIRLSQ_ENSURE_LDS(kern, lds);
     float* table = nullptr;
+    bool pooled = true;                                          // stream-ordered allocation; plain hipMalloc where the runtime has no pools
     if (nb > 0) {
         const size_t rows = (size_t)(a.t_stride ? a.count : 1) * a.m;
         hipError_t e = hipMallocAsync((void**)&table, rows * nb * sizeof(float), stream);
-        if (e != hipSuccess) return e;
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            pooled = false;
+            e = hipMalloc((void**)&table, rows * nb * sizeof(float));
+            if (e != hipSuccess) return e;
+        }
         const unsigned bb = (unsigned)std::min<size_t>((rows + 255) / 256, 4096);
         hipLaunchKernelGGL(k_batched_basis<MODEL>, dim3(bb), dim3(256), 0, stream, a.t, table, rows);
         a.basis = table;
     }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, stream, a);
     hipError_t e = hipGetLastError();
-    if (table) { const hipError_t f = hipFreeAsync(table, stream); if (e == hipSuccess) e = f; }
+    if (table) {
+        hipError_t f;
+        if (pooled) f = hipFreeAsync(table, stream);
+        else { f = hipStreamSynchronize(stream); (void)hipFree(table); }      // the kernel reads the table: wait before freeing it
+        if (e == hipSuccess) e = f;
+    }
     return e;
 }
 }  // namespace
