@@ -61,6 +61,27 @@ def main():
         json.dump(out, f, indent=1)
     print("wrote", os.path.join(HERE, "lm_cases.json"))
 
+    # float ?posvx('E','L') with fused multiply-adds (lmo_posvx_fused_s): the bit patterns the device's one-row-per-lane solve
+    # (posvx_rows) must reproduce. Matrices, right-hand sides and solutions as uint32 bit patterns of the floats.
+    rng = np.random.default_rng(2026)
+    systems = []
+    for n in (3, 8):
+        for k in range(12):
+            G = rng.standard_normal((2 * n, n))
+            if k % 2:
+                G = G * np.logspace(-2, 2, n)[None, :]
+            A = G.T @ G + 1e-3 * np.eye(n)
+            if k == 7:
+                A[n // 2, n // 2] = -abs(A[n // 2, n // 2])
+            A = A.astype(np.float32)
+            b = rng.standard_normal(n).astype(np.float32)
+            info, x, eq = O.posvx_fused_s(A, b)
+            systems.append(dict(n=n, A=[int(v) for v in A.view(np.uint32).ravel()], b=[int(v) for v in b.view(np.uint32)],
+                                info=int(info), equilibrated=bool(eq), x=[int(v) for v in x.view(np.uint32)]))
+    with open(os.path.join(HERE, "posvx_fused_s.json"), "w") as f:
+        json.dump({"_generator": "tests/golden/make_golden.py: oracle lmo_posvx_fused_s", "systems": systems}, f)
+    print("wrote", os.path.join(HERE, "posvx_fused_s.json"))
+
 
 if __name__ == "__main__":
     main()
