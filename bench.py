@@ -2,7 +2,9 @@
 """bench.py -- LM iterations/sec on the BASELINE.json headline workload.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+  N > 1 from a bare shell: this process starts the N rank processes itself (launch_ranks: children of this interpreter with
+  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; the parent never imports torch or touches HIP) and relays rank 0's JSON line.
+  Under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (WORLD_SIZE set) it is one rank.
 
 Workload (cfg 3): tanh-linear synthetic NLS, r_i(x) = tanh(a_i . x) - b_i, m = 1e6 rows x n = 128
 parameters, fp64, finite-difference Jacobian through the user's batched residual callbacks, defaults except absTolerance
@@ -342,6 +344,69 @@ def step_stats(ms):
     return [min(ms), statistics.median(ms), max(ms)] if ms else None
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` from a bare shell (no launcher): this process becomes the PARENT of N rank processes
+    -- `sys.executable bench.py <same arguments>` with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set -- and
+    never touches torch or HIP itself. Rank 0's stdout is relayed (its JSON line is the parent's last stdout line), the
+    other ranks' stdout goes to stderr. A rank that fails takes the job down: the others are terminated (by PID), the
+    parent exits with that rank's code; nothing is retried. No os.exec* anywhere."""
+    import socket
+    import subprocess
+    import threading
+
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", BENCH_SELF_LAUNCHED="1")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, min(os.cpu_count() or 1, 64) // n)))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, cwd=os.getcwd()))
+    lines = []
+
+    def pump():
+        for raw in procs[0].stdout:
+            lines.append(raw.decode(errors="replace").rstrip("\n"))
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.05)
+    if failed is not None:
+        print(f"[bench] rank {failed[0]} exited with code {failed[1]}: stopping the other ranks", file=sys.stderr, flush=True)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    t.join(timeout=10)
+    js = [l for l in lines if l.startswith('{"metric"')]
+    for l in lines:                                  # everything rank 0 printed that is not the line goes to stderr
+        if not l.startswith('{"metric"'):
+            print(l, file=sys.stderr)
+    sys.stderr.flush()
+    if failed is not None:
+        raise SystemExit(failed[1] if isinstance(failed[1], int) and 0 < failed[1] < 256 else 1)
+    if not js:
+        print("[bench] rank 0 printed no JSON line", file=sys.stderr, flush=True)
+        raise SystemExit(1)
+    print(js[-1], flush=True)
+
+
 def main():
     args = parse()
     if args.config == "cfg5":
@@ -349,12 +414,15 @@ def main():
     if args.config == "cfg2":
         os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 16)))
         return main_cfg2(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)                    # before torch / HIP are imported: the parent never initialises the GPU
     os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 64)))   # CPU baseline leg (oracle, OpenMP)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus N` (self-launching) or "
+                         "torch.distributed.run --nproc-per-node N")
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -364,8 +432,14 @@ def main():
 
     if not torch.cuda.is_available() or M.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: mir_optim_amd has no CPU path")
-    share = args.comm == "gloo-callback" or os.environ.get("BENCH_SHARE_GPU") == "1"   # rehearsals: ranks share the GPUs there are
-    torch.cuda.set_device(local_rank % torch.cuda.device_count() if share else local_rank)
+    # rehearsals: ranks share the GPUs there are (asked for, or forced: fewer visible devices than ranks -- RCCL then refuses
+    # the communicator and the run takes the labelled callback fallback below instead of dying in set_device)
+    ndev = torch.cuda.device_count()
+    share = args.comm == "gloo-callback" or os.environ.get("BENCH_SHARE_GPU") == "1" or ndev < world
+    if ndev < world and rank == 0:
+        print(f"[bench] {world} ranks on {ndev} visible GPU(s): ranks share devices (rehearsal, not a scaling measurement)",
+              file=sys.stderr, flush=True)
+    torch.cuda.set_device(local_rank % ndev if share else local_rank)
     comm = None
     comm_obj = None
     comm_fallback = None
@@ -656,6 +730,9 @@ def main():
                                                                  "gloo callback all-reduce (" + ("FALLBACK: RCCL unusable" if comm_fallback else "rehearsal") + ")"),
                 "rccl_ranks": api.lib().mir_lsq_comm_ranks(comm) if (comm and args.comm == "rccl") else None,
                 "rccl_fallback_reason": comm_fallback,
+                "launcher": ("bench.py (self-launched rank processes)" if os.environ.get("BENCH_SELF_LAUNCHED") == "1"
+                             else "external (torch.distributed.run)") if world > 1 else None,
+                "ranks_share_gpus": bool(share and world > 1), "visible_gpus": ndev,
                 "comm": describe_comm(api, comm),     # transport, the shared object RCCL was bound from, its version, ncclCommCount
                 # library kernel launches per round, by the kind of round (refresh / Broyden / re-solve after a rejection)
                 "library_launches_per_round": {k: (sta["round_launches"][i] / sta["rounds"][i] if sta["rounds"][i] else None)

@@ -150,3 +150,58 @@ def test_bench_falls_back_when_rccl_is_unusable():
     d = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{"metric"')][-1])
     assert d["n_gpus"] == 2 and d["config"]["rccl_fallback_reason"] and "callback" in d["config"]["parallelism"]
     assert d["config"]["status"] in ("xConverged", "furtherImprovement", "fConverged", "gConverged") and d["value"] > 0
+
+
+def test_bench_self_launch_reports_a_failed_rank_and_prints_no_line():
+    """`python bench.py --gpus 2` from a bare shell starts its own rank processes (bench.py: launch_ranks). With no usable
+    GPU every rank exits non-zero: the parent must exit non-zero too, print no JSON line and leave no rank behind."""
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--comm", "gloo-callback"], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0
+    assert p.stdout.decode().strip() == ""
+    assert "stopping the other ranks" in p.stderr.decode()
+
+
+@pytest.mark.gpu
+def test_bench_self_launches_its_ranks_from_a_bare_shell():
+    """The driver's command, literally: `python3 bench.py --gpus 2 --steps 3 --warmup 1` with no launcher around it. The
+    parent starts two rank processes (sharing the one GPU here: BENCH_SHARE_GPU=1, callback communicator over gloo) and
+    relays rank 0's line as its own LAST stdout line."""
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, BENCH_M="200000", BENCH_N="64", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--comm", "gloo-callback"]
+    p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{"metric"')          # the parent's stdout is the line and nothing else
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "strong"
+    assert d["config"]["m_total"] == 200000 and d["config"]["m_per_gpu"] == 100000
+    assert d["config"]["launcher"].startswith("bench.py") and d["config"]["ranks_share_gpus"] is True
+    assert d["config"]["status"] in ("xConverged", "furtherImprovement", "fConverged", "gConverged")
+    assert d["value"] == pytest.approx(d["config"]["iterations_per_solve"] / (d["ms_per_step"] * 1e-3), rel=1e-9)
+    assert d["config"]["allreduce_per_solve"]["packed_elems"] == 64 * 65 // 2 + 64
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_with_rccl_on_one_gpu_takes_the_labelled_fallback():
+    """`python3 bench.py --gpus 2` (default --comm rccl) on a box with ONE GPU and nothing in the environment: the ranks share
+    the device, RCCL refuses the communicator, every rank switches to the callback communicator -- a labelled line, rc 0."""
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, BENCH_M="100000", BENCH_N="32", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--survey-steps", "0"]
+    p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    d = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_fallback_reason"] and "callback" in d["config"]["parallelism"]
+    assert d["config"]["ranks_share_gpus"] is True and d["config"]["visible_gpus"] == 1
+    assert d["config"]["status"] in ("xConverged", "furtherImprovement", "fConverged", "gConverged") and d["value"] > 0
