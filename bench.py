@@ -95,9 +95,6 @@ def parse():
                          "panel (n <= 128; the caller's kernel subtracts the (+h, -h) pair, the library's fused kernel scales, writes J "
                          "and forms J^T J); rowmajor: the m x 2n row-major pair panel, same fused kernel; pointmajor: the point-major "
                          "batched callback + k_fd_fill -- or one call per point (serial)")
-    ap.add_argument("--fd-windows", type=int, default=0,
-                    help="--fd batched: two-stream finite-difference refresh in this many row windows (fbRowMajorDiffWindow: the caller's "
-                         "GEMM of window k + 1 on a side stream while the library's fused kernel consumes window k); 0 = one sweep")
     ap.add_argument("--gemm-read-a-once", action="store_true",
                     help="caller side, --fd batched: the difference-panel GEMM sweeps A once (stage-outer variant: 2.1 instead of "
                          "3.1 GB per call at cfg 3, ~3 %% slower -- the kernel is MFMA-bound; A/B only)")
@@ -162,13 +159,16 @@ def main_cfg5(args):
     dup = api.DeviceBuffer(np.full(n, np.inf, dtype=np.float32))
     dres = api.DeviceBuffer(nbytes=count * 24, dtype=np.uint8, shape=(count * 24,))
     stream = api.Stream()
+    # the per-row basis table of the model (4096 x ... no: t is shared, 512 rows x 4 floats) is the caller's: no allocation per launch
+    basis = api.DeviceBuffer(nbytes=m * 4 * 4, dtype=np.uint8, shape=(m * 16,))
+    bopt = api.BatchedOptions(stream=stream.handle, basis=basis.ptr, basis_bytes=m * 16)
 
     def step():
         # x is restored on the device (a D2D copy of 128 KB inside the timed region: part of "from the starting points")
         if L.mir_lsq_memcpy_d2d(dx.ptr, dx0.ptr, count * n * 4, stream.handle) != 0:
             raise SystemExit("d2d failed")
         rc = L.mir_lsq_batched_kernel_s(C.byref(s), count, m, M.MODEL_EXP_DECAY_PAD8, dx.ptr, dlo.ptr, dup.ptr, dt_.ptr, 0,
-                                        dd.ptr, dres.ptr, stream.handle)
+                                        dd.ptr, dres.ptr, C.byref(bopt))
         if rc != 0:
             raise SystemExit(f"batched kernel launch failed: {rc}")
     for _ in range(max(1, args.warmup)):
@@ -517,7 +517,6 @@ def main():
 
     def solve(stats=None, flags=0, s=settings):
         return prob.solve(data["x0"], settings=s, stats=stats, flags=flags, comm=comm_obj or comm, workspace=ws, variant=args.variant,
-                          fd_windows=args.fd_windows,
                           batched={"batched": True, "rowmajor": "rowmajor", "pointmajor": "pointmajor", "serial": False}[args.fd])
 
     # RCCL finishes part of its initialisation asynchronously: a few seconds after ncclCommInitRank every HIP launch of the
@@ -749,7 +748,6 @@ def main():
                 "iterations_per_solve": iters / K, "status": res.status.name,
                 "passes_per_solve": sta["passes"] / K, "fcalls_per_solve": res.fCalls,
                 "jacobian_full_per_solve": sta["jacobian_full"] / K, "residual": res.residual,
-                "fd_windows": args.fd_windows, "fd_window_refreshes_per_solve": sta["fd_window_refreshes"] / K,
                 "kernel_timing": f"HIP events on the solver's stream in {timed_steps} of the {K} timed steps (every {max(1, args.timing_every)}th)",
                 "time_split_ms_per_solve": {
                     "caller_fd_callbacks": st["fd_callback_ms"] / KT, "caller_trial_callbacks": st["trial_callback_ms"] / KT,

@@ -175,59 +175,34 @@ typedef struct mir_lsq_workspace mir_lsq_workspace;  /* reusable device workspac
  * 2n perturbed points together instead of one at a time. */
 typedef void (*mir_lsq_batched_function_d)(void* context, size_t m, size_t n, size_t p, const double* X, double* Y);
 typedef void (*mir_lsq_batched_function_s)(void* context, size_t m, size_t n, size_t p, const float* X, float* Y);
-/* Row-window form of fbRowMajorDiff (mir_lsq_gpu_options.fbRowMajorDiffWindow): D is the WHOLE m x n panel (write rows
- * row0 .. row0 + rows - 1 only), `stream` the HIP stream to enqueue on. */
-typedef void (*mir_lsq_window_function_d)(void* context, size_t m, size_t n, size_t p, const double* X, double* D,
-                                          size_t row0, size_t rows, void* stream);
-
 enum {
     MIR_LSQ_DEVICE_CALLBACKS = 1u,   /* f/g/fb receive DEVICE pointers and enqueue on `stream` (no host staging) */
     MIR_LSQ_TIME_KERNELS = 2u        /* bracket the hot kernels with HIP events and fill `stats` */
 };
 
-/* `variant` bits of mir_lsq_gpu_options: A/B switches for tests and diagnostics. 0 = the product path. Every variant
- * computes the same quantities (results agree to rounding, several bit for bit); they exist so that the tests can compare
- * the product kernels with literal restatements of the reference's operation order. Read per call, never latched. */
+/* `variant` bits of mir_lsq_gpu_options. 0 = the product path. The first six select LITERAL RESTATEMENTS of the reference's
+ * operation order that the parity tests compare the product kernels with (results agree to rounding, several bit for bit);
+ * the rest are diagnostics. Read per call, never latched; unknown bits are ignored. (Bit positions are those of earlier
+ * releases; the switches of experiments that were measured and retired -- profiles/r03/ab_*.txt -- are gone.) */
 enum {
     MIR_LSQ_VARIANT_BROYDEN_REWRITE = 1u << 0,   /* Broyden passes rewrite J every pass (LS:1003-1006 literally) instead of
                                                     the read-only sweep with pending rank-one terms (broyden_lr.h) */
-    MIR_LSQ_VARIANT_FD_SEPARATE_FILL = 1u << 1,  /* ignore fbRowMajor: point-major panel + column-fill pass + plain J^T J */
-    MIR_LSQ_VARIANT_JTJ_RING = 1u << 2,          /* plain J^T J on the LDS-DMA ring kernel (n % 16 == 0, m even) */
-    MIR_LSQ_VARIANT_JTJ_STREAM = 1u << 3,        /* register-streaming J^T J kernels (tile-pair jobs above n = 128) */
+    MIR_LSQ_VARIANT_FD_SEPARATE_FILL = 1u << 1,  /* ignore fbRowMajor / fbRowMajorDiff: point-major panel + column-fill pass
+                                                    (LS:1041-1047 as a kernel of its own) + plain J^T J */
     MIR_LSQ_VARIANT_NO_SPECULATION = 1u << 4,    /* one trial per pass instead of the lambda ladder */
     MIR_LSQ_VARIANT_NO_NULL_SKIP = 1u << 5,      /* evaluate f also for trials equal to x bit for bit */
     MIR_LSQ_VARIANT_SOLVE_BOUNDED = 1u << 6,     /* always the solve kernel with the BOXCQP loop compiled in */
-    MIR_LSQ_VARIANT_DEBUG_SOLVE = 1u << 7,       /* print phase stamps of the solve kernel (stderr) */
-    MIR_LSQ_VARIANT_HOST_PROFILE = 1u << 8,      /* print host wall time per category of runtime call (stderr) */
-    MIR_LSQ_VARIANT_NO_RESYNC = 1u << 9,         /* do not recompute J^T J / J^T y from J when the pending Broyden terms are
-                                                    folded into it (the recurrence then runs until the next full refresh) */
-    MIR_LSQ_VARIANT_SOLVE_GENERIC = 1u << 10,    /* the any-n solve path (biglinalg.h) also for n <= 256 */
-    MIR_LSQ_VARIANT_PIPELINE = 1u << 11,         /* enqueue the library part of the next Broyden round behind a device-side
-                                                    guard before the current decision is known (bit-identical results;
-                                                    measured: no gain at cfg 3, 3 % at cfg 2 -- on by default only for small
-                                                    problems, J up to 32 MB; this bit forces it for any size) */
-    MIR_LSQ_VARIANT_NO_TAIL_FUSION = 1u << 12,   /* round 2's launch sequence: k_unpack_grad as a kernel of its own (with
-                                                    |J^T y|_inf) instead of the slab reduction writing J^T J / J^T y and the
-                                                    solve kernel taking the maximum; bit-identical results */
-    MIR_LSQ_VARIANT_FINISH_IN_SOLVE = 1u << 23,  /* the n x n finish of a Broyden pass in the solve kernel's prologue (one workgroup)
-                                                    instead of the kernel k_lr_finish (n + 1 workgroups): one launch less,
-                                                    bit-identical, measured 1 % slower at cfg 3: not the default */
-    MIR_LSQ_VARIANT_NO_PIPELINE = 1u << 22,      /* never enqueue a round ahead of time (small problems -- J up to 32 MB -- do by default) */
-    MIR_LSQ_VARIANT_FD_PANEL_IS_J = 1u << 21,    /* after a difference-panel refresh keep the panel as J (the fused kernel does not
-                                                    write J; the Broyden sweep and the flush apply scal(1 / twh) at load time)
-                                                    instead of materialising J: bit-identical, 8 m n fewer bytes per refresh,
-                                                    measured a wash at cfg 3 (the scaled sweep is 8 % slower): not the default */
-    MIR_LSQ_VARIANT_SWEEP_TAIL = 1u << 14,       /* the Broyden sweep reduces its partials (and, single GPU, applies the n x n
-                                                    finish) in its last-arriving workgroups instead of k_lr_reduce: one launch
-                                                    less, bit-identical -- and measured slower on MI355X (cross-workgroup hops
-                                                    through memory cost more than the launch they save): not the default */
-    MIR_LSQ_VARIANT_SUMSQ_TAIL = 1u << 15,       /* ||f||^2 and the decision of a round (and the state at entry) in ONE launch:
-                                                    the last-arriving workgroup of the sum-of-squares sweep finishes; same */
+    MIR_LSQ_VARIANT_SOLVE_GENERIC = 1u << 10,    /* the any-n solve kernel (solve_big.h) also for n <= 256 */
     MIR_LSQ_VARIANT_FD_HOST_COLUMNS = 1u << 13,  /* host-callback finite differences column by column (per-slot staging vectors,
                                                     a strided column write and a stream synchronisation per task, under a
                                                     lock) instead of through the pinned point-major panel */
-    MIR_LSQ_VARIANT_LR_CAP_SHIFT = 16            /* bits 16..20: fold the pending Broyden terms into J after this many
-                                                    updates (1..16; 0 = 16) */
+    MIR_LSQ_VARIANT_NO_PIPELINE = 1u << 22,      /* never enqueue the library part of the next Broyden round behind a device-side
+                                                    guard before the current decision is known (small problems -- J up to
+                                                    32 MB -- do by default; bit-identical results either way) */
+    MIR_LSQ_VARIANT_DEBUG_SOLVE = 1u << 7,       /* diagnostic: print phase stamps of the solve kernel (stderr) */
+    MIR_LSQ_VARIANT_HOST_PROFILE = 1u << 8,      /* diagnostic: print host wall time per category of runtime call (stderr) */
+    MIR_LSQ_VARIANT_LR_CAP_SHIFT = 16            /* bits 16..20 (a field, not a switch): fold the pending Broyden terms into J
+                                                    after this many updates (1..16; 0 = 16) */
 };
 
 typedef struct mir_lsq_stats {
@@ -277,8 +252,6 @@ typedef struct mir_lsq_stats {
     uint64_t fd_host_columns;
     double host_f_ms;                /* host-callback mode: wall time inside the caller's f for the entry and trial evaluations */
     uint64_t host_f_calls;
-    uint64_t fd_window_refreshes;    /* refreshes that ran as the two-stream window pipeline (their time is in jtj_fd_ms: the
-                                        caller's kernels overlap the library's there, fd_callback_ms does not see them) */
 } mir_lsq_stats;
 /* Versioning of mir_lsq_stats: the library writes min(stats_size, sizeof(mir_lsq_stats)) bytes. A caller whose options
  * struct has no stats_size member (struct_size < 96), or leaves it 0, gets the layout of its era: 120 bytes (through
@@ -335,15 +308,7 @@ typedef struct mir_lsq_gpu_options {
                                         Preferred over fbRowMajor when both are given. Read only when struct_size covers it */
     uint32_t stats_size;             /* sizeof(mir_lsq_stats) as the CALLER compiled it: the library never writes past it
                                         (0 or not covered by struct_size: see "Versioning of mir_lsq_stats") */
-    uint32_t fd_windows;             /* row windows of the two-stream finite-difference refresh (fbRowMajorDiffWindow):
-                                        0 or 1 = off, 2..16 = that many windows */
-    void* fbRowMajorDiffWindow;      /* optional mir_lsq_window_function_d (f64, even n <= 128), context fbContext: fbRowMajorDiff
-                                        restricted to the rows [row0, row0 + rows) of the problem and enqueued on the stream it
-                                        is HANDED (not the options' stream): with fd_windows >= 2 the library runs the caller's
-                                        kernel for window k + 1 on a side stream while its fused finite-difference kernel
-                                        consumes window k on the solver's stream -- an MFMA-bound and an HBM-bound kernel
-                                        sharing the chip. Results differ from the one-window refresh by the summation order of
-                                        J^T J / J^T y only (J is bit-identical). Read only when struct_size covers it */
+    uint32_t reserved0;              /* must be 0 */
 } mir_lsq_gpu_options;
 
 /* Same algorithm and result contract as mir_optimize_least_squares_{d,s}; x/l/u stay host
@@ -385,20 +350,43 @@ enum { MIR_LSQ_MODEL_EXP_DECAY = 0, MIR_LSQ_MODEL_EXP3_AFFINE = 1,
        MIR_LSQ_MODEL_EXP_DECAY_PAD8 = 2 };   /* n = 8: p0 exp(-t p1) + p2 + p3 sin 2t + p4 cos 2t + p5 sin 5t + p6 cos 5t + p7 t
                                                 (BASELINE cfg 5: the exponential decay padded to n = 8 with terms linear in
                                                 their parameters: well conditioned in fp32) */
+/* Per-call options of the batched entries (nothing about them is process-wide). NULL = all defaults. */
+enum { MIR_LSQ_BATCHED_NO_LADDER = 1 };   /* variant bit: every damped solve is made for ONE lambda, as the reference's loop does
+                                             (boxcqp.d:194 per LS:1080); by default a solve covers lambda and the three values
+                                             the rejection rule would give it next (four 16-lane groups of the wave), with
+                                             the same steps, bit for bit */
+typedef struct mir_lsq_batched_options {
+    uint32_t struct_size;     /* = sizeof(mir_lsq_batched_options) */
+    uint32_t variant;         /* MIR_LSQ_BATCHED_* bits; 0 = default */
+    void* stream;             /* mir_lsq_batched_kernel_s: hipStream_t to enqueue on (NULL = the default stream) */
+    float* basis;             /* optional DEVICE buffer for the model's per-row basis table (models with a basis only:
+                                 (t_stride ? count : 1) x m x nb floats, 16-byte aligned), owned by the caller and filled by
+                                 every call. NULL: the call allocates the table stream-ordered (hipMallocAsync / hipFreeAsync);
+                                 where the runtime has no memory pools it falls back to hipMalloc + a stream synchronisation
+                                 before hipFree -- the ONLY case in which mir_lsq_batched_kernel_s synchronises */
+    size_t basis_bytes;       /* size of `basis` (the call fails with -1 when it is too small) */
+    uint64_t* timing;         /* profiling builds only (-DMIRLSQ_BATCHED_TIMING): DEVICE buffer of 10 cycle counters per
+                                 problem, written by the kernel; ignored otherwise */
+} mir_lsq_batched_options;
+
 int mir_optimize_least_squares_batched_s(const mir_least_squares_settings_s* settings, size_t count, size_t m, int model,
                                          float* x, const float* lower, const float* upper,
                                          const float* t, size_t t_stride, const float* data,
-                                         mir_least_squares_result_s* results);
+                                         mir_least_squares_result_s* results, const mir_lsq_batched_options* options);
 
 /* The same wave-per-problem kernel on DEVICE-RESIDENT data (every pointer is a device pointer; `results` receives
- * `count` records in place; enqueued on `stream`, no synchronisation): what bench.py --config cfg5 times. Problems whose
- * step reaches a finite bound come back with status -100 (MIR_LSQ_BATCHED_NEEDS_GENERAL): the host entry above completes
- * those with the general solver, this one leaves that to the caller. Returns 0 when the launch succeeded. */
+ * `count` records in place; enqueued on options->stream, no synchronisation -- see mir_lsq_batched_options.basis for the one
+ * exception): what bench.py --config cfg5 times. Problems whose step reaches a finite bound come back with status -100
+ * (MIR_LSQ_BATCHED_NEEDS_GENERAL): the host entry above completes those with the general solver, this one leaves that to
+ * the caller. Returns 0 when the launch succeeded.
+ * A caller with a residual model of its own -- the reference takes an arbitrary f, least_squares.d:73-80 -- compiles the
+ * same kernel for it from include/mir_optim_amd_batched.hpp (launch_batched<Model>); the three built-in models are
+ * instances of that template. */
 enum { MIR_LSQ_BATCHED_NEEDS_GENERAL = -100 };
 int mir_lsq_batched_kernel_s(const mir_least_squares_settings_s* settings, size_t count, size_t m, int model,
                              float* x, const float* lower, const float* upper,
                              const float* t, size_t t_stride, const float* data,
-                             mir_least_squares_result_s* results, void* stream);
+                             mir_least_squares_result_s* results, const mir_lsq_batched_options* options);
 
 /* Unit-level access to the damped solve of that kernel (?posvx('E','L') with one matrix row per lane; what boxcqp.d:194
  * calls): `count` systems of order n (3 or 8, the orders of the compiled-in models), device pointers; P count x 64 floats,
@@ -406,12 +394,6 @@ int mir_lsq_batched_kernel_s(const mir_least_squares_settings_s* settings, size_
  * >= n ignored / zero); info[p] = 0 or the order of the leading minor that is not positive (x of that system is zero).
  * Enqueued on `stream`, no synchronisation. */
 int mir_lsq_batched_posvx_s(size_t count, size_t n, const float* P, const float* rhs, float* x, int* info, void* stream);
-
-/* A/B switch of the two batched entries above (process-wide; 0 = default). MIR_LSQ_BATCHED_NO_LADDER: every damped solve is
- * made for ONE lambda, as the reference's loop does (boxcqp.d:194 per LS:1080); by default a solve covers lambda and the three
- * values the rejection rule would give it next (four 16-lane groups of the wave), with the same steps, bit for bit. */
-enum { MIR_LSQ_BATCHED_NO_LADDER = 1 };
-void mir_lsq_batched_set_variant(uint32_t variant);
 
 /* Unit-level access to the hot kernels (parity tests and micro-benchmarks). All pointers are
  * DEVICE pointers; stream may be NULL (default stream; the call synchronises before returning).
@@ -421,10 +403,6 @@ int mir_lsq_jtj_d(size_t m, size_t n, double* J, const double* y, const double* 
                   int broyden, double* JJ, double* Jy, void* stream, float* kernel_ms);
 int mir_lsq_jtj_s(size_t m, size_t n, float* J, const float* y, const float* y_old, const float* dx,
                   int broyden, float* JJ, float* Jy, void* stream, float* kernel_ms);
-/* same with MIR_LSQ_VARIANT_* kernel selection (JTJ_RING, JTJ_STREAM) */
-int mir_lsq_jtj_variant_d(size_t m, size_t n, double* J, const double* y, const double* y_old, const double* dx,
-                          int broyden, double* JJ, double* Jy, void* stream, float* kernel_ms, uint32_t variant);
-
 /* Finite-difference fill fused into the J^T J kernel (f64; n <= 128, or 128 < n <= 256 with n % 32 == 0; else -6). Yrm: m x 2n
  * row-major, Yrm[i][2j] = f(x + h e_j)_i, Yrm[i][2j+1] = f(x - h e_j)_i; twh[j] = (x_j + h) - (x_j - h) after clipping
  * (0 = collapsed interval: zero column, LS:1046). Writes J (m x n row-major, (Y+ - Y-) * (1 / twh) as LS:1041-1047),
@@ -457,6 +435,18 @@ mir_lsq_comm* mir_lsq_comm_create_callback(int nranks, int rank, mir_lsq_allredu
  * A rank that waits longer than 120 s at the barrier gives up (the solve then returns numericError). Returns 0. */
 int mir_lsq_comm_create_local_group(int nranks, mir_lsq_comm** out_comms);
 void mir_lsq_comm_destroy(mir_lsq_comm* comm);
+/* Record / replay of a rank's exchanges (a measurement tool: bench.py --replay-rank). A rank of an
+ * in-process group can RECORD the totals of all its all-reduces (as doubles, concatenated in call order) into a caller-owned
+ * host buffer: mir_lsq_comm_record(comm, buf, capacity_in_doubles) before the solve, mir_lsq_comm_recorded(comm) after it
+ * (the doubles written; (size_t)-1 after an overflow). A REPLAY communicator then lets ONE rank run alone on exactly the global
+ * trajectory: every all-reduce REPLACES the buffer by the next recorded total (a stream-ordered device copy; the rank's own
+ * contribution is computed and discarded) and, when `inner` is given, passes it through inner's all-reduce as well (a
+ * one-rank RCCL communicator: the launch cost of the real collective). mir_lsq_comm_replay_rewind restarts the tape for the
+ * next solve. f64 problems only. The replay handle does not own `inner`. */
+int mir_lsq_comm_record(mir_lsq_comm* comm, double* host_buf, size_t capacity);
+size_t mir_lsq_comm_recorded(const mir_lsq_comm* comm);
+mir_lsq_comm* mir_lsq_comm_create_replay(int nranks, int rank, const double* totals_host, size_t len, mir_lsq_comm* inner);
+int mir_lsq_comm_replay_rewind(mir_lsq_comm* comm);
 /* ranks of the communicator as its transport reports them (RCCL: ncclCommCount); -1 on error */
 int mir_lsq_comm_ranks(const mir_lsq_comm* comm);
 /* One line about the transport, for logs: "rccl path=<shared object ncclAllReduce was bound from> version=<ncclGetVersion>

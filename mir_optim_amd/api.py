@@ -32,9 +32,9 @@ __all__ = [
     "DeviceBuffer", "Stream", "jtj", "fd_jtj", "DEVICE_CALLBACKS", "TIME_KERNELS", "optimizeLeastSquaresBatched", "batchedPosvx", "BATCHED_NO_LADDER",
     "MODEL_EXP_DECAY", "MODEL_EXP3_AFFINE", "MODEL_EXP_DECAY_PAD8", "ResultS", "Trace", "TraceRecord", "Spline", "FitSplineResult", "fitSpline",
     "fit_spline_residuals", "variant_lr_cap",
-    "VARIANT_BROYDEN_REWRITE", "VARIANT_FD_SEPARATE_FILL", "VARIANT_JTJ_RING", "VARIANT_JTJ_STREAM",
-    "VARIANT_NO_SPECULATION", "VARIANT_NO_NULL_SKIP", "VARIANT_SOLVE_BOUNDED", "VARIANT_DEBUG_SOLVE",
-    "VARIANT_HOST_PROFILE", "VARIANT_NO_RESYNC", "VARIANT_SOLVE_GENERIC", "VARIANT_PIPELINE", "VARIANT_NO_TAIL_FUSION", "VARIANT_FD_HOST_COLUMNS", "VARIANT_SWEEP_TAIL", "VARIANT_SUMSQ_TAIL", "VARIANT_FD_PANEL_IS_J", "VARIANT_NO_PIPELINE", "VARIANT_FINISH_IN_SOLVE",
+    "VARIANT_BROYDEN_REWRITE", "VARIANT_FD_SEPARATE_FILL", "VARIANT_NO_SPECULATION", "VARIANT_NO_NULL_SKIP",
+    "VARIANT_SOLVE_BOUNDED", "VARIANT_DEBUG_SOLVE", "VARIANT_HOST_PROFILE", "VARIANT_SOLVE_GENERIC", "VARIANT_FD_HOST_COLUMNS",
+    "VARIANT_NO_PIPELINE", "BatchedOptions",
 ]
 
 MODEL_EXP_DECAY = 0      # n = 3: p0 exp(-t p1) + p2
@@ -44,26 +44,18 @@ MODEL_EXP_DECAY_PAD8 = 2  # n = 8: p0 exp(-t p1) + p2 + p3 sin 2t + p4 cos 2t + 
 DEVICE_CALLBACKS = 1
 TIME_KERNELS = 2
 
-# MIR_LSQ_VARIANT_* (include/mir_optim_amd.h): A/B switches for tests and diagnostics; 0 = the product path
+# MIR_LSQ_VARIANT_* (include/mir_optim_amd.h): literal restatements the tests compare the product path with, and
+# diagnostics; 0 = the product path
 VARIANT_BROYDEN_REWRITE = 1 << 0
 VARIANT_FD_SEPARATE_FILL = 1 << 1
-VARIANT_JTJ_RING = 1 << 2
-VARIANT_JTJ_STREAM = 1 << 3
 VARIANT_NO_SPECULATION = 1 << 4
 VARIANT_NO_NULL_SKIP = 1 << 5
 VARIANT_SOLVE_BOUNDED = 1 << 6
 VARIANT_DEBUG_SOLVE = 1 << 7
 VARIANT_HOST_PROFILE = 1 << 8
-VARIANT_NO_RESYNC = 1 << 9
 VARIANT_SOLVE_GENERIC = 1 << 10
-VARIANT_PIPELINE = 1 << 11
-VARIANT_NO_TAIL_FUSION = 1 << 12
 VARIANT_FD_HOST_COLUMNS = 1 << 13
-VARIANT_SWEEP_TAIL = 1 << 14
-VARIANT_SUMSQ_TAIL = 1 << 15
-VARIANT_FD_PANEL_IS_J = 1 << 21
 VARIANT_NO_PIPELINE = 1 << 22
-VARIANT_FINISH_IN_SOLVE = 1 << 23
 
 
 def variant_lr_cap(k):
@@ -160,7 +152,7 @@ class Stats(C.Structure):
                 ("trial_callback_points", C.c_uint64),
                 ("library_launches", C.c_uint64), ("round_launches", C.c_uint64 * 3), ("rounds", C.c_uint64 * 3),
                 ("fd_host_wall_ms", C.c_double), ("fd_host_f_ms", C.c_double), ("fd_host_columns", C.c_uint64),
-                ("host_f_ms", C.c_double), ("host_f_calls", C.c_uint64), ("fd_window_refreshes", C.c_uint64)]
+                ("host_f_ms", C.c_double), ("host_f_calls", C.c_uint64)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if isinstance(getattr(self, k), C.Array) else getattr(self, k)) for k, _ in self._fields_}
@@ -198,12 +190,23 @@ class GpuOptions(C.Structure):
                 ("workspace", C.c_void_p), ("fbContext", C.c_void_p), ("fb", C.c_void_p), ("fd_batch", C.c_uint32),
                 ("variant", C.c_uint32), ("stats", C.POINTER(Stats)), ("trace", C.POINTER(_TraceHeader)),
                 ("fbRowMajor", C.c_void_p), ("fbRowMajorDiff", C.c_void_p), ("stats_size", C.c_uint32),
-                ("fd_windows", C.c_uint32), ("fbRowMajorDiffWindow", C.c_void_p)]
+                ("reserved0", C.c_uint32)]
 
     def __init__(self, **kw):
         super().__init__(**kw)
         self.struct_size = C.sizeof(GpuOptions)
         self.stats_size = C.sizeof(Stats)
+
+
+class BatchedOptions(C.Structure):
+    """mir_lsq_batched_options: per-call options of the batched entries (variant bits, stream, caller-owned basis table,
+    profiling buffer)."""
+    _fields_ = [("struct_size", C.c_uint32), ("variant", C.c_uint32), ("stream", C.c_void_p), ("basis", C.c_void_p),
+                ("basis_bytes", C.c_size_t), ("timing", C.c_void_p)]
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.struct_size = C.sizeof(BatchedOptions)
 
 
 TASK_FN = C.CFUNCTYPE(None, _Task, C.c_uint32, C.c_uint32, C.c_uint32)
@@ -264,9 +267,6 @@ def lib():
             fn.restype = C.c_int
             fn.argtypes = [sz, sz, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                            C.c_void_p, C.POINTER(C.c_float)]
-        L.mir_lsq_jtj_variant_d.restype = C.c_int
-        L.mir_lsq_jtj_variant_d.argtypes = [sz, sz, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
-                                            C.c_void_p, C.POINTER(C.c_float), C.c_uint32]
         L.mir_lsq_comm_create_local_group.restype = C.c_int
         L.mir_lsq_comm_create_local_group.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.mir_lsq_fd_diff_jtj_d.restype = C.c_int
@@ -277,14 +277,12 @@ def lib():
                                        C.c_void_p, C.c_void_p]
         L.mir_optimize_least_squares_batched_s.restype = C.c_int
         L.mir_optimize_least_squares_batched_s.argtypes = [C.POINTER(_Ss), sz, sz, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                           C.c_void_p, sz, C.c_void_p, C.c_void_p]
+                                                           C.c_void_p, sz, C.c_void_p, C.c_void_p, C.POINTER(BatchedOptions)]
         L.mir_lsq_batched_kernel_s.restype = C.c_int
         L.mir_lsq_batched_kernel_s.argtypes = [C.POINTER(_Ss), sz, sz, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                               C.c_void_p, sz, C.c_void_p, C.c_void_p, C.c_void_p]
+                                               C.c_void_p, sz, C.c_void_p, C.c_void_p, C.POINTER(BatchedOptions)]
         L.mir_lsq_selftest_reductions.restype = C.c_int
         L.mir_lsq_selftest_reductions.argtypes = [C.c_int, C.POINTER(C.c_int * 4)]
-        L.mir_lsq_batched_set_variant.restype = None
-        L.mir_lsq_batched_set_variant.argtypes = [C.c_uint32]
         L.mir_lsq_batched_posvx_s.restype = C.c_int
         L.mir_lsq_batched_posvx_s.argtypes = [sz, sz, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mir_lsq_comm_describe.restype = C.c_int
@@ -299,6 +297,14 @@ def lib():
         L.mir_lsq_comm_create_callback.restype = C.c_void_p
         L.mir_lsq_comm_create_callback.argtypes = [C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]
         L.mir_lsq_comm_destroy.argtypes = [C.c_void_p]
+        L.mir_lsq_comm_record.restype = C.c_int
+        L.mir_lsq_comm_record.argtypes = [C.c_void_p, C.c_void_p, sz]
+        L.mir_lsq_comm_recorded.restype = sz
+        L.mir_lsq_comm_recorded.argtypes = [C.c_void_p]
+        L.mir_lsq_comm_create_replay.restype = C.c_void_p
+        L.mir_lsq_comm_create_replay.argtypes = [C.c_int, C.c_int, C.c_void_p, sz, C.c_void_p]
+        L.mir_lsq_comm_replay_rewind.restype = C.c_int
+        L.mir_lsq_comm_replay_rewind.argtypes = [C.c_void_p]
         L.mir_lsq_comm_ranks.restype = C.c_int
         L.mir_lsq_comm_ranks.argtypes = [C.c_void_p]
         for name in ("mir_lsq_comm_allreduce_d", "mir_lsq_comm_allreduce_s"):
@@ -573,10 +579,10 @@ def optimize(f, m, x, l=None, u=None, g=None, tm=None, settings=None, dtype=np.f
     return res, xo
 
 
-def optimizeLeastSquaresBatched(model, x, t, data, l=None, u=None, settings=None):
+def optimizeLeastSquaresBatched(model, x, t, data, l=None, u=None, settings=None, variant=0):
     """Many independent small fits, one wavefront per problem (mir_optimize_least_squares_batched_s, fp32).
     x: count x n starts (a copy is updated and returned), t: m (shared) or count x m, data: count x m.
-    Returns (list of LeastSquaresResult, x)."""
+    variant: BATCHED_* bits (per call). Returns (list of LeastSquaresResult, x)."""
     L = lib()
     x = np.array(x, dtype=np.float32, order="C")
     count, n = x.shape
@@ -590,7 +596,8 @@ def optimizeLeastSquaresBatched(model, x, t, data, l=None, u=None, settings=None
         settings = LeastSquaresSettings(np.float32)
     raw = (_Rs * count)()
     rc = L.mir_optimize_least_squares_batched_s(C.byref(settings), count, m, int(model), x.ctypes.data, lo.ctypes.data,
-                                                up.ctypes.data, t.ctypes.data, t_stride, data.ctypes.data, raw)
+                                                up.ctypes.data, t.ctypes.data, t_stride, data.ctypes.data, raw,
+                                                C.byref(BatchedOptions(variant=variant)))
     if rc != 0:
         raise RuntimeError(f"mir_optimize_least_squares_batched_s failed: {rc}")
     return [LeastSquaresResult(r) for r in raw], x
@@ -640,9 +647,9 @@ def solveBoxQP(P, q, l, u, x=None, settings=None, dtype=np.float64, unconstraine
     return BoxQPStatus(st), xo, it.value
 
 
-def jtj(J, y, y_old=None, dx=None, dtype=np.float64, variant=0):
-    """Unit-level access to the fused [Broyden +] J^T J + J^T y kernel (mir_lsq_jtj_*; `variant`: VARIANT_JTJ_RING /
-    VARIANT_JTJ_STREAM select the A/B kernels, f64 only). Returns (JJ full symmetric, Jy, J_after, kernel_ms)."""
+def jtj(J, y, y_old=None, dx=None, dtype=np.float64):
+    """Unit-level access to the J^T J + J^T y kernels (mir_lsq_jtj_*; with dx: the Broyden REWRITE kernels, the literal
+    restatement of LS:1003-1006). Returns (JJ full symmetric, Jy, J_after, kernel_ms)."""
     L = lib()
     J = np.ascontiguousarray(J, dtype=dtype)
     m, n = J.shape
@@ -654,13 +661,8 @@ def jtj(J, y, y_old=None, dx=None, dtype=np.float64, variant=0):
     dJJ = DeviceBuffer(nbytes=n * n * J.itemsize, dtype=dtype, shape=(n, n))
     dJy = DeviceBuffer(nbytes=n * J.itemsize, dtype=dtype, shape=(n,))
     ms = C.c_float(0)
-    if variant:
-        assert dtype == np.float64
-        rc = L.mir_lsq_jtj_variant_d(m, n, dJ.ptr, dy.ptr, dyo.ptr, ddx.ptr, 1 if broyden else 0, dJJ.ptr, dJy.ptr, None,
-                                     C.byref(ms), variant)
-    else:
-        fn = L.mir_lsq_jtj_d if dtype == np.float64 else L.mir_lsq_jtj_s
-        rc = fn(m, n, dJ.ptr, dy.ptr, dyo.ptr, ddx.ptr, 1 if broyden else 0, dJJ.ptr, dJy.ptr, None, C.byref(ms))
+    fn = L.mir_lsq_jtj_d if dtype == np.float64 else L.mir_lsq_jtj_s
+    rc = fn(m, n, dJ.ptr, dy.ptr, dyo.ptr, ddx.ptr, 1 if broyden else 0, dJJ.ptr, dJy.ptr, None, C.byref(ms))
     if rc != 0:
         raise RuntimeError(f"mir_lsq_jtj failed: {rc}")
     out = dJJ.download(), dJy.download(), dJ.download(), ms.value

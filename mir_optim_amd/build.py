@@ -2,18 +2,27 @@
 
   lib/libmir_optim_amd.so            the solver + C ABI (include/mir_optim_amd.h)
   lib/libmir_optim_amd_workloads.so  device residual callbacks of the synthetic workloads
+
+The solver is a dozen translation units (csrc/driver.h lists them): each is compiled to an object of its own under
+build/obj/ -- in parallel, and only when it or a header is newer -- and the objects are linked. A kernel edit costs the
+one translation unit that instantiates it (launch_*.hip), not the library.
 """
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(HERE, "build", "obj")
 SOLVER_LIB = os.path.join(LIBDIR, "libmir_optim_amd.so")
 WORKLOADS_LIB = os.path.join(LIBDIR, "libmir_optim_amd_workloads.so")
 
-_COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + os.environ.get("MIR_OPTIM_AMD_CXXFLAGS", "").split()
+SOLVER_UNITS = ["abi.hip", "workspace.hip", "solver_loop.hip", "solver_jacobian.hip", "launch_jtj.hip", "launch_broyden.hip",
+                "launch_solve_d.hip", "launch_solve_s.hip", "batched.hip", "comm.hip", "unit_entries.hip", "fit_spline.cpp"]
+
+_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("MIR_OPTIM_AMD_CXXFLAGS", "").split()
 
 
 def _hipcc():
@@ -30,20 +39,39 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
-def build(force=False, verbose=False):
+def _run(cmd, verbose):
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def build(force=False, verbose=False, jobs=None):
     os.makedirs(LIBDIR, exist_ok=True)
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "mir_optim_amd.h"))
-    jobs = [
-        (SOLVER_LIB, [os.path.join(CSRC, "lm_driver.hip"), os.path.join(CSRC, "fit_spline.cpp")], hdrs, ["-ldl"]),
-        (WORKLOADS_LIB, [os.path.join(CSRC, "workloads.hip")], [], ["-fopenmp"]),   # host-side data generation / host residual
-    ]
-    for target, srcs, deps, extra in jobs:
-        if force or _stale(target, srcs + deps):
-            cmd = [_hipcc()] + _COMMON + ["-o", target] + srcs + extra
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.check_call(cmd)
+    os.makedirs(OBJDIR, exist_ok=True)
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    hdrs += [os.path.join(inc, f) for f in os.listdir(inc)]
+    # the flags are part of what an object depends on (a profiling build must not reuse the product objects)
+    stamp = os.path.join(OBJDIR, "flags.txt")
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(_FLAGS):
+        force = True
+    todo = []
+    objs = []
+    for u in SOLVER_UNITS:
+        src = os.path.join(CSRC, u)
+        obj = os.path.join(OBJDIR, os.path.splitext(u)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            todo.append([_hipcc()] + _FLAGS + ["-c", src, "-o", obj])
+    if todo:
+        with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
+            list(ex.map(lambda c: _run(c, verbose), todo))
+        open(stamp, "w").write(" ".join(_FLAGS))
+    if force or todo or _stale(SOLVER_LIB, objs):
+        _run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SOLVER_LIB] + objs + ["-ldl"], verbose)
+    wsrc = os.path.join(CSRC, "workloads.hip")
+    if force or _stale(WORKLOADS_LIB, [wsrc]):
+        _run([_hipcc()] + _FLAGS + ["-shared", "-o", WORKLOADS_LIB, wsrc, "-fopenmp"], verbose)   # host-side data generation / host residual
     return SOLVER_LIB, WORKLOADS_LIB
 
 

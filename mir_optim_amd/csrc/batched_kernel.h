@@ -13,7 +13,7 @@
 #pragma once
 
 #include "common.h"
-#include "solve_kernel.h"
+#include "solve_types.h"
 
 namespace mirlsq {
 
@@ -22,16 +22,22 @@ constexpr int kBatchedNMax = 8;
 
 enum : int { kModelExpDecay = 0, kModelExp3Affine = 1, kModelExpDecayPad8 = 2 };
 
-// residual models: r = model(t, x) - d. A model may declare `nb` per-row BASIS values that do not depend on the parameters
-// (basis(t, b)); k_batched_basis tabulates them once per launch (rows x nb floats) and eval() reads the row's values instead
-// of evaluating them again at every trial point and finite-difference point: the same floats enter the same expression.
-template <int MODEL> struct BatchedModel;
-template <> struct BatchedModel<kModelExpDecay> {      // p0 exp(-t p1) + p2            (n = 3; reference unittest T5's family)
+// ---- residual models: r_i = Model::eval(t_i, basis_i, x) - data_i. The contract of a model (the built-in ones below and
+// any user model handed to launch_batched<Model>, include/mir_optim_amd_batched.hpp) -- the compile-time counterpart of the
+// reference's residual callback f(x, y) (least_squares.d:73-80), restricted to residuals that are a function of ONE abscissa:
+//     static constexpr int n;      number of parameters, 1 <= n <= 8
+//     static constexpr int nb;     per-row BASIS values that do not depend on the parameters (0 = none)
+//     __device__ static void basis(float t, float* b);                       fills b[0 .. nb)
+//     __device__ static float eval(float t, const float* b, const float* x); the model value at t; x has 8 entries, x[n..] = 0
+// The basis values of every row are tabulated once per launch (k_batched_basis: rows x nb floats) and eval() reads the row's
+// values instead of evaluating them again at every trial point and finite-difference point: the same floats enter the same
+// expression. eval must be pure (the reference declares its callbacks pure) and wave-uniform in control flow.
+struct ModelExpDecay {          // p0 exp(-t p1) + p2            (n = 3; reference unittest T5's family)
     static constexpr int n = 3, nb = 0;
     __device__ static inline void basis(float, float*) {}
     __device__ static inline float eval(float t, const float*, const float* x) { return x[0] * __expf(-t * x[1]) + x[2]; }
 };
-template <> struct BatchedModel<kModelExp3Affine> {    // sum_{k<3} p_{2k} exp(-t p_{2k+1}) + p6 + p7 t   (n = 8)
+struct ModelExp3Affine {        // sum_{k<3} p_{2k} exp(-t p_{2k+1}) + p6 + p7 t   (n = 8)
     static constexpr int n = 8, nb = 0;
     __device__ static inline void basis(float, float*) {}
     __device__ static inline float eval(float t, const float*, const float* x)
@@ -39,12 +45,11 @@ template <> struct BatchedModel<kModelExp3Affine> {    // sum_{k<3} p_{2k} exp(-
         return x[0] * __expf(-t * x[1]) + x[2] * __expf(-t * x[3]) + x[4] * __expf(-t * x[5]) + x[6] + x[7] * t;
     }
 };
-
 // BASELINE cfg 5's well-conditioned n = 8 family ("p0 exp(-t p1) + p2 + 5-term variants padded to n = 8"): the
 // exponential decay plus five terms that are LINEAR in their parameters (a two-frequency trigonometric pair and a slope),
 // so the only nonlinearity is the decay and J^T J stays well conditioned in fp32. Precise expf / sinf / cosf (the float
 // oracle evaluates the same expression with libm). The four trigonometric values of a row are its basis.
-template <> struct BatchedModel<kModelExpDecayPad8> {
+struct ModelExpDecayPad8 {
     static constexpr int n = 8, nb = 4;
     __device__ static inline void basis(float t, float* b)
     {
@@ -55,6 +60,11 @@ template <> struct BatchedModel<kModelExpDecayPad8> {
         return x[0] * expf(-t * x[1]) + x[2] + x[3] * b[0] + x[4] * b[1] + x[5] * b[2] + x[6] * b[3] + x[7] * t;
     }
 };
+// the compiled-in models of mir_optimize_least_squares_batched_s by their MIR_LSQ_MODEL_* id
+template <int ID> struct BuiltinModel;
+template <> struct BuiltinModel<kModelExpDecay> { using type = ModelExpDecay; };
+template <> struct BuiltinModel<kModelExp3Affine> { using type = ModelExp3Affine; };
+template <> struct BuiltinModel<kModelExpDecayPad8> { using type = ModelExpDecayPad8; };
 
 struct BatchedResult { int32_t status; uint32_t iterations, fCalls, gCalls; float residual, lambda; };
 
@@ -70,7 +80,7 @@ struct BatchedArgs {
     const float* upper;    // n
     BatchedResult* results;
     const float* basis;    // (t_stride ? count : 1) x m x nb: the model's per-row basis (k_batched_basis), nullptr when nb == 0
-    uint64_t* timing;      // profiling builds (MIRLSQ_BATCHED_TIMING): 6 x count cycle counters, else unused
+    uint64_t* timing;      // profiling builds (MIRLSQ_BATCHED_TIMING): 10 x count cycle counters (mir_lsq_batched_options.timing), else unused
     uint32_t variant;      // kBatchedNoLadder: one damping value per solve (A/B and the test of the ladder against it)
 };
 constexpr uint32_t kBatchedNoLadder = 1u;
@@ -90,13 +100,13 @@ template <int NB> struct BasisRow {
     }
 };
 
-template <int MODEL>
+template <class Model>
 __global__ __launch_bounds__(256) void k_batched_basis(const float* __restrict__ t, float* __restrict__ table, size_t rows)
 {
-    constexpr int NB = BatchedModel<MODEL>::nb;
+    constexpr int NB = Model::nb;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < rows; i += (size_t)gridDim.x * blockDim.x) {
         float b[NB > 0 ? NB : 1];
-        BatchedModel<MODEL>::basis(t[i], b);
+        Model::basis(t[i], b);
 #pragma unroll
         for (int k = 0; k < NB; ++k) table[i * NB + k] = b[k];
     }
@@ -274,10 +284,10 @@ __global__ __launch_bounds__(64) void k_posvx_rows(const float* __restrict__ P, 
 #define MIRLSQ_T1(k) ((void)0)
 #endif
 
-template <int MODEL>
-__global__ __launch_bounds__(64, BatchedModel<MODEL>::n <= 4 ? 4 : 2) void k_lm_batched(BatchedArgs a)   // waves per SIMD the LDS slices allow at m = 512
+template <class Model>
+__global__ __launch_bounds__(64, Model::n <= 4 ? 4 : 2) void k_lm_batched(BatchedArgs a)   // waves per SIMD the LDS slices allow at m = 512
 {
-    constexpr int N = BatchedModel<MODEL>::n;
+    constexpr int N = Model::n;
     constexpr int NMAX = kBatchedNMax;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     // one problem per (single-wave) workgroup: the dispatcher hands a finished wave's slot to the next problem, so a
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(64, BatchedModel<MODEL>::n <= 4 ? 4 : 2) void k_lm_
     float* mB = yv + m;
     const float* tp = a.t + (size_t)(a.t_stride ? prob : 0) * a.t_stride;
     const float* dp = a.data + (size_t)prob * m;
-    constexpr int NB = BatchedModel<MODEL>::nb;
+    constexpr int NB = Model::nb;
     const float* bp = NB ? a.basis + (size_t)(a.t_stride ? prob : 0) * a.t_stride * NB : nullptr;
     const LmSettingsDev<float>& S = a.set;
 
@@ -326,7 +336,7 @@ __global__ __launch_bounds__(64, BatchedModel<MODEL>::n <= 4 ? 4 : 2) void k_lm_
                 bv[u].load(bp, i);
             }
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) rv[u] = BatchedModel<MODEL>::eval(tv[u], bv[u].v, p) - dv[u];
+            for (int u = 0; u < UNR; ++u) rv[u] = Model::eval(tv[u], bv[u].v, p) - dv[u];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int i = base + kWave * u;
@@ -413,9 +423,9 @@ __global__ __launch_bounds__(64, BatchedModel<MODEL>::n <= 4 ? 4 : 2) void k_lm_
 #pragma unroll
                         for (int j = 0; j < N; ++j) {
                             p[j] = xph[j];
-                            const float fp = BatchedModel<MODEL>::eval(ti, b.v, p) - di;
+                            const float fp = Model::eval(ti, b.v, p) - di;
                             p[j] = xmh[j];
-                            const float fm = BatchedModel<MODEL>::eval(ti, b.v, p) - di;
+                            const float fm = Model::eval(ti, b.v, p) - di;
                             p[j] = x[j];
                             float v = fp;
                             v += -1.0f * fm;
@@ -588,18 +598,18 @@ __global__ __launch_bounds__(64, BatchedModel<MODEL>::n <= 4 ? 4 : 2) void k_lm_
 
 
 // residual of one problem as a DEVICE callback body (used when a batched problem falls back to the general solver)
-template <int MODEL>
+template <class Model>
 __global__ __launch_bounds__(256) void k_batched_model_eval(const float* __restrict__ t, const float* __restrict__ d,
                                                             const float* __restrict__ x, float* __restrict__ y, int m)
 {
-    constexpr int NB = BatchedModel<MODEL>::nb;
+    constexpr int NB = Model::nb;
     float p[kBatchedNMax];
 #pragma unroll
-    for (int j = 0; j < kBatchedNMax; ++j) p[j] = j < BatchedModel<MODEL>::n ? x[j] : 0.0f;
+    for (int j = 0; j < kBatchedNMax; ++j) p[j] = j < Model::n ? x[j] : 0.0f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
         float b[NB > 0 ? NB : 1];
-        BatchedModel<MODEL>::basis(t[i], b);
-        y[i] = BatchedModel<MODEL>::eval(t[i], b, p) - d[i];
+        Model::basis(t[i], b);
+        y[i] = Model::eval(t[i], b, p) - d[i];
     }
 }
 

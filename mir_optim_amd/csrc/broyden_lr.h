@@ -22,8 +22,9 @@
 // rows, per-block partials are summed in a fixed order by k_lr_reduce: results are bitwise reproducible.
 #pragma once
 
+#include "broyden_launch.h"
 #include "common.h"
-#include "solve_kernel.h"
+#include "solve_types.h"
 
 namespace mirlsq {
 
@@ -32,133 +33,10 @@ template <typename T> struct LrPair;
 template <> struct LrPair<double> { using type = double2; };
 template <> struct LrPair<float> { using type = float2; };
 
-template <typename T>
-struct LrArgs {
-    const T* J;        // m x n row-major, read only (J0)
-    T* U;              // kLrMax columns of length m (column l at U + l m); column k is written
-    const T* D;        // kLrMax x n, rows 0..k-1 valid
-    const T* dx;       // the accepted step of this update (length n)
-    const T* dx_dot;   // device scalar dx.dx (LS:1002: d = 1 / deltaX_dot)
-    const T* y;        // residual at the new point
-    const T* y_old;    // residual at the previous point (the reference's mBuffer after the swap LS:1136)
-    T* partials;       // gridDim.x x lr_len(n)
-    size_t m;
-    int n;
-    int k;
-    const T* colscale;      // SCALED kernels: J0 is the finite-difference DIFFERENCE panel D as the caller's kernel wrote it, and
-                            // the Jacobian entry is D_ij (1 / twh_j) (0 for a collapsed interval) -- colscale = twh. The same
-                            // multiplication k_jtj_fdp performs (LS:1046-1047), applied at load time: the values are bit-identical
-                            // to a materialised J, and the refresh does not have to write m x n doubles
-    const int32_t* guard;   // optional: the kernel does nothing when *guard == 0 (rounds enqueued ahead of time)
-    // ---- fused tail (tail_counters != nullptr): the reduction of k_lr_reduce and, without an all-reduce behind it, the
-    //      n x n work of k_lr_finish run inside the sweep, in the workgroups that arrive last (see lr_tail below)
-    uint32_t* tail_counters;   // kReduceRanges group counters + 1 top counter: zero before the launch, reset by the tail
-    T* range_sums;             // kReduceRanges x lr_len(n)
-    T* out;                    // the reduced sweep vector (lr_len(n))
-    int finish;                // 1: also apply k_lr_finish (single GPU); 0: an all-reduce of `out` follows
-    T* Dw;                     // finish: D (writable: row k receives dx)
-    T* JJ; T* Jy; LmState<T>* st;
-};
 
 
-// ---- the tail of the sweep. Workgroup b belongs to range r = b / per (per = ceil(nblk / 32): the ranges of k_lr_reduce).
-// Every workgroup publishes its partial vector and counts itself into its range; the LAST arrival of a range sums the
-// range's partials in index order into range_sums[r] and counts the range in; the last range to arrive sums the 32 range
-// vectors in index order. Same partition and same order as k_lr_reduce whichever workgroups happen to come last: bitwise
-// reproducible and bit-identical to the two-kernel path. With `finish` the final workgroup goes on with k_lr_finish's
-// work (v = v0 + D w, the rank-two update of J^T J, J^T y, |J^T y|_inf, D_k = dx) from the vector it holds in LDS.
-template <typename T>
-__device__ inline void lr_tail(const LrArgs<T>& a, T (*red)[lr_len(kLrMaxN)])
-{
-    const int len = lr_len(a.n), nblk = (int)gridDim.x, tid = threadIdx.x;
-    const int per = (nblk + kReduceRanges - 1) / kReduceRanges;
-    const int r = (int)blockIdx.x / per;
-    const int b0 = r * per, b1 = (b0 + per < nblk) ? b0 + per : nblk;
-    const int ngroups = (nblk + per - 1) / per;
-    if (!arrive_last(&a.tail_counters[r], (uint32_t)(b1 - b0))) return;
-    constexpr int kInFlight = 8;                           // loads in flight per thread: the tail must fit the registers of the main loop
-#pragma unroll 1
-    for (int e = tid; e < len; e += blockDim.x) {
-        T p[kInFlight];
-        T s = 0;
-#pragma unroll 1
-        for (int c0 = b0; c0 < b1; c0 += kInFlight) {
-            const T* src = a.partials + (size_t)c0 * len + e;
-#pragma unroll
-            for (int u = 0; u < kInFlight; ++u) p[u] = (c0 + u < b1) ? load_agent(src + (size_t)u * len) : T(0);
-#pragma unroll
-            for (int u = 0; u < kInFlight; ++u) if (c0 + u < b1) s += p[u];
-        }
-        store_agent(&a.range_sums[(size_t)r * len + e], s);
-    }
-    if (!arrive_last(&a.tail_counters[kReduceRanges], (uint32_t)ngroups)) return;
-    T* lrs = red[0];                                       // the reduced vector, kept in LDS for the finish
-#pragma unroll 1
-    for (int e = tid; e < len; e += blockDim.x) {
-        T p[kInFlight];
-        T tot = 0;
-#pragma unroll 1
-        for (int c0 = 0; c0 < kReduceRanges; c0 += kInFlight) {
-#pragma unroll
-            for (int u = 0; u < kInFlight; ++u) p[u] = (c0 + u < ngroups) ? load_agent(&a.range_sums[(size_t)(c0 + u) * len + e]) : T(0);
-#pragma unroll
-            for (int u = 0; u < kInFlight; ++u) tot = (c0 + u == 0) ? p[0] : tot + p[u];     // k_lr_reduce's order: part[0] + part[1] + ...
-        }
-        a.out[e] = tot;
-        lrs[e] = tot;
-    }
-    if (!a.finish) return;
-    __syncthreads();
-    const int n = a.n, k = a.k;
-    T* v = red[1];
-    T* dxs = red[2];
-    const T* w = lrs + 2 * n;
-    const T* h = w + kLrMax;
-    const T uu = lrs[2 * n + 2 * kLrMax], uy = lrs[2 * n + 2 * kLrMax + 1];
-    T mx = 0;
-    for (int j = tid; j < n; j += blockDim.x) {
-        const T dj = a.dx[j];
-        T s = lrs[j];
-        for (int l = 0; l < k; ++l) s += a.Dw[(size_t)l * n + j] * w[l];
-        v[j] = s;
-        dxs[j] = dj;
-        T g = lrs[n + j];
-        for (int l = 0; l < k; ++l) g += a.Dw[(size_t)l * n + j] * h[l];
-        g += dj * uy;
-        a.Jy[j] = g;
-        const T av = dabs(g);
-        if (av > mx) mx = av;
-    }
-    __syncthreads();                                       // also: every read of D rows < k is done before row k is written
-    for (int j = tid; j < n; j += blockDim.x) a.Dw[(size_t)k * n + j] = dxs[j];
-    const int nn = n * n;
-    for (int base = tid; base < nn; base += 8 * (int)blockDim.x) {         // loads in flight: see lr_finish_block
-        T old[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int idx = base + u * (int)blockDim.x; old[u] = a.JJ[idx < nn ? idx : nn - 1]; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = base + u * (int)blockDim.x;
-            if (idx < nn) {
-                const int i = idx / n, j = idx - i * n;
-                const int rr = i >= j ? i : j, cc = i >= j ? j : i;
-                a.JJ[idx] = old[u] + lr_jj_term(v[rr], v[cc], dxs[rr], dxs[cc], uu);
-            }
-        }
-    }
-    mx = wave_max(mx);
-    __shared__ T mred[4];
-    if ((tid & 63) == 0) mred[tid >> 6] = mx;
-    __syncthreads();
-    if (tid == 0) {
-        T m2 = mred[0];
-        for (int wv = 1; wv < (int)(blockDim.x >> 6); ++wv) m2 = mred[wv] > m2 ? mred[wv] : m2;
-        a.st->jy_inf = m2;
-    }
-}
-
-// (four workgroups per CU up to n = 128: the scaled variant would otherwise take 130 VGPRs and drop to three)
-template <typename T, int NCP, bool VEC, bool SCALED = false>
+// (four workgroups per CU up to n = 128)
+template <typename T, int NCP, bool VEC>
 __global__ __launch_bounds__(256, (NCP <= 4 ? 4 : 1)) void k_broyden_lr(const LrArgs<T> a)
 {
     using P2 = typename LrPair<T>::type;
@@ -189,15 +67,6 @@ __global__ __launch_bounds__(256, (NCP <= 4 ? 4 : 1)) void k_broyden_lr(const Lr
         const T t0 = a.dx[ok0[c] ? col : 0], t1 = a.dx[ok1[c] ? col + 1 : 0];
         d0[c] = ok0[c] ? t0 : T(0);
         d1[c] = ok1[c] ? t1 : T(0);
-    }
-    T sc0[SCALED ? NCP : 1], sc1[SCALED ? NCP : 1];        // 1 / twh of the lane's columns (0: collapsed interval, zero column)
-    if constexpr (SCALED) {
-#pragma unroll
-        for (int c = 0; c < NCP; ++c) {
-            const T t0 = a.colscale[ok0[c] ? coff[c] : 0], t1 = a.colscale[ok1[c] ? coff[c] + 1 : 0];
-            sc0[c] = (t0 == 0 || !ok0[c]) ? T(0) : T(1) / t0;
-            sc1[c] = (t1 == 0 || !ok1[c]) ? T(0) : T(1) / t1;
-        }
     }
     __syncthreads();
     const bool own = p < k;
@@ -232,10 +101,6 @@ __global__ __launch_bounds__(256, (NCP <= 4 ? 4 : 1)) void k_broyden_lr(const Lr
             } else {
                 v0[c] = rp[coff[c]];
                 v1[c] = rp[ok1[c] ? coff[c] + 1 : 0];
-            }
-            if constexpr (SCALED) {
-                v0[c] = sc0[c] == 0 ? T(0) : v0[c] * sc0[c];              // scal(1 / twh, Jj), LS:1047 (LS:1046: zero column)
-                v1[c] = sc1[c] == 0 ? T(0) : v1[c] * sc1[c];
             }
         }
         T yn = a.y[rr];
@@ -279,13 +144,7 @@ __global__ __launch_bounds__(256, (NCP <= 4 ? 4 : 1)) void k_broyden_lr(const Lr
     __syncthreads();
     const int len = lr_len(n);
     T* out = a.partials + (size_t)blockIdx.x * len;
-    if (a.tail_counters) {
-        // the partial vector crosses to another workgroup inside this kernel: agent-scope stores (common.h)
-        for (int e = threadIdx.x; e < len; e += blockDim.x) store_agent(&out[e], (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]));
-        lr_tail<T>(a, red);
-    } else {
-        for (int e = threadIdx.x; e < len; e += blockDim.x) out[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-    }
+    for (int e = threadIdx.x; e < len; e += blockDim.x) out[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
 // sum the per-block partial vectors in a fixed order: blockDim = 1024 = 32 entries x 32 block ranges (a thread walks
@@ -363,12 +222,10 @@ __global__ __launch_bounds__(256) void k_lr_finish(const T* __restrict__ lr, T* 
 }
 
 // fold the k pending terms into J: J[i,:] += u_0[i] dx_0 + ... + u_{k-1}[i] dx_{k-1}, in update order
-// src: what J is read from -- J itself (in place), or the unscaled difference panel with colscale = twh (SCALED, see LrArgs)
-template <typename T, int NCP, bool VEC, bool SCALED = false>
+template <typename T, int NCP, bool VEC>
 __global__ __launch_bounds__(256) void k_lr_flush(T* J, const T* __restrict__ U, const T* __restrict__ D,
-                                                  int k, size_t m, int n, const T* src = nullptr, const T* colscale = nullptr)
+                                                  int k, size_t m, int n)
 {
-    if (!src) src = J;
     using P2 = typename LrPair<T>::type;
     extern __shared__ unsigned char lr_smem[];
     T* Ds = reinterpret_cast<T*>(lr_smem);                 // k x n
@@ -385,15 +242,6 @@ __global__ __launch_bounds__(256) void k_lr_flush(T* J, const T* __restrict__ U,
         ok1[c] = col + 1 < n;
         coff[c] = ok0[c] ? col : 0;
     }
-    T sc0[SCALED ? NCP : 1], sc1[SCALED ? NCP : 1];
-    if constexpr (SCALED) {
-#pragma unroll
-        for (int c = 0; c < NCP; ++c) {
-            const T t0 = colscale[ok0[c] ? coff[c] : 0], t1 = colscale[ok1[c] ? coff[c] + 1 : 0];
-            sc0[c] = (t0 == 0 || !ok0[c]) ? T(0) : T(1) / t0;
-            sc1[c] = (t1 == 0 || !ok1[c]) ? T(0) : T(1) / t1;
-        }
-    }
     const size_t G = (m + 3) / 4;
     const size_t wave_id = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
@@ -402,7 +250,7 @@ __global__ __launch_bounds__(256) void k_lr_flush(T* J, const T* __restrict__ U,
         const bool rok = row < m;
         const size_t rr = rok ? row : m - 1;
         T* rp = J + rr * (size_t)n;
-        const T* sp = src + rr * (size_t)n;
+        const T* sp = rp;
         T v0[NCP], v1[NCP];
 #pragma unroll
         for (int c = 0; c < NCP; ++c) {
@@ -414,10 +262,6 @@ __global__ __launch_bounds__(256) void k_lr_flush(T* J, const T* __restrict__ U,
             } else {
                 v0[c] = sp[coff[c]];
                 v1[c] = sp[ok1[c] ? coff[c] + 1 : 0];
-            }
-            if constexpr (SCALED) {
-                v0[c] = sc0[c] == 0 ? T(0) : v0[c] * sc0[c];
-                v1[c] = sc1[c] == 0 ? T(0) : v1[c] * sc1[c];
             }
         }
         for (int l = 0; l < k; ++l) {
@@ -444,84 +288,6 @@ __global__ __launch_bounds__(256) void k_lr_flush(T* J, const T* __restrict__ U,
             }
         }
     }
-}
-
-// ---- host-side launchers
-template <typename T, int NCP>
-hipError_t lr_sweep_ncp(const LrArgs<T>& a, int nblk, bool vec, hipStream_t s)
-{
-    if (a.colscale) {
-        // only the f64, even-n shapes of the difference panel reach here (16-byte loads)
-        if constexpr (sizeof(T) == 8) {
-            if (!vec) return hipErrorInvalidValue;
-            MIRLSQ_LAUNCH((k_broyden_lr<T, NCP, true, true>), dim3(nblk), dim3(256), 0, s, a);
-            return hipGetLastError();
-        } else {
-            return hipErrorInvalidValue;
-        }
-    }
-    if (vec) MIRLSQ_LAUNCH((k_broyden_lr<T, NCP, true>), dim3(nblk), dim3(256), 0, s, a);
-    else MIRLSQ_LAUNCH((k_broyden_lr<T, NCP, false>), dim3(nblk), dim3(256), 0, s, a);
-    return hipGetLastError();
-}
-template <typename T>
-hipError_t lr_sweep(const LrArgs<T>& a, int nblk, hipStream_t s)
-{
-    if (a.n > kLrMaxN || a.k < 0 || a.k >= kLrMax) return hipErrorInvalidValue;
-    const bool vec = (a.n % 2 == 0) && (reinterpret_cast<uintptr_t>(a.J) % (2 * sizeof(T)) == 0);
-    const int ncp = (a.n + 31) / 32;
-    if (ncp <= 1) return lr_sweep_ncp<T, 1>(a, nblk, vec, s);
-    if (ncp <= 2) return lr_sweep_ncp<T, 2>(a, nblk, vec, s);
-    if (ncp <= 4) return lr_sweep_ncp<T, 4>(a, nblk, vec, s);
-    return lr_sweep_ncp<T, 8>(a, nblk, vec, s);
-}
-
-template <typename T, int NCP>
-hipError_t lr_flush_ncp(T* J, const T* U, const T* D, int k, size_t m, int n, int nblk, bool vec, hipStream_t s, const T* src, const T* colscale)
-{
-    const size_t lds = (size_t)k * n * sizeof(T);
-    if (colscale) {
-        if constexpr (sizeof(T) == 8) {
-            if (!vec) return hipErrorInvalidValue;
-            MIRLSQ_LAUNCH((k_lr_flush<T, NCP, true, true>), dim3(nblk), dim3(256), lds, s, J, U, D, k, m, n, src, colscale);
-            return hipGetLastError();
-        } else {
-            return hipErrorInvalidValue;
-        }
-    }
-    if (vec) MIRLSQ_LAUNCH((k_lr_flush<T, NCP, true>), dim3(nblk), dim3(256), lds, s, J, U, D, k, m, n, src, colscale);
-    else MIRLSQ_LAUNCH((k_lr_flush<T, NCP, false>), dim3(nblk), dim3(256), lds, s, J, U, D, k, m, n, src, colscale);
-    return hipGetLastError();
-}
-// J <- src (scaled by 1 / colscale when given) + the k pending terms; src == nullptr: J in place. With k == 0 and a scaled
-// source this just materialises J.
-template <typename T>
-hipError_t lr_flush(T* J, const T* U, const T* D, int k, size_t m, int n, int num_cu, hipStream_t s, const T* src = nullptr,
-                    const T* colscale = nullptr)
-{
-    if (k <= 0 && !colscale) return hipSuccess;
-    if (n > kLrMaxN || k > kLrMax) return hipErrorInvalidValue;
-    const size_t G = (m + 3) / 4;
-    size_t blocks = (G + 3) / 4;
-    if (blocks > (size_t)num_cu * 8) blocks = (size_t)num_cu * 8;
-    if (blocks < 1) blocks = 1;
-    const bool vec = (n % 2 == 0) && (reinterpret_cast<uintptr_t>(J) % (2 * sizeof(T)) == 0)
-        && (reinterpret_cast<uintptr_t>(src) % (2 * sizeof(T)) == 0);
-    const int ncp = (n + 31) / 32;
-    if (ncp <= 1) return lr_flush_ncp<T, 1>(J, U, D, k, m, n, (int)blocks, vec, s, src, colscale);
-    if (ncp <= 2) return lr_flush_ncp<T, 2>(J, U, D, k, m, n, (int)blocks, vec, s, src, colscale);
-    if (ncp <= 4) return lr_flush_ncp<T, 4>(J, U, D, k, m, n, (int)blocks, vec, s, src, colscale);
-    return lr_flush_ncp<T, 8>(J, U, D, k, m, n, (int)blocks, vec, s, src, colscale);
-}
-
-// workgroups of the sweep: 4 per CU, at least ~8 row steps per wave
-inline int lr_blocks(size_t m, int num_cu)
-{
-    const size_t G = (m + 3) / 4;
-    size_t want = (G + 4 * 8 - 1) / (4 * 8);
-    const size_t cap = (size_t)num_cu * 4;
-    if (want > cap) want = cap;
-    return (int)(want ? want : 1);
 }
 
 }  // namespace mirlsq

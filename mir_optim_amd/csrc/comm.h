@@ -51,7 +51,7 @@ struct LocalGroup {
 
 struct mir_lsq_comm {
     int nranks = 1, rank = 0;
-    int kind = 0;   // 1 = rccl, 2 = callback, 3 = in-process group
+    int kind = 0;   // 1 = rccl, 2 = callback, 3 = in-process group, 4 = replay of recorded totals
     mirlsq::LocalGroup* group = nullptr;
     uint64_t local_calls = 0;
     // rccl
@@ -67,6 +67,14 @@ struct mir_lsq_comm {
     void* cb_ctx = nullptr;
     double* cb_scratch = nullptr;   // device doubles for float problems
     size_t cb_scratch_len = 0;
+    // record (kind 3): the totals of this rank's all-reduces, appended to a caller-owned host buffer (mir_lsq_comm_record)
+    double* rec_buf = nullptr;
+    size_t rec_cap = 0, rec_len = 0;
+    bool rec_overflow = false;
+    // replay (kind 4): recorded totals on the device, a cursor, optionally an inner communicator every exchange also passes through
+    double* replay_dev = nullptr;
+    size_t replay_len = 0, replay_pos = 0;
+    mir_lsq_comm* replay_inner = nullptr;
 };
 
 namespace mirlsq {
@@ -127,9 +135,28 @@ inline int comm_allreduce(mir_lsq_comm* c, T* buf, size_t count, hipStream_t str
             const T* src = static_cast<const T*>(g->slots[par][r].host);
             for (size_t i = 0; i < count; ++i) out[i] += src[i];
         }
+        if (c->rec_buf) {
+            if (c->rec_len + count <= c->rec_cap) { for (size_t i = 0; i < count; ++i) c->rec_buf[c->rec_len + i] = (double)out[i]; c->rec_len += count; }
+            else c->rec_overflow = true;
+        }
         if (hipMemcpyAsync(buf, out, bytes, hipMemcpyHostToDevice, stream) != hipSuccess
             || hipStreamSynchronize(stream) != hipSuccess) return -1;
         return 0;
+    }
+    if (c->kind == 4) {
+        // replay: the recorded total of this exchange replaces the buffer (stream-ordered copy, no host synchronisation)
+        if constexpr (sizeof(T) == 8) {
+            if (c->replay_pos + count > c->replay_len) {
+                std::fprintf(stderr, "[mir_optim_amd] replay communicator: the tape ends at %zu, exchange needs %zu more\n", c->replay_len, count);
+                return -1;
+            }
+            if (hipMemcpyAsync(buf, c->replay_dev + c->replay_pos, count * sizeof(double), hipMemcpyDeviceToDevice, stream) != hipSuccess) return -1;
+            c->replay_pos += count;
+            return c->replay_inner ? comm_allreduce<T>(c->replay_inner, buf, count, stream) : 0;
+        } else {
+            std::fprintf(stderr, "[mir_optim_amd] replay communicator supports f64 problems only\n");
+            return -1;
+        }
     }
     if (c->kind == 2) {
         if constexpr (sizeof(T) == 8) {

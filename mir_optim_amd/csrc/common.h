@@ -28,51 +28,13 @@ constexpr int kWave = 64;  // CDNA wavefront
 inline thread_local uint64_t tl_launches = 0;
 #define MIRLSQ_LAUNCH(...) do { ++::mirlsq::tl_launches; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
-// ---- "last workgroup finishes" tails (broyden_lr.h, misc_kernels.h, jtj_kernel.h): partial results cross from one workgroup
-// to another INSIDE a kernel, and the eight XCDs of the chip have separate L2s. A device-scope release fence
-// (__threadfence) would make them visible, but on gfx950 it is a write-back of the whole L2 (buffer_wbl2) per executing wave:
-// with ~1000 workgroups that cost more than the kernels the tails replace (measured: k_broyden_lr 0.18 -> 0.44 ms). Instead
-// the few values that cross are written and read with AGENT-SCOPE ATOMIC stores / loads (sc1: write-through / coherent
-// read), which need no cache maintenance; every wave waits for its stores (s_waitcnt vmcnt(0)) and a workgroup barrier orders
-// them before the arrival count, and the finishing workgroup executes one agent-scope acquire (buffer_inv) after it.
-template <typename T> __device__ __forceinline__ void store_agent(T* p, T v)
-{
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <typename T> __device__ __forceinline__ T load_agent(const T* p)
-{
-    return __hip_atomic_load(const_cast<T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// count this workgroup in; true for the workgroup that arrives last (of `expected`). Collective over the workgroup; the
-// caller's agent-scope stores precede it. The counter is reset for the next launch by the last arrival.
-__device__ __forceinline__ bool arrive_last(uint32_t* counter, uint32_t expected)
-{
-    __shared__ int last_s;
-    // every wave waits for its own stores to complete (write-through to the device's coherence point) before the barrier that
-    // precedes the count: __syncthreads() alone does NOT wait for them -- on one CU (no threadgroup split) its workgroup-scope
-    // release needs no vmcnt wait
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last_s = prev == expected - 1;
-        if (last_s) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    const bool last = last_s != 0;
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // nothing stale in this CU's L1 / this XCD's L2
-    return last;
-}
-
 // ---- pending rank-one Broyden terms (broyden_lr.h): sizes shared by the sweep, its reduction and the n x n finish
 constexpr int kLrMax = 16;
 // [ v0 (n) | g0 (n) | w (kLrMax) | h (kLrMax) | uu | uy ]
 __host__ __device__ constexpr int lr_len(int n) { return 2 * n + 2 * kLrMax + 2; }
 constexpr int kLrMaxN = 256;
 constexpr int kReduceRanges = 32;
-// one entry of the symmetric rank-two update J_k^T J_k = J_{k-1}^T J_{k-1} + v dx^T + dx v^T + uu dx dx^T, r >= c: ONE
-// function for every place that applies it (k_lr_finish, the solve kernels' prologue, the sweep's fused tail), so that all
-// of them round the same way
+// one entry of the symmetric rank-two update J_k^T J_k = J_{k-1}^T J_{k-1} + v dx^T + dx v^T + uu dx dx^T, r >= c (k_lr_finish)
 template <typename T>
 __device__ __forceinline__ T lr_jj_term(T vr, T vc, T dr, T dc, T uu) { return (vr * dc + dr * vc) + uu * dr * dc; }
 

@@ -29,36 +29,10 @@
 #include <type_traits>
 
 #include "common.h"
+#include "jtj_plan.h"
 
 namespace mirlsq {
 
-template <typename T>
-struct JtjArgs {
-    const T* J;        // m x n row-major
-    T* Jout;           // BROYDEN: where updated rows are written (== J for in-place)
-    const T* y;        // residual at the current point (length m)
-    const T* y_old;    // BROYDEN: residual at the previous point (the reference's mBuffer after swap, LS:1136)
-    const T* dx;       // BROYDEN: accepted step (length n)
-    const T* dx_dot;   // BROYDEN: device scalar ||dx||^2 (LS:1002: d = 1 / deltaX_dot)
-    T* slabs;          // gridDim.x slabs of jtj_slab_len<NCB>() elements
-    size_t m;
-    int n;
-    const T* twh;      // finite-difference kernels (jtj_fdp.h, jtj_fdp8.h): interval widths xph - xmh (LS:1031); then J is the
-                       // m x 2n row-major panel of perturbed residuals [f(x + h e_j), f(x - h e_j)]_j and Jout receives the Jacobian
-};
-
-constexpr int kJtjWaves = 4;   // waves per workgroup
-
-template <int NCB> __host__ __device__ constexpr int jtj_nacc() { return NCB * (NCB + 1) / 2; }
-// slab: NACC blocks x 4 registers x 64 lanes, then NCB x 64 lanes of J^T y partials
-template <int NCB> __host__ __device__ constexpr int jtj_slab_len() { return (jtj_nacc<NCB>() * 4 + NCB) * kWave; }
-// The accumulator blocks are split over 1, 2 or 4 "roles" (waves that walk the same rows) so that
-// one wave keeps at most 96 accumulator VGPRs (regs_per_block = 4 for f32, 8 for f64).
-__host__ __device__ constexpr int jtj_roles_rt(int ncb, int regs_per_block)
-{
-    const int regs = ncb * (ncb + 1) / 2 * regs_per_block;
-    return regs <= 96 ? 1 : (regs <= 192 ? 2 : 4);
-}
 template <typename T, int NCB> __host__ __device__ constexpr int jtj_roles() { return jtj_roles_rt(NCB, 4 * (int)(sizeof(T) / 4)); }
 
 // block b (linear index I (I+1)/2 + J) belongs to role floor(b * ROLES / NACC)-ish: contiguous
@@ -301,242 +275,8 @@ __global__ __launch_bounds__(1024) void k_jtj_slab_reduce(const T* __restrict__ 
     }
 }
 
-// =========================================================================================
-// v2: the same fused pass with an LDS-DMA ring (f64, n = 16 NCB, m even).
-//
-// v1 above keeps only one 4-row group per wave in flight, so a CU has a few KB of J outstanding and
-// the kernel runs at HBM *latency* (measured 1.4 TB/s algorithmic at m = 1e6, n = 128). Here the
-// four waves of a workgroup ("roles", each owning a quarter of the accumulator blocks and walking the
-// same rows) stream J through a ring of NS LDS slots with `global_load_lds_dwordx4`: no VGPRs are
-// spent on data in flight, up to D stages (~60 KB) per workgroup are outstanding, each wave issues
-// its share of a stage's 1 KB DMA instructions, waits for its own with a COUNTED `s_waitcnt
-// vmcnt(N)` (N = D x the VMEM operations the wave issues per stage, DMA + Broyden stores) and one
-// raw `s_barrier` per stage publishes the stage to the other waves. The MFMA fragments are read
-// from the slot with ds_read_b64: lane (q, p) reads row 4 g + q, column 16 c + p -> exactly the
-// A/B operand layout. y / y_old ride in two small rings of their own (one 1 KB DMA per 128 rows),
-// so the main loop contains no VGPR-destination global load at all.
-// =========================================================================================
+// address-space-qualified pointers for global_load_lds (the LDS-DMA of the eight-wave ring, jtj_ring8.h)
 typedef __attribute__((address_space(3))) void* jtj_lds_ptr;
 typedef const __attribute__((address_space(1))) void* jtj_gbl_ptr;
-
-template <int NCB, bool BROYDEN> struct Jtj2Cfg {
-    // rows per stage: ~16 KB stages so that one barrier is amortised over 4+ row groups (a probe on
-    // MI355X: 4 KB stages 0.33 ms, 16 KB stages 0.27 ms for the n = 128 MFMA work; scripts/probes).
-    static constexpr int RS = NCB <= 4 ? 32 : (NCB == 5 ? 24 : (NCB == 6 ? 20 : 16));
-    static constexpr int GPS = RS / 4;                                                     // 4-row groups per stage
-    static constexpr int IPS = RS * NCB / 8;                                               // 1 KB DMA instructions per stage
-    static constexpr int SLOT_BYTES = IPS * 1024;
-    // DMA instructions the busier of the two loading waves issues per stage (waves 0, 1 issue every
-    // DMA and never store; waves 2, 3 do every Broyden write-back and issue no DMA: a counted vmcnt
-    // wait is only reliable over operations of one kind -- mixing stores into the count made the
-    // DMA wait pass early now and then, a run-to-run nondeterminism caught by scripts/diag_determinism.py)
-    static constexpr int MAX_OPS = (IPS + 1) / 2;
-    static constexpr int D0 = 60 / MAX_OPS;                                                // vmcnt is 6 bits
-    static constexpr int D1 = (64 * 1024) / SLOT_BYTES - 2;                                // 64 KB ring
-    static constexpr int D2 = D0 < D1 ? D0 : D1;
-    static constexpr int D = D2 < 1 ? 1 : (D2 > 15 ? 15 : D2);                             // stages in flight
-    static constexpr int NS = D + 2;                                                       // ring slots
-    static constexpr int RING_BYTES = NS * SLOT_BYTES;
-    // y / y_old travel through their own small rings: one 1 KB DMA instruction = one chunk of 128 rows
-    static constexpr int YNS = 4;                   // y ring slots (chunks c-1 .. c+2 may be live)
-    static constexpr int Y_OFF = RING_BYTES;
-    static constexpr int YO_OFF = RING_BYTES + YNS * 1024;
-    static constexpr int LDS_BYTES = RING_BYTES + 2 * YNS * 1024;
-};
-constexpr int kJtj2Threads = 4 * kWave;
-
-template <int NCB, bool BROYDEN, int ROLE>
-__device__ __forceinline__ void jtj2_body(const JtjArgs<double>& a, unsigned char* smem, int lane, size_t s0, size_t S)
-{
-    using T = double;
-    using Acc = typename Mma<T>::Acc;
-    using C = Jtj2Cfg<NCB, BROYDEN>;
-    constexpr int NACC = jtj_nacc<NCB>();
-    constexpr int n = 16 * NCB;
-    constexpr int RW = n;                                    // doubles per source row
-    // this wave's share of a stage: waves 0, 1 issue the DMA instructions (ROLE, ROLE + 2, ...) and never
-    // store; waves 2, 3 write back the Broyden-updated column blocks c = ROLE (mod 2) and never load
-    constexpr bool LOADER = ROLE < 2;
-    constexpr int MYI = LOADER ? (C::IPS + 1 - ROLE) / 2 : 0;
-    constexpr int OPS = MYI;
-    const int q = lane >> 4, p = lane & 15;
-    const size_t m = a.m;
-
-    const unsigned char* Jb = reinterpret_cast<const unsigned char*>(a.J);
-    const size_t total = m * (size_t)RW * sizeof(T);
-    auto issue = [&](size_t s) {
-        const size_t base = (s0 + s) * (size_t)C::RS * RW * sizeof(T);
-        unsigned char* slot = smem + (s % C::NS) * C::SLOT_BYTES;
-#pragma unroll
-        for (int k = 0; k < MYI; ++k) {
-            const int ins = ROLE + 2 * k;
-            size_t off = base + (size_t)(ins * 64 + lane) * 16;
-            if (off + 16 > total) off = base;            // rows past m: any valid bytes (masked by the consumers)
-            __builtin_amdgcn_global_load_lds((jtj_gbl_ptr)(Jb + off), (jtj_lds_ptr)(slot + ins * 1024), 16, 0, 2 /* nt: J is swept once per pass */);
-        }
-    };
-    // y / y_old chunks (128 rows each) are issued by role 1, two chunks ahead, in the same in-order queue
-    const unsigned char* yb = reinterpret_cast<const unsigned char*>(a.y);
-    const unsigned char* yob = reinterpret_cast<const unsigned char*>(a.y_old);
-    const size_t ytotal = m * sizeof(T);
-    const size_t nchunks = (S * C::RS + 127) / 128;
-    size_t next_chunk = 0;
-    auto issue_y = [&](size_t c) {
-        size_t off = ((s0 * C::RS) + c * 128) * sizeof(T) + (size_t)lane * 16;
-        if (off + 16 > ytotal) off = 0;
-        __builtin_amdgcn_global_load_lds((jtj_gbl_ptr)(yb + off), (jtj_lds_ptr)(smem + C::Y_OFF + (c % C::YNS) * 1024), 16, 0, 0);
-        if constexpr (BROYDEN)
-            __builtin_amdgcn_global_load_lds((jtj_gbl_ptr)(yob + off), (jtj_lds_ptr)(smem + C::YO_OFF + (c % C::YNS) * 1024), 16, 0, 0);
-    };
-
-    Acc acc[NACC];
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] = Acc{0, 0, 0, 0};
-    T jy[NCB], dxr[NCB];
-#pragma unroll
-    for (int c = 0; c < NCB; ++c) {
-        jy[c] = 0;
-        dxr[c] = 0;
-        if constexpr (BROYDEN) dxr[c] = a.dx[16 * c + p];
-    }
-    T neg_d = 0;
-    if constexpr (BROYDEN) neg_d = -(T(1) / *a.dx_dot);
-    // the loads above must have retired before the counted waits below start counting
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    if constexpr (ROLE == 1) {
-        while (next_chunk < 3 && next_chunk < nchunks) issue_y(next_chunk++);
-    }
-    constexpr int L = C::D;
-    const size_t pre = S < (size_t)L ? S : (size_t)L;
-    for (size_t s = 0; s < pre; ++s) issue(s);
-
-    for (size_t s = 0; s < S; ++s) {
-        if constexpr (ROLE == 1) {
-            // keep the chunk holding this stage's first row plus two more in flight / resident
-            while (next_chunk <= (s * C::RS) / 128 + 2 && next_chunk < nchunks) issue_y(next_chunk++);
-        }
-        if (s + C::D < S) {
-            issue(s + C::D);
-            // my DMA of stage s (and everything older) has landed once at most D * OPS younger ops remain
-            if constexpr (OPS > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::D * OPS) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();                       // stage s is complete in LDS for every wave
-        const T* slot = reinterpret_cast<const T*>(smem + (s % C::NS) * C::SLOT_BYTES);
-        const T* yring = reinterpret_cast<const T*>(smem + C::Y_OFF);
-        const T* yoring = reinterpret_cast<const T*>(smem + C::YO_OFF);
-        const size_t row0 = (s0 + s) * C::RS;               // first global row of the stage
-
-        // One group = 4 rows: fragments v[NCB] (+ y, y_old). Software pipeline inside the stage:
-        //   read(g + 1) is issued before the MFMAs of g, and prepare(g + 1) -- masking, Broyden update,
-        //   write-back, J^T y -- is independent VALU work the scheduler can slot between those MFMAs.
-        struct Grp { T v[NCB]; T y, yo; };
-        auto read = [&](int gi, Grp& g) {
-#pragma unroll
-            for (int c = 0; c < NCB; ++c) {
-                g.v[c] = slot[(4 * gi + q) * n + 16 * c + p];
-            }
-            const size_t lr = s * C::RS + 4 * gi + q;       // row index local to this workgroup
-            const int yidx = (int)((lr >> 7) % C::YNS) * 128 + (int)(lr & 127);
-            g.y = yring[yidx];
-            g.yo = 0;
-            if constexpr (BROYDEN) g.yo = yoring[yidx];
-        };
-        auto prepare = [&](int gi, Grp& g, auto full_tag) {
-            constexpr bool FULL = decltype(full_tag)::value;
-            const size_t row = row0 + 4 * gi + q;
-            const bool rok = FULL ? true : row < m;
-            if constexpr (!FULL) {
-#pragma unroll
-                for (int c = 0; c < NCB; ++c) g.v[c] = rok ? g.v[c] : T(0);
-                g.y = rok ? g.y : T(0);
-                g.yo = rok ? g.yo : T(0);
-            }
-            if constexpr (BROYDEN) {
-                T part = 0;
-#pragma unroll
-                for (int c = 0; c < NCB; ++c) part += g.v[c] * dxr[c];
-                part = sum16(part);
-                const T t = (g.yo - g.y) + part;          // LS:1003-1004
-                const T u = neg_d * t;                    // LS:1005
-                T* wp = a.Jout + (rok ? row : m - 1) * (size_t)n;
-#pragma unroll
-                for (int c = 0; c < NCB; ++c) {
-                    g.v[c] = g.v[c] + u * dxr[c];         // LS:1006
-                    if constexpr (!LOADER) { if (c % 2 == ROLE - 2) { if (rok) wp[16 * c + p] = g.v[c]; } }
-                }
-            }
-            if constexpr (ROLE == 0) {
-#pragma unroll
-                for (int c = 0; c < NCB; ++c) jy[c] += g.v[c] * g.y;     // LS:1052
-            }
-        };
-        auto mfmas = [&](const Grp& g) {
-#pragma unroll
-            for (int I = 0; I < NCB; ++I)
-#pragma unroll
-                for (int Jb2 = 0; Jb2 <= I; ++Jb2)
-                    if (jtj_owns<NCB, 4, ROLE>(I * (I + 1) / 2 + Jb2))
-                        acc[I * (I + 1) / 2 + Jb2] = Mma<T>::mma(g.v[I], g.v[Jb2], acc[I * (I + 1) / 2 + Jb2]);   // LS:1065
-        };
-        auto stage = [&](auto full_tag) {
-            Grp ga, gb;
-            read(0, ga);
-            prepare(0, ga, full_tag);
-#pragma unroll
-            for (int gi = 0; gi < C::GPS; gi += 2) {
-                if (gi + 1 < C::GPS) read(gi + 1, gb);
-                mfmas(ga);
-                if (gi + 1 < C::GPS) {
-                    prepare(gi + 1, gb, full_tag);
-                    if (gi + 2 < C::GPS) read(gi + 2, ga);
-                    mfmas(gb);
-                    if (gi + 2 < C::GPS) prepare(gi + 2, ga, full_tag);
-                }
-            }
-        };
-        if (row0 + C::RS <= m) stage(std::true_type{}); else stage(std::false_type{});
-    }
-
-    // every wave owns a disjoint part of the workgroup's slab: no LDS reduction needed
-    T* dst = a.slabs + (size_t)blockIdx.x * jtj_slab_len<NCB>();
-#pragma unroll
-    for (int i = 0; i < NACC; ++i)
-        if (jtj_owns<NCB, 4, ROLE>(i)) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dst[(i * 4 + r) * kWave + lane] = acc[i][r];
-        }
-    if constexpr (ROLE == 0) {
-#pragma unroll
-        for (int c = 0; c < NCB; ++c) {
-            jy[c] += wave_shfl_xor(jy[c], 16);
-            jy[c] += wave_shfl_xor(jy[c], 32);
-            dst[(NACC * 4 + c) * kWave + lane] = jy[c];
-        }
-    }
-}
-
-template <int NCB, bool BROYDEN>
-__global__ __launch_bounds__(kJtj2Threads, 2) void k_jtj2(JtjArgs<double> a)
-{
-    using C = Jtj2Cfg<NCB, BROYDEN>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    // contiguous range of stages for this workgroup
-    const size_t Stot = (a.m + C::RS - 1) / C::RS;
-    const size_t per = (Stot + gridDim.x - 1) / gridDim.x;
-    const size_t s0 = (size_t)blockIdx.x * per < Stot ? (size_t)blockIdx.x * per : Stot;
-    const size_t s1 = s0 + per < Stot ? s0 + per : Stot;
-    const size_t S = s1 - s0;
-
-    if (wave == 0) jtj2_body<NCB, BROYDEN, 0>(a, smem2, lane, s0, S);
-    else if (wave == 1) jtj2_body<NCB, BROYDEN, 1>(a, smem2, lane, s0, S);
-    else if (wave == 2) jtj2_body<NCB, BROYDEN, 2>(a, smem2, lane, s0, S);
-    else jtj2_body<NCB, BROYDEN, 3>(a, smem2, lane, s0, S);
-}
 
 }  // namespace mirlsq

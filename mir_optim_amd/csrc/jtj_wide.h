@@ -11,11 +11,10 @@
 #pragma once
 
 #include "common.h"
+#include "jtj_plan.h"
 
 namespace mirlsq {
 
-constexpr int kWideTile = 4;                                             // blocks per tile side
-constexpr int kWideSlabLen = (kWideTile * kWideTile * 4 + kWideTile) * kWave;   // 16 blocks x 4 regs + 4 jy regs, x 64 lanes
 
 template <typename T>
 struct JtjWideArgs {

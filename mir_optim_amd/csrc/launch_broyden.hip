@@ -1,0 +1,85 @@
+// launch_broyden.hip -- the translation unit that instantiates the read-only Broyden sweep and its companions
+// (broyden_lr.h) and defines the launch entry points declared in broyden_launch.h.
+#include <hip/hip_runtime.h>
+
+#include "broyden_launch.h"
+#include "launch_util.h"
+#include "broyden_lr.h"
+
+namespace mirlsq {
+
+namespace {
+template <typename T, int NCP>
+hipError_t lr_sweep_ncp(const LrArgs<T>& a, int nblk, bool vec, hipStream_t s)
+{
+    if (vec) MIRLSQ_LAUNCH((k_broyden_lr<T, NCP, true>), dim3(nblk), dim3(256), 0, s, a);
+    else MIRLSQ_LAUNCH((k_broyden_lr<T, NCP, false>), dim3(nblk), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+}  // namespace
+template <typename T>
+hipError_t lr_sweep(const LrArgs<T>& a, int nblk, hipStream_t s)
+{
+    if (a.n > kLrMaxN || a.k < 0 || a.k >= kLrMax) return hipErrorInvalidValue;
+    const bool vec = (a.n % 2 == 0) && (reinterpret_cast<uintptr_t>(a.J) % (2 * sizeof(T)) == 0);
+    const int ncp = (a.n + 31) / 32;
+    if (ncp <= 1) return lr_sweep_ncp<T, 1>(a, nblk, vec, s);
+    if (ncp <= 2) return lr_sweep_ncp<T, 2>(a, nblk, vec, s);
+    if (ncp <= 4) return lr_sweep_ncp<T, 4>(a, nblk, vec, s);
+    return lr_sweep_ncp<T, 8>(a, nblk, vec, s);
+}
+
+namespace {
+template <typename T, int NCP>
+hipError_t lr_flush_ncp(T* J, const T* U, const T* D, int k, size_t m, int n, int nblk, bool vec, hipStream_t s)
+{
+    const size_t lds = (size_t)k * n * sizeof(T);
+    if (vec) MIRLSQ_LAUNCH((k_lr_flush<T, NCP, true>), dim3(nblk), dim3(256), lds, s, J, U, D, k, m, n);
+    else MIRLSQ_LAUNCH((k_lr_flush<T, NCP, false>), dim3(nblk), dim3(256), lds, s, J, U, D, k, m, n);
+    return hipGetLastError();
+}
+}  // namespace
+template <typename T>
+hipError_t lr_flush(T* J, const T* U, const T* D, int k, size_t m, int n, int num_cu, hipStream_t s)
+{
+    if (k <= 0) return hipSuccess;
+    if (n > kLrMaxN || k > kLrMax) return hipErrorInvalidValue;
+    const size_t G = (m + 3) / 4;
+    size_t blocks = (G + 3) / 4;
+    if (blocks > (size_t)num_cu * 8) blocks = (size_t)num_cu * 8;
+    if (blocks < 1) blocks = 1;
+    const bool vec = (n % 2 == 0) && (reinterpret_cast<uintptr_t>(J) % (2 * sizeof(T)) == 0);
+    const int ncp = (n + 31) / 32;
+    if (ncp <= 1) return lr_flush_ncp<T, 1>(J, U, D, k, m, n, (int)blocks, vec, s);
+    if (ncp <= 2) return lr_flush_ncp<T, 2>(J, U, D, k, m, n, (int)blocks, vec, s);
+    if (ncp <= 4) return lr_flush_ncp<T, 4>(J, U, D, k, m, n, (int)blocks, vec, s);
+    return lr_flush_ncp<T, 8>(J, U, D, k, m, n, (int)blocks, vec, s);
+}
+
+template <typename T>
+hipError_t lr_reduce(const T* partials, int nblk, int n, T* out, const int32_t* guard, hipStream_t s)
+{
+    const int len = lr_len(n);
+    MIRLSQ_LAUNCH(k_lr_reduce<T>, dim3((len + 31) / 32), dim3(32 * kReduceRanges), 0, s, partials, nblk, len, out, guard);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t lr_finish(const T* lr, T* D, const T* dx, int k, int n, T* JJ, T* Jy, LmState<T>* st, const int32_t* guard, hipStream_t s)
+{
+    MIRLSQ_LAUNCH(k_lr_finish<T>, dim3(n + 1), dim3(256), 0, s, lr, D, dx, k, n, JJ, Jy, st, guard);
+    return hipGetLastError();
+}
+
+#define MIRLSQ_INSTANTIATE(T)                                                                                             \
+    template hipError_t lr_sweep<T>(const LrArgs<T>&, int, hipStream_t);                                                  \
+    template hipError_t lr_reduce<T>(const T*, int, int, T*, const int32_t*, hipStream_t);                                \
+    template hipError_t lr_finish<T>(const T*, T*, const T*, int, int, T*, T*, LmState<T>*, const int32_t*, hipStream_t); \
+    template hipError_t lr_flush<T>(T*, const T*, const T*, int, size_t, int, int, hipStream_t);
+MIRLSQ_INSTANTIATE(double)
+MIRLSQ_INSTANTIATE(float)
+#undef MIRLSQ_INSTANTIATE
+
+}  // namespace mirlsq
+
+MIRLSQ_DEFINE_PRELOAD(broyden)

@@ -9,7 +9,7 @@
 #pragma once
 
 #include "common.h"
-#include "solve_kernel.h"
+#include "solve_types.h"
 
 namespace mirlsq {
 
@@ -42,8 +42,7 @@ template <typename T>
 __device__ inline T sumsq_final_block(const T* partials, int nparts, T* red /* 4 */)
 {
     T s = 0;
-    for (int i = threadIdx.x; i < nparts; i += 256) s += load_agent(&partials[i]);   // (coherent read: the fused tails run this
-                                                                                     //  in the kernel that wrote the partials)
+    for (int i = threadIdx.x; i < nparts; i += 256) s += partials[i];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -210,9 +209,6 @@ struct DecideArgs {
     int nparts, pstride;  // sits between the stages: single GPU) -- this kernel runs stage 2 itself, one launch less per round
 };
 
-// The body is a device function: k_decide_chain runs it as a kernel of its own (a communicator's all-reduce sits between
-// the trial sums and the decision, or no residual was evaluated at all), k_sumsq_tail<., kSumsqTailDecide> runs it in the
-// last workgroup of the sum-of-squares sweep (single GPU: one launch per round instead of two).
 template <typename T>
 __device__ inline void decide_chain_body(const DecideArgs<T>& a)
 {
@@ -326,102 +322,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_decide_chain(DecideArgs<T> a)
     decide_chain_body(a);
 }
 
-// ---- sum of squares with the NEXT step of the pass fused into its tail ("last workgroup finishes"): every workgroup
-//      writes its stage-1 partial with an agent-scope store (common.h: the eight XCDs have separate L2s) and counts itself
-//      in; the workgroup that arrives last runs stage 2 -- the same fixed-order sum as k_sumsq_final,
-//      whichever workgroup that is, so the bits do not depend on the arrival order -- and then
-//        kSumsqTailFinal   writes the sums (an all-reduce over the row shards follows),
-//        kSumsqTailDecide  walks the lambda ladder and publishes the decision (decide_chain_body; LS:1117-1161),
-//        kSumsqTailInit    sets up the state at entry (LS:953-971).
-//      grid = (stage-1 workgroups, vectors). The counter is zero before the launch and is reset by the last workgroup.
-enum { kSumsqTailFinal = 0, kSumsqTailDecide = 1, kSumsqTailInit = 2 };
-template <typename T>
-struct SumsqTailArgs {
-    const T* v; size_t m, vstride;
-    T* partials; int pstride;
-    uint32_t* counter;
-    T* out;                  // Final / Init: the sums (vector k at out[k])
-    DecideArgs<T> dec;       // Decide (dec.partials / nparts / pstride are filled in here)
-    LmState<T>* st;          // Init
-    LmState<T>* host_st;
-    uint32_t seq;
-};
-
-template <typename T, int TAIL>
-__global__ __launch_bounds__(kSolveThreads) void k_sumsq_tail(SumsqTailArgs<T> a)
-{
-    __shared__ T red[4];
-    {
-        const T* __restrict__ v = a.v + (size_t)blockIdx.y * a.vstride;
-        T s = 0;
-        const size_t per = (a.m + gridDim.x - 1) / gridDim.x;
-        const size_t b0 = (size_t)blockIdx.x * per;
-        const size_t b1 = b0 + per < a.m ? b0 + per : a.m;
-        for (size_t i = b0 + threadIdx.x; i < b1; i += blockDim.x) { const T t = v[i]; s += t * t; }
-        s = wave_sum(s);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-        __syncthreads();
-        if (threadIdx.x == 0)                                            // crosses to the finishing workgroup: agent-scope store
-            store_agent(&a.partials[(size_t)blockIdx.y * a.pstride + blockIdx.x], (red[0] + red[1]) + (red[2] + red[3]));
-        if (!arrive_last(a.counter, gridDim.x * gridDim.y)) return;
-    }
-    if constexpr (TAIL == kSumsqTailDecide) {
-        DecideArgs<T> d = a.dec;
-        d.partials = a.partials; d.nparts = (int)gridDim.x; d.pstride = a.pstride;
-        decide_chain_body(d);
-    } else {
-        for (int k = 0; k < (int)gridDim.y; ++k) {
-            const T tot = sumsq_final_block(a.partials + (size_t)k * a.pstride, (int)gridDim.x, red);
-            if (threadIdx.x == 0) a.out[k] = tot;
-            if constexpr (TAIL == kSumsqTailInit) {
-                if (threadIdx.x == 0 && k == 0) {
-                    LmState<T> s{};
-                    s.lambda = 0;            // LS:966 (no warm start, quirk Q11)
-                    s.mu = 1;                // LS:969
-                    s.residual = tot;        // LS:955
-                    *a.st = s;
-                    publish_state(s, a.host_st, a.seq);
-                }
-            }
-        }
-    }
-}
-
 // ---- LS:984-989: forced refresh resets mu
 template <typename T>
 __global__ void k_reset_mu(LmState<T>* st) { st->mu = 1; }
-
-// Self-test of the wave reductions (mir_lsq_selftest_reductions): every wave_sum / wave_max of common.h against the plain
-// butterfly on __shfl_xor (16, 32 last: the order whose pairs the DPP forms reproduce), bit for bit, on `rounds` pseudo-random
-// inputs a lane. out[0..3] += mismatching lanes of sum<float>, sum<double>, max<float>, max<double>.
-__global__ __launch_bounds__(256) void k_selftest_reductions(int rounds, uint32_t seed, int* out)
-{
-    // no contraction here: the multiplication that makes an input would be fused into the FIRST addition of whichever form
-    // consumes it (one rounding less on one operand of one form), and the two forms would differ by construction
-#pragma clang fp contract(off)
-    uint32_t sr = seed ^ (0x9E3779B9u * (blockIdx.x * blockDim.x + threadIdx.x + 1));
-    auto rnd = [&]() { sr ^= sr << 13; sr ^= sr >> 17; sr ^= sr << 5; return sr; };
-    int bad[4] = {0, 0, 0, 0};
-    for (int it = 0; it < rounds; ++it) {
-        const float f = (float)(int32_t)rnd() * (1.0f / 65536.0f) * ((it & 7) == 0 ? 1e-20f : 1.0f);
-        const double d = ((double)(int32_t)rnd() + (double)rnd() * 2.3283064365386963e-10) * ((it & 3) == 0 ? 1e-200 : 1.0);
-        auto ref_sum = [](auto v) {
-            v += __shfl_xor(v, 8, kWave); v += __shfl_xor(v, 4, kWave); v += __shfl_xor(v, 2, kWave); v += __shfl_xor(v, 1, kWave);
-            v += __shfl_xor(v, 16, kWave); v += __shfl_xor(v, 32, kWave);
-            return v;
-        };
-        auto ref_max = [](auto v) {
-            for (int m : {8, 4, 2, 1, 16, 32}) { const auto o = __shfl_xor(v, m, kWave); v = o > v ? o : v; }
-            return v;
-        };
-        const float sf = wave_sum(f), rf = ref_sum(f);
-        const double sd = wave_sum(d), rdd = ref_sum(d);
-        bad[0] += __float_as_uint(sf) != __float_as_uint(rf);
-        bad[1] += __double_as_longlong(sd) != __double_as_longlong(rdd);
-        bad[2] += __float_as_uint(wave_max(f)) != __float_as_uint(ref_max(f));
-        bad[3] += __double_as_longlong(wave_max(d)) != __double_as_longlong(ref_max(d));
-    }
-    for (int k = 0; k < 4; ++k) if (bad[k]) atomicAdd(out + k, bad[k]);
-}
 
 }  // namespace mirlsq

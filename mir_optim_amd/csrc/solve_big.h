@@ -448,15 +448,13 @@ __global__ __launch_bounds__(kBigThreads) void k_lm_solve_big(LmSolveArgs<T> a)
 
     if (a.guard && *a.guard == 0) return;
     T jy_inf = 0;
-    if (a.lr) {                                                     // the n x n finish of a Broyden pass (n <= kLrMaxN there)
-        jy_inf = lr_finish_block<T>(a.lr, a.lrD, a.lr_dx, a.lr_k, n, a.JJw, a.Jyw, sm.span, sm.red);
-    } else if (a.check_grad) {
+    if (a.check_grad) {
         T mx = 0;
         for (int i = tid; i < n; i += kBigThreads) { const T av = dabs(a.Jy[i]); if (av > mx) mx = av; }
         jy_inf = big_max(mx, sm.red);
         __syncthreads();
     }
-    if ((a.lr || a.check_grad) && tid == 0 && kc == 0) a.st->jy_inf = jy_inf;
+    if (a.check_grad && tid == 0 && kc == 0) a.st->jy_inf = jy_inf;
     if (a.check_grad && !(jy_inf > a.set.gradTolerance)) {          // LS:1053
         if (tid == 0) { ChainRec<T> r{}; r.flags = kFlagGradSmall; a.rec[kc] = r; }
         return;

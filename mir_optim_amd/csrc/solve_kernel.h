@@ -20,64 +20,9 @@
 #pragma once
 
 #include "common.h"
+#include "solve_types.h"
 
 namespace mirlsq {
-
-constexpr int kSolveThreads = 256;
-constexpr int kSolveMaxN = 256;          // n-vectors are handled one element per thread
-constexpr int kSolveLdsBytes = 159 * 1024;
-
-// Device-resident scalars of the LM loop. The host mirrors it after each decision point.
-template <typename T>
-struct LmState {
-    T lambda, mu, residual, trial_residual;
-    T dx_dot, new_dx_dot, predicted, trial_xnorm;
-    T jy_inf, improvement, rho, pad0;
-    int32_t qp_status, qp_iterations, flags, decision;
-    uint32_t iterations;
-    int32_t accepted_k;        // chain index of the accepted trial (-1: none)
-    uint32_t consumed;         // chain steps the reference would have executed this round
-    uint32_t fcalls;           // residual evaluations among them (LS:1112)
-    uint32_t rejects, guards, qp_active;
-    uint32_t null_tail;        // the last consumed trial of the round was a null step (trial == x): the next ones probably are too
-    uint32_t seq;              // host mirror only: number of the decision point this image belongs to (written last)
-    int32_t spec_ok;           // set by the decision kernel: the round enqueued ahead of time behind this flag is the one the
-                               // reference would run next (accepted step, no exit test fired): its kernels may execute
-};
-
-// One solve of the lambda ladder (chain step k): everything the acceptance logic needs about it.
-constexpr int kChainMax = 8;
-template <typename T>
-struct ChainRec {
-    T lambda, new_dx_dot, predicted, trial_xnorm;
-    int32_t qp_status, qp_iterations, flags, pad;
-};
-// kFlagNullStep: the rounded step (LS:1096-1097) is exactly zero in every component, so trial == x bit for bit. The
-// callbacks are `pure` (LS:73-80): f(trial) is the residual vector the solver already holds, ||f(trial)||^2 == residual,
-// improvement == 0 and the pass is rejected (LS:1125) -- the evaluation can be elided without changing any result.
-enum : int32_t { kFlagDxNaN = 1, kFlagXNaN = 2, kFlagStepTooLong = 4, kFlagTrialNotFinite = 8, kFlagGradSmall = 16,
-                 kFlagNullStep = 32 };
-enum : int32_t {
-    kDecideNone = 0, kDecideReject = 1, kDecideAccept = 2, kDecideAcceptNoPrediction = 3,
-    kDecideNumericError = 4, kDecideGradSmall = 5
-};
-
-template <typename T>
-struct LmSettingsDev {   // the floating-point part of LeastSquaresSettings!T (LS:85-123)
-    T jacobianEpsilon, absTolerance, relTolerance, gradTolerance, maxGoodResidual, maxStep, maxLambda,
-      minLambda, minStepQuality, goodStepQuality, lambdaIncrease, lambdaDecrease, qpRelTolerance, qpAbsTolerance;
-    uint32_t qpMaxIterations, pad;
-};
-
-template <typename T>
-struct SolveScratch {    // global scratch, all L2 resident
-    T* Pm;      // n x n, P = JJ + lambda I, full symmetric (unscaled; BOXCQP reads it)
-    T* A;       // n x n, the (possibly equilibrated) matrix handed to posvx, full symmetric
-    T* Fg;      // n x (n|1) factor when it does not fit LDS
-    T* vec;     // 12 n-vectors: s, b, r, w, la, mu, sX, qpl, qpu, q, xq, spare
-    int32_t* ivec;  // 2 n: SI, flags
-    long long* dbg; // optional phase stamps (diagnostic builds of the host pass a buffer; else nullptr)
-};
 
 #define MIRLSQ_STAMP(ptr, k) do { if ((ptr) && threadIdx.x == 0) (ptr)[k] = wall_clock64(); } while (0)
 
@@ -713,132 +658,7 @@ __device__ __forceinline__ int box_qp_device(int n, const T* Pm, const T* q, con
     return 2;                                                       // QP:378
 }
 
-// ---------------------------------------------------------------- one LM pass, n x n part
-// fast-path tile count for n (0 = generic path with the factor in global memory) and its LDS bytes:
-// factor (n|1) x 16 NB, then colbuf, rdiag (16 NB each) and one scalar
-__host__ __device__ inline int solve_nb(int n, int elem)
-{
-    const int nb = n <= 16 ? 1 : (n <= 32 ? 2 : (n <= 64 ? 4 : (n <= 128 ? 8 : 0)));
-    if (nb == 0) return 0;
-    const long bytes = (long)lds_solve_elems(nb) * elem;      // L and A block triangles + three vectors (solve_lds.h)
-    return bytes <= kSolveLdsBytes ? nb : 0;
-}
-__host__ __device__ inline size_t solve_lds_bytes(int n, int elem)
-{
-    const int nb = solve_nb(n, elem);
-    return nb ? (size_t)lds_solve_elems(nb) * elem : 0;
-}
-
-template <typename T>
-struct LmSolveArgs {
-    const T* JJ;       // n x n full symmetric, undamped
-    const T* Jy;       // n
-    const T* x;        // n current point
-    const T* lower;    // n
-    const T* upper;    // n
-    T* dx;             // kChainMax x n out: rounded step (LS:1096-1097) of chain step blockIdx.x
-    T* trial;          // kChainMax x n out: clamp(x + dx) (LS:1108-1110)
-    LmState<T>* st;
-    ChainRec<T>* rec;  // kChainMax
-    LmSettingsDev<T> set;
-    SolveScratch<T> sc[kChainMax];
-    T lam[kChainMax];  // the lambda ladder lambda_k = lambda after k bumps (LS:1103/1127); workgroup k solves with lam[k]
-    int n;
-    int f_in_lds;
-    int check_grad;        // a new Jy was just computed: apply the gradient test LS:1053 first (chain of 1)
-    int lambda_from_state; // step 0 takes st->lambda and applies the lambda_0 rule LS:1067-1072
-    int lambda_from_device; // step 0 takes st->lambda as it is (a round enqueued before the host has seen the previous decision)
-    const int32_t* guard;  // optional: the kernel does nothing when *guard == 0 (rounds enqueued ahead of time)
-    // ---- the n x n finish of a Broyden pass (k_lr_finish), applied by workgroup 0 before anything else when lr != nullptr:
-    //      one launch less per Broyden pass. lr: the reduced (and all-reduced) sweep vector; the ladder has one entry then.
-    const T* lr; T* lrD; const T* lr_dx; int lr_k;
-    T* JJw; T* Jyw;        // writable aliases of JJ / Jy
-};
-
-// k_lr_finish's work by ONE workgroup (any size): v = v0 + D w; JJ += v dx^T + dx v^T + uu dx dx^T (lr_jj_term: the same
-// rounding as k_lr_finish); Jy = g0 + D h + dx uy; D_k = dx. Returns |Jy|_inf (LS:1053) to every thread.
-// scratch: 4 n + 2 kLrMax + 2 elements of LDS; red: one element per wave.
-template <typename T>
-__device__ inline T lr_finish_block(const T* lr, T* D, const T* dx, int k, int n, T* JJ, T* Jy, T* scratch, T* red)
-{
-    const int tid = threadIdx.x, nthr = blockDim.x, len = lr_len(n);
-    T* v = scratch;
-    T* dxs = scratch + n;
-    T* lrs = scratch + 2 * n;
-    for (int e = tid; e < len; e += nthr) lrs[e] = lr[e];
-    __syncthreads();
-    const T* w = lrs + 2 * n;
-    const T* h = w + kLrMax;
-    const T uu = lrs[2 * n + 2 * kLrMax], uy = lrs[2 * n + 2 * kLrMax + 1];
-    T mx = 0;
-    for (int j = tid; j < n; j += nthr) {
-        const T dj = dx[j];
-        T dl[kLrMax];                                          // the k pending steps' entry j: one batch of loads, then the sums
-#pragma unroll
-        for (int l = 0; l < kLrMax; ++l) dl[l] = l < k ? D[(size_t)l * n + j] : T(0);
-        T sv = lrs[j];
-#pragma unroll
-        for (int l = 0; l < kLrMax; ++l) if (l < k) sv += dl[l] * w[l];
-        v[j] = sv;
-        dxs[j] = dj;
-        T g = lrs[n + j];
-#pragma unroll
-        for (int l = 0; l < kLrMax; ++l) if (l < k) g += dl[l] * h[l];
-        g += dj * uy;
-        Jy[j] = g;
-        const T av = dabs(g);
-        if (av > mx) mx = av;
-    }
-    __syncthreads();                                       // also: every read of the D rows < k is done before row k is written
-    for (int j = tid; j < n; j += nthr) D[(size_t)k * n + j] = dxs[j];
-    // 16 loads in flight per thread: a plain read-modify-write loop serialises on may-alias load / store ordering (one L2
-    // round trip per element: 64 of them at n = 128)
-    const int nn = n * n;
-    auto term = [&](int idx) {
-        const int i = idx / n, j = idx - i * n;
-        const int rr = i >= j ? i : j, cc = i >= j ? j : i;
-        return lr_jj_term(v[rr], v[cc], dxs[rr], dxs[cc], uu);
-    };
-    if (nn % 2 == 0) {                                         // 16-byte accesses: half the round trips
-        typedef T v2 __attribute__((ext_vector_type(2)));
-        v2* J2 = reinterpret_cast<v2*>(JJ);
-        const int np = nn / 2;
-        for (int base = tid; base < np; base += 16 * nthr) {
-            v2 old[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) { const int idx = base + u * nthr; old[u] = J2[idx < np ? idx : np - 1]; }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int idx = base + u * nthr;
-                if (idx < np) {
-                    v2 t = old[u];
-                    t.x += term(2 * idx);
-                    t.y += term(2 * idx + 1);
-                    J2[idx] = t;
-                }
-            }
-        }
-    } else {
-        for (int base = tid; base < nn; base += 16 * nthr) {
-            T old[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) { const int idx = base + u * nthr; old[u] = JJ[idx < nn ? idx : nn - 1]; }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int idx = base + u * nthr;
-                if (idx < nn) JJ[idx] = old[u] + term(idx);
-            }
-        }
-    }
-    mx = wave_max(mx);
-    if ((tid & 63) == 0) red[tid >> 6] = mx;
-    __syncthreads();                                       // also: the updated JJ / Jy are visible to the whole workgroup
-    T m2 = red[0];
-    for (int wv = 1; wv < (nthr >> 6); ++wv) m2 = red[wv] > m2 ? red[wv] : m2;
-    __syncthreads();                                       // red may be reused
-    return m2;
-}
-
+// ---------------------------------------------------------------- one LM pass, n x n part (LmSolveArgs: solve_types.h)
 template <typename T, int NB, bool BOUNDED = true>
 __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
 {
@@ -860,18 +680,12 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
     if (a.guard && *a.guard == 0) return;
     MIRLSQ_STAMP(sc.dbg, 0);
     if (sc.dbg && threadIdx.x == 0) sc.dbg[9] = clock64();
-    // the n x n finish of a Broyden pass first (one workgroup: the ladder has one entry whenever J has just changed)
-    __shared__ T fin_s[NB == 0 ? 4 * kLrMaxN + 2 * kLrMax + 2 : 1];
     T jy_inf = 0;
-    if (a.lr) {
-        T* scratch;
-        if constexpr (NB > 0) scratch = F; else scratch = fin_s;         // the solve's LDS is still free
-        jy_inf = lr_finish_block<T>(a.lr, a.lrD, a.lr_dx, a.lr_k, n, a.JJw, a.Jyw, scratch, red);
-    } else if (a.check_grad) {
+    if (a.check_grad) {
         jy_inf = block_max(tid < n ? dabs(a.Jy[tid]) : T(0), red);       // |Jy[iamax(Jy)]|, LS:1053
         __syncthreads();
     }
-    if ((a.lr || a.check_grad) && tid == 0 && kc == 0) a.st->jy_inf = jy_inf;
+    if (a.check_grad && tid == 0 && kc == 0) a.st->jy_inf = jy_inf;
     // gradient test, LS:1053: stop before touching lambda when ||Jy||_inf <= gradTolerance
     if (a.check_grad && !(jy_inf > a.set.gradTolerance)) {
         if (tid == 0) { ChainRec<T> r{}; r.flags = kFlagGradSmall; a.rec[kc] = r; }
@@ -1063,13 +877,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
     }
 }
 
-// standalone BOXCQP (mir_solve_box_qp_gpu_*)
-template <typename T>
-struct BoxQpArgs {
-    const T* P; const T* q; const T* l; const T* u; T* x;
-    T relTol, absTol; uint32_t maxIterations; int unconstrained;
-    SolveScratch<T> sc; int n; int f_in_lds; int* out;   // out[0] = status, out[1] = iterations
-};
+// standalone BOXCQP (mir_solve_box_qp_gpu_*; BoxQpArgs: solve_types.h)
 template <typename T, int NB>
 __global__ __launch_bounds__(kSolveThreads) void k_box_qp(BoxQpArgs<T> a)
 {

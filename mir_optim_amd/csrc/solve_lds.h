@@ -29,10 +29,10 @@
 #pragma once
 
 #include "common.h"
+#include "solve_types.h"
 
 namespace mirlsq {
 
-constexpr int kLdsBlk = 272;     // 16 x 17 elements per block
 
 template <int NB> struct LdsSolveCfg {
     static constexpr int NBT = NB * (NB + 1) / 2;
@@ -45,7 +45,6 @@ template <int NB> struct LdsSolveCfg {
     static constexpr int ZERO_OFF = ZV_OFF + NV;         // one element that holds 0 (masked coefficient reads)
     static constexpr int ELEMS = ZERO_OFF + 2;
 };
-__host__ __device__ constexpr int lds_solve_elems(int nb) { return nb * (nb + 1) * kLdsBlk + 48 * nb + 2; }
 
 __device__ __forceinline__ int blk_off(int I, int J, int r, int c) { return (I * (I + 1) / 2 + J) * kLdsBlk + r + 17 * c; }
 

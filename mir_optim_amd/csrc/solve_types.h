@@ -1,0 +1,114 @@
+// solve_types.h -- the plain data shared by the n x n kernels (solve_kernel.h, solve_lds.h, solve_big.h), the decision
+// kernels (misc_kernels.h) and the host driver: device-resident LM state, the records of the lambda ladder, kernel
+// argument blocks, and the host-side shape queries. No device code: the host translation units include only this.
+#pragma once
+
+#include "common.h"
+
+namespace mirlsq {
+
+constexpr int kSolveThreads = 256;
+constexpr int kSolveMaxN = 256;          // n-vectors are handled one element per thread
+constexpr int kSolveLdsBytes = 159 * 1024;
+
+// Device-resident scalars of the LM loop. The host mirrors it after each decision point.
+template <typename T>
+struct LmState {
+    T lambda, mu, residual, trial_residual;
+    T dx_dot, new_dx_dot, predicted, trial_xnorm;
+    T jy_inf, improvement, rho, pad0;
+    int32_t qp_status, qp_iterations, flags, decision;
+    uint32_t iterations;
+    int32_t accepted_k;        // chain index of the accepted trial (-1: none)
+    uint32_t consumed;         // chain steps the reference would have executed this round
+    uint32_t fcalls;           // residual evaluations among them (LS:1112)
+    uint32_t rejects, guards, qp_active;
+    uint32_t null_tail;        // the last consumed trial of the round was a null step (trial == x): the next ones probably are too
+    uint32_t seq;              // host mirror only: number of the decision point this image belongs to (written last)
+    int32_t spec_ok;           // set by the decision kernel: the round enqueued ahead of time behind this flag is the one the
+                               // reference would run next (accepted step, no exit test fired): its kernels may execute
+};
+
+// One solve of the lambda ladder (chain step k): everything the acceptance logic needs about it.
+constexpr int kChainMax = 8;
+template <typename T>
+struct ChainRec {
+    T lambda, new_dx_dot, predicted, trial_xnorm;
+    int32_t qp_status, qp_iterations, flags, pad;
+};
+// kFlagNullStep: the rounded step (LS:1096-1097) is exactly zero in every component, so trial == x bit for bit. The
+// callbacks are `pure` (LS:73-80): f(trial) is the residual vector the solver already holds, ||f(trial)||^2 == residual,
+// improvement == 0 and the pass is rejected (LS:1125) -- the evaluation can be elided without changing any result.
+enum : int32_t { kFlagDxNaN = 1, kFlagXNaN = 2, kFlagStepTooLong = 4, kFlagTrialNotFinite = 8, kFlagGradSmall = 16,
+                 kFlagNullStep = 32 };
+enum : int32_t {
+    kDecideNone = 0, kDecideReject = 1, kDecideAccept = 2, kDecideAcceptNoPrediction = 3,
+    kDecideNumericError = 4, kDecideGradSmall = 5
+};
+
+template <typename T>
+struct LmSettingsDev {   // the floating-point part of LeastSquaresSettings!T (LS:85-123)
+    T jacobianEpsilon, absTolerance, relTolerance, gradTolerance, maxGoodResidual, maxStep, maxLambda,
+      minLambda, minStepQuality, goodStepQuality, lambdaIncrease, lambdaDecrease, qpRelTolerance, qpAbsTolerance;
+    uint32_t qpMaxIterations, pad;
+};
+
+template <typename T>
+struct SolveScratch {    // global scratch, all L2 resident
+    T* Pm;      // n x n, P = JJ + lambda I, full symmetric (unscaled; BOXCQP reads it)
+    T* A;       // n x n, the (possibly equilibrated) matrix handed to posvx, full symmetric
+    T* Fg;      // n x (n|1) factor when it does not fit LDS
+    T* vec;     // 12 n-vectors: s, b, r, w, la, mu, sX, qpl, qpu, q, xq, spare
+    int32_t* ivec;  // 2 n: SI, flags
+    long long* dbg; // optional phase stamps (diagnostic builds of the host pass a buffer; else nullptr)
+};
+
+constexpr int kLdsBlk = 272;     // solve_lds.h: 16 x 17 elements per LDS block
+__host__ __device__ constexpr int lds_solve_elems(int nb) { return nb * (nb + 1) * kLdsBlk + 48 * nb + 2; }
+
+// fast-path tile count for n (0 = generic path with the factor in global memory) and its LDS bytes:
+// factor (n|1) x 16 NB, then colbuf, rdiag (16 NB each) and one scalar
+__host__ __device__ inline int solve_nb(int n, int elem)
+{
+    const int nb = n <= 16 ? 1 : (n <= 32 ? 2 : (n <= 64 ? 4 : (n <= 128 ? 8 : 0)));
+    if (nb == 0) return 0;
+    const long bytes = (long)lds_solve_elems(nb) * elem;      // L and A block triangles + three vectors (solve_lds.h)
+    return bytes <= kSolveLdsBytes ? nb : 0;
+}
+__host__ __device__ inline size_t solve_lds_bytes(int n, int elem)
+{
+    const int nb = solve_nb(n, elem);
+    return nb ? (size_t)lds_solve_elems(nb) * elem : 0;
+}
+
+template <typename T>
+struct LmSolveArgs {
+    const T* JJ;       // n x n full symmetric, undamped
+    const T* Jy;       // n
+    const T* x;        // n current point
+    const T* lower;    // n
+    const T* upper;    // n
+    T* dx;             // kChainMax x n out: rounded step (LS:1096-1097) of chain step blockIdx.x
+    T* trial;          // kChainMax x n out: clamp(x + dx) (LS:1108-1110)
+    LmState<T>* st;
+    ChainRec<T>* rec;  // kChainMax
+    LmSettingsDev<T> set;
+    SolveScratch<T> sc[kChainMax];
+    T lam[kChainMax];  // the lambda ladder lambda_k = lambda after k bumps (LS:1103/1127); workgroup k solves with lam[k]
+    int n;
+    int f_in_lds;
+    int check_grad;        // a new Jy was just computed: apply the gradient test LS:1053 first (chain of 1)
+    int lambda_from_state; // step 0 takes st->lambda and applies the lambda_0 rule LS:1067-1072
+    int lambda_from_device; // step 0 takes st->lambda as it is (a round enqueued before the host has seen the previous decision)
+    const int32_t* guard;  // optional: the kernel does nothing when *guard == 0 (rounds enqueued ahead of time)
+};
+
+// standalone BOXCQP (mir_solve_box_qp_gpu_*)
+template <typename T>
+struct BoxQpArgs {
+    const T* P; const T* q; const T* l; const T* u; T* x;
+    T relTol, absTol; uint32_t maxIterations; int unconstrained;
+    SolveScratch<T> sc; int n; int f_in_lds; int* out;   // out[0] = status, out[1] = iterations
+};
+
+}  // namespace mirlsq

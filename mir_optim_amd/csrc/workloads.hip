@@ -858,8 +858,7 @@ bool launch_tanh_linear_batched(const double* A, const double* b, const double* 
 {
     if (n == 256 && m >= 32 && launch_tlb_dma<64>(A, b, X, Y, m, P, s)) return true;
     if (n % 2 != 0 || n > 128 || n < 4) return false;
-    static const bool v1_only = std::getenv("WL_BATCHED_V1") != nullptr;
-    if (!v1_only && m >= 32) {
+    if (m >= 32) {
         if (n == 128 && launch_tlb_dma<32>(A, b, X, Y, m, P, s)) return true;
         if (n == 64 && launch_tlb_dma<16>(A, b, X, Y, m, P, s)) return true;
         if (n == 32 && launch_tlb_dma<8>(A, b, X, Y, m, P, s)) return true;
@@ -995,16 +994,6 @@ void wl_tanh_linear_fbd_d(void* vctx, size_t m, size_t n, size_t p, const double
 {
     auto* c = static_cast<wl_tanh_linear_ctx*>(vctx);
     launch_tanh_linear_batched_diff((const double*)c->A, (const double*)c->b, X, D, m, (int)n, (int)p, (hipStream_t)c->stream, c->read_a_once);
-}
-// ... and its row-window form (mir_lsq_gpu_options.fbRowMajorDiffWindow): rows [row0, row0 + rows) only, on the stream
-// handed in. Rows are independent, so a window is the same kernel on offset pointers.
-void wl_tanh_linear_fbdw_d(void* vctx, size_t m, size_t n, size_t p, const double* X, double* D, size_t row0, size_t rows,
-                           void* stream)
-{
-    (void)m;
-    auto* c = static_cast<wl_tanh_linear_ctx*>(vctx);
-    launch_tanh_linear_batched_diff((const double*)c->A + row0 * n, (const double*)c->b + row0, X, D + row0 * n, rows, (int)n, (int)p,
-                                    (hipStream_t)stream, c->read_a_once);
 }
 void wl_tanh_linear_f_s(void* vctx, size_t m, size_t n, const float* x, float* y)
 {

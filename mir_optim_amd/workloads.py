@@ -43,7 +43,7 @@ class DeviceProblem:
 
     suffix = "d"
 
-    def options(self, flags=0, stats=None, comm=None, workspace=None, batched=False, fd_batch=0, trace=None, variant=0, fd_windows=0):
+    def options(self, flags=0, stats=None, comm=None, workspace=None, batched=False, fd_batch=0, trace=None, variant=0):
         o = api.GpuOptions()
         o.flags = api.DEVICE_CALLBACKS | flags
         o.variant = variant
@@ -58,9 +58,6 @@ class DeviceProblem:
                 o.fbRowMajor = self.fbr          # row-major FD panel: the fill is fused into the J^T J kernel
             if getattr(self, "fbd", None) is not None and batched not in ("pointmajor", "rowmajor"):
                 o.fbRowMajorDiff = self.fbd      # m x n difference panel: half the bytes between the two kernels
-                if getattr(self, "fbdw", None) is not None and fd_windows >= 2:
-                    o.fbRowMajorDiffWindow = self.fbdw   # ... in row windows, two streams
-                    o.fd_windows = fd_windows
         if stats is not None:
             o.stats = C.pointer(stats)
         if trace is not None:
@@ -92,7 +89,6 @@ class TanhLinear(DeviceProblem):
         self.fb = _addr("wl_tanh_linear_fb_d") if dtype == np.float64 else None
         self.fbr = _addr("wl_tanh_linear_fbr_d") if dtype == np.float64 else None
         self.fbd = _addr("wl_tanh_linear_fbd_d") if dtype == np.float64 else None
-        self.fbdw = _addr("wl_tanh_linear_fbdw_d") if dtype == np.float64 else None
 
 
 class TanhLinearView(TanhLinear):
@@ -110,7 +106,6 @@ class TanhLinearView(TanhLinear):
         self.fb = _addr("wl_tanh_linear_fb_d")
         self.fbr = _addr("wl_tanh_linear_fbr_d")
         self.fbd = _addr("wl_tanh_linear_fbd_d")
-        self.fbdw = _addr("wl_tanh_linear_fbdw_d")
 
 
 class Curve(DeviceProblem):

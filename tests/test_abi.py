@@ -120,15 +120,18 @@ def test_gpu_options_trace_field_is_appended():
     """mir_lsq_gpu_options is versioned by struct_size: `trace` was appended after `stats`, `fbRowMajor` after `trace`,
     `fbRowMajorDiff` after that, `stats_size` last; older callers (64-, 72-, 80- and 88-byte structs) stay valid. Offsets as
     declared in include/mir_optim_amd.h. mir_lsq_stats is versioned by `stats_size` (or by the era of struct_size): the sizes
-    the library falls back to are the historic ones (tests/test_gpu_tail_fusion.py checks the writes with a canary)."""
+    the library falls back to are the historic ones (tests/test_gpu_launch_budget.py checks the writes with a canary).
+    Round 4 removed the two trailing members of a retired experiment (fd_windows became reserved0, the window callback is
+    gone): the struct is 96 bytes; a caller that still passes 104 is simply read up to what this build knows."""
     import ctypes as C
     from mir_optim_amd import api
-    assert C.sizeof(api.GpuOptions) == 104 and api.GpuOptions.fbRowMajorDiffWindow.offset == 96 and api.GpuOptions.stats.offset == 56 and api.GpuOptions.trace.offset == 64
+    assert C.sizeof(api.GpuOptions) == 96 and api.GpuOptions.reserved0.offset == 92 and api.GpuOptions.stats.offset == 56 and api.GpuOptions.trace.offset == 64
     assert api.GpuOptions.fbRowMajor.offset == 72 and api.GpuOptions.fbRowMajorDiff.offset == 80
     assert api.GpuOptions.stats_size.offset == 88 and api.GpuOptions().stats_size == C.sizeof(api.Stats)
     assert api.Stats.qp_active_set_passes.offset + 8 == 120 and api.Stats.jtj_fd_launches.offset + 8 == 144
-    assert api.Stats.trial_callback_points.offset + 8 == 264 and C.sizeof(api.Stats) == 264 + 13 * 8
+    assert api.Stats.trial_callback_points.offset + 8 == 264 and C.sizeof(api.Stats) == 264 + 12 * 8
     assert C.sizeof(api.TraceRecord) == 40
+    assert C.sizeof(api.BatchedOptions) == 40 and api.BatchedOptions.basis.offset == 16 and api.BatchedOptions.timing.offset == 32
     t = api.Trace(8)
     assert t.count == 0 and t.records() == []
 

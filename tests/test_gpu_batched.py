@@ -235,14 +235,9 @@ def test_lambda_ladder_takes_the_steps_of_the_one_by_one_loop(model, maker):
     fCalls, status, residual and lambda on every problem."""
     count = 1024
     t, data, truth, x0 = {"pad8": P.cfg5_pad8, "exp3": make_exp3, "decay": make_exp_decay}[maker](count, 512)
-    L = M.lib()
     out = []
-    for variant in (0, M.BATCHED_NO_LADDER):
-        L.mir_lsq_batched_set_variant(variant)
-        try:
-            res, x = M.optimizeLeastSquaresBatched(model, x0, t, data, settings=M.LeastSquaresSettings(np.float32))
-        finally:
-            L.mir_lsq_batched_set_variant(0)
+    for variant in (0, M.BATCHED_NO_LADDER):           # per call (mir_lsq_batched_options.variant): nothing is process-wide
+        res, x = M.optimizeLeastSquaresBatched(model, x0, t, data, settings=M.LeastSquaresSettings(np.float32), variant=variant)
         out.append((x.view(np.uint32).copy(), [(int(r.status), r.iterations, r.fCalls, np.float32(r.residual).view(np.uint32),
                                                np.float32(r.lambda_).view(np.uint32)) for r in res]))
     assert (out[0][0] == out[1][0]).all()

@@ -55,19 +55,18 @@ def test_lowrank_broyden_matches_rewriting_kernels(m, n, dtype):
         assert np.isclose(rl.residual, rf.residual, rtol=1e-3)
 
 
-@pytest.mark.parametrize("resync", [True, False])
 @pytest.mark.parametrize("cap", [1, 2, 3])
 @pytest.mark.parametrize("m,n", [(20000, 32), (9973, 100), (30000, 208)])
-def test_lowrank_flush_into_J(m, n, cap, resync):
+def test_lowrank_flush_into_J(m, n, cap):
     """variant_lr_cap bounds the pending terms; beyond it they are folded into J (k_lr_flush), J^T J is recomputed from
-    the flushed J (unless VARIANT_NO_RESYNC) and the sweep restarts at k = 0. Any cap gives the same trajectory to rounding."""
+    the flushed J and the sweep restarts at k = 0. Any cap gives the same trajectory to rounding."""
     w = P.tanh_linear(m, n)
     prob = W.TanhLinear(w["A"], w["b"])
     s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
     r0, x0, t0, st0 = solve_with(prob, w, 0, s)
-    r1, x1, t1, st1 = solve_with(prob, w, M.variant_lr_cap(cap) | (0 if resync else M.VARIANT_NO_RESYNC), s)
+    r1, x1, t1, st1 = solve_with(prob, w, M.variant_lr_cap(cap), s)
     assert st1.jacobian_broyden > int(cap) and st1.broyden_flushes >= 1     # the cap really was reached
-    assert st1.jtj_resyncs == (st1.broyden_flushes if resync else 0)
+    assert st1.jtj_resyncs == st1.broyden_flushes
     assert np.allclose(x1, x0, rtol=1e-6, atol=1e-9)
     assert np.isclose(r1.residual, r0.residual, rtol=1e-9)
     assert_same_trajectory(t1, t0, (m, n, cap))

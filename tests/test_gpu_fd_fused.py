@@ -51,20 +51,18 @@ def test_fd_jtj_exact_integers(m, n):
 
 
 @pytest.mark.parametrize("m,n", [(4096, 128), (5000, 16), (30, 32), (10002, 64), (7778, 80), (12344, 96), (6, 112), (50000, 128)])
-def test_ring_and_streaming_variants_agree_with_producer_consumer_kernels(m, n):
-    """VARIANT_JTJ_RING / VARIANT_JTJ_STREAM select the LDS-DMA ring kernel (n % 16 == 0, m even) and the register-streaming
-    kernel for the plain J^T J: bit-exact on exact-integer inputs, like the producer / consumer kernels."""
+def test_plain_and_fused_producer_consumer_kernels_agree_on_exact_integers(m, n):
+    """The plain J^T J (k_jtj_fdp<., false>) of the J the fused finite-difference kernel wrote: bit-exact on exact-integer
+    inputs, like the fused kernel itself."""
     rng = np.random.default_rng(3 * m + n)
     Yrm = rng.integers(-8, 9, size=(m, 2 * n)).astype(np.float64)
     twh = np.full(n, 2.0 ** -25)
     y = rng.integers(-4, 5, size=m).astype(np.float64)
     J0, JJ0, Jy0, _ = M.fd_jtj(Yrm, twh, y)
     P0 = M.jtj(J0, y)
-    P1 = M.jtj(J0, y, variant=M.VARIANT_JTJ_RING)
-    P2 = M.jtj(J0, y, variant=M.VARIANT_JTJ_STREAM)
     Jr = ref_fill(Yrm, twh)
     assert np.array_equal(J0, Jr)
-    for JJ, Jy in ((JJ0, Jy0), (P0[0], P0[1]), (P1[0], P1[1]), (P2[0], P2[1])):
+    for JJ, Jy in ((JJ0, Jy0), (P0[0], P0[1])):
         assert np.array_equal(JJ, Jr.T @ Jr) or np.allclose(JJ, Jr.T @ Jr, rtol=1e-15, atol=0)
         assert np.array_equal(Jy, Jr.T @ y) or np.allclose(Jy, Jr.T @ y, rtol=1e-15, atol=0)
 
@@ -238,50 +236,3 @@ def test_solve_through_the_difference_panel_equals_the_pair_panel_solve(oracle, 
     else:
         assert np.allclose(xd, xp, rtol=1e-9, atol=1e-12) and np.isclose(rd.residual, rp.residual, rtol=1e-12)
     assert sd.jacobian_full == sp.jacobian_full >= 1
-
-
-@pytest.mark.parametrize("m,n,windows", [(200000, 128, 4), (70001, 64, 3), (40000, 32, 8), (150000, 128, 16)])
-def test_two_stream_window_refresh_matches_the_one_sweep_refresh(m, n, windows):
-    """fbRowMajorDiffWindow (round 3): the caller's difference-panel kernel in row windows on a side stream,
-    k_jtj_fdp window by window on the solver's stream, one slab reduction over all windows' slab sets. J is the same matrix;
-    J^T J / J^T y differ by the summation order only: same counters, x and residual to rounding, trace to 1e-9."""
-    import mir_optim_amd as M
-    from mir_optim_amd import workloads as W
-    import problems as P
-    w = P.tanh_linear(m, n)
-    prob = W.TanhLinear(w["A"], w["b"])
-    s = M.LeastSquaresSettings(); s.absTolerance = 1e-5      # every accept / reject decision has margin (DESIGN.md section 5)
-    st0, st1, t0, t1 = M.Stats(), M.Stats(), M.Trace(), M.Trace()
-    r0, x0 = prob.solve(w["x0"], settings=s, batched=True, stats=st0, trace=t0)
-    r1, x1 = prob.solve(w["x0"], settings=s, batched=True, stats=st1, trace=t1, fd_windows=windows)
-    assert st1.fd_window_refreshes == st1.jacobian_full >= 2 and st0.fd_window_refreshes == 0
-    assert (int(r1.status), r1.iterations, r1.fCalls) == (int(r0.status), r0.iterations, r0.fCalls)
-    assert np.allclose(x1, x0, rtol=1e-9, atol=1e-11) and np.isclose(r1.residual, r0.residual, rtol=1e-12)
-    a, b = t0.records(), t1.records()
-    assert len(a) == len(b)
-    for ra, rb in zip(a, b):
-        assert ra[:2] == rb[:2] and np.allclose(ra[2:5], rb[2:5], rtol=1e-9, atol=1e-300) and np.isclose(ra[5], rb[5], rtol=1e-5)   # dx.dx of a 5e-6 step
-
-
-@pytest.mark.parametrize("m,n,tol,lrcap", [(60000, 128, 1e-9, 0), (30000, 256, 1e-9, 0), (40000, 64, 1e-12, 3), (20001, 34, 0.0, 2),
-                                           (25000, 192, 1e-9, 5)])
-def test_panel_kept_as_jacobian_is_bit_identical_to_writing_J(m, n, tol, lrcap):
-    """Round 3, MIR_LSQ_VARIANT_FD_PANEL_IS_J: after a difference-panel refresh the fused kernel does not write J -- the PANEL
-    stays the Jacobian, the Broyden sweeps (and the flush that folds the pending terms in) apply scal(1 / twh) (LS:1046-1047)
-    at load time: the same multiplication on the same operands, so every pass must be bit-identical to the default
-    (materialised J), including runs whose pending terms are flushed several times (small caps) and the long rejection tail."""
-    import mir_optim_amd as M
-    from mir_optim_amd import workloads as W
-    import problems as P
-    w = P.tanh_linear(m, n)
-    prob = W.TanhLinear(w["A"], w["b"])
-    s = M.LeastSquaresSettings(); s.absTolerance = tol
-    cap = M.variant_lr_cap(lrcap) if lrcap else 0
-    out = []
-    for v in (0, M.VARIANT_FD_PANEL_IS_J):
-        st, tr = M.Stats(), M.Trace(4096)
-        r, x = prob.solve(w["x0"], settings=s, batched=True, stats=st, trace=tr, variant=v | cap)
-        out.append(((int(r.status), r.iterations, r.fCalls, r.residual, r.lambda_, x.tobytes()), tr.records(), st))
-    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
-    if lrcap:
-        assert out[0][2].broyden_flushes >= 1 and out[0][2].broyden_flushes == out[1][2].broyden_flushes

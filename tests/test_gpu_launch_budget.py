@@ -1,20 +1,13 @@
-"""The per-pass serial tail (round 3): fewer launches per pass, bit for bit the same solve.
+"""Launches per round and the statistics that report them.
 
-Default (a merge into the CONSUMER -- no cross-workgroup traffic inside a kernel):
-    k_jtj_* -> k_jtj_slab_reduce -> k_unpack_grad -> solve   =>  k_jtj_* -> k_jtj_slab_reduce (writes J^T J, J^T y) -> solve
-                                                                 (|J^T y|_inf in the solve kernel's prologue)
-Opt-in, MIR_LSQ_VARIANT_FINISH_IN_SOLVE (measured 1 % slower at cfg 3: one workgroup does the n^2 update):
-    k_broyden_lr -> k_lr_reduce -> k_lr_finish -> solve      =>  k_broyden_lr -> k_lr_reduce -> solve (n x n finish in the prologue)
-Opt-in ("last workgroup finishes" tails; MIR_LSQ_VARIANT_SWEEP_TAIL / SUMSQ_TAIL -- measured no faster on MI355X, kept as
-A/B: profiles/r03/ab_tails.txt):
-    k_broyden_lr -> k_lr_reduce (-> finish)                  =>  k_broyden_lr (ranges summed by their last arrivals, the
-                                                                 last range sums the ranges and applies the finish)
-    f(trial) -> k_sumsq_partial -> k_decide_chain            =>  f(trial) -> k_sumsq_tail<decide>
-    f(x0) -> k_sumsq_partial -> k_sumsq_final -> k_init      =>  f(x0) -> k_sumsq_tail<init>
-
-Every variant sums the same partials in the same fixed order and applies the same expressions, so the solves must be
-BIT-IDENTICAL to MIR_LSQ_VARIANT_NO_TAIL_FUSION (the round-2 launch sequence, kept as the literal restatement), and the
-launch counts per round (mir_lsq_stats.round_launches / rounds) must be what DESIGN.md section 4 says.
+Single GPU, the product sequence:
+    refresh round   k_fd_points | fused FD J^T J | slab reduce (writes J^T J, J^T y) | solve (|J^T y|_inf in its prologue) |
+                    sums of squares (stage 1) | decision (stage 2 + the ladder walk)                                    = 6
+    Broyden round   sweep | reduce | finish | solve | sums | decision                                                   = 6
+    re-solve round  solve | sums | decision (or solve | decision when every trial is a null step)                      <= 3
+With a communicator the all-reduce sits between a reduction and its consumer: k_unpack_grad and k_sumsq_final come back (7).
+(The "last workgroup finishes" tails and the finish-in-solve variant that round 3 built, measured and retired are gone from
+the library: profiles/r03/ab_tails.txt keeps the evidence.)
 Reference loop: least_squares.d:972-1175 (the reductions are LS:1052, 1065, 1115)."""
 import ctypes as C
 import threading
@@ -39,51 +32,15 @@ def counters(st):
             st.broyden_flushes, st.jtj_resyncs, st.elided_evaluations)
 
 
-@pytest.mark.parametrize("m,n,dtype,tol", [
-    (60000, 128, np.float64, 1e-9),      # cfg 3's kernels: k_jtj_fdp difference panel, LDS solve, 1024-workgroup sweep
-    (20000, 256, np.float64, 1e-9),      # cfg 4's: k_jtj_fdp8, sweep with 8 column pairs per lane
-    (9000, 33, np.float64, 1e-12),       # odd n: register-streaming J^T J, scalar loads, the long rejection tail (ladders)
-    (20001, 9, np.float64, 0.0),         # odd m, null-step tail
-    (30000, 64, np.float32, 1e-4),       # f32 through the general solver
-    (5000, 300, np.float64, 1e-9),       # n > 256: tile-pair J^T J (its own reduction; k_unpack_grad stays), Broyden rewrites J
-])
-def test_fused_tails_are_bit_identical_to_separate_kernels(m, n, dtype, tol):
-    w = P.tanh_linear(m, n)
-    prob = W.TanhLinear(w["A"], w["b"], dtype=dtype)
-    s = M.LeastSquaresSettings(dtype) if dtype == np.float32 else M.LeastSquaresSettings()
-    s.absTolerance = tol
-    out = []
-    for variant in (M.VARIANT_NO_TAIL_FUSION, M.VARIANT_FINISH_IN_SOLVE, M.VARIANT_SWEEP_TAIL, M.VARIANT_SUMSQ_TAIL,
-                    M.VARIANT_SWEEP_TAIL | M.VARIANT_SUMSQ_TAIL, 0):
-        st, tr = M.Stats(), M.Trace(4096)
-        r, x = prob.solve(w["x0"].astype(dtype), settings=s, batched=True, stats=st, trace=tr, variant=variant)
-        out.append((key(r, x), counters(st), tr.records(), st))
-    k0, c0, t0, st0 = out[0]
-    launches = [st0.library_launches]
-    for k1, c1, t1, st1 in out[1:]:
-        assert k1 == k0
-        assert c1 == c0
-        assert t1 == t0                                      # every pass: lambda, residuals, dx.dx bit for bit
-        launches.append(st1.library_launches)
-    if n <= 256:
-        assert launches[1] < launches[5] < launches[0] and launches[4] < launches[2] < launches[5] and launches[4] < launches[3] < launches[5]
-    else:                                                    # no low-rank sweep, tile-pair J^T J: only the sums / decision tail applies
-        assert launches[1] == launches[0] == launches[2] == launches[5] and launches[3] == launches[4] < launches[1]
-
-
-def test_bounded_gauss_sum_bit_identical_and_launch_counts():
-    """cfg 2's family (bounded: BOXCQP kernel, n = 16): same bits, and the launch budget of a round."""
+def test_bounded_gauss_sum_launch_counts():
+    """cfg 2's family (bounded: BOXCQP kernel, n = 16): the launch budget of a round."""
     g = P.gauss_sum(100000, K=5)
     prob = W.Curve("gauss_sum", g["t"], g["data"])
-    res = []
-    for variant in (0, M.VARIANT_NO_TAIL_FUSION, M.VARIANT_SWEEP_TAIL | M.VARIANT_SUMSQ_TAIL):
-        st = M.Stats()
-        # (no rounds enqueued ahead of time: this small problem would pipeline by default, and a guarded round that is
-        # dropped still counts its launches)
-        r, x = prob.solve(g["x0"], l=g["lower"], u=g["upper"], batched=True, stats=st, variant=variant | M.VARIANT_NO_PIPELINE)
-        res.append((key(r, x), counters(st), st))
-    assert res[0][0] == res[1][0] == res[2][0] and res[0][1] == res[1][1] == res[2][1]
-    st = res[0][2]
+    st = M.Stats()
+    # (no rounds enqueued ahead of time: this small problem would pipeline by default, and a guarded round that is
+    # dropped still counts its launches)
+    r, x = prob.solve(g["x0"], l=g["lower"], u=g["upper"], batched=True, stats=st, variant=M.VARIANT_NO_PIPELINE)
+    assert r.status >= 0
     assert st.rounds[0] == st.jacobian_full and st.rounds[1] == st.jacobian_broyden
     # library launches per round, single GPU (DESIGN.md section 4):
     #   Broyden round   sweep | reduce | finish | solve | sum of squares | decision                              = 6
@@ -92,11 +49,6 @@ def test_bounded_gauss_sum_bit_identical_and_launch_counts():
     assert st.round_launches[1] == 6 * st.rounds[1]
     assert st.round_launches[2] <= 3 * st.rounds[2]
     assert st.round_launches[0] <= 8 * st.rounds[0]          # point-major panel + fill pass here; + k_reset_mu when LS:984 forces the refresh
-    st0 = res[1][2]
-    assert st0.round_launches[1] == 6 * st0.rounds[1]        # round 2's sequence: sweep, reduce, finish, solve, sumsq, decide
-    st2 = res[2][2]
-    assert st2.round_launches[1] == 3 * st2.rounds[1]        # both tails: sweep (+ reduce + finish) | solve | sums + decision
-    assert st2.round_launches[2] == 2 * st2.rounds[2]
 
 
 def test_launch_budget_cfg3_shape():
@@ -111,15 +63,11 @@ def test_launch_budget_cfg3_shape():
     # FD points, k_jtj_fdp, slab reduce, solve, sums, decision (+ k_reset_mu in a refresh that LS:984-989 forces)
     assert 6 * st.rounds[0] <= st.round_launches[0] <= 6 * st.rounds[0] + 1
     assert st.library_launches == sum(st.round_launches) + 3  # + the sum of squares at entry (LS:955: two stages) and the state set-up
-    st2 = M.Stats()
-    r2, x2 = prob.solve(w["x0"], settings=s, batched=True, stats=st2, variant=M.VARIANT_SWEEP_TAIL | M.VARIANT_SUMSQ_TAIL)
-    assert key(r2, x2) == key(r, x)
-    assert st2.round_launches[1] == 3 * st2.rounds[1] and 5 * st2.rounds[0] <= st2.round_launches[0] <= 5 * st2.rounds[0] + 1
 
 
 def test_one_rank_communicator_keeps_the_reductions_apart():
-    """With a communicator the all-reduce sits between the reduction and its consumer: the sweep still reduces in its tail,
-    k_lr_finish / k_unpack_grad / k_decide_chain run behind the exchange. Same bits as without a communicator (one rank)."""
+    """With a communicator the all-reduce sits between the reduction and its consumer: k_lr_finish / k_unpack_grad /
+    k_decide_chain run behind the exchange. Same bits as without a communicator (one rank)."""
     n = 128
     w = P.tanh_linear(30000, n)
     prob = W.TanhLinear(w["A"], w["b"])
@@ -134,11 +82,11 @@ def test_one_rank_communicator_keeps_the_reductions_apart():
     assert st.round_launches[1] == 7 * st.rounds[1]
 
 
-def test_eight_shards_with_fused_tails_agree_bitwise():
+def test_eight_shards_agree_bitwise_run_after_run():
     world, m_total, n = 8, 64000, 128
     s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
     outs = []
-    for variant in (0, M.VARIANT_NO_TAIL_FUSION, M.VARIANT_SWEEP_TAIL | M.VARIANT_SUMSQ_TAIL):
+    for variant in (0, 0):
         comms, close = PAR.local_group(world)
         probs = []
         for r in range(world):
@@ -161,13 +109,11 @@ def test_eight_shards_with_fused_tails_agree_bitwise():
         close()
         assert not any(t.is_alive() for t in ts) and not any(err), err
         outs.append([key(r, x) for r, x in res])
-    assert len(set(outs[0])) == 1 and outs[0] == outs[1] == outs[2]
+    assert len(set(outs[0])) == 1 and outs[0] == outs[1]
 
 
-@pytest.mark.parametrize("variant", [0, M.VARIANT_SWEEP_TAIL | M.VARIANT_SUMSQ_TAIL])
-def test_repeated_solves_on_one_workspace_leave_the_counters_clean(variant):
-    """The arrival counters live in the workspace; every tail resets its own. 30 solves back to back on one workspace, all
-    bit-identical (a counter left non-zero would make a later tail fire early or never)."""
+def test_repeated_solves_on_one_workspace_are_bit_identical(variant=0):
+    """30 solves back to back on one workspace (device state, pinned mirrors and the event pool are reused), all bit-identical."""
     w = P.tanh_linear(40000, 64)
     prob = W.TanhLinear(w["A"], w["b"])
     s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
