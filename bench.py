@@ -110,6 +110,12 @@ def parse():
                          "with fewer GPUs, its callback communicator over gloo (ranks then share GPUs)")
     ap.add_argument("--force-comm", action="store_true",
                     help="N = 1: attach a one-rank RCCL communicator anyway (exercises the N > 1 code path on one GPU)")
+    ap.add_argument("--replay-ranks", type=int, default=0,
+                    help="N = 1 only: measure ONE rank of an R-rank strong-scaled job on this GPU. The R-shard solve of the global "
+                         "problem runs once (in-process group) and records rank 0's all-reduce totals; every timed solve is then "
+                         "rank 0's shard alone, each exchange replaced by the recorded total (mir_lsq_comm_create_replay) -- the "
+                         "global trajectory, the rank's own kernels uncontended, no xGMI hop. With --force-comm every exchange "
+                         "also passes through a one-rank ncclAllReduce")
     ap.add_argument("--stall-bound", type=float, default=8.0,
                     help="RCCL only: upper bound (s, from communicator creation) of the warm-up loop that waits for RCCL's "
                          "asynchronous initialisation stall to pass (it ends as soon as a stall has been seen and has passed)")
@@ -494,9 +500,10 @@ def main():
             comm = comm_obj.handle
 
     n = args.n
+    replay = args.replay_ranks if (world == 1 and args.replay_ranks > 1) else 0
     if args.scaling == "strong":
         m_total = args.rows
-        row0, m = PAR.row_shard(m_total, world, rank)
+        row0, m = PAR.row_shard(m_total, max(world, replay), rank)
     else:
         m = args.rows
         m_total = m * world
@@ -509,6 +516,29 @@ def main():
     ws = api.lib().mir_lsq_workspace_create(m, n, 8)
     if not ws:
         raise SystemExit("workspace allocation failed")
+    fdb = {"batched": True, "rowmajor": "rowmajor", "pointmajor": "pointmajor", "serial": False}[args.fd]
+    replay_info = None
+    inner_comm = None
+    if replay:
+        if args.scaling != "strong":
+            raise SystemExit("--replay-ranks measures a strong-scaled rank")
+
+        def shard(r):
+            o, ml = PAR.row_shard(m_total, replay, r)
+            d = W.tanh_linear_data(ml, n, row_offset=o)
+            return W.TanhLinear(d["A"], d["b"])
+        tape, rres, rx, rwall = PAR.record_rank_tape(shard, replay, data["x0"], settings=settings, batched=fdb, variant=args.variant)
+        inner = comm                                            # --force-comm: the one-rank RCCL communicator created above
+        inner_comm = inner
+        comm = PAR.replay_comm(replay, 0, tape, inner)
+        replay_info = {"ranks": replay, "tape_doubles": int(tape.size), "grouped_solve_wall_ms": rwall * 1e3,
+                       "grouped_solve": {"status": rres.status.name, "iterations": rres.iterations, "fcalls": rres.fCalls,
+                                         "residual": rres.residual},
+                       "inner": "one-rank RCCL all-reduce behind every replayed exchange" if inner else None,
+                       "note": "value = iterations of the GLOBAL solve per second as ONE rank would deliver them with a zero-latency "
+                               "interconnect: rank 0's shard on an otherwise idle GPU, every all-reduce replaced by the recorded total "
+                               "of the real 8-shard run (stream-ordered device copy)"}
+        args.survey_steps = 0                                   # the tape belongs to the headline settings
 
     def barrier():
         if distributed:
@@ -516,8 +546,10 @@ def main():
         torch.cuda.synchronize()
 
     def solve(stats=None, flags=0, s=settings):
+        if replay:
+            api.lib().mir_lsq_comm_replay_rewind(comm)
         return prob.solve(data["x0"], settings=s, stats=stats, flags=flags, comm=comm_obj or comm, workspace=ws, variant=args.variant,
-                          batched={"batched": True, "rowmajor": "rowmajor", "pointmajor": "pointmajor", "serial": False}[args.fd])
+                          batched=fdb)
 
     # RCCL finishes part of its initialisation asynchronously: a few seconds after ncclCommInitRank every HIP launch of the
     # process stalls once or twice for 60-150 ms (measured on a one-GPU box with --force-comm: 160-310 it/s when that lands
@@ -725,7 +757,8 @@ def main():
                             f"absTolerance={args.abs_tolerance:g}, whole solves x0 -> termination, {args.scaling} scaling "
                             f"({m} rows on rank 0)",
                 "m_total": m_total, "m_per_gpu": m, "n": n, "scaling": args.scaling,
-                "parallelism": f"rows sharded x{world}, " + ("RCCL all-reduce" if args.comm == "rccl" else
+                "parallelism": (f"ONE rank of {replay} (rows sharded x{replay}; all-reduce totals replayed from the recorded {replay}-shard solve)"
+                                if replay else f"rows sharded x{world}, ") + ("" if replay else "RCCL all-reduce" if args.comm == "rccl" else
                                                                  "gloo callback all-reduce (" + ("FALLBACK: RCCL unusable" if comm_fallback else "rehearsal") + ")"),
                 "rccl_ranks": api.lib().mir_lsq_comm_ranks(comm) if (comm and args.comm == "rccl") else None,
                 "rccl_fallback_reason": comm_fallback,
@@ -741,6 +774,7 @@ def main():
                                         "sweep_calls": sta["allreduce_calls"][1] / K, "sweep_elems": sta["allreduce_elems"][1] / max(1, sta["allreduce_calls"][1]),
                                         "scalar_calls": sta["allreduce_calls"][2] / K},
                 "rccl_stall_probe": stall if t_comm is not None else None,
+                "replay": replay_info,
                 "abs_tolerance": args.abs_tolerance,
                 "abs_tolerance_note": "1e-5: every accept/reject decision of the solve has margin; at the survey's 1e-9 the last "
                                       "acceptance compares rounding noise (12 it / 16 passes or 11 it / 56 passes): see survey_setting",
@@ -779,6 +813,8 @@ def main():
         comm_obj.close()
     elif comm:
         api.lib().mir_lsq_comm_destroy(comm)
+    if inner_comm:
+        api.lib().mir_lsq_comm_destroy(inner_comm)
     api.lib().mir_lsq_workspace_destroy(ws)
     if distributed:
         dist.destroy_process_group()

@@ -77,3 +77,16 @@ def build(force=False, verbose=False, jobs=None):
 
 if __name__ == "__main__":
     build(force=True, verbose=True)
+
+
+def build_user_model_example(force=False, verbose=False):
+    """tests/user_model/: a caller's own residual model compiled against include/mir_optim_amd_batched.hpp (the device header
+    of the batched fit) into a library of its own -- what a user of that header does. Built here so that it travels prebuilt."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tests", "user_model", "user_model.hip")
+    out = os.path.join(root, "tests", "user_model", "libuser_model.so")
+    deps = [src, os.path.join(root, "include", "mir_optim_amd_batched.hpp"), os.path.join(root, "include", "mir_optim_amd.h"),
+            os.path.join(CSRC, "batched_kernel.h"), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "solve_types.h")]
+    if force or _stale(out, deps):
+        _run([_hipcc()] + _FLAGS + ["-shared", "-I", os.path.join(root, "include"), "-o", out, src], verbose)
+    return out

@@ -113,3 +113,50 @@ def local_group(world):
         for h in handles:
             L.mir_lsq_comm_destroy(h)
     return handles, close
+
+
+def record_rank_tape(make_problem, world, x0, rank=0, capacity=1 << 22, **solve_kw):
+    """Run the `world`-shard solve ONCE in this process (in-process group, one host thread per shard, all on the current
+    device) and record the totals of rank `rank`'s all-reduces (mir_lsq_comm_record): the tape a replay communicator
+    (replay_comm) needs to let that one rank re-run the GLOBAL trajectory alone. make_problem(r) builds shard r's
+    DeviceProblem. Returns (tape: np.ndarray[float64], result of `rank`, x, wall seconds of the grouped solve)."""
+    import threading
+    import time
+
+    L = api.lib()
+    comms, close = local_group(world)
+    probs = [make_problem(r) for r in range(world)]
+    tape = np.zeros(capacity, dtype=np.float64)
+    if L.mir_lsq_comm_record(comms[rank], tape.ctypes.data, capacity) != 0:
+        raise RuntimeError("mir_lsq_comm_record failed")
+    res, err = [None] * world, [None] * world
+
+    def one(r):
+        try:
+            res[r] = probs[r].solve(x0, comm=comms[r], **solve_kw)
+        except BaseException as e:   # noqa: BLE001
+            err[r] = e
+    t0 = time.perf_counter()
+    ts = [threading.Thread(target=one, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(1200)
+    wall = time.perf_counter() - t0
+    n = L.mir_lsq_comm_recorded(comms[rank])
+    close()
+    if any(t.is_alive() for t in ts) or any(err):
+        raise RuntimeError(f"grouped solve failed: {err}")
+    if n == C.c_size_t(-1).value:
+        raise RuntimeError("tape overflow: raise `capacity`")
+    return tape[:n].copy(), res[rank][0], res[rank][1], wall
+
+
+def replay_comm(world, rank, tape, inner=None):
+    """mir_lsq_comm_create_replay: every all-reduce is replaced by the next recorded total (and also passes through
+    `inner`, e.g. a one-rank RCCL communicator, when given). Rewind it (mir_lsq_comm_replay_rewind) before every solve."""
+    tape = np.ascontiguousarray(tape, dtype=np.float64)
+    h = api.lib().mir_lsq_comm_create_replay(world, rank, tape.ctypes.data, tape.size, inner)
+    if not h:
+        raise RuntimeError("mir_lsq_comm_create_replay failed")
+    return h
