@@ -46,32 +46,52 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F64_MFMA_PEAK_TF = 78.6        # dense f64 MFMA (= f64 vector) peak
 
 
-def pmc_file():
+def _round_no(path):
+    import re
+    m_ = re.search(r"profiles/r(\d+)/", path.replace(os.sep, "/"))
+    return int(m_.group(1)) if m_ else -1
+
+
+def pmc_file(m=1_000_000, n=128):
+    """The newest (by round NUMBER) committed PMC summary for the per-GPU shape: profiles/rNN/pmc_traffic.json was taken at
+    m = 1e6 x n = 128 (cfg 3), profiles/rNN/n256_pmc.json at m = 1e6 x n = 256 (cfg 4's per-GPU shape)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))
+    name = {(1_000_000, 128): "pmc_traffic.json", (1_000_000, 256): "n256_pmc.json"}.get((m, n))
+    if name is None:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)), key=_round_no)
     return files[-1] if files else None
 
 
+def csrc_sha16(name):
+    import hashlib
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, "mir_optim_amd", "csrc", name), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def pmc_field(kernel, m, n, field):
-    """HBM bytes per launch (or MFMA pipe utilisation) of `kernel` from the COMMITTED rocprofv3 PMC summary
-    (profiles/rNN/pmc_traffic.json, made by scripts/pmc_summary.py from separate --pmc passes of this same command):
-    PMC counters cannot be read from inside the timed run, so this is a stored measurement -- `traffic_source` in the JSON
-    line says so. None if absent or if the per-GPU shape differs from the profiled one (m = 1e6, n = 128)."""
-    f = pmc_file()
-    if (m, n) != (1_000_000, 128) or f is None:
+    """HBM bytes per launch (or MFMA pipe utilisation) of `kernel` from the COMMITTED rocprofv3 PMC summary (made by
+    scripts/pmc_summary.py / pmc_summary2.py from separate --pmc passes of this same command): PMC counters cannot be read
+    from inside the timed run, so this is a stored measurement -- `traffic_source` in the JSON line says so. None if absent
+    or if the per-GPU shape is not one of the profiled ones (m = 1e6 with n = 128 or 256)."""
+    f = pmc_file(m, n)
+    if f is None:
         return None
     try:
         ks = json.load(open(f))["kernels"]
-        if kernel not in ks:            # template arguments appended since (k_broyden_lr<double, 4, true> -> <..., true, false>)
-            kernel = next(k for k in ks if k.startswith(kernel[:-1] + ","))
+        if kernel not in ks:            # template arguments added or dropped since (k_broyden_lr<double, 4, true> <-> <..., true, false>)
+            stem = kernel[:-1]
+            kernel = next(k for k in ks if k.startswith(stem + ",") or stem.startswith(k[:-1] + ","))
         return ks[kernel][field]
     except (KeyError, ValueError, StopIteration):
         return None
 
 
 def traffic_source(m, n):
-    f = pmc_file()
-    if (m, n) != (1_000_000, 128) or f is None:
+    f = pmc_file(m, n)
+    if f is None:
         return None
     return os.path.relpath(f, ROOT) + " (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)"
 
@@ -308,11 +328,16 @@ def cfg5_roofline(ms, evals, steps, count, m, n):
     (4 x SQ_ACTIVE_INST_VALU over GRBM_GUI_ACTIVE x 1024 SIMDs) from the same pass."""
     import glob
     peak = 1024 * 2.4e9 / 4.0 / 1e9
-    pm = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "cfg5_pmc.json"))):
+    pm, stale = None, None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "cfg5_pmc.json")), key=_round_no):
         try:
-            pm = next(v for k, v in json.load(open(f))["kernels"].items() if "k_lm_batched" in k)
+            doc = json.load(open(f))
+            pm = next(v for k, v in doc["kernels"].items() if "k_lm_batched" in k)
             src = os.path.relpath(f, ROOT)
+            # the instruction count of a launch belongs to the kernel source (and the LM settings) it was counted on: the
+            # summary records the hash of batched_kernel.h; a different (or missing) hash leaves achieved / frac empty
+            have, want = (doc.get("csrc_sha16") or {}).get("batched_kernel.h"), csrc_sha16("batched_kernel.h")
+            stale = None if have == want else f"{src} was counted on batched_kernel.h {have}, this tree has {want}: re-profile (scripts/profile_any.sh cfg5 ... VALU SQ1)"
         except (StopIteration, KeyError, ValueError):
             pass
     out = {"kernel": "mirlsq::k_lm_batched<2> (one wavefront = one workgroup per problem: J, y in its 20 KB of LDS, FD + Broyden + "
@@ -325,7 +350,9 @@ def cfg5_roofline(ms, evals, steps, count, m, n):
                    "waves per SIMD (20 KB a problem); while two are resident the VALU pipe is ~85 % busy, but the launch ends with "
                    "its longest fits (29 iterations where the mean is 10; 4096 problems on 2048 slots): on average 1.1 waves are "
                    "resident per SIMD (mean_resident_waves_per_simd), which is what holds the fraction near one half"}
-    if pm and pm.get("SQ_INSTS_VALU"):
+    if stale:
+        out["counters_stale"] = stale
+    elif pm and pm.get("SQ_INSTS_VALU"):
         out["achieved"] = pm["SQ_INSTS_VALU"] / (ms * 1e-3) / 1e9
         out["frac"] = out["achieved"] / peak
         out["valu_instructions_per_launch"] = pm["SQ_INSTS_VALU"]

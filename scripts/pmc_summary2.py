@@ -46,8 +46,11 @@ if stats:
         k = kname(r["Name"])
         if k in out:
             out[k]["avg_ns"] = float(r["AverageNs"]); out[k]["calls"] = int(r["Calls"])
+import hashlib
+csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mir_optim_amd", "csrc")
+sha = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest()[:16] for f in sorted(os.listdir(csrc)) if f.endswith((".h", ".hip", ".inc"))}
 json.dump({"note": "rocprofv3 --pmc, one counter set per pass (scripts/profile_any.sh); per-launch averages; hbm_bytes = (2 FETCH_SIZE + WRITE_SIZE) KB",
-           "source": src, "kernels": out}, open(os.path.join(dst, prefix + "_pmc.json"), "w"), indent=1)
+           "source": src, "csrc_sha16": sha, "kernels": out}, open(os.path.join(dst, prefix + "_pmc.json"), "w"), indent=1)
 for k in sorted(out, key=lambda k: -out[k].get("avg_ns", 0) * out[k].get("calls", 0))[:10]:
     d = out[k]
     print(f"{k[:58]:58s} {d.get('avg_ns', 0) / 1e3:9.1f} us  hbm {d.get('hbm_bytes_per_launch', 0) / 1e9:7.3f} GB  mfma {d.get('mfma_util', 0):.3f}  valu {d.get('valu_util', 0):.3f}")

@@ -386,6 +386,16 @@ def test_cfg2_gauss_sum_full_size_with_binding_width_bounds(oracle):
     assert on_gpu.sum() >= 4 and np.array_equal(on_gpu, on_cpu)
     assert np.allclose(x, xo, rtol=1e-6, atol=1e-9) and np.isclose(res.residual, ro.residual, rtol=1e-9)
     assert_traces_agree_until_noise(tr.records(), ev, min_passes=8)
+    # The run above passes trace=, which turns the pipelining of rounds off. The DEFAULT path of this small problem enqueues
+    # rounds ahead of time behind the device-side guard -- with BOXCQP active-set passes inside the speculative rounds: it must
+    # give the same bits and the same counters as VARIANT_NO_PIPELINE.
+    outs = []
+    for variant in (0, M.VARIANT_NO_PIPELINE):
+        s2 = M.Stats()
+        r2, x2 = prob.solve(x0, lower, upper, stats=s2, batched=True, variant=variant)
+        outs.append((x2.tobytes(), int(r2.status), r2.iterations, r2.fCalls, r2.residual, r2.lambda_, s2.passes, s2.accepted, s2.rejected,
+                     s2.qp_active_set_passes, s2.jacobian_full, s2.jacobian_broyden))
+    assert outs[0] == outs[1] and outs[0][9] >= 3
 
 
 def test_gauss_sum_batched_callback_equals_pointwise(oracle):
