@@ -513,8 +513,8 @@ __device__ __forceinline__ int posvx_device(int n, T* A, int lda, T* F, int ldf,
 template <typename T, int NB, bool BOUNDED = true>
 __device__ __forceinline__ int box_qp_device(int n, const T* Pm, const T* q, const T* l, const T* u, T* x,
                              bool unconstrainedSolution, T relTol, T absTol, uint32_t maxIterations,
-                             SolveScratch<T>& sc, T* F, int ldf, T* red, int* ired, int* iters, bool a_prefilled = false,
-                             const T* src0 = nullptr, T shift0 = T(0), bool* a_in_lds = nullptr)
+                             SolveScratch<T>& sc, T* F, int ldf, T* red, int* ired, int* iters, bool a_prefilled,
+                             const T* src0, T shift0, bool* a_in_lds, LdsPreload<T, (NB > 0 ? NB : 1)>& pre0, bool preloaded0)
 {
     const int tid = threadIdx.x;
     T* s = sc.vec;
@@ -533,7 +533,7 @@ __device__ __forceinline__ int box_qp_device(int n, const T* Pm, const T* q, con
         if (!unconstrainedSolution) {                               // QP:168-214
             T xi = 0;
             bool scaled = false;
-            const int info = posvx_lds<T, NB>(n, src0 ? src0 : Pm, n, shift0, tid < n ? -q[tid] : T(0), xi, F, red, ired + 8, sc.dbg, &scaled);
+            const int info = posvx_lds<T, NB>(n, src0 ? src0 : Pm, n, shift0, tid < n ? -q[tid] : T(0), xi, F, red, ired + 8, sc.dbg, &scaled, pre0, preloaded0);
             if (a_in_lds) *a_in_lds = !scaled;                      // the LDS copy of A is src0 + shift0 I, unscaled
             if (info != 0) return 1;                                // QP:212-213 (info == n+1 is never produced)
             if (tid < n) x[tid] = xi;
@@ -622,7 +622,7 @@ __device__ __forceinline__ int box_qp_device(int n, const T* Pm, const T* q, con
         if constexpr (NB > 0) {
             if (sN) {                                               // QP:307-325
                 T xi = 0;
-                const int info = posvx_lds<T, NB>(sN, sc.A, sN, T(0), tid < sN ? b[tid] : T(0), xi, F, red, ired + 8);
+                const int info = posvx_lds<T, NB>(sN, sc.A, sN, T(0), tid < sN ? b[tid] : T(0), xi, F, red, ired + 8, nullptr, nullptr, pre0, false);
                 if (info != 0) return 1;
                 if (tid < sN) sX[tid] = xi;
             }
@@ -680,6 +680,9 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
     if (a.guard && *a.guard == 0) return;
     MIRLSQ_STAMP(sc.dbg, 0);
     if (sc.dbg && threadIdx.x == 0) sc.dbg[9] = clock64();
+    // the LDS path: the loads of J^T J go out now and are collected inside ?posvx, behind this prologue (solve_lds.h)
+    LdsPreload<T, (NB > 0 ? NB : 1)> pre;
+    if constexpr (NB > 0) lds_load_issue<T, NB>(n, a.JJ, n, pre);
     T jy_inf = 0;
     if (a.check_grad) {
         jy_inf = block_max(tid < n ? dabs(a.Jy[tid]) : T(0), red);       // |Jy[iamax(Jy)]|, LS:1053
@@ -769,7 +772,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
     int qp_iters = 0;
     bool a_in_lds = false;
     const int qp = box_qp_device<T, NB, BOUNDED>(n, sc.Pm, a.Jy, qpl, qpu, xq, false, a.set.qpRelTolerance, a.set.qpAbsTolerance,
-                                          a.set.qpMaxIterations, sc, F, ldf, red, ired, &qp_iters, true, a.JJ, lambda, &a_in_lds);   // LS:1080
+                                          a.set.qpMaxIterations, sc, F, ldf, red, ired, &qp_iters, true, a.JJ, lambda, &a_in_lds,
+                                          pre, NB > 0);   // LS:1080
 
     MIRLSQ_STAMP(sc.dbg, 7);
     int flags = 0;
@@ -894,8 +898,9 @@ __global__ __launch_bounds__(kSolveThreads) void k_box_qp(BoxQpArgs<T> a)
     }
     __syncthreads();
     int it = 0;
+    LdsPreload<T, (NB > 0 ? NB : 1)> pre;
     const int st = box_qp_device<T, NB>(n, a.sc.Pm, a.q, a.l, a.u, a.x, a.unconstrained != 0, a.relTol, a.absTol,
-                                 a.maxIterations, a.sc, F, n | 1, red, ired, &it);
+                                 a.maxIterations, a.sc, F, n | 1, red, ired, &it, false, nullptr, T(0), nullptr, pre, false);
     if (threadIdx.x == 0) { a.out[0] = st; a.out[1] = it; }
 }
 

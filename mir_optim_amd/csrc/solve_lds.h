@@ -49,28 +49,46 @@ template <int NB> struct LdsSolveCfg {
 __device__ __forceinline__ int blk_off(int I, int J, int r, int c) { return (I * (I + 1) / 2 + J) * kLdsBlk + r + 17 * c; }
 
 // ---- load: L = A = src (+ shift on the diagonal), identity past n. src: n x n full symmetric, leading dimension ld.
+//      Two halves: lds_load_issue puts the global loads in flight (a thread's NBT = NB (NB + 1) / 2 values, one per block, and
+//      the diagonal entry of row tid), lds_load_commit adds the shift and writes the LDS blocks. k_lm_solve issues the loads
+//      of J^T J at kernel entry, BEFORE its prologue (|J^T y|_inf, lambda_0: dependent global loads and workgroup reductions of
+//      their own), so that the memory latency (J^T J was written by another kernel, on other XCDs: it comes from the memory
+//      side, not from this CU's L2) runs behind the prologue instead of being waited for inside ?posvx.
+template <typename T, int NB> struct LdsPreload {
+    T v[LdsSolveCfg<NB>::NBT];
+    T diag;                                                  // src[tid][tid] (tid < n), unshifted
+};
 template <typename T, int NB>
-__device__ __forceinline__ void lds_load_blocks(int n, const T* __restrict__ src, int ld, T shift, T* smem)
+__device__ __forceinline__ void lds_load_issue(int n, const T* __restrict__ src, int ld, LdsPreload<T, NB>& p)
 {
-    using C = LdsSolveCfg<NB>;
     const int c = threadIdx.x & 15, r = threadIdx.x >> 4;      // lanes along a row of src: coalesced reads
-    T v[C::NBT];
 #pragma unroll
     for (int I = 0; I < NB; ++I)
 #pragma unroll
         for (int J = 0; J <= I; ++J) {
             const int gi = 16 * I + r, gj = 16 * J + c;
             const bool in = gi < n && gj < n;
-            const T t = src[(size_t)(in ? gi : 0) * ld + (in ? gj : 0)];
-            v[I * (I + 1) / 2 + J] = in ? (gi == gj ? t + shift : t) : (gi == gj ? T(1) : T(0));
+            p.v[I * (I + 1) / 2 + J] = src[(size_t)(in ? gi : 0) * ld + (in ? gj : 0)];
         }
+    const int t = (int)threadIdx.x < n ? (int)threadIdx.x : 0;
+    p.diag = src[(size_t)t * ld + t];
+}
+template <typename T, int NB>
+__device__ __forceinline__ void lds_load_commit(int n, const LdsPreload<T, NB>& p, T shift, T* smem)
+{
+    using C = LdsSolveCfg<NB>;
+    const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
 #pragma unroll
     for (int I = 0; I < NB; ++I)
 #pragma unroll
         for (int J = 0; J <= I; ++J) {
+            const int gi = 16 * I + r, gj = 16 * J + c;
+            const bool in = gi < n && gj < n;
+            const T t = p.v[I * (I + 1) / 2 + J];
+            const T v = in ? (gi == gj ? t + shift : t) : (gi == gj ? T(1) : T(0));
             const int o = blk_off(I, J, r, c);
-            smem[C::L_OFF + o] = v[I * (I + 1) / 2 + J];
-            smem[C::A_OFF + o] = v[I * (I + 1) / 2 + J];
+            smem[C::L_OFF + o] = v;
+            smem[C::A_OFF + o] = v;
         }
     if (threadIdx.x == 0) smem[C::ZERO_OFF] = T(0);
 }
@@ -79,8 +97,12 @@ __device__ __forceinline__ void lds_load_blocks(int n, const T* __restrict__ src
 constexpr int kInfoBase = 0x40000000;                      // *info_s = kInfoBase - (first bad pivot, 1-based), 0 = none
 
 template <typename T, int NB>
-__device__ __forceinline__ int lds_potrf(int n, T* smem, int* info_s)
+__device__ __forceinline__ int lds_potrf(int n, T* smem, int* info_s, long long* dbg = nullptr)
 {
+    // MIR_LSQ_VARIANT_DEBUG_SOLVE: shader-clock cycles of thread 0 (wave 0 = the critical chain), summed over the panels:
+    // dbg[20] diagonal update + factorisation, [21] wait at the barrier behind it, [22] rows below, [23] wait behind them
+    long long ph[5] = {0, 0, 0, 0, 0};
+#define MIRLSQ_PH(k_) do { if (dbg && threadIdx.x == 0) { const long long t_ = clock64(); ph[k_] += t_ - ph[4]; ph[4] = t_; } } while (0)
     using C = LdsSolveCfg<NB>;
     using Acc = typename Mma<T>::Acc;
     T* L = smem + C::L_OFF;
@@ -99,6 +121,15 @@ __device__ __forceinline__ int lds_potrf(int n, T* smem, int* info_s)
         const int i = lane & 15, g = lane >> 4;
         const int r = Mma<T>::perm(i);                       // the matrix row of this lane
         int bad = 0;
+        // The IDENTITY rides along as a second block in the same layout (lane (i, g), register q: X[perm(i)][4 g + q]): the column
+        // operations that turn A_kk into L_kk turn it into X = inv(L_kk)^T (A L^-T = L, I L^-T = L^-T; upper triangular, its
+        // diagonal the reciprocal pivots). One more multiply / FMA per column operation and one more MFMA per four-column
+        // panel on this wave's chain (+0.3 us a block) buy (a) the inverses of the diagonal blocks that ?potrs needs -- a pass
+        // of their own before (2.5 us at n = 128) -- and (b) the rows below the diagonal block as a matrix product
+        // L_Ik = A_Ik X on the matrix cores instead of one forward substitution per thread (step (2) below).
+        Acc inv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) inv[q] = (r == 4 * g + q) ? T(1) : T(0);
         static_for<4>([&](auto jj) {
             constexpr int jb = decltype(jj)::value;
             if (g == jb) {
@@ -110,26 +141,31 @@ __device__ __forceinline__ int lds_potrf(int n, T* smem, int* info_s)
                     T rinv, d;
                     rsqrt_sqrt(piv > 0 ? piv : T(1), rinv, d);
                     acc[t] = r > c ? acc[t] * rinv : (r == c ? d : acc[t]);
+                    inv[t] = inv[t] * rinv;
                     if (r == c) rd[16 * k + c] = rinv;
                     static_for<4>([&](auto uu) {
                         constexpr int t2 = decltype(uu)::value;
                         if constexpr (t2 > t) {
                             const T l = dpp_row_bcast<Mma<T>::perm(4 * jb + t2)>(acc[t]);   // L[c2][c]
                             acc[t2] -= acc[t] * l;           // rows <= c: entries above the diagonal, which nothing reads
+                            inv[t2] -= inv[t] * l;
                         }
                     });
                 });
             }
             if constexpr (jb < 3) {
                 const T x = group_pick<jb>(acc[0], acc[1], acc[2], acc[3]);      // lane (i, t) <- L[perm(i)][4 jb + t]
+                const T xb = group_pick<jb>(inv[0], inv[1], inv[2], inv[3]);     // lane (i, t) <- X[perm(i)][4 jb + t]
                 const T v = r > 4 * jb + 3 ? x : T(0);       // columns up to this panel are final: their operand is zero
                 acc = Mma<T>::mma(-v, v, acc);               // A[r][c] -= sum_t L[r][4 jb + t] L[c][4 jb + t],  r, c > 4 jb + 3
+                inv = Mma<T>::mma(-v, xb, inv);              // X[r][c] -= sum_t X[r][4 jb + t] L[c][4 jb + t],  c > 4 jb + 3
             }
         });
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int c = 4 * g + q;
             if (c <= r) L[blk_off(k, k, r, c)] = acc[q];
+            else L[blk_off(k, k, r, c)] = inv[q];            // X(r, c) = inv(L_kk)(c, r), r < c: the unused upper triangle
         }
         // the first bad pivot (?potrf's info): groups see different pivots, keep the smallest index. Encoded so that 0 = none.
         if (bad != 0 && i == 0) atomicMax(info_s, kInfoBase - bad);
@@ -178,29 +214,51 @@ __device__ __forceinline__ int lds_potrf(int n, T* smem, int* info_s)
     // Look-ahead: wave 0 brings block (k + 1, k + 1) up to date and factors it WHILE waves 1..3 apply panel k to the rest of
     // the trailing matrix -- the serial 16-pivot factorisation (~1.9 us) was a third of a panel step with three idle waves.
     __syncthreads();                                         // the blocks are loaded
+    if (dbg && threadIdx.x == 0) ph[4] = clock64();
     if (wave == 0) factor_diag(0, load_diag(0));
+    MIRLSQ_PH(0);
     for (int k = 0; k < nbl; ++k) {
         __syncthreads();                                     // block (k, k) is factored; column k carries every earlier update
+        MIRLSQ_PH(1);
         if (*info_s != 0) return kInfoBase - *info_s;        // uniform
         if (k + 1 >= nbl) break;
-        // ---- (2) rows below the diagonal block against L_kk: one thread per row
-        if (tid < 16 * (nbl - 1 - k)) {
-            const int i = 16 * (k + 1) + tid, I = i >> 4, r = i & 15;
-            T p[16];
+        // ---- (2) rows below the diagonal block: L_Ik = A_Ik X, X = inv(L_kk)^T (upper triangle of block (k, k), its diagonal
+        //      in rd), on the matrix cores: block I of wave w = (I - k - 1) mod 4, two blocks (two MFMA chains) a wave at a time.
+        //      (Before: one forward substitution per row and thread, 120 dependent FMAs: 1.2 us of every panel step's 4.1.)
+        {
+            constexpr int roff = C::RD_OFF - C::L_OFF, zoff2 = C::ZERO_OFF - C::L_OFF;
+            const int lr = lane & 15, lk = lane >> 4;
+            T xb[4];                                          // B operand: X[4 s + lk][lr]
 #pragma unroll
-            for (int c = 0; c < 16; ++c) p[c] = L[blk_off(I, k, r, c)];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                T v = p[c];
-#pragma unroll
-                for (int t = 0; t < 16; ++t)
-                    if (t < c) v -= p[t] * L[blk_off(k, k, c, t)];       // same address in every lane: LDS broadcast
-                p[c] = v * rd[16 * k + c];
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int kk = 4 * s4 + lk;
+                xb[s4] = L[kk < lr ? blk_off(k, k, kk, lr) : (kk == lr ? roff + 16 * k + kk : zoff2)];
             }
+            for (int I0 = k + 1 + wave; I0 < nbl; I0 += 8) {
+                const int I1 = I0 + 4;
+                const bool two = I1 < nbl;
+                T a0[4], a1[4];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) L[blk_off(I, k, r, c)] = p[c];
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    a0[s4] = L[blk_off(I0, k, lr, 4 * s4 + lk)];
+                    a1[s4] = L[blk_off(two ? I1 : I0, k, lr, 4 * s4 + lk)];
+                }
+                Acc d0 = Acc{0, 0, 0, 0}, d1 = Acc{0, 0, 0, 0};
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    d0 = Mma<T>::mma(a0[s4], xb[s4], d0);
+                    d1 = Mma<T>::mma(a1[s4], xb[s4], d1);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    L[blk_off(I0, k, Mma<T>::row(lane, q), lr)] = d0[q];
+                    if (two) L[blk_off(I1, k, Mma<T>::row(lane, q), lr)] = d1[q];
+                }
+            }
         }
+        MIRLSQ_PH(2);
         __syncthreads();
+        MIRLSQ_PH(3);
         // ---- (3) + (1) of the next panel
         {
             const int rem = nbl - 1 - k, cnt = rem * (rem + 1) / 2;
@@ -240,45 +298,11 @@ __device__ __forceinline__ int lds_potrf(int n, T* smem, int* info_s)
                 }
             }
         }
+        MIRLSQ_PH(0);
     }
-    __syncthreads();
-    // ---- inverses of the diagonal blocks, stored TRANSPOSED in the unused upper triangles: inv(r, c), r > c, at (c, r).
-    //      Both forms do the same operations in the same order (bitwise the same inverse).
-    if (nbl <= 3) {
-        // few blocks: all 16 columns of a block at once, 16 lanes per column (lane r holds x_r of its column c): right-looking
-        // forward substitution, step q broadcasts the finished x_q inside the 16-lane group (DPP) and every later row
-        // subtracts L(r, q) x_q -- 0.6 us per block (n = 16: the factorisation 5.3 -> 3.4 us)
-        const int c = tid >> 4, r = tid & 15;
-        constexpr int zoff = C::ZERO_OFF - C::L_OFF;
-        for (int k = 0; k < nbl; ++k) {
-            T lrow[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) lrow[q] = L[q < r ? blk_off(k, k, r, q) : zoff];   // only the lower triangle is read
-            const T ri = rd[16 * k + r];
-            T v = r == c ? T(1) : T(0);
-            static_for<16>([&](auto qq) {
-                constexpr int q = decltype(qq)::value;
-                if (r == q) v *= ri;
-                const T xq = dpp_row_bcast<q>(v);
-                if (r > q) v -= lrow[q] * xq;
-            });
-            if (r > c) L[blk_off(k, k, c, r)] = v;
-        }
-    } else if (tid < 16 * nbl) {
-        // many blocks: thread (k, c) forms column c of inv(L_kk) on its own, all blocks in parallel (2.5 us, any n)
-        const int k = tid >> 4, c = tid & 15;
-        T x[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            T s = 0;
-#pragma unroll
-            for (int q = 0; q < 16; ++q)
-                if (q < r) s -= L[blk_off(k, k, r, q)] * x[q];
-            x[r] = r < c ? T(0) : (r == c ? rd[16 * k + r] : s * rd[16 * k + r]);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) if (r > c) L[blk_off(k, k, c, r)] = x[r];
-    }
+    if (dbg && threadIdx.x == 0) { dbg[20] = ph[0]; dbg[21] = ph[1]; dbg[22] = ph[2]; dbg[23] = ph[3]; }
+#undef MIRLSQ_PH
+    // (the inverses of the diagonal blocks sit, transposed, in the unused upper triangles: factor_diag put them there)
     __syncthreads();
     return 0;
 }
@@ -510,7 +534,7 @@ __device__ __forceinline__ void lds_residual(int n, T* smem, T bi, T xi, T& ri, 
 // LS:1079). Thread tid < n passes its right-hand-side entry bi and receives its solution entry in xi. Returns info.
 template <typename T, int NB>
 __device__ __forceinline__ int posvx_lds(int n, const T* src, int ld, T shift, T bi, T& xi, T* smem, T* red, int* info_s,
-                                         long long* dbg = nullptr, bool* scaled = nullptr)
+                                         long long* dbg, bool* scaled, LdsPreload<T, NB>& pre, bool preloaded)
 {
     using C = LdsSolveCfg<NB>;
     const int tid = threadIdx.x;
@@ -518,13 +542,23 @@ __device__ __forceinline__ int posvx_lds(int n, const T* src, int ld, T shift, T
     const T safmin = Lim<T>::min_normal;        // dlamch('Safe minimum')
     T* zv = smem + C::ZV_OFF;
     MIRLSQ_STAMP(dbg, 2);
-    lds_load_blocks<T, NB>(n, src, ld, shift, smem);
-    __syncthreads();
-
-    // ?poequ / ?laqsy
-    const T di = tid < n ? smem[C::A_OFF + blk_off(tid >> 4, tid >> 4, tid & 15, tid & 15)] : T(0);
-    const T smin = block_min(tid < n ? di : Lim<T>::inf(), red);
-    const T amax = block_max(tid < n ? di : -Lim<T>::inf(), red);
+    if (!preloaded) lds_load_issue<T, NB>(n, src, ld, pre);     // (`pre` by reference, never through a pointer: the values stay in registers)
+    // ?poequ / ?laqsy. The diagonal comes straight from the loaded values (the sum the LDS copy holds: t + shift), its minimum
+    // and maximum in ONE workgroup reduction; the LDS blocks are written between the reduction's two barriers
+    const T di = tid < n ? pre.diag + shift : T(0);
+    if (dbg && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg[24] = wall_clock64(); }   // every load has landed
+    T smin, amax;
+    {
+        const T mn = wave_min(tid < n ? di : Lim<T>::inf()), mx = wave_max(tid < n ? di : -Lim<T>::inf());
+        __syncthreads();                                       // red / the LDS blocks may still be read by the previous user
+        if ((tid & 63) == 0) { red[tid >> 6] = mn; red[4 + (tid >> 6)] = mx; }
+        lds_load_commit<T, NB>(n, pre, shift, smem);
+        __syncthreads();
+        smin = red[0]; amax = red[4];
+#pragma unroll
+        for (int w = 1; w < kSolveThreads / kWave; ++w) { smin = red[w] < smin ? red[w] : smin; amax = red[4 + w] > amax ? red[4 + w] : amax; }
+    }
+    MIRLSQ_STAMP(dbg, 25);
     bool rcequ = false;
     T si = 1;
     if (smin > 0) {
@@ -553,7 +587,7 @@ __device__ __forceinline__ int posvx_lds(int n, const T* src, int ld, T shift, T
     }
     MIRLSQ_STAMP(dbg, 3);
 
-    const int info = lds_potrf<T, NB>(n, smem, info_s);
+    const int info = lds_potrf<T, NB>(n, smem, info_s, dbg);
     if (info != 0) return info;
     MIRLSQ_STAMP(dbg, 4);
 
@@ -568,6 +602,7 @@ __device__ __forceinline__ int posvx_lds(int n, const T* src, int ld, T shift, T
         T ri, wi;
         lds_residual<T, NB>(n, smem, bi, x, ri, wi);
         if (count == 1) MIRLSQ_STAMP(dbg, 11);
+        if (count == 2) MIRLSQ_STAMP(dbg, 14);
         T qv = 0;
         if (tid < n) qv = (wi > safe2) ? dabs(ri) / wi : (dabs(ri) + safe1) / (wi + safe1);
         const T berr = block_max(qv, red);
@@ -575,6 +610,7 @@ __device__ __forceinline__ int posvx_lds(int n, const T* src, int ld, T shift, T
         if (berr > eps && 2 * berr <= lstres && count <= 5) {
             T dz = tid < n ? ri : T(0);
             dz = lds_potrs<T, NB>(n, smem, dz);
+            if (count == 1) MIRLSQ_STAMP(dbg, 13);
             x += dz;
             lstres = berr;
             continue;
@@ -582,6 +618,7 @@ __device__ __forceinline__ int posvx_lds(int n, const T* src, int ld, T shift, T
         break;
     }
     xi = rcequ ? si * x : x;
+    if (dbg && threadIdx.x == 0) dbg[15] = lstres == T(3) ? 0 : 1;     // was a correction applied?
     MIRLSQ_STAMP(dbg, 6);
     return 0;
 }

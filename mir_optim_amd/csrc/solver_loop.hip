@@ -498,6 +498,14 @@ typename Solver<T>::Result Solver<T>::run()
             if (hipMemcpy(h, B.sc[0].dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
                 std::fprintf(stderr, "[solve dbg] (10ns ticks) build %lld  copy/equil %lld  scale %lld  potrf %lld  potrs %lld  refine %lld  epilogue %lld  total %lld  shader MHz %.0f  [matvec1 %lld berr %lld]\n",
                              h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[8] - h[7], h[8] - h[0], (double)(h[10] - h[9]) / (double)(h[8] - h[0]) * 100.0, h[11] - h[5], h[12] - h[11]);
+                if (n <= 128)
+                    std::fprintf(stderr, "[solve dbg] load (10ns ticks): kernel entry -> loads landed %lld (of which inside posvx %lld)  reduction + LDS commit %lld  rest of the phase %lld\n",
+                                 h[24] - h[0], h[24] - h[2], h[25] - h[24], h[3] - h[25]);
+                if (n <= 128)
+                    std::fprintf(stderr, "[solve dbg] refinement (10ns ticks): residual 1 %lld  berr 1 %lld  potrs 2 %lld  residual 2 %lld  rest %lld  (correction applied: %lld)\n",
+                                 h[11] - h[5], h[12] - h[11], h[13] - h[12], h[14] - h[13], h[6] - h[14], h[15]);
+                if (n <= 128)
+                    std::fprintf(stderr, "[solve dbg] lds_potrf, wave 0 (shader cycles, summed over the panels): diagonal update + factor %lld  wait %lld  rows below %lld  wait %lld\n", h[20], h[21], h[22], h[23]);
                 if (n > 128 && n <= (uint32_t)kSolveMaxN)
                     std::fprintf(stderr, "[solve dbg] potrf_panel steps (10ns ticks, summed over the panels): earlier panels on MFMA %lld  diagonal rows %lld  other rows + store %lld\n", h[16], h[17], h[18]);
             }
