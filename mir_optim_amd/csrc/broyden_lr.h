@@ -85,45 +85,62 @@ __global__ __launch_bounds__(256, (NCP <= 4 ? 4 : 1)) void k_broyden_lr(const Lr
     const size_t per = (G + nw - 1) / nw;
     const size_t gb = wid * per;
     const size_t ge = gb + per < G ? gb + per : G;
-    for (size_t g = gb; g < ge; ++g) {
-        const size_t row = 4 * g + q;
-        const bool rok = row < m;
-        const size_t rr = rok ? row : m - 1;
-        const T* __restrict__ rp = a.J + rr * (size_t)n;
-        T v0[NCP], v1[NCP];
+    // UNR row groups per trip: their loads are issued together, then the groups are taken in order (the same per-lane order of
+    // sums as one group per trip: same bits). Narrow problems (n <= 64: one or two 16-byte loads a lane and group) are small
+    // in bytes as well -- cfg 2's J is 12.8 MB, 8 groups a wave -- and ran at one memory latency PER GROUP (12 us for a 2 us
+    // sweep); n = 128 and above keep one group per trip (HBM-bound at 0.73-0.78 of the peak, four workgroups a CU by registers).
+    constexpr int UNR = NCP == 1 ? 4 : (NCP == 2 ? 2 : 1);
+    for (size_t g0 = gb; g0 < ge; g0 += UNR) {
+        T v0[UNR][NCP], v1[UNR][NCP], ynv[UNR], yov[UNR], ulv[UNR];
 #pragma unroll
-        for (int c = 0; c < NCP; ++c) {
-            if constexpr (VEC) {
-                typedef T lr_v2 __attribute__((ext_vector_type(2)));
-                const lr_v2 t = __builtin_nontemporal_load(reinterpret_cast<const lr_v2*>(rp + coff[c]));   // J is swept once per pass and is larger than the Infinity Cache
-                v0[c] = t.x;
-                v1[c] = t.y;
-            } else {
-                v0[c] = rp[coff[c]];
-                v1[c] = rp[ok1[c] ? coff[c] + 1 : 0];
+        for (int e = 0; e < UNR; ++e) {
+            const size_t g = g0 + e < ge ? g0 + e : ge - 1;    // (a trip's spare slots re-read the last group: valid addresses)
+            const size_t row = 4 * g + q;
+            const size_t rr = row < m ? row : m - 1;
+            const T* __restrict__ rp = a.J + rr * (size_t)n;
+#pragma unroll
+            for (int c = 0; c < NCP; ++c) {
+                if constexpr (VEC) {
+                    typedef T lr_v2 __attribute__((ext_vector_type(2)));
+                    const lr_v2 t = __builtin_nontemporal_load(reinterpret_cast<const lr_v2*>(rp + coff[c]));   // J is swept once per pass and is larger than the Infinity Cache
+                    v0[e][c] = t.x;
+                    v1[e][c] = t.y;
+                } else {
+                    v0[e][c] = rp[coff[c]];
+                    v1[e][c] = rp[ok1[c] ? coff[c] + 1 : 0];
+                }
+            }
+            ynv[e] = a.y[rr];
+            yov[e] = a.y_old[rr];
+            ulv[e] = own ? Up[rr] : T(0);
+        }
+#pragma unroll
+        for (int e = 0; e < UNR; ++e) {
+            if (g0 + e < ge) {
+                const size_t row = 4 * (g0 + e) + q;
+                const bool rok = row < m;
+                T yn = ynv[e];
+                const T yo = yov[e], ul = ulv[e];
+                T s = ul * cp;
+#pragma unroll
+                for (int c = 0; c < NCP; ++c) s += v0[e][c] * d0[c] + v1[e][c] * d1[c];
+                s = sum16(s);
+                T u = nd * ((yo - yn) + s);                        // LS:1003-1005: axpy(-1, y, mBuffer); gemv; scal(-d)
+                if (!rok) { u = 0; yn = 0; }
+                if (rok && p == 0) Uk[row] = u;
+#pragma unroll
+                for (int c = 0; c < NCP; ++c) {
+                    va0[c] += v0[e][c] * u;
+                    va1[c] += v1[e][c] * u;
+                    ga0[c] += v0[e][c] * yn;
+                    ga1[c] += v1[e][c] * yn;
+                }
+                wl += ul * u;
+                hl += ul * yn;
+                uu += u * u;
+                uy += u * yn;
             }
         }
-        T yn = a.y[rr];
-        const T yo = a.y_old[rr];
-        const T ul = own ? Up[rr] : T(0);
-        T s = ul * cp;
-#pragma unroll
-        for (int c = 0; c < NCP; ++c) s += v0[c] * d0[c] + v1[c] * d1[c];
-        s = sum16(s);
-        T u = nd * ((yo - yn) + s);                        // LS:1003-1005: axpy(-1, y, mBuffer); gemv; scal(-d)
-        if (!rok) { u = 0; yn = 0; }
-        if (rok && p == 0) Uk[row] = u;
-#pragma unroll
-        for (int c = 0; c < NCP; ++c) {
-            va0[c] += v0[c] * u;
-            va1[c] += v1[c] * u;
-            ga0[c] += v0[c] * yn;
-            ga1[c] += v1[c] * yn;
-        }
-        wl += ul * u;
-        hl += ul * yn;
-        uu += u * u;
-        uy += u * yn;
     }
 
     // the four row groups of the wave, then the four waves of the block, in a fixed order
