@@ -591,31 +591,32 @@ __device__ __forceinline__ int posvx_lds(int n, const T* src, int ld, T shift, T
     if (info != 0) return info;
     MIRLSQ_STAMP(dbg, 4);
 
-    T x = tid < n ? bi : T(0);
-    x = lds_potrs<T, NB>(n, smem, x);
-    MIRLSQ_STAMP(dbg, 5);
-
-    // ?porfs: iterative refinement, ITMAX = 5
+    // ?potrs, then ?porfs (iterative refinement, ITMAX = 5): ONE call site of the triangular solves and of the residual -- round 0
+    // solves for x, round c > 0 for the correction of the residual that round c - 1 left (two inlined copies of the unrolled
+    // ?potrs were 15 KB of a 66 KB kernel: more than the instruction cache holds).
+    // (Round 4 also built the residual of round c STREAMED under the backward sweep of its ?potrs -- waves 1, 2 one row each,
+    // taking a block of x the moment wave 0 published it behind an LDS flag. Correct, and 0.25 us faster per round, not 1.6:
+    // one thread a row needs 0.49 us per 16-column block where a sweep step takes 0.26, so the stream finished 1.75 us after
+    // the sweep; the two-threads-a-row residual below does the same work in 2.0 us on four waves. Not kept.)
     const T safe1 = T(n + 1) * safmin, safe2 = safe1 / eps;
     T lstres = 3;
-    for (int count = 1;; ++count) {
+    T x = 0, zin = tid < n ? bi : T(0);
+    for (int count = 0;; ++count) {
+        const T dz = lds_potrs<T, NB>(n, smem, zin);
+        x = count == 0 ? dz : x + dz;
+        if (count == 0) MIRLSQ_STAMP(dbg, 5);
+        if (count == 1) MIRLSQ_STAMP(dbg, 13);
         T ri, wi;
         lds_residual<T, NB>(n, smem, bi, x, ri, wi);
-        if (count == 1) MIRLSQ_STAMP(dbg, 11);
-        if (count == 2) MIRLSQ_STAMP(dbg, 14);
+        if (count == 0) MIRLSQ_STAMP(dbg, 11);
+        if (count == 1) MIRLSQ_STAMP(dbg, 14);
         T qv = 0;
         if (tid < n) qv = (wi > safe2) ? dabs(ri) / wi : (dabs(ri) + safe1) / (wi + safe1);
         const T berr = block_max(qv, red);
-        if (count == 1) MIRLSQ_STAMP(dbg, 12);
-        if (berr > eps && 2 * berr <= lstres && count <= 5) {
-            T dz = tid < n ? ri : T(0);
-            dz = lds_potrs<T, NB>(n, smem, dz);
-            if (count == 1) MIRLSQ_STAMP(dbg, 13);
-            x += dz;
-            lstres = berr;
-            continue;
-        }
-        break;
+        if (count == 0) MIRLSQ_STAMP(dbg, 12);
+        if (!(berr > eps && 2 * berr <= lstres && count + 1 <= 5)) break;
+        lstres = berr;
+        zin = tid < n ? ri : T(0);
     }
     xi = rcequ ? si * x : x;
     if (dbg && threadIdx.x == 0) dbg[15] = lstres == T(3) ? 0 : 1;     // was a correction applied?
