@@ -93,7 +93,8 @@ bool Solver<T>::setup()
     // Rounds enqueued ahead of time: measured on one MI355X they do not pay at cfg 3 (7.08 ms per solve with, 7.02 without: the
     // stream is busy > 97 % of a solve anyway) but do for SMALL problems (J up to 32 MB: every kernel of a round is a few
     // microseconds and the host's decision latency is a visible share of it): cfg 2 63.5 -> 61.8 us per round. So: on for
-    // those, MIR_LSQ_VARIANT_NO_PIPELINE turns it off.
+    // those, MIR_LSQ_VARIANT_NO_PIPELINE turns it off. (Re-measured in round 4 with the threshold at 1 GB: cfg 3 1001 / 1002 it/s
+    // with, 1020 / 1009 without; a strong-scaled rank's 125 000 x 128 on the global trajectory 1.365 vs 1.375 ms: still nothing.)
     const bool small_problem = (double)m * (double)n * sizeof(T) <= 32.0 * 1024 * 1024;
     pipeline = device_cb && lowrank && !big_solve && !trace && !dbg_solve
         && small_problem && !(variant & MIR_LSQ_VARIANT_NO_PIPELINE)
@@ -350,6 +351,9 @@ template <typename T>
 void Solver<T>::drop_spec_round()
 {
     for (size_t i = spec_events_from; i < events.size(); ++i) if (events[i].kind >= 100) events[i].kind = -1;
+    // a replay communicator has already handed out the recorded total of the dropped round's one exchange (the sweep vector;
+    // the guarded kernels behind it did not run): put it back on the tape
+    if (comm && comm->kind == 4) comm->replay_pos -= (size_t)lr_len((int)n);
 }
 
 template <typename T>
