@@ -17,9 +17,10 @@ for name, model, maker, n in (("EXP_DECAY n=3", M.MODEL_EXP_DECAY, T.make_exp_de
     dlo = api.DeviceBuffer(np.full(n, -np.inf, dtype=np.float32)); dup = api.DeviceBuffer(np.full(n, np.inf, dtype=np.float32))
     dres = api.DeviceBuffer(nbytes=count * 24, dtype=np.uint8, shape=(count * 24,))
     st = api.Stream()
+    opt = api.BatchedOptions(stream=st.handle)
     def step():
         L.mir_lsq_memcpy_d2d(dx.ptr, dx0.ptr, count * n * 4, st.handle)
-        assert L.mir_lsq_batched_kernel_s(C.byref(s), count, m, model, dx.ptr, dlo.ptr, dup.ptr, dt_.ptr, 0, dd.ptr, dres.ptr, st.handle) == 0
+        assert L.mir_lsq_batched_kernel_s(C.byref(s), count, m, model, dx.ptr, dlo.ptr, dup.ptr, dt_.ptr, 0, dd.ptr, dres.ptr, C.byref(opt)) == 0
     for _ in range(3): step()
     st.synchronize()
     t0 = time.perf_counter()

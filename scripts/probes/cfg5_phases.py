@@ -25,14 +25,13 @@ dt_, dd, dx = api.DeviceBuffer(t), api.DeviceBuffer(data), api.DeviceBuffer(x0)
 dlo = api.DeviceBuffer(np.full(n, -np.inf, dtype=np.float32)); dup = api.DeviceBuffer(np.full(n, np.inf, dtype=np.float32))
 dres = api.DeviceBuffer(nbytes=count * 24, dtype=np.uint8, shape=(count * 24,))
 st = api.Stream()
+dtm = api.DeviceBuffer(np.zeros((count, 10), dtype=np.uint64))      # mir_lsq_batched_options.timing: 10 counters per problem
+opt = api.BatchedOptions(stream=st.handle, timing=dtm.ptr)
 for rep in range(2):
     dx.upload(x0)
-    assert L.mir_lsq_batched_kernel_s(C.byref(s), count, m, M.MODEL_EXP_DECAY_PAD8, dx.ptr, dlo.ptr, dup.ptr, dt_.ptr, 0, dd.ptr, dres.ptr, st.handle) == 0
+    assert L.mir_lsq_batched_kernel_s(C.byref(s), count, m, M.MODEL_EXP_DECAY_PAD8, dx.ptr, dlo.ptr, dup.ptr, dt_.ptr, 0, dd.ptr, dres.ptr, C.byref(opt)) == 0
     st.synchronize()
-tm = np.zeros((count, 10), dtype=np.uint64)
-L.mir_lsq_batched_timing.argtypes = [C.c_void_p, C.c_size_t]
-assert L.mir_lsq_batched_timing(tm.ctypes.data, count) == 0
-tm = tm.astype(np.float64)
+tm = dtm.download().reshape(count, 10).astype(np.float64)
 names = ["residual evaluations", "Jacobian refresh (FD / Broyden)", "J^T J, J^T y + reductions", "damped solves", "whole fit"]
 tot = tm[:, 4]
 print("s_memtime ticks (shader clock); mean per fit, share of the fit")
