@@ -26,7 +26,7 @@ solves. Inputs are resident in HBM before the timed region.
 The JSON line also carries
   roofline       the LIBRARY kernel with the most time in the timed region, HIP-event timed on the solver's stream
   broyden_kernel / jtj_kernel   the other one of the two hot library kernels
-  residual_gemm, trial_residual the CALLER-side device callbacks (the synthetic workload's kernels, csrc/workloads.hip),
+  residual_gemm, trial_residual the CALLER-side device callbacks (the synthetic workload's kernels, csrc/workloads.hip + workloads_gemm.hip),
                                 event-timed on the same stream: they are most of a solve and get their own roofline objects
   solve_kernel   the one-workgroup n x n kernel (latency-bound; time only)
   cpu_baseline   the oracle (CPU port of the reference algorithm, OpenBLAS for syrk/gemv/ger/posvx) on a bounded sample of

@@ -21,6 +21,7 @@ WORKLOADS_LIB = os.path.join(LIBDIR, "libmir_optim_amd_workloads.so")
 
 SOLVER_UNITS = ["abi.hip", "workspace.hip", "solver_loop.hip", "solver_jacobian.hip", "launch_jtj.hip", "launch_broyden.hip",
                 "launch_solve_d.hip", "launch_solve_s.hip", "batched.hip", "comm.hip", "unit_entries.hip", "fit_spline.cpp"]
+WORKLOAD_UNITS = ["workloads.hip", "workloads_gemm.hip"]
 
 _FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("MIR_OPTIM_AMD_CXXFLAGS", "").split()
 
@@ -48,7 +49,7 @@ def _run(cmd, verbose):
 def build(force=False, verbose=False, jobs=None):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc")) and not f.startswith("workloads_")]
     inc = os.path.join(os.path.dirname(HERE), "include")
     hdrs += [os.path.join(inc, f) for f in os.listdir(inc)]
     # the flags are part of what an object depends on (a profiling build must not reuse the product objects)
@@ -69,9 +70,20 @@ def build(force=False, verbose=False, jobs=None):
         open(stamp, "w").write(" ".join(_FLAGS))
     if force or todo or _stale(SOLVER_LIB, objs):
         _run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SOLVER_LIB] + objs + ["-ldl"], verbose)
-    wsrc = os.path.join(CSRC, "workloads.hip")
-    if force or _stale(WORKLOADS_LIB, [wsrc]):
-        _run([_hipcc()] + _FLAGS + ["-shared", "-o", WORKLOADS_LIB, wsrc, "-fopenmp"], verbose)   # host-side data generation / host residual
+    # the caller side: residual kernels of the synthetic workloads (two units: the C entries + small kernels, the batched GEMM)
+    wobjs, wtodo = [], []
+    whdrs = [os.path.join(CSRC, f) for f in ("workloads_device.h", "workloads_gemm.h")]
+    for u in WORKLOAD_UNITS:
+        src = os.path.join(CSRC, u)
+        obj = os.path.join(OBJDIR, os.path.splitext(u)[0] + ".o")
+        wobjs.append(obj)
+        if force or _stale(obj, [src] + whdrs):
+            wtodo.append([_hipcc()] + _FLAGS + ["-fopenmp", "-c", src, "-o", obj])   # OpenMP: host-side data generation / host residual
+    if wtodo:
+        with ThreadPoolExecutor(max_workers=2) as ex:
+            list(ex.map(lambda c: _run(c, verbose), wtodo))
+    if force or wtodo or _stale(WORKLOADS_LIB, wobjs):
+        _run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fopenmp", "-o", WORKLOADS_LIB] + wobjs, verbose)
     return SOLVER_LIB, WORKLOADS_LIB
 
 
