@@ -164,33 +164,50 @@ __device__ __noinline__ int potrf_panel(int n, const T* A_, int lda, T* F_, int 
                 live[u] = rb >= k && 16 * rb < n;               // wave-uniform
             }
             const int rowb = c0 + lr < n ? c0 + lr : n - 1;
-            T fa[2][4][4], fb[2][4];                            // [buffer][k-step][row block]
-            auto load = [&](int j, int buf) {
+            // Ring of three register buffers: the fragments of TWO earlier panels in flight beyond the one on the matrix cores.
+            // The loads of a panel are issued unconditionally -- a count the compiler can keep in vmcnt; with `if (live[u])` around
+            // them it cannot know how many are in flight and waits for all of them before each batch of MFMAs -- so the loop is
+            // compiled once per first live block UMIN (this wave's blocks UMIN .. 3 reach into the panel; blocks past n read
+            // their clamped rows for nothing): no load is issued for a block above the panel.
+            constexpr int kAheadF = 2, kRingF = kAheadF + 1;
+            auto sweep = [&](auto UMIN_) {
+                constexpr int UMIN = decltype(UMIN_)::value;
+                T fa[kRingF][4][4], fb[kRingF][4];              // [buffer][k-step][row block]
+                auto load = [&](int j, auto B) {
+                    constexpr int buf = decltype(B)::value;
+                    const int jc = j < k ? j : k - 1;
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    const size_t col = (size_t)(16 * j + 4 * s4 + lk) * ldf;
-                    fb[buf][s4] = F[rowb + col];
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const size_t col = (size_t)(16 * jc + 4 * s4 + lk) * ldf;
+                        fb[buf][s4] = F[rowb + col];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) if (live[u]) fa[buf][s4][u] = F[rowa[u] + col];
-                }
-            };
-            auto mmas = [&](int buf) {
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) if (live[u]) acc[u] = Mma<T>::mma(fa[buf][s4][u], fb[buf][s4], acc[u]);
-            };
-            if (live[0] || live[1] || live[2] || live[3]) {
-                // (four panels in flight instead of two: 88 -> 118 us for the sixteen panel steps at n = 256 -- not the loads)
-                load(0, 0);
-                for (int j = 0; j < k; j += 2) {
-                    if (j + 1 < k) load(j + 1, 1);
-                    mmas(0);
-                    if (j + 1 < k) {
-                        if (j + 2 < k) load(j + 2, 0);
-                        mmas(1);
+                        for (int u = UMIN; u < 4; ++u) fa[buf][s4][u] = F[rowa[u] + col];
                     }
+                };
+                auto mmas = [&](auto B) {
+                    constexpr int buf = decltype(B)::value;
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                        for (int u = UMIN; u < 4; ++u) if (live[u]) acc[u] = Mma<T>::mma(fa[buf][s4][u], fb[buf][s4], acc[u]);
+                };
+                static_for<kAheadF>([&](auto U) { load(decltype(U)::value, U); });
+                for (int j0 = 0; j0 < k; j0 += kRingF) {
+                    static_for<kRingF>([&](auto U) {
+                        constexpr int u0 = decltype(U)::value;
+                        if (j0 + u0 < k) {
+                            load(j0 + u0 + kAheadF, IntC<(u0 + kAheadF) % kRingF>{});
+                            mmas(U);
+                        }
+                    });
                 }
+            };
+            const int umin = k > wave ? (k - wave + 3) / 4 : 0;     // first u with wave + 4 u >= k (wave-uniform)
+            if (live[0] || live[1] || live[2] || live[3]) {
+                if (umin == 0) sweep(IntC<0>{});
+                else if (umin == 1) sweep(IntC<1>{});
+                else if (umin == 2) sweep(IntC<2>{});
+                else sweep(IntC<3>{});
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     if (live[u]) {
@@ -429,21 +446,42 @@ __device__ __forceinline__ int posvx_device(int n, T* A, int lda, T* F, int ldf,
             const T* Ap = A;
             const T* xp = x;
             T ra = 0, rb = 0, wa = 0, wb = 0;
-            for (int kb = k0; kb < k1; kb += 16) {
-                v2 av[16];
-                T xv[16];
+            // x through LDS (gpanel is free here), A in batches of 16 columns with TWO batches in flight beyond the one being
+            // summed (always 16 loads a batch, indices clamped: a count the compiler can keep in vmcnt): the sweep pays the
+            // latency of L2 once, not once per batch (19 us per residual at n = 256 with one batch at a time)
+            const lds_ptr<T> xs = as_lds(gpanel);
+            __syncthreads();
+            if (tid < n) xs[tid] = xp[tid];
+            __syncthreads();
+            constexpr int kAheadR = 2, kRingR = kAheadR + 1;
+            v2 av[kRingR][16];
+            const int nbat = (k1 - k0 + 15) / 16;
+            auto issue = [&](int bt, auto B) {
+                constexpr int bb = decltype(B)::value;
+                const int kb = k0 + 16 * (bt < nbat ? bt : nbat - 1);
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     const int k = kb + u < k1 ? kb + u : k1 - 1;
-                    av[u] = *reinterpret_cast<const v2*>(Ap + i0 + (size_t)k * lda);
-                    xv[u] = xp[k];
+                    av[bb][u] = *reinterpret_cast<const v2*>(Ap + i0 + (size_t)k * lda);
                 }
+            };
+            static_for<kAheadR>([&](auto U) { issue(decltype(U)::value, U); });
+            for (int b0 = 0; b0 < nbat; b0 += kRingR) {
+                static_for<kRingR>([&](auto U) {
+                    constexpr int u0 = decltype(U)::value;
+                    const int bt = b0 + u0;
+                    if (bt < nbat) {
+                        issue(bt + kAheadR, IntC<(u0 + kAheadR) % kRingR>{});
+                        const int kb = k0 + 16 * bt;
 #pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    if (kb + u < k1) {
-                        ra -= av[u].x * xv[u]; wa += dabs(av[u].x) * dabs(xv[u]);
-                        rb -= av[u].y * xv[u]; wb += dabs(av[u].y) * dabs(xv[u]);
+                        for (int u = 0; u < 16; ++u)
+                            if (kb + u < k1) {
+                                const T xu = xs[kb + u];
+                                ra -= av[u0][u].x * xu; wa += dabs(av[u0][u].x) * dabs(xu);
+                                rb -= av[u0][u].y * xu; wb += dabs(av[u0][u].y) * dabs(xu);
+                            }
                     }
+                });
             }
             ra += wave_shfl_xor(ra, 1); wa += wave_shfl_xor(wa, 1);
             rb += wave_shfl_xor(rb, 1); wb += wave_shfl_xor(wb, 1);
