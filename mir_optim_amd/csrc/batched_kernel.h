@@ -45,10 +45,34 @@ struct ModelExp3Affine {        // sum_{k<3} p_{2k} exp(-t p_{2k+1}) + p6 + p7 t
         return x[0] * __expf(-t * x[1]) + x[2] * __expf(-t * x[3]) + x[4] * __expf(-t * x[5]) + x[6] + x[7] * t;
     }
 };
+// exp(y) in float, the SAME bits on the device and on a host: every operation is written out (Cody-Waite reduction with a
+// two-part ln 2, degree-7 Taylor polynomial on |r| <= ln 2 / 2: truncation 5e-9, ldexp) and is exactly rounded on both sides
+// (fmaf, rintf, ldexpf); ~1.5 ulp. The float oracle's fused variant (oracle/lm_batched_fused.c) repeats it instruction for
+// instruction, which libm's / the device library's expf would not allow (both are "<= 1 ulp", not the same ulp).
+__host__ __device__ inline float det_expf(float y)
+{
+#pragma clang fp contract(off)
+    y = fminf(fmaxf(y, -87.0f), 88.0f);
+    const float k = rintf(y * 1.44269504f);
+    float r = __builtin_fmaf(k, -0.693145752f, y);
+    r = __builtin_fmaf(k, -1.42860677e-06f, r);
+    float p = 1.0f / 5040.0f;
+    p = __builtin_fmaf(p, r, 1.0f / 720.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 120.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 24.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 6.0f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    return ldexpf(p, (int)k);
+}
+
 // BASELINE cfg 5's well-conditioned n = 8 family ("p0 exp(-t p1) + p2 + 5-term variants padded to n = 8"): the
 // exponential decay plus five terms that are LINEAR in their parameters (a two-frequency trigonometric pair and a slope),
-// so the only nonlinearity is the decay and J^T J stays well conditioned in fp32. Precise expf / sinf / cosf (the float
-// oracle evaluates the same expression with libm). The four trigonometric values of a row are its basis.
+// so the only nonlinearity is the decay and J^T J stays well conditioned in fp32. The four trigonometric values of a row are
+// its basis (tabulated once a launch: device sinf / cosf; the fused oracle takes the table as an input). eval is ONE chain of
+// fused multiply-adds around det_expf, nothing left to the compiler: the fused float oracle reproduces a fit of this model
+// bit for bit (tests/test_gpu_batched.py); the libm oracle evaluates the same expression with expf and agrees to fp32 rounding.
 struct ModelExpDecayPad8 {
     static constexpr int n = 8, nb = 4;
     __device__ static inline void basis(float t, float* b)
@@ -57,7 +81,14 @@ struct ModelExpDecayPad8 {
     }
     __device__ static inline float eval(float t, const float* b, const float* x)
     {
-        return x[0] * expf(-t * x[1]) + x[2] + x[3] * b[0] + x[4] * b[1] + x[5] * b[2] + x[6] * b[3] + x[7] * t;
+#pragma clang fp contract(off)
+        const float e = det_expf(-t * x[1]);
+        float v = __builtin_fmaf(x[0], e, x[2]);
+        v = __builtin_fmaf(x[3], b[0], v);
+        v = __builtin_fmaf(x[4], b[1], v);
+        v = __builtin_fmaf(x[5], b[2], v);
+        v = __builtin_fmaf(x[6], b[3], v);
+        return __builtin_fmaf(x[7], t, v);
     }
 };
 // the compiled-in models of mir_optimize_least_squares_batched_s by their MIR_LSQ_MODEL_* id
@@ -287,6 +318,10 @@ __global__ __launch_bounds__(64) void k_posvx_rows(const float* __restrict__ P, 
 template <class Model>
 __global__ __launch_bounds__(64, Model::n <= 4 ? 4 : 2) void k_lm_batched(BatchedArgs a)   // waves per SIMD the LDS slices allow at m = 512
 {
+    // Nothing in this body is left to the compiler's choice of what to fuse: contraction is off and every multiply-add that is
+    // meant to be ONE rounding is a __builtin_fmaf. The arithmetic of a fit is then a fixed sequence of IEEE operations that
+    // oracle/lm_batched_fused.c repeats on the host (per-lane partial sums, the butterfly of wave_sum): bit-identical results.
+#pragma clang fp contract(off)
     constexpr int N = Model::n;
     constexpr int NMAX = kBatchedNMax;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
@@ -396,11 +431,11 @@ __global__ __launch_bounds__(64, Model::n <= 4 ? 4 : 2) void k_lm_batched(Batche
                         float* Ji = Jl + (size_t)i * N;
                         float dot = 0;
 #pragma unroll
-                        for (int j = 0; j < N; ++j) dot += Ji[j] * dx[j];
+                        for (int j = 0; j < N; ++j) dot = __builtin_fmaf(Ji[j], dx[j], dot);
                         const float t = (mB[i] - yv[i]) + dot;             // mB holds the previous residual
                         const float u = -d * t;
 #pragma unroll
-                        for (int j = 0; j < N; ++j) Ji[j] += u * dx[j];
+                        for (int j = 0; j < N; ++j) Ji[j] = __builtin_fmaf(u, dx[j], Ji[j]);
                     }
                 } else {                                                   // FD LS:1016-1050
                     age = 0;
@@ -427,8 +462,7 @@ __global__ __launch_bounds__(64, Model::n <= 4 ? 4 : 2) void k_lm_batched(Batche
                             p[j] = xmh[j];
                             const float fm = Model::eval(ti, b.v, p) - di;
                             p[j] = x[j];
-                            float v = fp;
-                            v += -1.0f * fm;
+                            const float v = fp - fm;
                             Jl[(size_t)i * N + j] = inv[j] != 0 ? v * inv[j] : 0.0f;
                         }
                     }
@@ -452,9 +486,9 @@ __global__ __launch_bounds__(64, Model::n <= 4 ? 4 : 2) void k_lm_batched(Batche
                     for (int j = 0; j < NMAX; ++j) row[j] = j < N ? Ji[j] : 0.0f;
 #pragma unroll
                     for (int j = 0; j < N; ++j) {
-                        accy[j] += row[j] * yi;
+                        accy[j] = __builtin_fmaf(row[j], yi, accy[j]);
 #pragma unroll
-                        for (int k = 0; k <= j; ++k) accJ[j][k] += row[j] * row[k];
+                        for (int k = 0; k <= j; ++k) accJ[j][k] = __builtin_fmaf(row[j], row[k], accJ[j][k]);
                     }
                 }
 #pragma unroll
@@ -531,7 +565,7 @@ __global__ __launch_bounds__(64, Model::n <= 4 ? 4 : 2) void k_lm_batched(Batche
                 float d = sol[j] + x[j];                                   // LS:1096-1097
                 d = d - x[j];
                 sol[j] = j < N ? d : 0.0f;
-                ndd += sol[j] * sol[j];
+                ndd = __builtin_fmaf(sol[j], sol[j], ndd);
                 trial[j] = fmaxf(fminf(sol[j] + x[j], up[j]), lo[j]);      // LS:1108-1110
             }
             if (!(sqrtf(ndd) < S.maxStep)) { lambda *= S.lambdaIncrease * mu; mu *= 2; continue; }   // LS:1101-1106
@@ -561,10 +595,10 @@ __global__ __launch_bounds__(64, Model::n <= 4 ? 4 : 2) void k_lm_batched(Batche
             {
                 float tj = 0;                                              // row r of J^T J dx + 2 J^T y, then the dot with dx
 #pragma unroll
-                for (int k = 0; k < NMAX; ++k) tj += JJrow[k] * dx[k];
+                for (int k = 0; k < NMAX; ++k) tj = __builtin_fmaf(JJrow[k], dx[k], tj);
                 tj = tj + 2 * Jy_r;
 #pragma unroll
-                for (int j = 0; j < NMAX; ++j) pred += lane_get(tj, j) * dx[j];
+                for (int j = 0; j < NMAX; ++j) pred = __builtin_fmaf(lane_get(tj, j), dx[j], pred);
             }
             pred = -pred;
             if (!(pred > 0)) { ret.status = 0; break; }                    // LS:1144-1148
@@ -573,7 +607,7 @@ __global__ __launch_bounds__(64, Model::n <= 4 ? 4 : 2) void k_lm_batched(Batche
             else if (rho >= S.goodStepQuality) lambda = fmaxf(S.lambdaDecrease * lambda * mu, S.minLambda);
             float xn = 0;
 #pragma unroll
-            for (int j = 0; j < NMAX; ++j) xn += x[j] * x[j];
+            for (int j = 0; j < NMAX; ++j) xn = __builtin_fmaf(x[j], x[j], xn);
 #ifdef MIRLSQ_BATCHED_TIMING
             tacc[7] += __builtin_readcyclecounter() - t7_;
 #endif

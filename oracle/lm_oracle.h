@@ -152,6 +152,15 @@ int lmo_posvx_s(int n, float* a, int lda, float* af, int ldaf, char* equed, floa
  * leading minor that is not positive); *equilibrated reports ?laqsy's decision. */
 int lmo_posvx_fused_s(int n, const float* a, int lda, const float* b, float* x, int* equilibrated);
 
+/* lm_batched_fused.c: ONE float fit of BASELINE cfg 5's padded exponential-decay model (n = 8) with the arithmetic of the device's
+ * one-wavefront-per-problem kernel (csrc/batched_kernel.h): fused multiply-adds where the kernel fuses, its per-lane partial sums
+ * and wave butterfly, its det_expf, lmo_posvx_fused_s for the damped solve. t: m abscissae, basis: m x 4 (sin 2t, cos 2t, sin 5t,
+ * cos 5t AS THE DEVICE TABULATED THEM), data: m, x: 8 in/out. The kernel's results are tested against this bit for bit.
+ * Returns 0 (out filled; out->status = LMO_BATCHED_NEEDS_GENERAL when a step hits a finite bound) or -1 (allocation). */
+#define LMO_BATCHED_NEEDS_GENERAL (-100)
+int lmo_optimize_batched_fused_pad8_s(const lmo_settings_s* S, int m, const float* t, const float* basis, const float* data,
+                                      float* x, const float* lower, const float* upper, lmo_result_s* out);
+
 void lmo_apply_bounds_d(size_t n, double* x, const double* l, const double* u);
 void lmo_apply_bounds_s(size_t n, float* x, const float* l, const float* u);
 

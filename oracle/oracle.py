@@ -273,6 +273,35 @@ def posvx_fused_s(A, b):
     return info, x, bool(eq.value)
 
 
+def optimize_batched_fused_pad8_s(settings, t, basis, data, x0, lower=None, upper=None):
+    """lmo_optimize_batched_fused_pad8_s (lm_batched_fused.c): ONE float fit of cfg 5's padded exponential-decay model with the
+    arithmetic of the device's wave-per-problem kernel. settings: an lmo_settings_s-layout ctypes structure (LeastSquaresSettings
+    of the product has the same layout: LS:85-123); basis: m x 4 float32 as the device tabulated it.
+    Returns ((status, iterations, fCalls, gCalls, residual, lambda), x)."""
+    L = lib()
+
+    class Res(C.Structure):
+        _fields_ = [("status", C.c_int32), ("iterations", C.c_uint32), ("fCalls", C.c_uint32), ("gCalls", C.c_uint32),
+                    ("residual", C.c_float), ("lam", C.c_float)]
+    t = np.ascontiguousarray(t, dtype=np.float32)
+    basis = np.ascontiguousarray(basis, dtype=np.float32)
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    m = t.size
+    assert basis.size == 4 * m and data.size == m
+    x = np.array(x0, dtype=np.float32).copy()
+    assert x.size == 8
+    lo = np.full(8, -np.inf, dtype=np.float32) if lower is None else np.ascontiguousarray(lower, dtype=np.float32)
+    up = np.full(8, np.inf, dtype=np.float32) if upper is None else np.ascontiguousarray(upper, dtype=np.float32)
+    r = Res()
+    L.lmo_optimize_batched_fused_pad8_s.restype = C.c_int
+    L.lmo_optimize_batched_fused_pad8_s.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7
+    rc = L.lmo_optimize_batched_fused_pad8_s(C.addressof(settings), m, t.ctypes.data, basis.ctypes.data, data.ctypes.data,
+                                             x.ctypes.data, lo.ctypes.data, up.ctypes.data, C.addressof(r))
+    if rc != 0:
+        raise MemoryError("lmo_optimize_batched_fused_pad8_s")
+    return (r.status, r.iterations, r.fCalls, r.gCalls, r.residual, r.lam), x
+
+
 def openblas_path():
     import scipy
     cands = glob.glob(os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs", "libscipy_openblas*.so"))
