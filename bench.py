@@ -406,7 +406,12 @@ def launch_ranks(args):
     t = threading.Thread(target=pump, daemon=True)
     t.start()
     failed = None
+    deadline = time.monotonic() + float(os.environ.get("BENCH_RANK_TIMEOUT_S", "1500"))   # a rank stuck in a rendezvous must not hang the job
     while True:
+        if time.monotonic() > deadline:
+            failed = (-1, 124)
+            print("[bench] ranks still running at the deadline (BENCH_RANK_TIMEOUT_S): stopping them", file=sys.stderr, flush=True)
+            break
         codes = [p.poll() for p in procs]
         bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
         if bad:
@@ -416,7 +421,8 @@ def launch_ranks(args):
             break
         time.sleep(0.05)
     if failed is not None:
-        print(f"[bench] rank {failed[0]} exited with code {failed[1]}: stopping the other ranks", file=sys.stderr, flush=True)
+        if failed[0] >= 0:
+            print(f"[bench] rank {failed[0]} exited with code {failed[1]}: stopping the other ranks", file=sys.stderr, flush=True)
         for p in procs:
             if p.poll() is None:
                 p.terminate()
