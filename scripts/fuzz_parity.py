@@ -1,0 +1,85 @@
+"""Randomised differential sweep: the GPU solver against the oracle on tanh-linear problems of random shape, bounds, starting
+point and settings (run on the GPU box). Not a test of the tiers -- those pin named cases -- but a search for disagreements
+outside them: every case prints one line only when something differs; the summary counts the categories.
+
+  python scripts/fuzz_parity.py [cases=300] [seed0=0]
+
+Compared per case: status, iterations, fCalls (exact), x (1e-6 of max(1, |x|_inf)), residual (rtol 1e-6: one LM step from the same
+point already differs by ~3e-8 relative -- the finite-difference Jacobian divides the 2e-16 difference of two tanh implementations by 2h = 3e-8). A case whose counters
+differ while x and the residual agree is reported as `trajectory` (two roundings of one tie), anything else as `MISMATCH`."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+import mir_optim_amd as M
+from mir_optim_amd import workloads as W
+from oracle import oracle as O
+import problems as P
+
+
+def case(seed):
+    rng = np.random.default_rng(seed)
+    # small shapes: the oracle's plain loops must finish a case in well under a second (the sweep runs on GPU-box minutes)
+    n = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 24, 31, 32, 33, 48, 63, 64, 65, 96, 128, 129]))
+    m = int(n + rng.integers(0, 2 * n + 50)) if rng.random() < 0.5 else int(rng.integers(max(n, 2), 1500))
+    A = (2 * rng.random((m, n)) - 1) * np.sqrt(3.0 / n)
+    xs = 2 * rng.random(n) - 1
+    b = np.tanh(A @ xs) + 10.0 ** rng.integers(-6, -1) * (2 * rng.random(m) - 1)
+    x0 = xs + 10.0 ** rng.integers(-3, 0) * (2 * rng.random(n) - 1)
+    kind = rng.integers(0, 5)
+    lo = np.full(n, -np.inf); up = np.full(n, np.inf)
+    if kind >= 1:                                  # some bounds, a share of them binding at the minimiser
+        sel = rng.random(n) < 0.5
+        lo[sel] = xs[sel] - rng.random(sel.sum()) * 0.3 + (rng.random(sel.sum()) < 0.4) * 0.2
+        sel = rng.random(n) < 0.5
+        up[sel] = np.maximum(lo[sel] + 1e-3, xs[sel] + rng.random(sel.sum()) * 0.3 - (rng.random(sel.sum()) < 0.3) * 0.15)
+    if kind == 3:                                  # a few pinned variables (lower == upper)
+        sel = rng.random(n) < 0.15
+        v = np.where(np.isfinite(lo), lo, np.where(np.isfinite(up), up, 0.1))
+        lo[sel] = v[sel]; up[sel] = v[sel]
+    if kind == 4:                                  # every variable boxed tightly
+        lo = xs - 0.05 - 0.1 * rng.random(n); up = xs + 0.02 + 0.1 * rng.random(n)
+    up = np.maximum(up, lo)
+    x0 = np.clip(x0, lo, up)
+    s = dict(maxIterations=int(rng.choice([1, 2, 5, 12, 40])), absTolerance=float(rng.choice([1e-3, 1e-6, 1e-9])),
+             maxAge=int(rng.choice([0, 0, 1, 3])), gradTolerance=float(rng.choice([2.2e-16, 1e-8, 1e-3])))
+    return dict(A=A, b=b, x0=x0, lo=lo, up=up, m=m, n=n, s=s, bounded=kind >= 1)
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    tally = {"same": 0, "trajectory": 0, "MISMATCH": 0}
+    for k in range(cases):
+        c = case(seed0 + k)
+        sg = M.LeastSquaresSettings(); so = O.default_settings()
+        for key, v in c["s"].items():
+            setattr(sg, key, v); setattr(so, key, v)
+        prob = W.TanhLinear(c["A"], c["b"])
+        lo = c["lo"] if c["bounded"] else None
+        up = c["up"] if c["bounded"] else None
+        res, x = prob.solve(c["x0"], lo, up, settings=sg, batched=bool(k % 2))
+        prob.dA.free(); prob.db.free()
+        ctx = O.TanhLinearCtx(c["A"].ctypes.data, c["b"].ctypes.data)
+        ro, xo = O.optimize(O.native_fn("wlc_tanh_linear_f"), c["m"], c["x0"], lower=lo, upper=up, settings=so, fctx=C.addressof(ctx))
+        scale = max(1.0, float(np.abs(xo).max()))
+        xerr = float(np.abs(x - xo).max()) / scale
+        rerr = abs(res.residual - ro.residual) / max(abs(ro.residual), 1e-300)
+        counters = (int(res.status), res.iterations, res.fCalls) == (ro.status, ro.iterations, ro.fCalls)
+        close = xerr <= 1e-6 and (rerr <= 1e-6 or abs(res.residual - ro.residual) <= 1e-18)
+        cat = "same" if (counters and close) else ("trajectory" if close else "MISMATCH")
+        tally[cat] += 1
+        if cat != "same":
+            print(f"{cat:10s} seed {seed0 + k} m {c['m']} n {c['n']} bounded {c['bounded']} {c['s']}  gpu ({int(res.status)}, {res.iterations}, {res.fCalls}, "
+                  f"{res.residual:.17g})  oracle ({ro.status}, {ro.iterations}, {ro.fCalls}, {ro.residual:.17g})  xerr {xerr:.2e} rerr {rerr:.2e}", flush=True)
+        elif k % 50 == 0:
+            print(f"... case {k}: ok (m {c['m']} n {c['n']})", flush=True)
+    print("summary:", tally)
+
+
+if __name__ == "__main__":
+    main()
