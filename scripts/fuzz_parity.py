@@ -2,7 +2,8 @@
 point and settings (run on the GPU box). Not a test of the tiers -- those pin named cases -- but a search for disagreements
 outside them: every case prints one line only when something differs; the summary counts the categories.
 
-  python scripts/fuzz_parity.py [cases=300] [seed0=0]
+  python scripts/fuzz_parity.py [cases=300] [seed0=0] [device|host]     host = the reference ABI: python host callbacks, optional analytic
+                                                                       Jacobian and thread manager, f64 and f32, small shapes
 
 Compared per case: status, iterations, fCalls (exact), x (1e-6 of max(1, |x|_inf)), residual (rtol 1e-6: one LM step from the same
 point already differs by ~3e-8 relative -- the finite-difference Jacobian divides the 2e-16 difference of two tanh implementations by 2h = 3e-8). A case whose counters
@@ -50,31 +51,87 @@ def case(seed):
     return dict(A=A, b=b, x0=x0, lo=lo, up=up, m=m, n=n, s=s, bounded=kind >= 1)
 
 
+def host_case(seed, dtype):
+    """the reference ABI: host callbacks (python), optional analytic Jacobian, optional thread manager; small shapes"""
+    c = case(seed)
+    rng = np.random.default_rng(seed + 77)
+    n = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 33]))
+    m = int(n + rng.integers(0, 60))
+    c["A"] = np.ascontiguousarray(c["A"][: min(m, c["m"]), : min(n, c["n"])]) if c["n"] >= n and c["m"] >= m else (2 * rng.random((m, n)) - 1) * np.sqrt(3.0 / n)
+    m, n = c["A"].shape
+    xs = 2 * rng.random(n) - 1
+    c["b"] = np.tanh(c["A"] @ xs) + 1e-3 * (2 * rng.random(m) - 1)
+    c["lo"] = np.full(n, -np.inf); c["up"] = np.full(n, np.inf)
+    if rng.random() < 0.6:
+        sel = rng.random(n) < 0.5
+        c["lo"][sel] = xs[sel] - 0.2 * rng.random(sel.sum()) + 0.15 * (rng.random(sel.sum()) < 0.4)
+        c["up"] = np.maximum(c["lo"], np.where(rng.random(n) < 0.5, xs + 0.2 * rng.random(n) - 0.1 * (rng.random(n) < 0.3), np.inf))
+        c["bounded"] = True
+    else:
+        c["bounded"] = False
+    c["x0"] = np.clip(xs + 0.1 * (2 * rng.random(n) - 1), c["lo"], c["up"])
+    c["m"], c["n"] = m, n
+    c["analytic"] = bool(rng.random() < 0.4)
+    c["tm"] = bool(rng.random() < 0.5)
+    if dtype == np.float32:
+        c["s"]["absTolerance"] = max(c["s"]["absTolerance"], 1e-6)
+        c["s"]["gradTolerance"] = max(c["s"]["gradTolerance"], 1e-7)
+    return c
+
+
+def run_host(c, dtype, sg, so):
+    A = c["A"].astype(dtype); b = c["b"].astype(dtype)
+
+    def f(x, y):
+        y[:] = np.tanh(A @ x) - b
+
+    def g(x, J):
+        J[:, :] = (1 - np.tanh(A @ x) ** 2)[:, None] * A
+
+    def tm(count, task):                       # a thread manager that runs the tasks in reverse order on "4 threads"
+        for i in reversed(range(count)):
+            task(4, i % 4, i)
+    lo = c["lo"].astype(dtype) if c["bounded"] else None
+    up = c["up"].astype(dtype) if c["bounded"] else None
+    res, x = M.optimizeLeastSquares(f, c["m"], c["x0"].astype(dtype), lo, up, g=g if c["analytic"] else None, tm=tm if c["tm"] else None,
+                                    settings=sg, dtype=dtype)
+    ro, xo = O.optimize(f, c["m"], c["x0"].astype(dtype), lower=lo, upper=up, g=g if c["analytic"] else None, settings=so, dtype=dtype)
+    return res, x, ro, xo
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    mode = sys.argv[3] if len(sys.argv) > 3 else "device"       # device: device callbacks, f64 | host: reference ABI, f64 and f32
     tally = {"same": 0, "trajectory": 0, "MISMATCH": 0}
     for k in range(cases):
-        c = case(seed0 + k)
-        sg = M.LeastSquaresSettings(); so = O.default_settings()
+        dtype = np.float32 if (mode == "host" and k % 3 == 2) else np.float64
+        c = case(seed0 + k) if mode == "device" else host_case(seed0 + k, dtype)
+        sg = M.LeastSquaresSettings(dtype); so = O.default_settings(dtype)
         for key, v in c["s"].items():
             setattr(sg, key, v); setattr(so, key, v)
-        prob = W.TanhLinear(c["A"], c["b"])
         lo = c["lo"] if c["bounded"] else None
         up = c["up"] if c["bounded"] else None
-        res, x = prob.solve(c["x0"], lo, up, settings=sg, batched=bool(k % 2))
-        prob.dA.free(); prob.db.free()
-        ctx = O.TanhLinearCtx(c["A"].ctypes.data, c["b"].ctypes.data)
-        ro, xo = O.optimize(O.native_fn("wlc_tanh_linear_f"), c["m"], c["x0"], lower=lo, upper=up, settings=so, fctx=C.addressof(ctx))
+        if mode == "host":
+            res, x, ro, xo = run_host(c, dtype, sg, so)
+            xtol, rtol = (1e-6, 1e-6) if dtype == np.float64 else (5e-3, 5e-3)
+            x = np.asarray(x, dtype=np.float64); xo = np.asarray(xo, dtype=np.float64)
+        else:
+            xtol, rtol = 1e-6, 1e-6
+            prob = W.TanhLinear(c["A"], c["b"])
+            res, x = prob.solve(c["x0"], lo, up, settings=sg, batched=bool(k % 2))
+            prob.dA.free(); prob.db.free()
+            ctx = O.TanhLinearCtx(c["A"].ctypes.data, c["b"].ctypes.data)
+            ro, xo = O.optimize(O.native_fn("wlc_tanh_linear_f"), c["m"], c["x0"], lower=lo, upper=up, settings=so, fctx=C.addressof(ctx))
         scale = max(1.0, float(np.abs(xo).max()))
         xerr = float(np.abs(x - xo).max()) / scale
         rerr = abs(res.residual - ro.residual) / max(abs(ro.residual), 1e-300)
         counters = (int(res.status), res.iterations, res.fCalls) == (ro.status, ro.iterations, ro.fCalls)
-        close = xerr <= 1e-6 and (rerr <= 1e-6 or abs(res.residual - ro.residual) <= 1e-18)
+        close = xerr <= xtol and (rerr <= rtol or abs(res.residual - ro.residual) <= 1e-18)
         cat = "same" if (counters and close) else ("trajectory" if close else "MISMATCH")
         tally[cat] += 1
         if cat != "same":
-            print(f"{cat:10s} seed {seed0 + k} m {c['m']} n {c['n']} bounded {c['bounded']} {c['s']}  gpu ({int(res.status)}, {res.iterations}, {res.fCalls}, "
+            print(f"{cat:10s} seed {seed0 + k} {mode} {np.dtype(dtype).name} m {c['m']} n {c['n']} bounded {c['bounded']} g {c.get('analytic')} tm {c.get('tm')} {c['s']}  gpu ({int(res.status)}, {res.iterations}, {res.fCalls}, "
                   f"{res.residual:.17g})  oracle ({ro.status}, {ro.iterations}, {ro.fCalls}, {ro.residual:.17g})  xerr {xerr:.2e} rerr {rerr:.2e}", flush=True)
         elif k % 50 == 0:
             print(f"... case {k}: ok (m {c['m']} n {c['n']})", flush=True)
