@@ -137,41 +137,73 @@ void launch_tanh_linear(const T* A, const T* b, const T* x, T* out, size_t m, in
 }
 
 // ---- Gaussian-sum: n = 3K+1, x = [a | c | w | b]; y_i = sum_k a_k exp(-(t_i-c_k)^2/(2 w_k^2)) + b - data_i
+// ONE expression for the single-point and the batched kernels (they must round alike): per Gaussian the constants (a, c, g) with
+// g = -1 / (2 w w) -- one division per POINT and Gaussian, not one per row, point and Gaussian: 16 M of them at cfg 2's refresh --
+// and per row s = fma(a, exp((d d) g), s), k ascending from s = b.
+constexpr int kGaussMax = 16;                        // Gaussians whose constants a thread keeps in registers (cfg 2: 5)
+template <typename T> __device__ inline T gauss_g(T w) { return T(-1) / (2 * w * w); }
+template <typename T, int KC>
+__device__ inline T gauss_row(T ti, const T (&a)[KC], const T (&c)[KC], const T (&g)[KC], int K, T base)
+{
+    T s = base;
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+        if (k < K) { const T d = ti - c[k]; s = fma(a[k], dexp((d * d) * g[k]), s); }
+    return s;
+}
+template <typename T> __device__ inline T gauss_row_any(T ti, const T* x, int K)    // more than kGaussMax Gaussians: constants from memory
+{
+    T s = x[3 * K];
+    for (int k = 0; k < K; ++k) { const T d = ti - x[K + k]; s = fma(x[k], dexp((d * d) * gauss_g(x[2 * K + k])), s); }
+    return s;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_gauss_sum(const T* __restrict__ t, const T* __restrict__ data,
                                                    const T* __restrict__ x, T* __restrict__ y, size_t m, int n)
 {
     const int K = (n - 1) / 3;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (size_t)gridDim.x * blockDim.x) {
-        const T ti = t[i];
-        T s = x[3 * K];
-        for (int k = 0; k < K; ++k) {
-            const T d = ti - x[K + k], w = x[2 * K + k];
-            s += x[k] * dexp(-(d * d) / (2 * w * w));
-        }
-        y[i] = s - data[i];
+    if (K <= kGaussMax) {
+        T a[kGaussMax], c[kGaussMax], g[kGaussMax];
+#pragma unroll
+        for (int k = 0; k < kGaussMax; ++k) { a[k] = k < K ? x[k] : T(0); c[k] = k < K ? x[K + k] : T(0); g[k] = k < K ? gauss_g(x[2 * K + k]) : T(0); }
+        const T base = x[3 * K];
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (size_t)gridDim.x * blockDim.x)
+            y[i] = gauss_row<T, kGaussMax>(t[i], a, c, g, K, base) - data[i];
+    } else {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (size_t)gridDim.x * blockDim.x)
+            y[i] = gauss_row_any(t[i], x, K) - data[i];
     }
 }
 
 // P points in one launch (the batched callback of mir_lsq_gpu_options): element e <-> (row i, point k);
-// RM = false: Y[k m + i] (point-major), RM = true: Y[i P + k] (row-major, the layout of the fused finite-difference kernel)
-template <typename T, bool RM>
+// RM = false: Y[k m + i] (point-major), RM = true: Y[i P + k] (row-major, the layout of the fused finite-difference kernel).
+// FIXED (the launcher's choice when the grid's thread count is a multiple of P, row-major): a thread keeps ONE point for all its
+// rows -- its constants are formed once, and the row index advances by a constant instead of a 64-bit division per element.
+template <typename T, bool RM, bool FIXED>
 __global__ __launch_bounds__(256) void k_gauss_sum_batched(const T* __restrict__ t, const T* __restrict__ data,
                                                            const T* __restrict__ X, T* __restrict__ Y, size_t m, int n, int P)
 {
     const int K = (n - 1) / 3;
     const size_t total = m * (size_t)P;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const size_t i = RM ? e / P : e % m;
-        const int k = (int)(RM ? e % P : e / m);
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    if constexpr (FIXED) {
+        static_assert(RM, "a fixed point per thread is the row-major walk");
+        const int k = (int)(gid % (size_t)P);
         const T* x = X + (size_t)k * n;
-        const T ti = t[i];
-        T s = x[3 * K];
-        for (int q = 0; q < K; ++q) {
-            const T d = ti - x[K + q], w = x[2 * K + q];
-            s += x[q] * dexp(-(d * d) / (2 * w * w));
+        T a[kGaussMax], c[kGaussMax], g[kGaussMax];
+#pragma unroll
+        for (int q = 0; q < kGaussMax; ++q) { a[q] = q < K ? x[q] : T(0); c[q] = q < K ? x[K + q] : T(0); g[q] = q < K ? gauss_g(x[2 * K + q]) : T(0); }
+        const T base = x[3 * K];
+        const size_t rstep = stride / (size_t)P;
+        size_t i = gid / (size_t)P;
+        for (size_t e = gid; e < total; e += stride, i += rstep) Y[e] = gauss_row<T, kGaussMax>(t[i], a, c, g, K, base) - data[i];
+    } else {
+        for (size_t e = gid; e < total; e += stride) {
+            const size_t i = RM ? e / P : e % m;
+            const int k = (int)(RM ? e % P : e / m);
+            Y[e] = gauss_row_any(t[i], X + (size_t)k * n, K) - data[i];
         }
-        Y[e] = s - data[i];
     }
 }
 
@@ -381,14 +413,20 @@ void wl_gauss_sum_f_s(void* vctx, size_t m, size_t n, const float* x, float* y)
 void wl_gauss_sum_fb_d(void* vctx, size_t m, size_t n, size_t p, const double* X, double* Y)
 {
     auto* c = static_cast<wl_curve_ctx*>(vctx);
-    hipLaunchKernelGGL((k_gauss_sum_batched<double, false>), dim3(blocks_for(m * p)), dim3(256), 0, (hipStream_t)c->stream,
+    hipLaunchKernelGGL((k_gauss_sum_batched<double, false, false>), dim3(blocks_for(m * p)), dim3(256), 0, (hipStream_t)c->stream,
                        (const double*)c->t, (const double*)c->data, X, Y, m, (int)n, (int)p);
 }
 void wl_gauss_sum_fbr_d(void* vctx, size_t m, size_t n, size_t p, const double* X, double* Y)
 {
     auto* c = static_cast<wl_curve_ctx*>(vctx);
-    hipLaunchKernelGGL((k_gauss_sum_batched<double, true>), dim3(blocks_for(m * p)), dim3(256), 0, (hipStream_t)c->stream,
-                       (const double*)c->t, (const double*)c->data, X, Y, m, (int)n, (int)p);
+    // a point per thread when the thread count of the grid is a multiple of p (cfg 2: p = 32 points, 256-thread workgroups)
+    const unsigned nb = blocks_for(m * p);
+    if ((n - 1) / 3 <= (size_t)kGaussMax && p > 0 && ((size_t)nb * 256) % p == 0)
+        hipLaunchKernelGGL((k_gauss_sum_batched<double, true, true>), dim3(nb), dim3(256), 0, (hipStream_t)c->stream,
+                           (const double*)c->t, (const double*)c->data, X, Y, m, (int)n, (int)p);
+    else
+        hipLaunchKernelGGL((k_gauss_sum_batched<double, true, false>), dim3(nb), dim3(256), 0, (hipStream_t)c->stream,
+                           (const double*)c->t, (const double*)c->data, X, Y, m, (int)n, (int)p);
 }
 void wl_exp_decay_f_d(void* vctx, size_t m, size_t n, const double* x, double* y)
 {

@@ -67,10 +67,11 @@ void wlc_gauss_sum_f(void* vctx, size_t m, size_t n, const double* x, double* y)
     const size_t K = (n - 1) / 3;
 #pragma omp parallel for schedule(static) if (m * n > 200000)
     for (ptrdiff_t i = 0; i < (ptrdiff_t)m; ++i) {
+        /* the expression of the device kernels (csrc/workloads.hip: gauss_row): g = -1 / (2 w w), s = fma(a, exp((d d) g), s) */
         double t = c->t[i], s = x[3 * K];
         for (size_t k = 0; k < K; ++k) {
             double d = t - x[K + k], w = x[2 * K + k];
-            s += x[k] * exp(-(d * d) / (2 * w * w));
+            s = fma(x[k], exp((d * d) * (-1.0 / (2 * w * w))), s);
         }
         y[i] = s - c->data[i];
     }
