@@ -99,20 +99,68 @@ def run_host(c, dtype, sg, so):
     return res, x, ro, xo
 
 
+def run_shards(c, sg, world):
+    """the row-sharded solve on `world` in-process shards (one host thread each, all on this GPU): every rank's result"""
+    import threading
+    from mir_optim_amd import parallel as PAR
+    comms, close = PAR.local_group(world)
+    probs = []
+    for r in range(world):
+        off, ml = PAR.row_shard(c["m"], world, r)
+        probs.append(W.TanhLinear(c["A"][off:off + ml], c["b"][off:off + ml]))
+    lo = c["lo"] if c["bounded"] else None
+    up = c["up"] if c["bounded"] else None
+    out, err = [None] * world, [None] * world
+
+    def one(r):
+        try:
+            out[r] = probs[r].solve(c["x0"], lo, up, settings=sg, comm=comms[r], batched=True)
+        except BaseException as e:      # noqa: BLE001
+            err[r] = e
+    ts = [threading.Thread(target=one, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    hung = any(t.is_alive() for t in ts)
+    close()
+    for pb in probs:
+        pb.dA.free(); pb.db.free()
+    if hung or any(err):
+        raise RuntimeError(f"sharded solve failed: hung={hung} {err}")
+    return out
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    mode = sys.argv[3] if len(sys.argv) > 3 else "device"       # device: device callbacks, f64 | host: reference ABI, f64 and f32
+    mode = sys.argv[3] if len(sys.argv) > 3 else "device"       # device | host (reference ABI, f64 + f32) | shards (2 .. 8 in-process row shards)
     tally = {"same": 0, "trajectory": 0, "MISMATCH": 0}
     for k in range(cases):
         dtype = np.float32 if (mode == "host" and k % 3 == 2) else np.float64
-        c = case(seed0 + k) if mode == "device" else host_case(seed0 + k, dtype)
+        c = host_case(seed0 + k, dtype) if mode == "host" else case(seed0 + k)
         sg = M.LeastSquaresSettings(dtype); so = O.default_settings(dtype)
         for key, v in c["s"].items():
             setattr(sg, key, v); setattr(so, key, v)
         lo = c["lo"] if c["bounded"] else None
         up = c["up"] if c["bounded"] else None
-        if mode == "host":
+        if mode == "shards":
+            rng = np.random.default_rng(seed0 + k + 12345)
+            world = int(rng.choice([2, 3, 4, 8]))
+            if c["m"] < 2 * world:
+                tally["same"] += 1
+                continue
+            outs = run_shards(c, sg, world)
+            res, x = outs[0]
+            for r in range(1, world):            # every rank returns the same bits
+                rr, xr = outs[r]
+                if not (np.array_equal(xr, x) and rr.residual == res.residual and (int(rr.status), rr.iterations, rr.fCalls) == (int(res.status), res.iterations, res.fCalls)):
+                    print(f"MISMATCH   seed {seed0 + k} shards: rank {r} of {world} differs from rank 0", flush=True)
+                    tally["MISMATCH"] += 1
+            xtol, rtol = 1e-6, 1e-6
+            ctx = O.TanhLinearCtx(c["A"].ctypes.data, c["b"].ctypes.data)
+            ro, xo = O.optimize(O.native_fn("wlc_tanh_linear_f"), c["m"], c["x0"], lower=lo, upper=up, settings=so, fctx=C.addressof(ctx))
+        elif mode == "host":
             res, x, ro, xo = run_host(c, dtype, sg, so)
             xtol, rtol = (1e-6, 1e-6) if dtype == np.float64 else (5e-3, 5e-3)
             x = np.asarray(x, dtype=np.float64); xo = np.asarray(xo, dtype=np.float64)
