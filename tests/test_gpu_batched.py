@@ -379,3 +379,17 @@ def test_cfg5_pad8_all_4096_fits_are_bit_identical_with_the_fused_float_oracle(o
                         float(np.abs(xo - x[k]).max())))
     assert not bad, (len(bad), bad[:8])
     assert np.all(raw["status"] >= 0) and raw["iterations"].sum() > 3 * count
+
+
+def test_ragged_random_fits_are_bit_identical_with_the_fused_float_oracle(oracle):
+    """The same bit-for-bit comparison off the benchmark's shape: 40 launches of scripts/fuzz_batched.py -- row counts 1 .. 1400
+    (1, 2, 7 .. 9, 63 .. 65, 127 .. 129, 511 .. 513 and random: ragged against the 64 lanes and the chunks of eight loads), 1 .. 48
+    problems a launch, noise 0 .. 0.1, near and far starts, maxIterations from 1, maxAge 0 / 1 / 4. (200 launches = 5022 fits: 0 differ,
+    profiles/r04/fuzz_batched_200.txt.)"""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_batched.py")
+    spec = importlib.util.spec_from_file_location("fuzz_batched", path)
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    fits, bad = mod.run(40, 700, verbose=False)
+    assert fits > 500 and bad == 0, (fits, bad)
