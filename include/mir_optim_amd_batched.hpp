@@ -18,6 +18,11 @@
 //     };
 // The residual of row i is eval(t_i, basis_i, x) - data_i. eval must be pure (as the reference's callbacks are declared)
 // and free of lane-dependent control flow. A problem needs (n + 2) m floats of LDS ((n + 2) m * 4 <= 160 KB - 512).
+// Reproducibility: the kernel's own arithmetic is a fixed sequence of IEEE operations (contraction off, every fused multiply-add
+// written out: batched_kernel.h), so a fit is reproducible bit for bit on a host (oracle/lm_batched_fused.c does it for the
+// built-in cfg 5 model) -- PROVIDED eval is written the same way: `#pragma clang fp contract(off)` as its first statement, explicit
+// __builtin_fmaf, and no library transcendental whose bits differ between implementations (mirlsq::det_expf is one that does not).
+// An eval written as in the example above is still deterministic on the device; only a host twin would differ in the last bit.
 //
 //     mir_optim_amd::launch_batched<MyModel>(&settings, count, m, x, lower, upper, t, t_stride, data, results, &options);
 // has the contract of mir_lsq_batched_kernel_s (include/mir_optim_amd.h): every pointer a DEVICE pointer, enqueued on
