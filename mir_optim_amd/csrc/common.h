@@ -32,7 +32,7 @@ inline thread_local uint64_t tl_launches = 0;
 constexpr int kLrMax = 16;
 // [ v0 (n) | g0 (n) | w (kLrMax) | h (kLrMax) | uu | uy ]
 __host__ __device__ constexpr int lr_len(int n) { return 2 * n + 2 * kLrMax + 2; }
-constexpr int kLrMaxN = 256;
+constexpr int kLrMaxN = 512;     // widest problem of the read-only Broyden sweep (16 column-pair chunks of 32 a lane); above, J is rewritten
 constexpr int kReduceRanges = 32;
 // one entry of the symmetric rank-two update J_k^T J_k = J_{k-1}^T J_{k-1} + v dx^T + dx v^T + uu dx dx^T, r >= c (k_lr_finish)
 template <typename T>

@@ -26,7 +26,8 @@ hipError_t lr_sweep(const LrArgs<T>& a, int nblk, hipStream_t s)
     if (ncp <= 1) return lr_sweep_ncp<T, 1>(a, nblk, vec, s);
     if (ncp <= 2) return lr_sweep_ncp<T, 2>(a, nblk, vec, s);
     if (ncp <= 4) return lr_sweep_ncp<T, 4>(a, nblk, vec, s);
-    return lr_sweep_ncp<T, 8>(a, nblk, vec, s);
+    if (ncp <= 8) return lr_sweep_ncp<T, 8>(a, nblk, vec, s);
+    return lr_sweep_ncp<T, 16>(a, nblk, vec, s);            // 256 < n <= 512: one workgroup a CU by registers, still one sweep over J
 }
 
 namespace {
@@ -53,7 +54,8 @@ hipError_t lr_flush(T* J, const T* U, const T* D, int k, size_t m, int n, int nu
     if (ncp <= 1) return lr_flush_ncp<T, 1>(J, U, D, k, m, n, (int)blocks, vec, s);
     if (ncp <= 2) return lr_flush_ncp<T, 2>(J, U, D, k, m, n, (int)blocks, vec, s);
     if (ncp <= 4) return lr_flush_ncp<T, 4>(J, U, D, k, m, n, (int)blocks, vec, s);
-    return lr_flush_ncp<T, 8>(J, U, D, k, m, n, (int)blocks, vec, s);
+    if (ncp <= 8) return lr_flush_ncp<T, 8>(J, U, D, k, m, n, (int)blocks, vec, s);
+    return lr_flush_ncp<T, 16>(J, U, D, k, m, n, (int)blocks, vec, s);
 }
 
 template <typename T>

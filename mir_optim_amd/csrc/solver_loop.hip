@@ -89,7 +89,7 @@ bool Solver<T>::setup()
     mB = B.mB;
     fr = B.ytmp;
     big_solve = n > (uint32_t)kSolveMaxN || (variant & MIR_LSQ_VARIANT_SOLVE_GENERIC) != 0;
-    if (n > (uint32_t)kLrMaxN) lowrank = false;    // the read-only Broyden sweep keeps n <= 256; above, J is rewritten
+    if (n > (uint32_t)kLrMaxN) lowrank = false;    // the read-only Broyden sweep keeps n <= kLrMaxN = 512; above, J is rewritten
     // Rounds enqueued ahead of time: measured on one MI355X they do not pay at cfg 3 (7.08 ms per solve with, 7.02 without: the
     // stream is busy > 97 % of a solve anyway) but do for SMALL problems (J up to 32 MB: every kernel of a round is a few
     // microseconds and the host's decision latency is a visible share of it): cfg 2 63.5 -> 61.8 us per round. So: on for

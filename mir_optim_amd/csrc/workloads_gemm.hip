@@ -568,6 +568,75 @@ __global__ __launch_bounds__(256) void k_tanh_linear_batched_diff_generic(const 
     }
 }
 
+// ---- any n above the LDS-DMA shapes (n > 256, n % 8 == 0): the same GEMM on the matrix cores with both operands read straight
+//      from memory (A streamed once per workgroup: its four waves share a 16-row tile through L1 / L2; X, a few MB, lives in L2).
+//      A wave owns 16 rows x 64 points (four accumulators reuse each A fragment); the K index is permuted as in the LDS-DMA kernel
+//      so that one 16-byte load feeds two k-steps: lane (fr, fq) reads columns 8 j + 2 fq, + 1 of its row / of its point.
+//      (Before: one thread per (row, point) with a scalar dot product, 236 ms for the 1024 points of an n = 512 refresh at
+//      m = 250 000 -- 1.1 TFLOP/s; the solver's own work at that shape is 20 ms.)
+// OUT: 0 = Y m x P row-major, 1 = the m x P/2 row-major DIFFERENCE panel, 2 = Y point-major (Y[k m + i])
+template <int OUT>
+__global__ __launch_bounds__(256) void k_tanh_linear_batched_wide(const double* __restrict__ A, const double* __restrict__ b,
+                                                                    const double* __restrict__ X, double* __restrict__ Y,
+                                                                    size_t m, int n, int P)
+{
+    using Acc = __attribute__((ext_vector_type(4))) double;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const size_t ntiles = (m + 15) / 16;
+    const int ngroups = (P + 63) / 64;
+    const int npairs = n / 8;
+    for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const size_t arow = t * 16 + fr < m ? t * 16 + fr : m - 1;
+        const double2* __restrict__ ap = reinterpret_cast<const double2*>(A + arow * (size_t)n) + fq;
+        double bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const size_t row = t * 16 + fq + 4 * r; bv[r] = b[row < m ? row : m - 1]; }
+        for (int g = wave; g < ngroups; g += 4) {
+            const double2* __restrict__ xp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int pt = 64 * g + 16 * u + fr;
+                pt = pt < P ? pt : P - 1;
+                xp[u] = reinterpret_cast<const double2*>(X + (size_t)pt * n) + fq;
+            }
+            Acc acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = Acc{0, 0, 0, 0};
+#pragma unroll 4
+            for (int j = 0; j < npairs; ++j) {
+                const double2 a = ap[4 * j];
+                double2 x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = xp[u][4 * j];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, x[u].x, acc[u], 0, 0, 0);
+                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, x[u].y, acc[u], 0, 0, 0);
+                }
+            }
+            // D: column = lane & 15 = point, rows fq + 4 r
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pt = 64 * g + 16 * u + fr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t row = t * 16 + fq + 4 * r;
+                    const double y = dtanh(acc[u][r]) - bv[r];
+                    if constexpr (OUT == 1) {
+                        const double d = y - lane_pair_swap(y);              // f(x + h e_j) - f(x - h e_j): points 2 j, 2 j + 1 are adjacent lanes
+                        if ((fr & 1) == 0 && pt < P && row < m) Y[row * (size_t)(P >> 1) + (pt >> 1)] = d;
+                    } else if constexpr (OUT == 0) {
+                        if (pt < P && row < m) Y[row * (size_t)P + pt] = y;
+                    } else {
+                        if (pt < P && row < m) Y[(size_t)pt * m + row] = y;
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 void launch_tanh_linear_batched_diff(const double* A, const double* b, const double* X, double* D, size_t m, int n, int P,
@@ -578,6 +647,11 @@ void launch_tanh_linear_batched_diff(const double* A, const double* b, const dou
         if (n == 128 && launch_tlb_dma<32, true, true>(A, b, X, D, m, P, s, read_a_once)) return;
         if (n == 64 && launch_tlb_dma<16, true, true>(A, b, X, D, m, P, s, read_a_once)) return;
         if (n == 32 && launch_tlb_dma<8, true, true>(A, b, X, D, m, P, s, read_a_once)) return;
+    }
+    if (n > 256 && n % 8 == 0 && P % 2 == 0 && m > 0) {
+        const size_t nt = (m + 15) / 16;
+        hipLaunchKernelGGL(k_tanh_linear_batched_wide<1>, dim3((unsigned)(nt < 256 * 8 ? nt : 256 * 8)), dim3(256), 0, s, A, b, X, D, m, n, P);
+        return;
     }
     size_t blocks = (m * (size_t)(P / 2) + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
@@ -593,6 +667,11 @@ void launch_tanh_linear_batched_rm(const double* A, const double* b, const doubl
         if (n == 64 && launch_tlb_dma<16, true>(A, b, X, Y, m, P, s)) return;
         if (n == 32 && launch_tlb_dma<8, true>(A, b, X, Y, m, P, s)) return;
     }
+    if (n > 256 && n % 8 == 0 && m > 0) {
+        const size_t nt = (m + 15) / 16;
+        hipLaunchKernelGGL(k_tanh_linear_batched_wide<0>, dim3((unsigned)(nt < 256 * 8 ? nt : 256 * 8)), dim3(256), 0, s, A, b, X, Y, m, n, P);
+        return;
+    }
     size_t blocks = (m * (size_t)P + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(k_tanh_linear_batched_rm_generic, dim3((unsigned)(blocks ? blocks : 1)), dim3(256), 0, s, A, b, X, Y, m, n, P);
@@ -602,6 +681,11 @@ bool launch_tanh_linear_batched(const double* A, const double* b, const double* 
                                 hipStream_t s)
 {
     if (n == 256 && m >= 32 && launch_tlb_dma<64>(A, b, X, Y, m, P, s)) return true;
+    if (n > 256 && n % 8 == 0 && m > 0) {
+        const size_t nt = (m + 15) / 16;
+        hipLaunchKernelGGL(k_tanh_linear_batched_wide<2>, dim3((unsigned)(nt < 256 * 8 ? nt : 256 * 8)), dim3(256), 0, s, A, b, X, Y, m, n, P);
+        return true;
+    }
     if (n % 2 != 0 || n > 128 || n < 4) return false;
     if (m >= 32) {
         if (n == 128 && launch_tlb_dma<32>(A, b, X, Y, m, P, s)) return true;

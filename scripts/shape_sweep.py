@@ -46,10 +46,10 @@ for m, n, dt, note in shapes:
     if nbr:
         ms = q["jtj_broyden_ms"] / nbr
         kbar = q["broyden_lr_columns"] / nbr
-        lowrank = n <= 256
+        lowrank = n <= 512            # kLrMaxN (csrc/common.h)
         by = T * (m * n + (kbar + 3) * m) if lowrank else T * (2.0 * m * n + 3 * m)
         out["broyden_kernel"] = {"avg_ms": ms, "launches": int(nbr), "GBs": by / ms / 1e6, "hbm_frac": by / ms / 1e6 / HBM,
-                                 "kind": "read-only sweep (k_broyden_lr)" if lowrank else "rewrite + tile-pair J^T J (n > 256)"}
+                                 "kind": "read-only sweep (k_broyden_lr)" if lowrank else "rewrite + tile-pair J^T J (n > 512)"}
     out["solve_kernel"] = {"avg_ms": q["solve_ms"] / max(1, q["solve_launches"]), "launches": int(q["solve_launches"])}
     if q["fd_callback_calls"]:
         out["caller_fd"] = {"ms_per_refresh": q["fd_callback_ms"] / max(1, q["jacobian_full"]), "calls_per_refresh": q["fd_callback_calls"] / max(1, q["jacobian_full"])}
