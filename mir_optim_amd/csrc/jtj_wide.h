@@ -71,46 +71,52 @@ __global__ __launch_bounds__(256) void k_jtj_wide(JtjWideArgs<T> a)
         ci[c] = oki[c] ? coli : n - 1;
         cj[c] = okj[c] ? colj : n - 1;
     }
-    struct Frag { T vi[kWideTile], vj[kWideTile], y; };
+    // a fragment holds what was LOADED; rows past m and columns past n are zeroed when it is used (a select right behind the load
+    // would wait for the load where it is issued and serialise the ring)
+    struct Frag { T vi[kWideTile], vj[kWideTile], y; bool rok; };
     auto load = [&](size_t g, Frag& f) {
         const size_t row = 4 * g + q;
-        const bool rok = row < m;
-        const size_t rc = rok ? row : m - 1;
+        f.rok = row < m;
+        const size_t rc = f.rok ? row : m - 1;
         const T* rp = a.J + rc * (size_t)n;
 #pragma unroll
-        for (int c = 0; c < kWideTile; ++c) {
-            const T t = rp[ci[c]];
-            f.vi[c] = (rok && oki[c]) ? t : T(0);
-        }
+        for (int c = 0; c < kWideTile; ++c) f.vi[c] = rp[ci[c]];
 #pragma unroll
-        for (int c = 0; c < kWideTile; ++c) {
-            const T t = rp[cj[c]];
-            f.vj[c] = (rok && okj[c]) ? t : T(0);
-        }
-        const T t = a.y[rc];
-        f.y = rok ? t : T(0);
+        for (int c = 0; c < kWideTile; ++c) f.vj[c] = rp[cj[c]];
+        f.y = a.y[rc];
     };
     auto compute = [&](const Frag& f) {
+        T vi[kWideTile], vj[kWideTile];
+#pragma unroll
+        for (int c = 0; c < kWideTile; ++c) { vi[c] = (f.rok && oki[c]) ? f.vi[c] : T(0); vj[c] = (f.rok && okj[c]) ? f.vj[c] : T(0); }
+        const T yv = f.rok ? f.y : T(0);
         if (diag) {
 #pragma unroll
-            for (int c = 0; c < kWideTile; ++c) jy[c] += f.vi[c] * f.y;       // LS:1052
+            for (int c = 0; c < kWideTile; ++c) jy[c] += vi[c] * yv;       // LS:1052
         }
 #pragma unroll
         for (int i = 0; i < kWideTile; ++i)
 #pragma unroll
-            for (int j = 0; j < kWideTile; ++j) acc[i][j] = Mma<T>::mma(f.vi[i], f.vj[j], acc[i][j]);   // LS:1065
+            for (int j = 0; j < kWideTile; ++j) acc[i][j] = Mma<T>::mma(vi[i], vj[j], acc[i][j]);   // LS:1065
     };
-    Frag fa, fb;
-    size_t g = g0;
-    if (g < g1) load(g, fa);
-    while (g < g1) {
-        if (g + 1 < g1) load(g + 1, fb);
-        compute(fa);
-        ++g;
-        if (g >= g1) break;
-        if (g + 1 < g1) load(g + 1, fa);
-        compute(fb);
-        ++g;
+    // Ring of kRing fragments, kAhead row groups in flight beyond the one on the matrix cores. The loads of a group are issued
+    // UNCONDITIONALLY (past the end the last group is read again): a load under `if` makes the number of loads in flight
+    // unknowable to the compiler, which then waits for all of them before the first use -- one memory latency per row group with
+    // two waves a SIMD was 0.16 of the MFMA peak at n = 512 (the rule found on the n = 256 solve).
+    constexpr int kAhead = 3, kRing = kAhead + 1;
+    Frag fr_[kRing];
+    if (g0 < g1) {
+        auto issue = [&](size_t g, auto B) { load(g < g1 ? g : g1 - 1, fr_[decltype(B)::value]); };
+        static_for<kAhead>([&](auto U) { issue(g0 + decltype(U)::value, U); });
+        for (size_t gb = g0; gb < g1; gb += kRing) {
+            static_for<kRing>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                if (gb + u < g1) {
+                    issue(gb + u + kAhead, IntC<(u + kAhead) % kRing>{});
+                    compute(fr_[u]);
+                }
+            });
+        }
     }
 #pragma unroll
     for (int c = 0; c < kWideTile; ++c) {

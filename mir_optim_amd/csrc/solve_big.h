@@ -168,101 +168,120 @@ __device__ __noinline__ int potrf_big(int n, const T* A, int lda, T* F, int ldf,
 }
 
 // ---------------------------------------------------------------- ?potrs: L L^T x = z, z in/out (global n-vector)
+// The vector lives in LDS (sm.span) during the two sweeps. Block step kb: the 16 lanes of wave 0's first DPP row solve the
+// diagonal block among themselves -- lane r holds row r (forward) / column r (backward) of L_kk and its reciprocal pivot; unknown
+// after unknown: a multiply, a row broadcast, a multiply-add (0.4 us a block with its loads; before, ONE thread walked the 120
+// dependent products through LDS: 3 us a block, 128 blocks a solve at n = 512) --, one barrier, then every remaining row subtracts
+// its 16 products, the 16 factor entries loaded together (indices clamped: always 16 loads in flight). 330 -> 250 us a call at
+// n = 512. (Tried on top and measured no better: the next step's loads issued ahead of the diagonal solve, and a transposed copy of
+// the factor for a coalesced backward sweep -- stamps in profiles/r04/solve_big_phases_n512.txt.)
 template <typename T>
 __device__ __noinline__ void potrs_big(int n, const T* F, int ldf, T* z, BigLds<T>& sm)
 {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int nblk = (n + 15) / 16;
+    T* zs = sm.span;
     __syncthreads();
-    // forward: L w = z
-    for (int kb = 0; kb < nblk; ++kb) {
-        const int c0 = 16 * kb;
-        if (tid < 256) {                                        // L_kk into LDS
-            const int r = tid & 15, c = tid >> 4;
-            const int gr = c0 + r < n ? c0 + r : n - 1, gc = c0 + c < n ? c0 + c : n - 1;
-            const T v = F[gr + (size_t)gc * ldf];
-            sm.blk[r * 17 + c] = (c0 + r < n && c0 + c < n) ? v : (r == c ? T(1) : T(0));
-        }
-        __syncthreads();
-        if (tid == 0) {                                         // 16 unknowns, forward substitution
-            T x[16];
+    for (int i = tid; i < n; i += kBigThreads) zs[i] = z[i];
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {
+        const bool fwd = pass == 0;
+        for (int kk = 0; kk < nblk; ++kk) {
+            const int kb = fwd ? kk : nblk - 1 - kk;
+            const int c0 = 16 * kb;
+            if (tid < kWave) {                                   // wave 0; its lanes 16 .. 63 repeat the work of lanes 0 .. 15
+                const int r = lane & 15;
+                const bool live = c0 + r < n;
+                const int gr = live ? c0 + r : n - 1;
+                T lv[16];                                        // fwd: L[c0 + r][c0 + q], q < r; bwd: L[c0 + q][c0 + r], q > r; else 0
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                T s = c0 + r < n ? z[c0 + r] : T(0);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) if (q < r) s -= sm.blk[r * 17 + q] * x[q];
-                x[r] = s / sm.blk[r * 17 + r];
-                sm.xk[r] = x[r];
-                if (c0 + r < n) z[c0 + r] = x[r];
+                for (int q = 0; q < 16; ++q) {
+                    const int gq = c0 + q < n ? c0 + q : n - 1;
+                    const T v = fwd ? F[gr + (size_t)gq * ldf] : F[gq + (size_t)gr * ldf];
+                    lv[q] = ((fwd ? q < r : q > r) && live && c0 + q < n) ? v : T(0);
+                }
+                const T dg = F[gr + (size_t)gr * ldf];
+                const T rinv = live ? T(1) / dg : T(1);
+                T sv = live ? zs[c0 + r] : T(0), xr = 0;
+                // lane q's candidate sv * rinv is x_q once every earlier unknown has been subtracted from its row
+                if (fwd) {
+                    static_for<16>([&](auto QQ) {
+                        constexpr int q = decltype(QQ)::value;
+                        const T xq = dpp_row_bcast<q>(sv * rinv);
+                        xr = (r == q) ? xq : xr;
+                        sv -= lv[q] * xq;
+                    });
+                } else {
+                    static_for<16>([&](auto QQ) {
+                        constexpr int q = 15 - decltype(QQ)::value;
+                        const T xq = dpp_row_bcast<q>(sv * rinv);
+                        xr = (r == q) ? xq : xr;
+                        sv -= lv[q] * xq;
+                    });
+                }
+                if (lane < 16) { if (live) zs[c0 + r] = xr; sm.xk[r] = live ? xr : T(0); }
             }
-        }
-        __syncthreads();
-        for (int i = c0 + 16 + tid; i < n; i += kBigThreads) {
-            T acc = 0;
+            __syncthreads();
+            if (fwd) {
+                for (int i = c0 + 16 + tid; i < n; i += kBigThreads) {
+                    T lf[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) acc += F[i + (size_t)(c0 + c) * ldf] * sm.xk[c];   // c0 + c < n here: i > c0 + 15
-            z[i] -= acc;
-        }
-        __syncthreads();
-    }
-    // backward: L^T x = w
-    for (int kb = nblk - 1; kb >= 0; --kb) {
-        const int c0 = 16 * kb;
-        if (tid < 256) {
-            const int r = tid & 15, c = tid >> 4;
-            const int gr = c0 + r < n ? c0 + r : n - 1, gc = c0 + c < n ? c0 + c : n - 1;
-            const T v = F[gr + (size_t)gc * ldf];
-            sm.blk[r * 17 + c] = (c0 + r < n && c0 + c < n) ? v : (r == c ? T(1) : T(0));
-        }
-        __syncthreads();
-        if (tid == 0) {                                         // L_kk^T x = z_k, backward substitution
-            T x[16];
+                    for (int c = 0; c < 16; ++c) lf[c] = F[i + (size_t)(c0 + c) * ldf];          // c0 + c < n here: i > c0 + 15
+                    T acc = 0;
 #pragma unroll
-            for (int r = 15; r >= 0; --r) {
-                T s = c0 + r < n ? z[c0 + r] : T(0);
+                    for (int c = 0; c < 16; ++c) acc += lf[c] * sm.xk[c];
+                    zs[i] -= acc;
+                }
+            } else {
+                for (int i = tid; i < c0; i += kBigThreads) {
+                    T lf[16];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) if (q > r) s -= sm.blk[q * 17 + r] * x[q];
-                x[r] = s / sm.blk[r * 17 + r];
-                sm.xk[r] = x[r];
-                if (c0 + r < n) z[c0 + r] = x[r];
+                    for (int c = 0; c < 16; ++c) lf[c] = F[(c0 + c < n ? c0 + c : n - 1) + (size_t)i * ldf];   // L(c0 + c, i)
+                    T acc = 0;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) if (c0 + c < n) acc += lf[c] * sm.xk[c];
+                    zs[i] -= acc;
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
-        for (int i = tid; i < c0; i += kBigThreads) {
-            T acc = 0;
-#pragma unroll
-            for (int c = 0; c < 16; ++c)
-                if (c0 + c < n) acc += F[(c0 + c) + (size_t)i * ldf] * sm.xk[c];           // L(c0 + c, i)
-            z[i] -= acc;
-        }
-        __syncthreads();
     }
+    for (int i = tid; i < n; i += kBigThreads) z[i] = zs[i];
+    __syncthreads();
 }
 
-// r = b - A x, w = |b| + |A| |x|: one wave per row, lanes along the row (A is symmetric: row i is read as column i)
+// r = b - A x, w = |b| + |A| |x|: one ROW per thread (rows strided by the workgroup), A symmetric: entry (i, k) is read as
+// A[i + k lda], consecutive rows in consecutive lanes; 16 columns' loads are issued together (indices clamped: always 16, a count
+// the compiler can keep in flight) and x comes from LDS. (Before: one wave per row with a wave reduction per row -- 64 dependent
+// round trips a wave, 115 us per residual at n = 512.)
 template <typename T>
-__device__ __noinline__ void residual_big(int n, const T* A, int lda, const T* b, const T* x, T* r, T* w)
+__device__ __noinline__ void residual_big(int n, const T* A, int lda, const T* b, const T* x, T* r, T* w, T* xs /* LDS, >= n */)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
-    for (int i = wave; i < n; i += kBigWaves) {
+    for (int i = threadIdx.x; i < n; i += kBigThreads) xs[i] = x[i];
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += kBigThreads) {
+        const int i = i0 + threadIdx.x;
+        const int ic = i < n ? i : n - 1;
         T ra = 0, wa = 0;
-        for (int k = lane; k < n; k += kWave) {
-            const T a = A[k + (size_t)i * lda], xv = x[k];
-            ra += a * xv;
-            wa += dabs(a) * dabs(xv);
+        for (int k0 = 0; k0 < n; k0 += 16) {
+            T av[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) av[u] = A[ic + (size_t)(k0 + u < n ? k0 + u : n - 1) * lda];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (k0 + u < n) { const T xv = xs[k0 + u]; ra += av[u] * xv; wa += dabs(av[u]) * dabs(xv); }
         }
-        ra = wave_sum(ra);
-        wa = wave_sum(wa);
-        if (lane == 0) { r[i] = b[i] - ra; w[i] = dabs(b[i]) + wa; }
+        if (i < n) { r[i] = b[i] - ra; w[i] = dabs(b[i]) + wa; }
     }
     __syncthreads();
 }
 
 // ---------------------------------------------------------------- ?posvx('E','L'), nrhs = 1 (same semantics as posvx_device)
 template <typename T>
-__device__ __noinline__ int posvx_big(int n, T* A, int lda, T* F, int ldf, T* s, T* b, T* x, T* r, T* w, BigLds<T>& sm)
+__device__ __noinline__ int posvx_big(int n, T* A, int lda, T* F, int ldf, T* s, T* b, T* x, T* r, T* w, BigLds<T>& sm, long long* dbg = nullptr)
 {
+    MIRLSQ_STAMP(dbg, 2);
     const int tid = threadIdx.x;
     const T eps = Lim<T>::eps / 2;
     const T safmin = Lim<T>::min_normal;
@@ -287,21 +306,26 @@ __device__ __noinline__ int posvx_big(int n, T* A, int lda, T* F, int ldf, T* s,
         for (int i = tid; i < n; i += kBigThreads) b[i] = s[i] * b[i];
     }
     __syncthreads();
+    MIRLSQ_STAMP(dbg, 3);
     const int info = potrf_big<T>(n, A, lda, F, ldf, sm);
     if (info != 0) return info;
+    MIRLSQ_STAMP(dbg, 4);
     for (int i = tid; i < n; i += kBigThreads) x[i] = b[i];
     potrs_big<T>(n, F, ldf, x, sm);
+    MIRLSQ_STAMP(dbg, 5);
     // ?porfs, ITMAX = 5
     const T safe1 = T(n + 1) * safmin, safe2 = safe1 / eps;
     T lstres = 3;
     for (int count = 1;; ++count) {
-        residual_big<T>(n, A, lda, b, x, r, w);
+        residual_big<T>(n, A, lda, b, x, r, w, sm.span);
+        if (count == 1) MIRLSQ_STAMP(dbg, 11);
         T qv = 0;
         for (int i = tid; i < n; i += kBigThreads) {
             const T q = (w[i] > safe2) ? dabs(r[i]) / w[i] : (dabs(r[i]) + safe1) / (w[i] + safe1);
             qv = q > qv ? q : qv;
         }
         const T berr = big_max(qv, sm.red);
+        if (count == 1) MIRLSQ_STAMP(dbg, 12);
         if (berr > eps && 2 * berr <= lstres && count <= 5) {
             potrs_big<T>(n, F, ldf, r, sm);
             for (int i = tid; i < n; i += kBigThreads) x[i] += r[i];
@@ -313,6 +337,7 @@ __device__ __noinline__ int posvx_big(int n, T* A, int lda, T* F, int ldf, T* s,
     }
     if (rcequ) for (int i = tid; i < n; i += kBigThreads) x[i] = s[i] * x[i];
     __syncthreads();
+    MIRLSQ_STAMP(dbg, 6);
     return 0;
 }
 
@@ -339,7 +364,7 @@ __device__ __noinline__ int box_qp_big(int n, const T* Pm, const T* q, const T* 
     if (!unconstrainedSolution) {                                   // QP:168-214
         for (int i = tid; i < n; i += kBigThreads) b[i] = -q[i];
         __syncthreads();
-        const int info = posvx_big<T>(n, sc.A, n, sc.Fg, ldf, s, b, x, r, w, sm);
+        const int info = posvx_big<T>(n, sc.A, n, sc.Fg, ldf, s, b, x, r, w, sm, sc.dbg);
         if (info != 0) return 1;
     }
     {                                                               // QP:216-219
@@ -447,6 +472,8 @@ __global__ __launch_bounds__(kBigThreads) void k_lm_solve_big(LmSolveArgs<T> a)
     T* xq = sc.vec + 10 * (size_t)n;
 
     if (a.guard && *a.guard == 0) return;
+    MIRLSQ_STAMP(sc.dbg, 0);
+    if (sc.dbg && threadIdx.x == 0) sc.dbg[9] = clock64();
     T jy_inf = 0;
     if (a.check_grad) {
         T mx = 0;
@@ -484,18 +511,32 @@ __global__ __launch_bounds__(kBigThreads) void k_lm_solve_big(LmSolveArgs<T> a)
     // step bounds LS:1074-1077; Pm = A = JJ + lambda I, LS:1078-1079
     for (int i = tid; i < n; i += kBigThreads) { qpl[i] = a.lower[i] - a.x[i]; qpu[i] = a.upper[i] - a.x[i]; }
     {
+        // 16 loads in flight a thread; the damping goes onto the diagonal in a pass of its own (an `idx % (n + 1)` per element was
+        // a 64-bit division per element: 205 us of this kernel at n = 512)
         const size_t nn = (size_t)n * n;
-        for (size_t idx = tid; idx < nn; idx += kBigThreads) {
-            const T v = a.JJ[idx];
-            const T t = (idx % ((size_t)n + 1) == 0) ? v + lambda : v;
-            sc.Pm[idx] = t;
-            sc.A[idx] = t;
+        for (size_t base = tid; base < nn; base += (size_t)16 * kBigThreads) {
+            T v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const size_t idx = base + (size_t)u * kBigThreads; v[u] = a.JJ[idx < nn ? idx : nn - 1]; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const size_t idx = base + (size_t)u * kBigThreads;
+                if (idx < nn) { sc.Pm[idx] = v[u]; sc.A[idx] = v[u]; }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += kBigThreads) {
+            const T t = a.JJ[(size_t)i * n + i] + lambda;
+            sc.Pm[(size_t)i * n + i] = t;
+            sc.A[(size_t)i * n + i] = t;
         }
     }
     __syncthreads();
+    MIRLSQ_STAMP(sc.dbg, 1);
     int qp_iters = 0;
     const int qp = box_qp_big<T>(n, sc.Pm, a.Jy, qpl, qpu, xq, false, a.set.qpRelTolerance, a.set.qpAbsTolerance,
                                  a.set.qpMaxIterations, sc, sm, &qp_iters);   // LS:1080
+    MIRLSQ_STAMP(sc.dbg, 7);
 
     int flags = 0;
     T ndd = 0, pred = 0, xn = 0;
@@ -522,11 +563,22 @@ __global__ __launch_bounds__(kBigThreads) void k_lm_solve_big(LmSolveArgs<T> a)
         if (!big_or(moved, sm.ired)) flags |= kFlagNullStep;
         ndd = big_sum(sdd, sm.red);                                  // LS:1099
         // predicted reduction with the UNDAMPED JJ, LS:1141-1142: t = JJ dx + 2 Jy ; pred = -(t . dx)
-        for (int i = wave; i < n; i += kBigWaves) {
+        // (JJ dx)_i with one row per thread: JJ is symmetric, entry (i, k) is read as JJ[k n + i] -- consecutive rows in consecutive
+        // lanes --, dx from LDS, 16 loads in flight (before: a wave per row and a wave reduction per row, 160 us at n = 512)
+        __syncthreads();
+        for (int i = tid; i < n; i += kBigThreads) sm.span[i] = dx_out[i];
+        __syncthreads();
+        for (int i0 = 0; i0 < n; i0 += kBigThreads) {
+            const int i = i0 + tid, ic = i < n ? i : n - 1;
             T acc = 0;
-            for (int k = lane; k < n; k += kWave) acc += a.JJ[(size_t)i * n + k] * dx_out[k];
-            acc = wave_sum(acc);
-            if (lane == 0) tv[i] = acc;
+            for (int k0 = 0; k0 < n; k0 += 16) {
+                T av[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) av[u] = a.JJ[(size_t)(k0 + u < n ? k0 + u : n - 1) * n + ic];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) if (k0 + u < n) acc += av[u] * sm.span[k0 + u];
+            }
+            if (i < n) tv[i] = acc;
         }
         __syncthreads();
         T sp = 0;
@@ -539,6 +591,8 @@ __global__ __launch_bounds__(kBigThreads) void k_lm_solve_big(LmSolveArgs<T> a)
         xn = amax > 0 ? amax * dsqrt(big_sum(sc2, sm.red)) : T(0);
         if (!(dsqrt(ndd) < a.set.maxStep)) flags |= kFlagStepTooLong; // LS:1101
     }
+    MIRLSQ_STAMP(sc.dbg, 8);
+    if (sc.dbg && threadIdx.x == 0) sc.dbg[10] = clock64();
     if (tid == 0) {
         ChainRec<T> r{};
         r.lambda = lambda; r.new_dx_dot = ndd; r.predicted = pred; r.trial_xnorm = xn;
