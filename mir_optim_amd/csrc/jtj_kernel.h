@@ -77,25 +77,27 @@ __device__ __forceinline__ void jtj_body(const JtjArgs<T>& a, T* red, int lane, 
     T neg_d = 0;
     if constexpr (BROYDEN) neg_d = -(T(1) / *a.dx_dot);
 
-    struct Frag { T v[NCB]; T y, yo; };
+    // a fragment holds what was LOADED; rows past m and columns past n are zeroed when it is used (a select right behind a load waits
+    // for the load where it is issued)
+    struct Frag { T v[NCB]; T y, yo; bool rok; };
 
     auto load = [&](size_t g, Frag& f) {
         const size_t row = 4 * g + q;
-        const bool rok = row < m;
-        const size_t rc = rok ? row : m - 1;
+        f.rok = row < m;
+        const size_t rc = f.rok ? row : m - 1;
         const T* rp = a.J + rc * (size_t)n;
 #pragma unroll
-        for (int c = 0; c < NCB; ++c) {
-            const T t = rp[coff[c]];
-            f.v[c] = (rok && cok[c]) ? t : T(0);
-        }
-        const T t = a.y[rc];
-        f.y = rok ? t : T(0);
+        for (int c = 0; c < NCB; ++c) f.v[c] = rp[coff[c]];
+        f.y = a.y[rc];
         f.yo = 0;
-        if constexpr (BROYDEN) { const T t2 = a.y_old[rc]; f.yo = rok ? t2 : T(0); }
+        if constexpr (BROYDEN) f.yo = a.y_old[rc];
     };
 
     auto compute = [&](size_t g, Frag& f) {
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) f.v[c] = (f.rok && cok[c]) ? f.v[c] : T(0);
+        f.y = f.rok ? f.y : T(0);
+        if constexpr (BROYDEN) f.yo = f.rok ? f.yo : T(0);
         if constexpr (BROYDEN) {
             // LS:1003-1006 for the 4 rows of this group
             T part = 0;
@@ -125,18 +127,54 @@ __device__ __forceinline__ void jtj_body(const JtjArgs<T>& a, T* red, int lane, 
                     acc[I * (I + 1) / 2 + Jb] = Mma<T>::mma(f.v[I], f.v[Jb], acc[I * (I + 1) / 2 + Jb]);   // LS:1065
     };
 
-    // software pipeline, two named fragment sets (no register copies)
-    Frag fa, fb;
-    size_t g = g0;
-    if (g < g1) load(g, fa);
-    while (g < g1) {
-        if (g + 1 < g1) load(g + 1, fb);
-        compute(g, fa);
-        ++g;
-        if (g >= g1) break;
-        if (g + 1 < g1) load(g + 1, fa);
-        compute(g, fb);
-        ++g;
+    // Ring of kRing fragment sets, kAhead row groups in flight beyond the one being used; the loads of a group are issued
+    // unconditionally (past the end the last group is read again): under `if` the compiler cannot count the loads in flight and
+    // waits for all of them at the first use (the same change took k_jtj_wide from 0.16 to 0.56 of the MFMA peak)
+    if constexpr (BROYDEN) {
+        // The Broyden REWRITE variant (a reference path: MIR_LSQ_VARIANT_BROYDEN_REWRITE) keeps its original pipeline: one group ahead,
+        // every load WAITED FOR where it is issued. With several roles a row group is read by every role and rewritten in place by
+        // role 0: that is safe only while a role's read of group g + 1 is complete before role 0, one group further on, stores it --
+        // asynchronous loads in a deeper ring let the store overtake the read (seen in test_broyden_fused_update[30000-128] and
+        // test_lowrank_broyden_matches_rewriting_kernels[9973-100] the day the ring was tried here).
+        auto load_now = [&](size_t g, Frag& f) {
+            load(g, f);
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) asm volatile("" : "+v"(f.v[c]));          // the values are in registers before anything else happens
+        };
+        // ROLES > 1: a workgroup barrier per group makes it certain -- every wave of the workgroup runs the same `per` trips (guarded
+        // past its own range), role 0 stores group g + 1 in trip g + 1, which no wave enters before all have finished trip g and
+        // with it their (waited-for) load of group g + 1.
+        Frag fa, fb;
+        if (g0 < g1) load_now(g0, fa);
+        for (size_t it = 0; it < per; it += 2) {
+            if constexpr (ROLES > 1) __syncthreads();
+            const size_t g = g0 + it;
+            if (g < g1) {
+                if (g + 1 < g1) load_now(g + 1, fb);
+                compute(g, fa);
+            }
+            if constexpr (ROLES > 1) __syncthreads();
+            if (g + 1 < g1) {
+                if (g + 2 < g1) load_now(g + 2, fa);
+                compute(g + 1, fb);
+            }
+        }
+    } else {
+        constexpr int kAhead = 2, kRing = kAhead + 1;
+        Frag fr_[kRing];
+        if (g0 < g1) {
+            auto issue = [&](size_t g, auto B) { load(g < g1 ? g : g1 - 1, fr_[decltype(B)::value]); };
+            static_for<kAhead>([&](auto U) { issue(g0 + decltype(U)::value, U); });
+            for (size_t gb = g0; gb < g1; gb += kRing) {
+                static_for<kRing>([&](auto U) {
+                    constexpr int u = decltype(U)::value;
+                    if (gb + u < g1) {
+                        issue(gb + u + kAhead, IntC<(u + kAhead) % kRing>{});
+                        compute(gb + u, fr_[u]);
+                    }
+                });
+            }
+        }
     }
 
     if constexpr (ROLE == 0) {
