@@ -163,27 +163,34 @@ __device__ __forceinline__ void fdp_producer_plain(const JtjArgs<double>& a, dou
         }
     }
 
-    fdp_v2d b[NI];
-    double yb = 0;
-    auto issue = [&](size_t s) {
-        const size_t row0 = (s0 + s) * C::RS + C::RP * (size_t)w;
+    // TWO stages of loads in flight per producer wave (a ring of two register buffers): the loads of a stage are issued
+    // unconditionally (past the end the last stage is read again), so the compiler can count them across the loop's back edge and
+    // convert(t) waits for stage t only -- with `if (t + 1 < S) issue(t + 1)` it could not, every wait was vmcnt(0) and one stage
+    // in flight was all a producer could have (the "deeper register pipeline" that rounds 2-3 gave up on).
+    fdp_v2d b[2][NI];
+    double yb[2] = {0, 0};
+    auto issue = [&](size_t s, auto B) {
+        constexpr int bb = decltype(B)::value;
+        const size_t sc = s < S ? s : S - 1;
+        const size_t row0 = (s0 + sc) * C::RS + C::RP * (size_t)w;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             size_t row = row0 + prow[i];
             row = row < m ? row : m - 1;
-            if constexpr (DIFF) b[i] = __builtin_nontemporal_load(&Jp[row * hr + pcol[i]]);   // the panel is read once
-            else b[i] = Jp[row * hr + pcol[i]];
+            if constexpr (DIFF) b[bb][i] = __builtin_nontemporal_load(&Jp[row * hr + pcol[i]]);   // the panel is read once
+            else b[bb][i] = Jp[row * hr + pcol[i]];
         }
         size_t yr = row0 + (lane & (C::RP - 1));
         yr = yr < m ? yr : m - 1;
-        yb = a.y[yr];
+        yb[bb] = a.y[yr];
     };
-    auto convert = [&](size_t s) {
+    auto convert = [&](size_t s, auto B) {
+        constexpr int bb = decltype(B)::value;
         double* slot = smem + (s & 1) * C::SLOT_DOUBLES;
         const size_t row0 = (s0 + s) * C::RS + C::RP * (size_t)w;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            fdp_v2d v = b[i];
+            fdp_v2d v = b[bb][i];
             if constexpr (DIFF) {
                 v.x = inv0[i] == 0 ? 0.0 : v.x * inv0[i];      // scal(1 / twh, Jj), LS:1047 (LS:1046: zero column)
                 v.y = inv1[i] == 0 ? 0.0 : v.y * inv1[i];
@@ -191,15 +198,23 @@ __device__ __forceinline__ void fdp_producer_plain(const JtjArgs<double>& a, dou
             if (pad[i] || row0 + prow[i] >= m) v = fdp_v2d{0.0, 0.0};
             *reinterpret_cast<fdp_v2d*>(slot + w * C::RP * n + 2 * (64 * i + lane)) = v;
         }
-        if (lane < C::RP) slot[C::RS * n + C::RP * w + lane] = (row0 + lane < m) ? yb : 0.0;
+        if (lane < C::RP) slot[C::RS * n + C::RP * w + lane] = (row0 + lane < m) ? yb[bb] : 0.0;
     };
 
-    if (S > 0) issue(0);
-    for (size_t t = 0; t < S; ++t) {
-        convert(t);
-        if (t + 1 < S) issue(t + 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+    if (S > 0) {
+        issue(0, IntC<0>{});
+        issue(1, IntC<1>{});
+        for (size_t t = 0; t < S; t += 2) {
+            static_for<2>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                if (t + u < S) {
+                    convert(t + u, U);
+                    issue(t + u + 2, U);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my LDS writes of the stage are done
+                    __builtin_amdgcn_s_barrier();                        // the stage is complete for the consumers
+                }
+            });
+        }
     }
 }
 
