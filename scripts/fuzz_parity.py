@@ -27,6 +27,9 @@ def case(seed):
     # small shapes: the oracle's plain loops must finish a case in well under a second (the sweep runs on GPU-box minutes)
     n = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 24, 31, 32, 33, 48, 63, 64, 65, 96, 128, 129]))
     m = int(n + rng.integers(0, 2 * n + 50)) if rng.random() < 0.5 else int(rng.integers(max(n, 2), 1500))
+    if os.environ.get("FUZZ_WIDE") == "1":              # the paths above n = 256: tile-pair J^T J, the any-n solve, the wide sweep / rewrite
+        n = int(rng.choice([257, 264, 300, 320, 384, 500, 512, 513, 520]))
+        m = int(n + rng.integers(0, 300)) if rng.random() < 0.6 else int(n + rng.integers(300, 1500))
     A = (2 * rng.random((m, n)) - 1) * np.sqrt(3.0 / n)
     xs = 2 * rng.random(n) - 1
     b = np.tanh(A @ xs) + 10.0 ** rng.integers(-6, -1) * (2 * rng.random(m) - 1)
@@ -46,7 +49,7 @@ def case(seed):
         lo = xs - 0.05 - 0.1 * rng.random(n); up = xs + 0.02 + 0.1 * rng.random(n)
     up = np.maximum(up, lo)
     x0 = np.clip(x0, lo, up)
-    s = dict(maxIterations=int(rng.choice([1, 2, 5, 12, 40])), absTolerance=float(rng.choice([1e-3, 1e-6, 1e-9])),
+    s = dict(maxIterations=int(rng.choice([1, 2, 5, 12, 40] if os.environ.get("FUZZ_WIDE") != "1" else [1, 2, 4, 6, 12])), absTolerance=float(rng.choice([1e-3, 1e-6, 1e-9])),
              maxAge=int(rng.choice([0, 0, 1, 3])), gradTolerance=float(rng.choice([2.2e-16, 1e-8, 1e-3])))
     return dict(A=A, b=b, x0=x0, lo=lo, up=up, m=m, n=n, s=s, bounded=kind >= 1)
 
@@ -136,6 +139,11 @@ def main():
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     mode = sys.argv[3] if len(sys.argv) > 3 else "device"       # device | host (reference ABI, f64 + f32) | shards (2 .. 8 in-process row shards)
     tally = {"same": 0, "trajectory": 0, "MISMATCH": 0}
+    # (no OpenBLAS in this process: its thread pool and the GPU runtime do not share a process well -- tests/test_gpu_fullsize.py runs it in one of its own)
+    wide_blas = False
+    wide = os.environ.get("FUZZ_WIDE") == "1"
+    if wide:
+        O.lib().lmo_set_omp_threads(8)      # the oracle's tanh-linear residual goes OpenMP above 200 000 elements; a GPU box shows every host core but shares 16
     for k in range(cases):
         dtype = np.float32 if (mode == "host" and k % 3 == 2) else np.float64
         c = host_case(seed0 + k, dtype) if mode == "host" else case(seed0 + k)
@@ -170,7 +178,10 @@ def main():
             res, x = prob.solve(c["x0"], lo, up, settings=sg, batched=bool(k % 2))
             prob.dA.free(); prob.db.free()
             ctx = O.TanhLinearCtx(c["A"].ctypes.data, c["b"].ctypes.data)
-            ro, xo = O.optimize(O.native_fn("wlc_tanh_linear_f"), c["m"], c["x0"], lower=lo, upper=up, settings=so, fctx=C.addressof(ctx))
+            ro, xo = O.optimize(O.native_fn("wlc_tanh_linear_f"), c["m"], c["x0"], lower=lo, upper=up, settings=so, fctx=C.addressof(ctx),
+                                use_openblas=wide_blas)
+            if wide:
+                print(f"... case {k} done (m {c['m']} n {c['n']})", flush=True)      # wide cases take seconds each: keep the log moving
         scale = max(1.0, float(np.abs(xo).max()))
         xerr = float(np.abs(x - xo).max()) / scale
         rerr = abs(res.residual - ro.residual) / max(abs(ro.residual), 1e-300)
