@@ -122,10 +122,14 @@ template <int NK> struct TlbCfg {
     static constexpr int N = 4 * NK;
     static constexpr int PPR = N / 2;                       // 16-byte pieces per row
     // n <= 128: 8 compute waves x 16 points, two 16-row tiles per stage (two MFMA chains per wave), 168 VGPRs;
-    // n = 256: the X fragments alone are 128 VGPRs -> 6 compute waves (8 waves per workgroup: 256 VGPRs each), one
-    // tile per stage with the K range split over two accumulator chains
+    // n = 256: the X fragments alone are 128 VGPRs -> 8 waves per workgroup (256 VGPRs each), one tile per stage with the
+    // K range split over two accumulator chains
     static constexpr int TILES = NK <= 32 ? 2 : 1;
-    static constexpr int COMPUTE_WAVES = NK <= 32 ? 8 : 6, LOADER_WAVES = 2;
+    // SELF (n = 256): no loader waves -- eight compute waves (two per SIMD, as at n <= 128) each issue an eighth of a stage's DMA
+    // and wait for it with a count over the YOUNGER DMA only (see tlb_compute); with two loader waves among eight, two SIMDs
+    // carried one compute wave and the MFMA pipe could not pass 0.75 (measured 0.59, A swept six times for 512 points)
+    static constexpr bool SELF = NK > 32;
+    static constexpr int COMPUTE_WAVES = 8, LOADER_WAVES = SELF ? 0 : 2;
     static constexpr int CHUNK = 16 * COMPUTE_WAVES;        // points per sweep over A
     static constexpr int ROWS = 16 * TILES;                 // rows per stage
     static constexpr int STAGE_BYTES = ROWS * N * 8;
@@ -186,7 +190,8 @@ __device__ __forceinline__ void tlb_loader(const double* __restrict__ A, const d
 // panel D[i][j] = y_{2j}[i] - y_{2j+1}[i] (mir_lsq_gpu_options.fbRowMajorDiff): the even lane of a pair subtracts its
 // neighbour's residual (a DPP move) and stores; half the panel bytes of RM
 template <int NK, bool ALIGNED, int GROUP, bool RM = false, bool DIFF = false>
-__device__ __forceinline__ void tlb_compute(const double* __restrict__ X, double* __restrict__ Y, size_t m, int P,
+__device__ __forceinline__ void tlb_compute(const double* __restrict__ A, const double* __restrict__ b,
+                                            const double* __restrict__ X, double* __restrict__ Y, size_t m, int P,
                                             unsigned char* smem, int lane, int wave, size_t S, int nchunks)
 {
     using C = TlbCfg<NK>;
@@ -199,12 +204,73 @@ __device__ __forceinline__ void tlb_compute(const double* __restrict__ X, double
 #pragma unroll
     for (int k = 0; k < 4; ++k) laddr[k] = fr * C::N * 8 + ((4 * k) ^ v) * 16;
 
+    // SELF: this wave's share of the DMA (instructions wave, wave + 8, ... of a stage; wave 0 also b). Loads return in issue
+    // order among themselves, stores do not keep order with loads: a count of the YOUNGER LOADS ONLY is a safe wait for a
+    // stage (if one of its loads were pending, so would be every younger one: more than the count) -- pending stores can only
+    // make it wait longer, and the wait sits before the epilogue's stores, behind a stage's worth of matrix-core work.
+    constexpr int MYI = C::SELF ? C::IPS / C::COMPUTE_WAVES : 1;
+    [[maybe_unused]] int roff[MYI], soff[MYI];
+    [[maybe_unused]] unsigned is_next = 0, slot_next = 0, bslot_next = 0;          // stage (of S), ring slot, b slot of the next issue
+    [[maybe_unused]] const size_t Ftot = S * (size_t)nchunks;
+    [[maybe_unused]] size_t fissued = 0;
+    const unsigned char* Ab = reinterpret_cast<const unsigned char*>(A);
+    const unsigned char* bb = reinterpret_cast<const unsigned char*>(b);
+    if constexpr (C::SELF) {
+#pragma unroll
+        for (int k = 0; k < MYI; ++k) {
+            const int g = (wave + C::COMPUTE_WAVES * k) * 64 + lane;
+            const int R = g / C::PPR, sp = g % C::PPR;
+            roff[k] = (R & 16) + tlb_rho(R & 15);
+            soff[k] = 2 * (sp ^ tlb_sigma(R & 15)) * 8;
+        }
+    }
+    auto issue = [&]() {
+        const size_t row0 = (blockIdx.x + (size_t)is_next * gridDim.x) * C::ROWS;
+        unsigned char* slot = smem + slot_next * C::STAGE_BYTES;
+#pragma unroll
+        for (int k = 0; k < MYI; ++k) {
+            size_t row = row0 + roff[k];
+            row = row < m ? row : m - 1;
+            __builtin_amdgcn_global_load_lds((wl_gbl_ptr)(Ab + row * (C::N * 8) + soff[k]),
+                                             (wl_lds_ptr)(slot + (wave + C::COMPUTE_WAVES * k) * 1024), 16, 0, 2 /* nt */);
+        }
+        if (wave == 0) {
+            size_t row = row0 + (lane >> 1);
+            row = row < m ? row : m - 1;
+            __builtin_amdgcn_global_load_lds((wl_gbl_ptr)(bb + row * 8 + (lane & 1) * 4),
+                                             (wl_lds_ptr)(smem + C::B_OFF + bslot_next * 256), 4, 0, 0);
+        }
+        is_next = is_next + 1 == (unsigned)S ? 0 : is_next + 1;
+        slot_next = (slot_next + 1) % C::NS;
+        bslot_next = (bslot_next + 1) % C::NSB;
+        ++fissued;
+    };
+    // own share of stage ff complete (stages ff + 1 .. ff + D issued behind it)
+    auto advance = [&]() {
+        if constexpr (C::SELF) {
+            if (fissued < Ftot) {
+                issue();
+                if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::D * (MYI + 1)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::D * MYI) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+    };
+    if constexpr (C::SELF) {
+        for (int d = 0; d < C::D && fissued < Ftot; ++d) issue();
+        advance();                                              // stage 0
+    }
+
     size_t f = 0;
     for (int ch = 0; ch < nchunks; ++ch) {
         const bool wave_active = ch * C::CHUNK + wave * 16 < P; // wave-uniform
-        if (!wave_active) {                                     // nothing to compute: keep the barrier count
-            for (size_t s = 0; s < S; ++s) __builtin_amdgcn_s_barrier();
-            f += S;
+        if (!wave_active) {                                     // nothing to compute: keep the barrier count (and the DMA share)
+            for (size_t s = 0; s < S; ++s) {
+                __builtin_amdgcn_s_barrier();
+                ++f;
+                if (f < Ftot) advance();
+            }
             continue;
         }
         // lanes past P duplicate point P - 1 (same inputs, same outputs, same addresses): the stores of the sweep
@@ -299,24 +365,29 @@ __device__ __forceinline__ void tlb_compute(const double* __restrict__ X, double
         // MFMA chains without relying on instruction scheduling. Only the last stage of a workgroup can be
         // partial (stages ascend).
         Acc acc0, acc1;
+        // (SELF: the wait for this wave's share of the next stage follows the matrix-core chain and precedes the stores)
         if constexpr (GROUP == 0) {
             for (size_t s = 0; s + 1 < S; ++s, ++f) {
                 __builtin_amdgcn_s_barrier();                   // stage f is complete in LDS
                 mfma_stage(f, acc0, acc1);
+                advance();
                 epilogue(acc0, acc1, s, f, std::true_type{});
             }
             __builtin_amdgcn_s_barrier();
             mfma_stage(f, acc0, acc1);
+            if (f + 1 < Ftot) advance();
             epilogue(acc0, acc1, S - 1, f, std::false_type{});
             ++f;
         } else {
             __builtin_amdgcn_s_barrier();
             mfma_stage(f, acc0, acc1);
             ++f;
+            if (f < Ftot) advance();
             for (size_t s = 1; s < S; ++s, ++f) {
                 __builtin_amdgcn_s_barrier();
                 epilogue(acc0, acc1, s - 1, f - 1, std::true_type{});
                 mfma_stage(f, acc0, acc1);
+                if (f + 1 < Ftot) advance();
             }
             epilogue(acc0, acc1, S - 1, f - 1, std::false_type{});
         }
@@ -492,8 +563,8 @@ __global__ __launch_bounds__(TlbCfg<NK>::THREADS) void k_tanh_linear_batched_dma
     const bool once = DIFF && read_a_once && NK <= 32 && P == 2 * C::N;
     const size_t F = once ? S : S * (size_t)nchunks;            // flat (chunk, stage) sequence: the ring never drains
     if (S == 0) return;
-    if (wave == C::COMPUTE_WAVES) tlb_loader<NK, 0>(A, b, m, tlb_smem, lane, S, F);
-    else if (wave == C::COMPUTE_WAVES + 1) tlb_loader<NK, 1>(A, b, m, tlb_smem, lane, S, F);
+    if (!C::SELF && wave == C::COMPUTE_WAVES) tlb_loader<NK, 0>(A, b, m, tlb_smem, lane, S, F);
+    else if (!C::SELF && wave == C::COMPUTE_WAVES + 1) tlb_loader<NK, 1>(A, b, m, tlb_smem, lane, S, F);
     else if (DIFF && once) {
         if constexpr (DIFF) {
             if (wave < 4) tlb_compute_once<NK, 0>(X, Y, m, tlb_smem, lane, wave, S);     // waves w and w + 4 share a SIMD
@@ -501,16 +572,16 @@ __global__ __launch_bounds__(TlbCfg<NK>::THREADS) void k_tanh_linear_batched_dma
         }
     } else {
         if constexpr (RM) {
-            if (wave < 4) tlb_compute<NK, false, 0, true, DIFF>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
-            else tlb_compute<NK, false, 1, true, DIFF>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
+            if (wave < 4) tlb_compute<NK, false, 0, true, DIFF>(A, b, X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
+            else tlb_compute<NK, false, 1, true, DIFF>(A, b, X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
         } else {
             const bool aligned = ((m & 1) == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
             if (wave < 4) {
-                if (aligned) tlb_compute<NK, true, 0>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
-                else tlb_compute<NK, false, 0>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
+                if (aligned) tlb_compute<NK, true, 0>(A, b, X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
+                else tlb_compute<NK, false, 0>(A, b, X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
             } else {
-                if (aligned) tlb_compute<NK, true, 1>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
-                else tlb_compute<NK, false, 1>(X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
+                if (aligned) tlb_compute<NK, true, 1>(A, b, X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
+                else tlb_compute<NK, false, 1>(A, b, X, Y, m, P, tlb_smem, lane, wave, S, nchunks);
             }
         }
     }

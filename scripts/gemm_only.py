@@ -14,7 +14,9 @@ prob = W.TanhLinear(d["A"], d["b"])
 p = 2 * n
 X = np.tile(d["x0"], (p, 1)); X[np.arange(p), np.arange(p) // 2] += 1e-8 * (1 - 2 * (np.arange(p) % 2))
 dX = api.DeviceBuffer(X); dY = api.DeviceBuffer(nbytes=m * n * 8, dtype=np.float64, shape=(m, n))
-WL = C.CDLL(sys.argv[3]) if len(sys.argv) > 3 else api.workloads_lib()
+# RTLD_DEEPBIND: the in-tree library is loaded RTLD_GLOBAL, and without it the other build's calls across its own translation
+# units (wl_* -> launch_*) would bind to the in-tree definitions -- an A/B of one build against itself
+WL = C.CDLL(sys.argv[3], mode=os.RTLD_LOCAL | os.RTLD_DEEPBIND) if len(sys.argv) > 3 else api.workloads_lib()
 ctx = C.c_void_p(C.addressof(prob.ctx))
 s = torch.cuda.ExternalStream(prob.stream.handle)
 def call():
