@@ -114,6 +114,36 @@ def test_row_major_batched_residual_equals_point_major(m, n):
         b.free()
 
 
+@pytest.mark.parametrize("m,p", [(5000, 512), (4113, 144), (33, 16), (2048, 400), (777, 272), (16 * 256 * 3 + 5, 128)])
+def test_batched_residual_n256_any_point_count(m, p):
+    """workloads_gemm.hip at n = 256: eight compute waves that issue their own DMA. Point counts that leave waves without points in
+    the last sweep over A (they keep loading their share and keep the barrier count), row counts that end inside a 16-row stage,
+    more stages than workgroups: all three layouts against numpy, and against each other bit for bit."""
+    n = 256
+    w = P.tanh_linear(m, n)
+    prob = W.TanhLinear(w["A"], w["b"])
+    rng = np.random.default_rng(p)
+    X = w["x0"][None, :] + 1e-3 * rng.standard_normal((p, n))
+    dX = api.DeviceBuffer(np.ascontiguousarray(X))
+    dY1 = api.DeviceBuffer(np.zeros((p, m)))
+    dY2 = api.DeviceBuffer(np.zeros((m, p)))
+    dD = api.DeviceBuffer(np.zeros((m, p // 2)))
+    WL = api.workloads_lib()
+    ctx = C.c_void_p(C.addressof(prob.ctx))
+    args = (ctx, C.c_size_t(m), C.c_size_t(n), C.c_size_t(p), C.c_void_p(dX.ptr))
+    WL.wl_tanh_linear_fb_d(*args, C.c_void_p(dY1.ptr))
+    WL.wl_tanh_linear_fbr_d(*args, C.c_void_p(dY2.ptr))
+    WL.wl_tanh_linear_fbd_d(*args, C.c_void_p(dD.ptr))
+    prob.stream.synchronize()
+    Y1, Y2, D = dY1.download(), dY2.download(), dD.download()
+    expect = np.tanh(w["A"] @ X.T) - w["b"][:, None]
+    assert np.allclose(Y2, expect, rtol=0, atol=1e-13)
+    assert np.array_equal(Y2, Y1.T)
+    assert np.array_equal(D, Y2[:, 0::2] - Y2[:, 1::2])
+    for b in (dX, dY1, dY2, dD):
+        b.free()
+
+
 @pytest.mark.parametrize("m,n,bounded", [(20000, 32, False), (50000, 128, False), (4096, 16, False), (30000, 64, False),
                                          (7000, 48, False), (3000, 16, True), (10000, 96, True), (20001, 32, False),
                                          (9999, 128, False), (5001, 80, True), (9973, 100, False), (6000, 7, False),
