@@ -53,7 +53,8 @@ struct BigLds {                 // static LDS of the big-n kernels
     T span[kBigThreads * 17];   // S of the current chunk (row per thread after the MFMA stage)
     T blk[16 * 17];             // the current diagonal block L_kk
     T rd[16];                   // its reciprocal pivots
-    T xk[16];                   // published solution block of a triangular-solve step
+    T xk[32];                   // published solution block of a triangular-solve step (two slots: potrs_big_rows alternates)
+    T dinv[(kBigThreads / 16) * 272];   // n <= kBigThreads: inverses of the 16 x 16 diagonal blocks of the factor (potrs_big_rows)
     T red[kBigWaves];
     int ired[kBigWaves + 4];
 };
@@ -61,8 +62,14 @@ struct BigLds {                 // static LDS of the big-n kernels
 // ---------------------------------------------------------------- ?potrf 'L', left-looking by 16-column panels
 // A: n x n full symmetric (lda), F: the factor (ldf), both column-major in global memory. Collective; returns info.
 template <typename T>
-__device__ __noinline__ int potrf_big(int n, const T* A, int lda, T* F, int ldf, BigLds<T>& sm)
+__device__ __noinline__ int potrf_big(int n, const T* A_, int lda, T* F_, int ldf, BigLds<T>& sm, long long* dbg = nullptr)
 {
+    // address spaces spelled out: through the generic pointers of an out-of-line function every access is a FLAT instruction, which
+    // counts on lgkmcnt as well (16 outstanding at most, shared with the LDS reads) -- no ring of loads survives that
+    const gbl_cptr<T> A = as_global(A_);
+    const gbl_ptr<T> F = as_global_w(F_);
+    const lds_ptr<T> span = as_lds(sm.span), blk = as_lds(sm.blk), rd = as_lds(sm.rd);
+    long long ph[4] = {0, 0, 0, 0};       // DEBUG_SOLVE: time in steps 1, 2, 3 summed over the panels (thread 0)
     using Acc = typename Mma<T>::Acc;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
@@ -72,7 +79,19 @@ __device__ __noinline__ int potrf_big(int n, const T* A, int lda, T* F, int ldf,
     for (int k = 0; k < nblk; ++k) {
         const int c0 = 16 * k;
         for (int base = (c0 / kBigThreads) * kBigThreads; base < n; base += kBigThreads) {
-            // ---- 1. S = L[rows, :c0] L[c0:c0+16, :c0]^T for the 64 rows of this wave, on MFMA (skip rows above the panel)
+            if (dbg && tid == 0) ph[3] = wall_clock64();
+            // the panel's entries of A (row i, 16 columns) do not depend on step 1: their loads fly while the matrix cores work
+            const int i = base + tid;
+            const int ic = i < n ? i : n - 1;
+            T pa[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) pa[c] = A[ic + (size_t)(c0 + c < n ? c0 + c : n - 1) * lda];
+            // ---- 1. S = L[rows, :c0] L[c0:c0+16, :c0]^T for the 64 rows of this wave, on MFMA (skip rows above the panel).
+            //      (Round 4 tried, one by one and with the stamps of scripts/solve_phases.py: row blocks dealt cyclically, the counted
+            //      three-buffer ring of potrf_panel, 16-byte loads of row pairs, a branch-free loop body, per-lane offsets on a scalar
+            //      base instead of a 64-bit multiply per address. The stage stayed at 400-450 us at n = 512 -- 2 x the matrix-core time
+            //      of its busiest SIMD -- with every one of them, so the plain loop stays; what is left is spread over ring fills
+            //      per panel and the two waves of a SIMD taking turns.)
             if (k > 0 && base + 64 * wave + 63 >= c0) {
                 Acc acc[4];
 #pragma unroll
@@ -99,19 +118,17 @@ __device__ __noinline__ int potrf_big(int n, const T* A, int lda, T* F, int ldf,
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        sm.span[(64 * wave + 16 * u + Mma<T>::row(lane, r)) * 17 + lr] = acc[u][r];
+                        span[(64 * wave + 16 * u + Mma<T>::row(lane, r)) * 17 + lr] = acc[u][r];
             }
             __syncthreads();
+            if (dbg && tid == 0) { const long long t = wall_clock64(); ph[0] += t - ph[3]; ph[3] = t; }
             // ---- 2. one row per thread: p = A[i, panel] - S[i, :]
-            const int i = base + tid;
             const bool active = i < n && i >= c0;
-            const int ic = i < n ? i : n - 1;
             T p[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                const int col = c0 + c < n ? c0 + c : n - 1;
-                const T v = A[ic + (size_t)col * lda];
-                const T sv = (k > 0 && i >= c0) ? sm.span[tid * 17 + c] : T(0);
+                const T v = pa[c];
+                const T sv = (k > 0 && i >= c0) ? span[tid * 17 + c] : T(0);
                 p[c] = (active && c0 + c < n) ? v - sv : ((i == c0 + c) ? T(1) : T(0));   // identity padding past n
             }
             const bool diag_chunk = base <= c0 && c0 < base + kBigThreads;
@@ -128,7 +145,7 @@ __device__ __noinline__ int potrf_big(int n, const T* A, int lda, T* F, int ldf,
                         T rinv, d;
                         rsqrt_sqrt(piv > 0 ? piv : T(1), rinv, d);
                         if (r > c) p[c] *= rinv; else if (r == c) p[c] = d;
-                        if (r == c) sm.rd[c] = rinv;
+                        if (r == c) rd[c] = rinv;
                         static_for<16>([&](auto cc2) {
                             constexpr int c2 = decltype(cc2)::value;
                             if constexpr (c2 > c) {
@@ -138,13 +155,14 @@ __device__ __noinline__ int potrf_big(int n, const T* A, int lda, T* F, int ldf,
                         });
                     });
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) sm.blk[r * 17 + c] = p[c];
+                    for (int c = 0; c < 16; ++c) blk[r * 17 + c] = p[c];
                     if (bad != 0 && r == 0) sm.ired[kBigWaves] = bad;
                 }
                 __syncthreads();
                 const int info = sm.ired[kBigWaves];
                 if (info != 0) return info;                     // uniform
             }
+            if (dbg && tid == 0) { const long long t = wall_clock64(); ph[1] += t - ph[3]; ph[3] = t; }
             // ---- 3. the rows below the diagonal block solve against L_kk; store the panel
             if (active && i >= c0 + 16) {
 #pragma unroll
@@ -152,8 +170,8 @@ __device__ __noinline__ int potrf_big(int n, const T* A, int lda, T* F, int ldf,
                     T v = p[c];
 #pragma unroll
                     for (int t = 0; t < 16; ++t)
-                        if (t < c) v -= p[t] * sm.blk[c * 17 + t];
-                    p[c] = v * sm.rd[c];
+                        if (t < c) v -= p[t] * blk[c * 17 + t];
+                    p[c] = v * rd[c];
                 }
             }
             if (active) {
@@ -162,8 +180,10 @@ __device__ __noinline__ int potrf_big(int n, const T* A, int lda, T* F, int ldf,
                     if (c0 + c < n && i >= c0 + c) F[i + (size_t)(c0 + c) * ldf] = p[c];
             }
             __syncthreads();                                    // span reusable; the panel rows are visible
+            if (dbg && tid == 0) { const long long t = wall_clock64(); ph[2] += t - ph[3]; }
         }
     }
+    if (dbg && tid == 0) { dbg[16] = ph[0]; dbg[17] = ph[1]; dbg[18] = ph[2]; }
     return 0;
 }
 
@@ -250,13 +270,102 @@ __device__ __noinline__ void potrs_big(int n, const T* F, int ldf, T* z, BigLds<
     __syncthreads();
 }
 
+// ?potrs for n <= kBigThreads: ONE ROW PER THREAD, the scheme of potrs_rows (solve_kernel.h) on 512 threads. z stays in a register;
+// block step kb: the 16 owners of rows 16 kb .. 16 kb + 15 (one DPP row of one wave) form x_kb = inv(L_kk) z_kb -- 16 independent
+// products, no substitution chain -- and publish it; after ONE barrier every remaining row subtracts its 16 products, whose factor
+// entries were loaded a step ahead (they do not depend on the solution). inv(L_kk): sm.dinv, filled once per factorisation
+// (invert_diag_blocks). 245 -> ~80 us a call at n = 512 (potrs_big: a substitution chain, two barriers and two exposed L2 round trips
+// per block step; it stays the routine for n > kBigThreads).
+template <typename T>
+__device__ __noinline__ void potrs_big_rows(int n, const T* F_, int ldf, T* xv_, BigLds<T>& sm)
+{
+    const gbl_cptr<T> F = as_global(F_);
+    const gbl_ptr<T> xv = as_global_w(xv_);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = tid, ic = i < n ? i : n - 1;
+    const int nb = (n + 15) / 16;
+    const lds_ptr<T> Dinv = as_lds(sm.dinv), xk = as_lds(sm.xk);
+    __syncthreads();
+    T z = i < n ? xv[i] : T(0);
+    T lnext[16];
+    // (a wave none of whose rows takes part in a step skips that step's loads -- half of them on average: eight waves' 16 loads a
+    //  step are 0.85 us of the CU's vector-memory address rate)
+    auto load_row = [&](int kb) {                              // L[i][16 kb .. 16 kb + 15], used by rows i >= 16 kb + 16
+        if (64 * wave + 63 >= 16 * kb + 16) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) lnext[c] = F[ic + (size_t)(16 * kb + c < n ? 16 * kb + c : n - 1) * ldf];
+        }
+    };
+    auto load_col = [&](int kb) {                              // L[16 kb .. 16 kb + 15][i], used by rows i < 16 kb
+        if (64 * wave < 16 * kb) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) lnext[c] = F[(16 * kb + c < n ? 16 * kb + c : n - 1) + (size_t)ic * ldf];
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < 16; ++c) lnext[c] = 0;
+    // ---- forward: L z = b
+    load_row(0);
+    for (int kb = 0; kb < nb; ++kb) {
+        const int c0 = 16 * kb;
+        T lrow[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) lrow[c] = lnext[c];
+        if (kb + 1 < nb) load_row(kb + 1); else load_col(nb - 1);
+        if (wave == (c0 >> 6)) {
+            const int l0 = c0 & 63, r = lane & 15;
+            T dv[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) dv[c] = Dinv[kb * 272 + r + 17 * c];                         // entries above the diagonal are 0
+            T xn = 0;
+            static_for<16>([&](auto cc) { constexpr int c = decltype(cc)::value; xn += dv[c] * dpp_row_bcast<c>(z); });
+            if (lane >= l0 && lane < l0 + 16) { z = xn; xk[(kb & 1) * 16 + r] = xn; }
+        }
+        __syncthreads();
+        if (i >= c0 + 16 && i < n) {
+            T acc = 0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc += lrow[c] * ((c0 + c < n) ? xk[(kb & 1) * 16 + c] : T(0));
+            z -= acc;
+        }
+    }
+    // ---- backward: L^T x = z
+    for (int kb = nb - 1; kb >= 0; --kb) {
+        const int c0 = 16 * kb;
+        T lcol[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) lcol[c] = lnext[c];
+        if (kb > 0) load_col(kb - 1);
+        if (wave == (c0 >> 6)) {
+            const int l0 = c0 & 63, r = lane & 15;
+            T dv[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) dv[c] = Dinv[kb * 272 + c + 17 * r];                         // (inv L_kk)^T (r, c) = inv(c, r)
+            T xn = 0;
+            static_for<16>([&](auto cc) { constexpr int c = decltype(cc)::value; xn += dv[c] * dpp_row_bcast<c>(z); });
+            if (lane >= l0 && lane < l0 + 16) { z = xn; xk[(kb & 1) * 16 + r] = xn; }
+        }
+        __syncthreads();
+        if (i < c0) {
+            T acc = 0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc += lcol[c] * ((c0 + c < n) ? xk[(kb & 1) * 16 + c] : T(0));
+            z -= acc;
+        }
+    }
+    if (i < n) xv[i] = z;
+    __syncthreads();
+}
+
 // r = b - A x, w = |b| + |A| |x|: one ROW per thread (rows strided by the workgroup), A symmetric: entry (i, k) is read as
 // A[i + k lda], consecutive rows in consecutive lanes; 16 columns' loads are issued together (indices clamped: always 16, a count
 // the compiler can keep in flight) and x comes from LDS. (Before: one wave per row with a wave reduction per row -- 64 dependent
 // round trips a wave, 115 us per residual at n = 512.)
 template <typename T>
-__device__ __noinline__ void residual_big(int n, const T* A, int lda, const T* b, const T* x, T* r, T* w, T* xs /* LDS, >= n */)
+__device__ __noinline__ void residual_big(int n, const T* A_, int lda, const T* b, const T* x, T* r, T* w, T* xs_ /* LDS, >= n */)
 {
+    const gbl_cptr<T> A = as_global(A_);
+    const lds_ptr<T> xs = as_lds(xs_);
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += kBigThreads) xs[i] = x[i];
     __syncthreads();
@@ -264,13 +373,26 @@ __device__ __noinline__ void residual_big(int n, const T* A, int lda, const T* b
         const int i = i0 + threadIdx.x;
         const int ic = i < n ? i : n - 1;
         T ra = 0, wa = 0;
-        for (int k0 = 0; k0 < n; k0 += 16) {
-            T av[16];
+        // two batches of 16 columns: the next one is in flight while this one is multiplied (loads unconditional, indices clamped;
+        // the column guard sits at the use -- the if-around-a-load rule of DESIGN section 3.2)
+        T av[2][16];
+        auto issue = [&](int k0, auto B) {
+            constexpr int buf = decltype(B)::value;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) av[u] = A[ic + (size_t)(k0 + u < n ? k0 + u : n - 1) * lda];
+            for (int u = 0; u < 16; ++u) av[buf][u] = A[ic + (size_t)(k0 + u < n ? k0 + u : n - 1) * lda];
+        };
+        auto use = [&](int k0, auto B) {
+            constexpr int buf = decltype(B)::value;
 #pragma unroll
             for (int u = 0; u < 16; ++u)
-                if (k0 + u < n) { const T xv = xs[k0 + u]; ra += av[u] * xv; wa += dabs(av[u]) * dabs(xv); }
+                if (k0 + u < n) { const T xv = xs[k0 + u]; ra += av[buf][u] * xv; wa += dabs(av[buf][u]) * dabs(xv); }
+        };
+        issue(0, IntC<0>{});
+        for (int k0 = 0; k0 < n; k0 += 32) {
+            issue(k0 + 16, IntC<1>{});
+            use(k0, IntC<0>{});
+            issue(k0 + 32, IntC<0>{});
+            use(k0 + 16, IntC<1>{});
         }
         if (i < n) { r[i] = b[i] - ra; w[i] = dabs(b[i]) + wa; }
     }
@@ -307,11 +429,13 @@ __device__ __noinline__ int posvx_big(int n, T* A, int lda, T* F, int ldf, T* s,
     }
     __syncthreads();
     MIRLSQ_STAMP(dbg, 3);
-    const int info = potrf_big<T>(n, A, lda, F, ldf, sm);
+    const int info = potrf_big<T>(n, A, lda, F, ldf, sm, dbg);
     if (info != 0) return info;
     MIRLSQ_STAMP(dbg, 4);
+    const bool rows = n <= kBigThreads;                         // uniform: one row per thread, inverse diagonal blocks in LDS
+    if (rows) invert_diag_blocks<T, kBigThreads / 16>(n, F, ldf, sm.dinv);
     for (int i = tid; i < n; i += kBigThreads) x[i] = b[i];
-    potrs_big<T>(n, F, ldf, x, sm);
+    if (rows) potrs_big_rows<T>(n, F, ldf, x, sm); else potrs_big<T>(n, F, ldf, x, sm);
     MIRLSQ_STAMP(dbg, 5);
     // ?porfs, ITMAX = 5
     const T safe1 = T(n + 1) * safmin, safe2 = safe1 / eps;
@@ -327,7 +451,7 @@ __device__ __noinline__ int posvx_big(int n, T* A, int lda, T* F, int ldf, T* s,
         const T berr = big_max(qv, sm.red);
         if (count == 1) MIRLSQ_STAMP(dbg, 12);
         if (berr > eps && 2 * berr <= lstres && count <= 5) {
-            potrs_big<T>(n, F, ldf, r, sm);
+            if (rows) potrs_big_rows<T>(n, F, ldf, r, sm); else potrs_big<T>(n, F, ldf, r, sm);
             for (int i = tid; i < n; i += kBigThreads) x[i] += r[i];
             lstres = berr;
             __syncthreads();

@@ -510,7 +510,7 @@ typename Solver<T>::Result Solver<T>::run()
                                  h[11] - h[5], h[12] - h[11], h[13] - h[12], h[14] - h[13], h[6] - h[14], h[15]);
                 if (n <= 128)
                     std::fprintf(stderr, "[solve dbg] lds_potrf, wave 0 (shader cycles, summed over the panels): diagonal update + factor %lld  wait %lld  rows below %lld  wait %lld\n", h[20], h[21], h[22], h[23]);
-                if (n > 128 && n <= (uint32_t)kSolveMaxN)
+                if (n > 128)
                     std::fprintf(stderr, "[solve dbg] potrf_panel steps (10ns ticks, summed over the panels): earlier panels on MFMA %lld  diagonal rows %lld  other rows + store %lld\n", h[16], h[17], h[18]);
             }
         }
