@@ -307,14 +307,22 @@ __device__ __noinline__ void potrs_rows(int n, const T* F_, int ldf, const T* Di
     // The factor entries a row needs in block step kb do not depend on the solution: the loads of step kb + 1 are issued
     // before step kb's barrier, so a step costs the diagonal solve + one barrier instead of an L2 round trip (45 -> ~15 us
     // per call at n = 256).
+    // A wave none of whose rows takes part in a block step skips that step's loads (half of them on average): the ablation of
+    // profiles/r04/potrs_rows_ablation_n256.txt puts 15 of a call's 40 us on ISSUING the loads -- the CU's vector-memory address rate.
     T lnext[16];
-    auto load_row = [&](int kb) {                              // L[i][16 kb .. 16 kb + 15]
 #pragma unroll
-        for (int c = 0; c < 16; ++c) lnext[c] = F[ic + (size_t)(16 * kb + c < n ? 16 * kb + c : n - 1) * ldf];
+    for (int c = 0; c < 16; ++c) lnext[c] = 0;
+    auto load_row = [&](int kb) {                              // L[i][16 kb .. 16 kb + 15], used by rows i >= 16 kb + 16
+        if (64 * wave + 63 >= 16 * kb + 16) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) lnext[c] = F[ic + (size_t)(16 * kb + c < n ? 16 * kb + c : n - 1) * ldf];
+        }
     };
-    auto load_col = [&](int kb) {                              // L[16 kb .. 16 kb + 15][i]
+    auto load_col = [&](int kb) {                              // L[16 kb .. 16 kb + 15][i], used by rows i < 16 kb
+        if (64 * wave < 16 * kb) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) lnext[c] = F[(16 * kb + c < n ? 16 * kb + c : n - 1) + (size_t)ic * ldf];
+            for (int c = 0; c < 16; ++c) lnext[c] = F[(16 * kb + c < n ? 16 * kb + c : n - 1) + (size_t)ic * ldf];
+        }
     };
     // ---- forward: L z = b
     load_row(0);
