@@ -361,9 +361,9 @@ typedef struct mir_lsq_batched_options {
     void* stream;             /* mir_lsq_batched_kernel_s: hipStream_t to enqueue on (NULL = the default stream) */
     float* basis;             /* optional DEVICE buffer for the model's per-row basis table (models with a basis only:
                                  (t_stride ? count : 1) x m x nb floats, 16-byte aligned), owned by the caller and filled by
-                                 every call. NULL: the call allocates the table stream-ordered (hipMallocAsync / hipFreeAsync);
-                                 where the runtime has no memory pools it falls back to hipMalloc + a stream synchronisation
-                                 before hipFree -- the ONLY case in which mir_lsq_batched_kernel_s synchronises */
+                                 every call. NULL: the call allocates the table (hipMalloc) and synchronises the stream before
+                                 freeing it -- the ONLY case in which mir_lsq_batched_kernel_s synchronises; pass a table to
+                                 stay asynchronous (bench.py does) */
     size_t basis_bytes;       /* size of `basis` (the call fails with -1 when it is too small) */
     uint64_t* timing;         /* profiling builds only (-DMIRLSQ_BATCHED_TIMING): DEVICE buffer of 10 cycle counters per
                                  problem, written by the kernel; ignored otherwise */

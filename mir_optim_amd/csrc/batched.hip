@@ -11,6 +11,11 @@ using namespace mirlsq;
 
 namespace {
 
+inline int batched_model_nb(int model)
+{
+    using namespace mir_optim_amd;
+    return model == kModelExpDecay ? ModelExpDecay::nb : model == kModelExp3Affine ? ModelExp3Affine::nb : ModelExpDecayPad8::nb;
+}
 inline int batched_model_n(int model)
 {
     return model == kModelExpDecay ? 3 : ((model == kModelExp3Affine || model == kModelExpDecayPad8) ? 8 : 0);
@@ -99,14 +104,17 @@ int mir_optimize_least_squares_batched_s(const mir_least_squares_settings_s* S, 
     }
     mir_lsq_batched_options o = batched_options(options);
     o.stream = nullptr;
-    o.basis = nullptr; o.basis_bytes = 0;      // (host entry: the table is allocated per call)
+    // the model's per-row basis table is part of this call's one allocation
+    const size_t basis_b = (t_stride ? count : 1) * m * (size_t)batched_model_nb(model) * sizeof(float);
     const size_t tb = (t_stride ? count : 1) * m * sizeof(float), db = count * m * sizeof(float), xb = count * n * sizeof(float);
     char* base = nullptr;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o_ = off; off = align_up(off + bytes, 256); return o_; };
     const size_t ot = take(tb), od = take(db), ox = take(xb), ol = take(n * sizeof(float)), ou = take(n * sizeof(float)),
-                 orr = take(count * sizeof(BatchedResult));
+                 orr = take(count * sizeof(BatchedResult)), obasis = take(basis_b);
     if (hipMalloc((void**)&base, off) != hipSuccess) return -4;
+    o.basis = basis_b ? (float*)(base + obasis) : nullptr;
+    o.basis_bytes = basis_b;
     bool good = hipMemcpy(base + ot, t, tb, hipMemcpyHostToDevice) == hipSuccess
         && hipMemcpy(base + od, data, db, hipMemcpyHostToDevice) == hipSuccess
         && hipMemcpy(base + ox, x, xb, hipMemcpyHostToDevice) == hipSuccess

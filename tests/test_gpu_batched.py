@@ -248,6 +248,22 @@ def test_lambda_ladder_takes_the_steps_of_the_one_by_one_loop(model, maker):
     assert sum(r[1] for r in out[0][1]) > 4 * count            # the fits did iterate
 
 
+def test_repeated_launches_with_a_large_basis_table_agree():
+    """Regression: with per-problem abscissae the basis table is count x m rows (2 MB here). While the launch took it from the
+    stream-ordered pool (hipMallocAsync / hipFreeAsync), about one call in 150 returned wrong fits for a contiguous range of
+    problems; the table now lives in ordinary memory. 120 launches, every one bit-identical with the shared-abscissae fit."""
+    count = 256
+    t, data, truth, x0 = P.cfg5_pad8(count, 512)
+    s = M.LeastSquaresSettings(np.float32)
+    res0, xa = M.optimizeLeastSquaresBatched(M.MODEL_EXP_DECAY_PAD8, x0, t, data, settings=s)
+    t2 = np.tile(t, (count, 1))
+    ref = xa.view(np.uint32)
+    for rep in range(120):
+        res1, xb = M.optimizeLeastSquaresBatched(M.MODEL_EXP_DECAY_PAD8, x0, t2, data, settings=s)
+        bad = np.argwhere((xb.view(np.uint32) != ref).any(axis=1)).ravel()
+        assert bad.size == 0, (rep, bad[:8])
+
+
 @pytest.mark.parametrize("model,maker", [(M.MODEL_EXP_DECAY_PAD8, "pad8"), (M.MODEL_EXP_DECAY, "decay")])
 def test_per_problem_abscissae_give_the_bits_of_shared_ones(model, maker):
     """t may be one vector for all problems (t_stride = 0) or count x m (t_stride = m: the basis table of a model is then

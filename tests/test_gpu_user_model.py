@@ -77,7 +77,7 @@ def test_user_model_matches_the_float_oracle_on_every_problem(oracle):
         raw = np.frombuffer(dres.download().tobytes(), dtype=np.dtype([("status", "<i4"), ("iterations", "<u4"), ("fCalls", "<u4"),
                                                                        ("gCalls", "<u4"), ("residual", "<f4"), ("lambda", "<f4")])).copy()
         out.append((raw, dx.download().reshape(count, N).copy()))
-    # the caller's table and the library's stream-ordered one hold the same floats: the same fits, bit for bit
+    # the caller's table and the one the library allocates hold the same floats: the same fits, bit for bit
     assert out[0][0].tobytes() == out[1][0].tobytes() and out[0][1].tobytes() == out[1][1].tobytes()
     raw, x = out[0]
     # a too-small caller table is refused, not overrun
