@@ -651,18 +651,28 @@ __global__ __launch_bounds__(256) void k_tanh_linear_batched_wide(const double* 
                                                                     const double* __restrict__ X, double* __restrict__ Y,
                                                                     size_t m, int n, int P)
 {
+    // A wave owns RT = 2 row tiles x 4 point tiles (32 rows x 64 points): per pair of k-steps 2 + 4 sixteen-byte loads feed 16
+    // MFMAs. With one row tile (1 + 4 loads for 8 MFMAs) the kernel ran at the CU's vector-memory address rate, not at the matrix
+    // cores' (8.8 -> 7.4 ms for the 1024 points of an n = 512 refresh at m = 250 000: 30 -> 35 TFLOP/s; what is left is X: every 32-row
+    // tile re-reads its 64 points' 256 KB from L2).
+    constexpr int RT = 2;
     using Acc = __attribute__((ext_vector_type(4))) double;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
-    const size_t ntiles = (m + 15) / 16;
+    const size_t ntiles = (m + 16 * RT - 1) / (16 * RT);
     const int ngroups = (P + 63) / 64;
     const int npairs = n / 8;
     for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const size_t arow = t * 16 + fr < m ? t * 16 + fr : m - 1;
-        const double2* __restrict__ ap = reinterpret_cast<const double2*>(A + arow * (size_t)n) + fq;
-        double bv[4];
+        const double2* __restrict__ ap[RT];
+        double bv[RT][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const size_t row = t * 16 + fq + 4 * r; bv[r] = b[row < m ? row : m - 1]; }
+        for (int rt = 0; rt < RT; ++rt) {
+            const size_t r0 = (t * RT + rt) * 16;
+            const size_t arow = r0 + fr < m ? r0 + fr : m - 1;
+            ap[rt] = reinterpret_cast<const double2*>(A + arow * (size_t)n) + fq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const size_t row = r0 + fq + 4 * r; bv[rt][r] = b[row < m ? row : m - 1]; }
+        }
         for (int g = wave; g < ngroups; g += 4) {
             const double2* __restrict__ xp[4];
 #pragma unroll
@@ -671,39 +681,46 @@ __global__ __launch_bounds__(256) void k_tanh_linear_batched_wide(const double* 
                 pt = pt < P ? pt : P - 1;
                 xp[u] = reinterpret_cast<const double2*>(X + (size_t)pt * n) + fq;
             }
-            Acc acc[4];
+            Acc acc[RT][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] = Acc{0, 0, 0, 0};
-#pragma unroll 4
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[rt][u] = Acc{0, 0, 0, 0};
+#pragma unroll 2
             for (int j = 0; j < npairs; ++j) {
-                const double2 a = ap[4 * j];
-                double2 x[4];
+                double2 a[RT], x[4];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) a[rt] = ap[rt][4 * j];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) x[u] = xp[u][4 * j];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, x[u].x, acc[u], 0, 0, 0);
-                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, x[u].y, acc[u], 0, 0, 0);
-                }
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        acc[rt][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt].x, x[u].x, acc[rt][u], 0, 0, 0);
+                        acc[rt][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt].y, x[u].y, acc[rt][u], 0, 0, 0);
+                    }
             }
             // D: column = lane & 15 = point, rows fq + 4 r
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int pt = 64 * g + 16 * u + fr;
+            for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const size_t row = t * 16 + fq + 4 * r;
-                    const double y = dtanh(acc[u][r]) - bv[r];
-                    if constexpr (OUT == 1) {
-                        const double d = y - lane_pair_swap(y);              // f(x + h e_j) - f(x - h e_j): points 2 j, 2 j + 1 are adjacent lanes
-                        if ((fr & 1) == 0 && pt < P && row < m) Y[row * (size_t)(P >> 1) + (pt >> 1)] = d;
-                    } else if constexpr (OUT == 0) {
-                        if (pt < P && row < m) Y[row * (size_t)P + pt] = y;
-                    } else {
-                        if (pt < P && row < m) Y[(size_t)pt * m + row] = y;
+                for (int u = 0; u < 4; ++u) {
+                    const int pt = 64 * g + 16 * u + fr;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const size_t row = (t * RT + rt) * 16 + fq + 4 * r;
+                        const double y = dtanh(acc[rt][u][r]) - bv[rt][r];
+                        if constexpr (OUT == 1) {
+                            const double d = y - lane_pair_swap(y);              // f(x + h e_j) - f(x - h e_j): points 2 j, 2 j + 1 are adjacent lanes
+                            if ((fr & 1) == 0 && pt < P && row < m) Y[row * (size_t)(P >> 1) + (pt >> 1)] = d;
+                        } else if constexpr (OUT == 0) {
+                            if (pt < P && row < m) Y[row * (size_t)P + pt] = y;
+                        } else {
+                            if (pt < P && row < m) Y[(size_t)pt * m + row] = y;
+                        }
                     }
                 }
-            }
         }
     }
 }
@@ -720,7 +737,7 @@ void launch_tanh_linear_batched_diff(const double* A, const double* b, const dou
         if (n == 32 && launch_tlb_dma<8, true, true>(A, b, X, D, m, P, s, read_a_once)) return;
     }
     if (n > 256 && n % 8 == 0 && P % 2 == 0 && m > 0) {
-        const size_t nt = (m + 15) / 16;
+        const size_t nt = (m + 31) / 32;
         hipLaunchKernelGGL(k_tanh_linear_batched_wide<1>, dim3((unsigned)(nt < 256 * 8 ? nt : 256 * 8)), dim3(256), 0, s, A, b, X, D, m, n, P);
         return;
     }
@@ -739,7 +756,7 @@ void launch_tanh_linear_batched_rm(const double* A, const double* b, const doubl
         if (n == 32 && launch_tlb_dma<8, true>(A, b, X, Y, m, P, s)) return;
     }
     if (n > 256 && n % 8 == 0 && m > 0) {
-        const size_t nt = (m + 15) / 16;
+        const size_t nt = (m + 31) / 32;
         hipLaunchKernelGGL(k_tanh_linear_batched_wide<0>, dim3((unsigned)(nt < 256 * 8 ? nt : 256 * 8)), dim3(256), 0, s, A, b, X, Y, m, n, P);
         return;
     }
@@ -753,7 +770,7 @@ bool launch_tanh_linear_batched(const double* A, const double* b, const double* 
 {
     if (n == 256 && m >= 32 && launch_tlb_dma<64>(A, b, X, Y, m, P, s)) return true;
     if (n > 256 && n % 8 == 0 && m > 0) {
-        const size_t nt = (m + 15) / 16;
+        const size_t nt = (m + 31) / 32;
         hipLaunchKernelGGL(k_tanh_linear_batched_wide<2>, dim3((unsigned)(nt < 256 * 8 ? nt : 256 * 8)), dim3(256), 0, s, A, b, X, Y, m, n, P);
         return true;
     }
