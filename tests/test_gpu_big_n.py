@@ -120,3 +120,47 @@ def test_jtj_above_256(m, n):
     Jr = J + np.outer(u, dx)
     assert np.allclose(Jn, Jr, rtol=1e-14, atol=1e-13)
     assert np.allclose(JJ2, Jr.T @ Jr, rtol=1e-12, atol=1e-9) and np.allclose(Jy2, Jr.T @ y, rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("n", [257, 320, 512])
+def test_boxcqp_any_n_float32(oracle, n):
+    """The same entry in single precision (mir_solve_box_qp_s; the reference is a template over T, boxcqp.d:122): k_box_qp_big<float>
+    against the float oracle. A well-conditioned matrix (float Cholesky + two refinement steps decide the last digits)."""
+    Pm = spd(n, n, cond=30.0)
+    rng = np.random.default_rng(n + 3)
+    q = rng.standard_normal(n) * 3
+    xu = np.linalg.solve(Pm, -q)
+    l = np.where(rng.random(n) < 0.3, xu + 0.05 * np.abs(xu) + 1e-2, -np.inf)
+    u = np.where(rng.random(n) < 0.2, np.maximum(l, xu) + 0.5, np.inf)
+    st, x, it = M.solveBoxQP(Pm, q, l, u, dtype=np.float32)
+    so, xo, ito = oracle.solve_box_qp(Pm, q, l, u, dtype=np.float32)
+    assert int(st) == so == 0 and it >= 1 and ito >= 1
+    l32, u32 = l.astype(np.float32), u.astype(np.float32)
+    assert np.array_equal((x == l32) | (x == u32), (xo == l32) | (xo == u32))    # same active set
+    assert np.allclose(x, xo, rtol=2e-4, atol=2e-5)
+    xq = np.asarray(x, dtype=np.float64)                                          # and it IS the constrained minimiser: KKT to float accuracy
+    g = Pm @ xq + q
+    free = (x != l32) & (x != u32)
+    assert np.abs(g[free]).max() <= 2e-3 * (np.abs(Pm) @ np.abs(xq) + np.abs(q)).max()
+
+
+@pytest.mark.parametrize("m,n", [(900, 264), (700, 320)])
+def test_whole_path_above_256_float32_reference_abi(oracle, m, n):
+    """mir_optimize_least_squares_s above n = 256 (host residual callback, finite differences by the library): the any-n solve
+    kernel, the tile-pair J^T J and the rewriting Broyden kernels in single precision, against the float oracle on the same
+    callback. Float finite differences are noisy: x to 5e-3, the residual to 5e-3 (the tolerances of the float host sweeps)."""
+    w = P.tanh_linear(m, n)
+    A32, b32 = w["A"].astype(np.float32), w["b"].astype(np.float32)
+
+    def f(x, y):
+        y[:] = np.tanh(A32 @ x) - b32
+
+    s = M.LeastSquaresSettings(np.float32); s.maxIterations = 6
+    so = oracle.default_settings(np.float32); so.maxIterations = 6
+    x0 = w["x0"].astype(np.float32)
+    res, x = M.optimizeLeastSquares(f, m, x0.copy(), settings=s, dtype=np.float32)
+    ro, xo = oracle.optimize(f, m, x0.copy(), settings=so, dtype=np.float32)
+    assert int(res.status) >= -1 and ro.status >= -1
+    assert res.residual < 0.05 * float(np.sum((np.tanh(A32 @ x0) - b32) ** 2))   # it did minimise
+    assert np.abs(np.asarray(x, dtype=np.float64) - np.asarray(xo, dtype=np.float64)).max() <= 5e-3 * max(1.0, float(np.abs(xo).max()))
+    assert abs(res.residual - ro.residual) <= 5e-3 * abs(ro.residual) + 1e-6
