@@ -651,11 +651,11 @@ __global__ __launch_bounds__(256) void k_tanh_linear_batched_wide(const double* 
                                                                     const double* __restrict__ X, double* __restrict__ Y,
                                                                     size_t m, int n, int P)
 {
-    // A wave owns RT = 2 row tiles x 4 point tiles (32 rows x 64 points): per pair of k-steps 2 + 4 sixteen-byte loads feed 16
-    // MFMAs. With one row tile (1 + 4 loads for 8 MFMAs) the kernel ran at the CU's vector-memory address rate, not at the matrix
-    // cores' (8.8 -> 7.4 ms for the 1024 points of an n = 512 refresh at m = 250 000: 30 -> 35 TFLOP/s; what is left is X: every 32-row
-    // tile re-reads its 64 points' 256 KB from L2).
-    constexpr int RT = 2;
+    // A wave owns RT = 4 row tiles x 4 point tiles (64 rows x 64 points, 128 accumulator registers): per pair of k-steps 4 + 4
+    // sixteen-byte loads feed 32 MFMAs. With one row tile (1 + 4 loads for 8 MFMAs) the kernel ran at the CU's vector-memory address
+    // rate and re-read its points' 256 KB of X from L2 for every 16 rows: the 1024 points of an n = 512 refresh at m = 250 000 took
+    // 8.8 ms (30 TFLOP/s); two row tiles 7.4, four 6.7 (39 TFLOP/s, one wave a SIMD). The next step would be X and A through LDS.
+    constexpr int RT = 4;
     using Acc = __attribute__((ext_vector_type(4))) double;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -737,7 +737,7 @@ void launch_tanh_linear_batched_diff(const double* A, const double* b, const dou
         if (n == 32 && launch_tlb_dma<8, true, true>(A, b, X, D, m, P, s, read_a_once)) return;
     }
     if (n > 256 && n % 8 == 0 && P % 2 == 0 && m > 0) {
-        const size_t nt = (m + 31) / 32;
+        const size_t nt = (m + 63) / 64;
         hipLaunchKernelGGL(k_tanh_linear_batched_wide<1>, dim3((unsigned)(nt < 256 * 8 ? nt : 256 * 8)), dim3(256), 0, s, A, b, X, D, m, n, P);
         return;
     }
@@ -756,7 +756,7 @@ void launch_tanh_linear_batched_rm(const double* A, const double* b, const doubl
         if (n == 32 && launch_tlb_dma<8, true>(A, b, X, Y, m, P, s)) return;
     }
     if (n > 256 && n % 8 == 0 && m > 0) {
-        const size_t nt = (m + 31) / 32;
+        const size_t nt = (m + 63) / 64;
         hipLaunchKernelGGL(k_tanh_linear_batched_wide<0>, dim3((unsigned)(nt < 256 * 8 ? nt : 256 * 8)), dim3(256), 0, s, A, b, X, Y, m, n, P);
         return;
     }
@@ -770,7 +770,7 @@ bool launch_tanh_linear_batched(const double* A, const double* b, const double* 
 {
     if (n == 256 && m >= 32 && launch_tlb_dma<64>(A, b, X, Y, m, P, s)) return true;
     if (n > 256 && n % 8 == 0 && m > 0) {
-        const size_t nt = (m + 31) / 32;
+        const size_t nt = (m + 63) / 64;
         hipLaunchKernelGGL(k_tanh_linear_batched_wide<2>, dim3((unsigned)(nt < 256 * 8 ? nt : 256 * 8)), dim3(256), 0, s, A, b, X, Y, m, n, P);
         return true;
     }
