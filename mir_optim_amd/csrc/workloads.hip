@@ -47,39 +47,60 @@ __global__ __launch_bounds__(256) void k_tanh_linear(const T* __restrict__ A, co
     const size_t per = (G + nwaves - 1) / nwaves;
     const size_t gb = wave_id * per < G ? wave_id * per : G;
     const size_t ge = gb + per < G ? gb + per : G;
-    for (size_t g = gb; g < ge; ++g) {
-        const size_t row = 4 * g + q;
-        const bool rok = row < m;
-        const T* rp = A + (rok ? row : m - 1) * (size_t)n;
-        T v0[NCP], v1[NCP];
+    // A ring of row groups in flight: the loads of groups g + 1 .. g + kAhead are issued (unconditionally, indices clamped: counted
+    // waits) before group g is summed. With one group in flight a wave had 4 KB on its way and the sweep ran at 6.0-6.3 TB/s; a plain
+    // streaming read of the same gigabyte reaches 7.1 on this part (scripts/probes/copy_bw_probe.hip).
+    constexpr int kAhead = (VEC && MODE == 0) ? 3 : 0, kRing = kAhead + 1;
+    T v0[kRing][NCP], v1[kRing][NCP], bv[kRing];
+    auto load = [&](size_t g, auto B) {
+        constexpr int buf = decltype(B)::value;
+        const size_t gc = g < ge ? g : (ge > gb ? ge - 1 : gb);
+        const size_t row = 4 * gc + q;
+        const T* rp = A + (row < m ? row : m - 1) * (size_t)n;
+        if constexpr (MODE == 0) bv[buf] = b[row < m ? row : m - 1];   // with the group's loads, not under the store's `if`: a load
+                                                                       // there drains the ring (s_waitcnt vmcnt(0) per group)
 #pragma unroll
         for (int c = 0; c < NCP; ++c) {
             if constexpr (VEC) {                           // n even: a pair never straddles the row end
                 typedef T wl_v2 __attribute__((ext_vector_type(2)));
                 const wl_v2 t = __builtin_nontemporal_load(reinterpret_cast<const wl_v2*>(rp + coff[c]));   // A is swept once per call
-                v0[c] = t.x;
-                v1[c] = t.y;
+                v0[buf][c] = t.x;
+                v1[buf][c] = t.y;
             } else {
-                v0[c] = rp[coff[c]];
-                v1[c] = rp[ok1[c] ? coff[c] + 1 : 0];
+                v0[buf][c] = rp[coff[c]];
+                v1[buf][c] = rp[ok1[c] ? coff[c] + 1 : 0];
             }
         }
+    };
+    auto use = [&](size_t g, auto B) {
+        constexpr int buf = decltype(B)::value;
+        const size_t row = 4 * g + q;
+        const bool rok = row < m;
         T s = 0;
 #pragma unroll
-        for (int c = 0; c < NCP; ++c) s += v0[c] * x0[c] + v1[c] * x1[c];
+        for (int c = 0; c < NCP; ++c) s += v0[buf][c] * x0[c] + v1[buf][c] * x1[c];
         s = sum16(s);
         const T t = dtanh(s);
         if constexpr (MODE == 0) {
-            if (rok && p == 0) out[row] = t - b[row];
+            if (rok && p == 0) out[row] = t - bv[buf];
         } else {
             const T d = 1 - t * t;
             T* op = out + (rok ? row : m - 1) * (size_t)n;
 #pragma unroll
             for (int c = 0; c < NCP; ++c) {
-                if (rok && ok0[c]) op[coff[c]] = d * v0[c];
-                if (rok && ok1[c]) op[coff[c] + 1] = d * v1[c];
+                if (rok && ok0[c]) op[coff[c]] = d * v0[buf][c];
+                if (rok && ok1[c]) op[coff[c] + 1] = d * v1[buf][c];
             }
         }
+    };
+    if (gb >= ge) return;
+    wl_static_for<kAhead>([&](auto U) { load(gb + decltype(U)::value, U); });
+    for (size_t g0 = gb; g0 < ge; g0 += kRing) {
+        wl_static_for<kRing>([&](auto U) {
+            constexpr int u0 = decltype(U)::value;
+            load(g0 + u0 + kAhead, std::integral_constant<int, (u0 + kAhead) % kRing>{});
+            if (g0 + u0 < ge) use(g0 + u0, U);
+        });
     }
 }
 
