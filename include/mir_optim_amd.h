@@ -388,6 +388,33 @@ int mir_lsq_batched_kernel_s(const mir_least_squares_settings_s* settings, size_
                              const float* t, size_t t_stride, const float* data,
                              mir_least_squares_result_s* results, const mir_lsq_batched_options* options);
 
+/* Resident-J solver (include/mir_optim_amd_resident.hpp, launch_resident<Model>): the whole loop of least_squares.d:972-1175
+ * in ONE cooperative launch for problems whose Jacobian, residuals and per-row data fit the LDS of the chip (BASELINE
+ * cfg 2). The residual model is a compile-time type of the caller's, as on the batched path. Options and statistics of
+ * that launch; every pointer is a DEVICE pointer. */
+enum { MIR_LSQ_RESIDENT_NO_NULL_SKIP = 1u,     /* variant bit: evaluate f also for trials equal to x bit for bit */
+       MIR_LSQ_RESIDENT_UNBOUNDED = 2u };       /* variant bit: the caller asserts that every lower / upper entry is infinite
+                                                  (the BOXCQP active-set loop is compiled out of workgroup 0's solve) */
+typedef struct mir_lsq_resident_stats {         /* written by the kernel at exit; times in 10 ns ticks of workgroup 0 */
+    uint64_t rounds, passes, accepted, rejected, step_guard_rejects, jacobian_full, jacobian_broyden, qp_active_set_passes,
+        elided_evaluations;
+    uint64_t t_total, t_stage, t_worker, t_group, t_total_wait, t_solver, t_solve_body, t_cmd_wait;
+    uint32_t abort_code, grid, rows, groups;
+} mir_lsq_resident_stats;
+typedef struct mir_lsq_resident_options {
+    uint32_t struct_size;            /* = sizeof(mir_lsq_resident_options) */
+    uint32_t variant;                /* MIR_LSQ_RESIDENT_* bits */
+    void* stream;                    /* hipStream_t to enqueue on (NULL = the default stream) */
+    void* workspace;                 /* optional device scratch of >= resident_workspace_bytes<Model>(m) bytes, owned by the
+                                        caller; NULL: the call allocates it and synchronises the stream before freeing it */
+    size_t workspace_bytes;
+    mir_lsq_trace_record* trace_records;   /* optional per-pass trace (same events as mir_lsq_trace) */
+    uint32_t trace_capacity;
+    uint32_t max_workgroups;         /* 0 = one workgroup per CU of the device */
+    uint32_t* trace_count;           /* events of the solve (also beyond the capacity) */
+    mir_lsq_resident_stats* stats;   /* optional */
+} mir_lsq_resident_options;
+
 /* Unit-level access to the damped solve of that kernel (?posvx('E','L') with one matrix row per lane; what boxcqp.d:194
  * calls): `count` systems of order n (3 or 8, the orders of the compiled-in models), device pointers; P count x 64 floats,
  * system p at P + 64 p, row-major with row stride 8, the LOWER triangle is read; rhs and x count x 8 floats (components

@@ -21,7 +21,7 @@ WORKLOADS_LIB = os.path.join(LIBDIR, "libmir_optim_amd_workloads.so")
 
 SOLVER_UNITS = ["abi.hip", "workspace.hip", "solver_loop.hip", "solver_jacobian.hip", "launch_jtj.hip", "launch_broyden.hip",
                 "launch_solve_d.hip", "launch_solve_s.hip", "batched.hip", "comm.hip", "unit_entries.hip", "fit_spline.cpp"]
-WORKLOAD_UNITS = ["workloads.hip", "workloads_gemm.hip"]
+WORKLOAD_UNITS = ["workloads.hip", "workloads_gemm.hip", "workloads_resident.hip"]
 
 _FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("MIR_OPTIM_AMD_CXXFLAGS", "").split()
 
@@ -73,14 +73,17 @@ def build(force=False, verbose=False, jobs=None):
     # the caller side: residual kernels of the synthetic workloads (two units: the C entries + small kernels, the batched GEMM)
     wobjs, wtodo = [], []
     whdrs = [os.path.join(CSRC, f) for f in ("workloads_device.h", "workloads_gemm.h")]
+    # the resident models are compiled against the device header of the resident-J solver, like a caller's own model would be
+    rhdrs = whdrs + [os.path.join(inc, "mir_optim_amd_resident.hpp"), os.path.join(inc, "mir_optim_amd.h")] + [
+        os.path.join(CSRC, f) for f in ("resident_kernel.h", "solve_kernel.h", "solve_lds.h", "solve_types.h", "common.h")]
     for u in WORKLOAD_UNITS:
         src = os.path.join(CSRC, u)
         obj = os.path.join(OBJDIR, os.path.splitext(u)[0] + ".o")
         wobjs.append(obj)
-        if force or _stale(obj, [src] + whdrs):
+        if force or _stale(obj, [src] + (rhdrs if u == "workloads_resident.hip" else whdrs)):
             wtodo.append([_hipcc()] + _FLAGS + ["-fopenmp", "-c", src, "-o", obj])   # OpenMP: host-side data generation / host residual
     if wtodo:
-        with ThreadPoolExecutor(max_workers=2) as ex:
+        with ThreadPoolExecutor(max_workers=3) as ex:
             list(ex.map(lambda c: _run(c, verbose), wtodo))
     if force or wtodo or _stale(WORKLOADS_LIB, wobjs):
         _run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fopenmp", "-o", WORKLOADS_LIB] + wobjs, verbose)

@@ -705,15 +705,16 @@ __device__ __forceinline__ int box_qp_device(int n, const T* Pm, const T* q, con
 }
 
 // ---------------------------------------------------------------- one LM pass, n x n part (LmSolveArgs: solve_types.h)
+// The body of k_lm_solve as a device function: ladder entry kc of `a`, collective over a workgroup of kSolveThreads threads;
+// smem_raw: LdsSolveCfg<NB>::ELEMS elements of LDS when NB > 0. Also called by the resident-J cooperative solver
+// (resident_kernel.h), whose workgroup 0 runs the n x n part of every pass inside the one launch.
 template <typename T, int NB, bool BOUNDED = true>
-__global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
+__device__ __forceinline__ void lm_solve_body(const LmSolveArgs<T>& a, const int kc, unsigned char* smem_raw)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ T red[8];
     __shared__ int ired[12];
     const int n = a.n, tid = threadIdx.x;
     const int ldf = n | 1;
-    const int kc = blockIdx.x;                       // chain step
     SolveScratch<T> sc = a.sc[kc];
     T* dx_out = a.dx + (size_t)kc * n;
     T* trial_out = a.trial + (size_t)kc * n;
@@ -925,6 +926,13 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
         r.qp_status = qp; r.qp_iterations = qp_iters; r.flags = flags;
         a.rec[kc] = r;
     }
+}
+
+template <typename T, int NB, bool BOUNDED = true>
+__global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    lm_solve_body<T, NB, BOUNDED>(a, (int)blockIdx.x, smem_raw);      // blockIdx.x: chain step
 }
 
 // standalone BOXCQP (mir_solve_box_qp_gpu_*; BoxQpArgs: solve_types.h)

@@ -125,3 +125,131 @@ class Curve(DeviceProblem):
         gs64 = kind == "gauss_sum" and dtype == np.float64
         self.fb = _addr("wl_gauss_sum_fb_d") if gs64 else None       # batched residuals: one launch for the 2n FD points
         self.fbr = _addr("wl_gauss_sum_fbr_d") if gs64 else None
+
+
+# ---- resident-J solver (include/mir_optim_amd_resident.hpp; models in csrc/workloads_resident.hip) --------------------
+
+class ResidentStats(C.Structure):
+    """mir_lsq_resident_stats (times in 10 ns ticks of workgroup 0)."""
+    _fields_ = ([(k, C.c_uint64) for k in ("rounds", "passes", "accepted", "rejected", "step_guard_rejects", "jacobian_full",
+                                            "jacobian_broyden", "qp_active_set_passes", "elided_evaluations", "t_total", "t_stage",
+                                            "t_worker", "t_group", "t_total_wait", "t_solver", "t_solve_body", "t_cmd_wait")]
+                + [(k, C.c_uint32) for k in ("abort_code", "grid", "rows", "groups")])
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class ResidentOptions(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("variant", C.c_uint32), ("stream", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t), ("trace_records", C.c_void_p), ("trace_capacity", C.c_uint32),
+                ("max_workgroups", C.c_uint32), ("trace_count", C.c_void_p), ("stats", C.c_void_p)]
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.struct_size = C.sizeof(ResidentOptions)
+
+
+RESIDENT_NO_NULL_SKIP = 1
+RESIDENT_UNBOUNDED = 2
+RESIDENT_MODELS = {"gauss5": 0, "tanh32": 1, "gauss3": 2, "exp_decay1": 3}
+
+
+class ResidentDoesNotFit(Exception):
+    """The problem's slices do not fit the chip's LDS (launch_resident returns -3): use the launch-chain path."""
+
+
+class Resident:
+    """A problem on the resident-J path: ONE cooperative launch runs the whole LM loop with J, y and the row data in LDS.
+    `rowdata`: m x nd table of the model (gauss*: [t_i, data_i]; tanh32: [a_i (32), b_i]; exp_decay1: [t_i, data_i])."""
+
+    def __init__(self, model, rowdata, stream=None, max_workgroups=0, fallback=None):
+        self.model = RESIDENT_MODELS[model] if isinstance(model, str) else int(model)
+        rowdata = np.ascontiguousarray(rowdata, dtype=np.float64)
+        self.m = rowdata.shape[0]
+        self.stream = stream or api.Stream()
+        self.fallback = fallback                       # a DeviceProblem with the same residual: used when the slices do not fit
+        self.max_workgroups = int(max_workgroups)
+        WL = api.workloads_lib()
+        out4 = (C.c_int * 4)()
+        out2 = (C.c_size_t * 2)()
+        self.plan_rc = WL.wl_resident_plan(C.c_int(self.model), C.c_size_t(self.m), C.c_int(self.max_workgroups or 256), out4, out2)
+        self.grid, self.rows, self.groups, self.n = (int(v) for v in out4)
+        self.lds_bytes, self.workspace_bytes = (int(v) for v in out2)
+        if self.plan_rc == 0:
+            self.d_rows = api.DeviceBuffer(rowdata)
+            self.d_ws = api.DeviceBuffer(nbytes=self.workspace_bytes, dtype=np.uint8, shape=(self.workspace_bytes,))
+            self.d_x = api.DeviceBuffer(nbytes=8 * 3 * self.n, dtype=np.float64, shape=(3 * self.n,))     # x | lower | upper
+            self.d_res = api.DeviceBuffer(nbytes=32, dtype=np.uint8, shape=(32,))
+            self.d_stats = api.DeviceBuffer(nbytes=C.sizeof(ResidentStats), dtype=np.uint8, shape=(C.sizeof(ResidentStats),))
+            self.d_trace = None
+            self.d_tcount = api.DeviceBuffer(nbytes=8, dtype=np.uint32, shape=(2,))
+
+    @classmethod
+    def gauss_sum(cls, t, data, K=5, **kw):
+        return cls({5: "gauss5", 3: "gauss3"}[K], np.stack([t, data], axis=1), **kw)
+
+    @classmethod
+    def tanh_linear(cls, A, b, **kw):
+        assert A.shape[1] == 32
+        return cls("tanh32", np.concatenate([A, np.asarray(b)[:, None]], axis=1), **kw)
+
+    def upload_point(self, x0, l=None, u=None):
+        n = self.n
+        xlu = np.empty(3 * n)
+        xlu[:n] = x0
+        xlu[n:2 * n] = -np.inf if l is None else l
+        xlu[2 * n:] = np.inf if u is None else u
+        self.d_x.upload(xlu)
+
+    def launch(self, settings=None, trace_capacity=0, variant=0):
+        """Enqueue one solve from the uploaded point (asynchronous). Returns launch_resident's code."""
+        n = self.n
+        s = settings if settings is not None else api.LeastSquaresSettings()
+        o = ResidentOptions()
+        o.variant = variant
+        o.stream = self.stream.handle
+        o.workspace = self.d_ws.ptr
+        o.workspace_bytes = self.workspace_bytes
+        o.max_workgroups = self.max_workgroups
+        if trace_capacity:
+            if self.d_trace is None or self.d_trace.nbytes < 40 * trace_capacity:
+                self.d_trace = api.DeviceBuffer(nbytes=40 * trace_capacity, dtype=np.uint8, shape=(40 * trace_capacity,))
+            o.trace_records = self.d_trace.ptr
+            o.trace_capacity = trace_capacity
+        o.trace_count = self.d_tcount.ptr
+        o.stats = self.d_stats.ptr
+        st = C.c_int(0)
+        rc = api.workloads_lib().wl_resident_launch_d(
+            C.c_int(self.model), C.byref(s), C.c_size_t(self.m), C.c_void_p(self.d_x.ptr), C.c_void_p(self.d_x.ptr + 8 * n),
+            C.c_void_p(self.d_x.ptr + 16 * n), C.c_void_p(self.d_rows.ptr), C.c_void_p(self.d_res.ptr), C.byref(o), C.byref(st))
+        self.last_status_out = st.value
+        return rc
+
+    def solve(self, x0, l=None, u=None, settings=None, trace=None, variant=0, **fallback_kw):
+        """(LeastSquaresResult, x, stats dict). trace: an api.Trace to fill (same events as the launch-chain path's)."""
+        if self.plan_rc != 0:
+            if self.plan_rc == -3 and self.fallback is not None:
+                res, x = self.fallback.solve(x0, l, u, settings=settings, trace=trace, **fallback_kw)
+                return res, x, None
+            raise ResidentDoesNotFit(f"resident plan failed with {self.plan_rc}")
+        n = self.n
+        self.upload_point(x0, l, u)
+        cap = int(trace.header.capacity) if trace is not None else 0
+        rc = self.launch(settings, cap, variant)
+        if rc != 0:
+            if rc == -1 and self.last_status_out:
+                raw = api._Rd(self.last_status_out, 0, 0, 0, np.inf, 0.0)
+                return api.LeastSquaresResult(raw), np.array(x0, dtype=np.float64), None
+            raise RuntimeError(f"launch_resident failed with {rc}")
+        self.stream.synchronize()
+        raw = api._Rd.from_buffer_copy(self.d_res.download().tobytes())
+        x = self.d_x.download()[:n].copy()
+        stats = ResidentStats.from_buffer_copy(self.d_stats.download().tobytes())
+        if trace is not None:
+            cnt = int(self.d_tcount.download()[0])
+            trace.header.count = cnt
+            k = min(cnt, cap)
+            if k:
+                C.memmove(trace._buf, self.d_trace.download().tobytes()[:40 * k], 40 * k)
+        return api.LeastSquaresResult(raw), x, stats.as_dict()

@@ -1,0 +1,225 @@
+"""The resident-J solver (include/mir_optim_amd_resident.hpp, csrc/resident_kernel.h): the whole loop of
+least_squares.d:972-1175 in ONE cooperative launch, J sharded over the CUs' LDS. Compared with the oracle -- minimiser,
+residual, status class AND the per-pass trace, event by event up to the first noise-decided pass -- and with the launch-chain
+path (mir_optimize_least_squares_gpu_d with device callbacks), which minimises the same residual expression.
+BASELINE cfg 2 (Gaussian sum, m = 1e5 x n = 16, width bounds) at full size, with and without binding bounds."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import mir_optim_amd as M
+from mir_optim_amd import workloads as W
+import problems as P
+from test_gpu_lm import assert_traces_agree_until_noise, first_noisy_pass
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_gauss(oracle, g, x0, lower, upper, settings=None):
+    ctx = oracle.GaussSumCtx(g["t"].ctypes.data, g["data"].ctypes.data)
+    ev = []
+    ro, xo = oracle.optimize(oracle.native_fn("wlc_gauss_sum_f"), g["m"], x0, lower=lower, upper=upper, fctx=C.addressof(ctx),
+                             settings=settings, trace=lambda *a: ev.append(a))
+    return ro, xo, ev
+
+
+def test_cfg2_gauss_sum_full_size_resident(oracle):
+    """BASELINE cfg 2 through the resident path: same minimiser as the oracle (x rtol 1e-6, residual rtol 1e-9), traces equal
+    pass by pass up to the first noise-decided one, every counter consistent with the trace."""
+    g = P.gauss_sum(100000, K=5)
+    r = W.Resident.gauss_sum(g["t"], g["data"], K=5)
+    assert r.plan_rc == 0 and r.n == 16 and r.grid == 256
+    tr = M.Trace(4096)
+    res, x, st = r.solve(g["x0"], g["lower"], g["upper"], trace=tr)
+    ro, xo, ev = oracle_gauss(oracle, g, g["x0"], g["lower"], g["upper"])
+    assert res.status >= 0 and ro.status >= 0 and st["abort_code"] == 0
+    assert np.allclose(x, xo, rtol=1e-6, atol=1e-9) and np.isclose(res.residual, ro.residual, rtol=1e-9)
+    assert np.allclose(x, g["truth"], rtol=5e-3, atol=1e-3)
+    recs = tr.records()
+    k_end = assert_traces_agree_until_noise(recs, ev, min_passes=30)
+    assert sum(1 for q in recs[:k_end] if q[0] == 3) >= 12
+    # the counters are those of the trace
+    assert res.iterations == sum(1 for q in recs if q[0] == 3) == st["accepted"]
+    assert st["rejected"] == sum(1 for q in recs if q[0] == 2) and st["jacobian_full"] == sum(1 for q in recs if q[0] == 0)
+    assert st["jacobian_broyden"] == sum(1 for q in recs if q[0] == 1)
+    assert res.fCalls == 1 + 16 * st["jacobian_full"] + st["accepted"] + st["rejected"]         # LS:953, 1049 (Q5), 1112
+    # one round per executed pass that needs a residual, one more per refresh: elided null steps cost none
+    assert st["rounds"] == 1 + st["jacobian_full"] + st["accepted"] + st["rejected"] - st["elided_evaluations"]
+
+
+def test_cfg2_binding_width_bounds_resident(oracle):
+    """cfg 2 with two widths boxed in above their true value and two amplitudes from above: BOXCQP's active-set loop
+    (boxcqp.d:234-376) runs inside the launch in nearly every pass; same active set and minimiser as the oracle."""
+    g = P.gauss_sum(100000, K=5)
+    K = g["K"]
+    lower, upper = g["lower"].copy(), g["upper"].copy()
+    lower[2 * K] = 0.045; lower[2 * K + 3] = 0.05
+    upper[0] = 0.95; upper[3] = 0.85
+    x0 = np.clip(g["x0"], lower, upper)
+    r = W.Resident.gauss_sum(g["t"], g["data"], K=5)
+    tr = M.Trace(4096)
+    res, x, st = r.solve(x0, lower, upper, trace=tr)
+    ro, xo, ev = oracle_gauss(oracle, g, x0, lower, upper)
+    assert res.status >= 0 and ro.status >= 0
+    assert st["qp_active_set_passes"] >= 3
+    on_gpu = (x == lower) | (x == upper)
+    on_cpu = (xo == lower) | (xo == upper)
+    assert on_gpu.sum() >= 4 and np.array_equal(on_gpu, on_cpu)
+    assert np.allclose(x, xo, rtol=1e-6, atol=1e-9) and np.isclose(res.residual, ro.residual, rtol=1e-9)
+    assert_traces_agree_until_noise(tr.records(), ev, min_passes=8)
+    # and the launch-chain path lands on the same point
+    prob = W.Curve("gauss_sum", g["t"], g["data"])
+    res2, x2 = prob.solve(x0, lower, upper)
+    assert np.allclose(x, x2, rtol=1e-6, atol=1e-9) and np.isclose(res.residual, res2.residual, rtol=1e-9)
+
+
+def test_tanh_linear_20000x32_resident(oracle):
+    """A second model (two 16-column blocks: three accumulator blocks a wave, the NB = 2 solve): cfg 3's family at an
+    LDS-resident size, unbounded (the kernel without the active-set loop)."""
+    w = P.tanh_linear(20000, 32)
+    r = W.Resident.tanh_linear(w["A"], w["b"])
+    assert r.plan_rc == 0 and r.n == 32
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
+    so = oracle.default_settings(); so.absTolerance = 1e-9
+    ctx = oracle.TanhLinearCtx(w["A"].ctypes.data, w["b"].ctypes.data)
+    ev = []
+    ro, xo = oracle.optimize(oracle.native_fn("wlc_tanh_linear_f"), w["m"], w["x0"], settings=so, fctx=C.addressof(ctx),
+                             trace=lambda *a: ev.append(a))
+    outs = []
+    for variant in (W.RESIDENT_UNBOUNDED, 0):
+        tr = M.Trace(1024)
+        res, x, st = r.solve(w["x0"], settings=s, trace=tr, variant=variant)
+        assert res.status >= 0 and ro.status >= 0
+        assert np.allclose(x, xo, rtol=1e-6, atol=1e-9) and np.isclose(res.residual, ro.residual, rtol=1e-9)
+        # pass by pass as tests/test_gpu_lm.py::test_pass_by_pass_trajectory_matches_oracle does for this family (the device tanh
+        # and libm's differ by 2e-16, which the finite differences amplify to 1e-8 in J: lambda to 1e-8, residuals to 1e-7)
+        got = tr.records()
+        K = min(first_noisy_pass(got), first_noisy_pass(ev), len(got), len(ev))
+        assert K >= 9, (K, len(got), len(ev))
+        assert [q[:2] for q in got[:K]] == [(e[0], e[1]) for e in ev[:K]] and {0, 1, 3} <= {q[0] for q in got[:K]}
+        for k, (q, e) in enumerate(zip(got[:K], ev[:K])):
+            assert np.isclose(q[2], e[2], rtol=1e-8) and np.isclose(q[3], e[3], rtol=1e-7), (k, q, e)
+            assert np.isclose(q[4], e[4], rtol=1e-7, atol=1e-300) and np.isclose(q[5], e[5], rtol=1e-3, atol=1e-22), (k, q, e)
+        outs.append((x.tobytes(), int(res.status), res.iterations, res.fCalls, res.residual, res.lambda_, tuple(got)))
+    assert outs[0] == outs[1]          # with or without the active-set loop compiled in: the same bits when no bound exists
+
+
+def test_resident_equals_launch_chain_on_the_small_family(oracle):
+    g = P.gauss_sum(20000, K=3)
+    r = W.Resident.gauss_sum(g["t"], g["data"], K=3)
+    res, x, st = r.solve(g["x0"], g["lower"], g["upper"])
+    prob = W.Curve("gauss_sum", g["t"], g["data"])
+    res2, x2 = prob.solve(g["x0"], g["lower"], g["upper"])
+    ro, xo, _ = oracle_gauss(oracle, g, g["x0"], g["lower"], g["upper"])
+    assert res.status >= 0 and res2.status >= 0 and ro.status >= 0
+    assert np.allclose(x, xo, rtol=1e-6, atol=1e-9) and np.allclose(x, x2, rtol=1e-6, atol=1e-9)
+    assert np.isclose(res.residual, ro.residual, rtol=1e-8) and np.isclose(res.residual, res2.residual, rtol=1e-9)
+
+
+def test_resident_is_reproducible_bit_for_bit():
+    """Fixed-order sums, no float atomics: every launch returns the same bits (least_squares.d:73-80: pure callbacks)."""
+    g = P.gauss_sum(100000, K=5)
+    r = W.Resident.gauss_sum(g["t"], g["data"], K=5)
+    outs = set()
+    for _ in range(6):
+        tr = M.Trace(4096)
+        res, x, st = r.solve(g["x0"], g["lower"], g["upper"], trace=tr)
+        outs.add((x.tobytes(), int(res.status), res.iterations, res.fCalls, res.residual, res.lambda_, tuple(tr.records())))
+    assert len(outs) == 1
+
+
+@pytest.mark.parametrize("wgs,m", [(1, 800), (3, 2400), (16, 6000), (17, 6001), (100, 20000), (255, 20000)])
+def test_resident_any_grid(oracle, wgs, m):
+    """The slice / group / leader arithmetic for grids that are not 256: one workgroup, fewer groups than sixteen, ragged groups."""
+    g = P.gauss_sum(m, K=3)
+    r = W.Resident.gauss_sum(g["t"], g["data"], K=3, max_workgroups=wgs)
+    assert r.plan_rc == 0 and r.grid <= wgs and r.grid >= min(wgs, 254)
+    tr = M.Trace(2048)
+    res, x, st = r.solve(g["x0"], g["lower"], g["upper"], trace=tr)
+    ro, xo, ev = oracle_gauss(oracle, g, g["x0"], g["lower"], g["upper"])
+    assert res.status >= 0 and st["abort_code"] == 0 and st["grid"] == r.grid
+    assert np.allclose(x, xo, rtol=1e-6, atol=1e-9) and np.isclose(res.residual, ro.residual, rtol=1e-8)
+    assert_traces_agree_until_noise(tr.records(), ev, min_passes=10)
+
+
+def test_resident_bounded_three_parameter_fit(oracle):
+    """Reference unittest T5's family (least_squares.d:366-411) on two workgroups: the bounds bind, x stays inside."""
+    a, b = P.t5()
+    for p in (a, b):
+        t, yd = p["t"], p["data"]
+        lower = np.full(3, -np.inf) if p["lower"] is None else np.array(p["lower"], dtype=float)
+        upper = np.full(3, np.inf) if p["upper"] is None else np.array(p["upper"], dtype=float)
+        r = W.Resident("exp_decay1", np.stack([t, yd], axis=1))
+        res, x, st = r.solve(p["x0"], lower, upper)
+        ctx = oracle.ExpDecayCtx(t.ctypes.data, yd.ctypes.data, 1)
+        ro, xo = oracle.optimize(oracle.native_fn("wlc_exp_decay_f"), 100, p["x0"], lower=lower, upper=upper, fctx=C.addressof(ctx))
+        assert res.status >= 0 and ro.status >= 0
+        assert np.all(x >= lower) and np.all(x <= upper)                                           # LS:395, 410
+        assert np.allclose(x, xo, rtol=1e-6, atol=1e-9) and np.isclose(res.residual, ro.residual, rtol=1e-9)
+
+
+def test_resident_validation_and_exits(oracle):
+    g = P.gauss_sum(5000, K=3)
+    r = W.Resident.gauss_sum(g["t"], g["data"], K=3)
+    S = M.LeastSquaresStatus
+    # LS:930-932 inside the kernel (x, lower, upper are device data)
+    bad = g["x0"].copy(); bad[1] = np.nan
+    res, x, _ = r.solve(bad, g["lower"], g["upper"])
+    assert res.status == S.badGuess and res.iterations == 0 and res.fCalls == 0 and res.residual == np.inf
+    lo = g["lower"].copy(); lo[0] = g["x0"][0] + 1
+    res, x, _ = r.solve(g["x0"], lo, g["upper"])
+    assert res.status == S.badBounds
+    # LS:933-943 on the host
+    s = M.LeastSquaresSettings(); s.minStepQuality = 1.5
+    res, x, _ = r.solve(g["x0"], g["lower"], g["upper"], settings=s)
+    assert res.status == S.badMinStepQuality
+    s = M.LeastSquaresSettings(); s.lambdaIncrease = 0.5
+    res, x, _ = r.solve(g["x0"], g["lower"], g["upper"], settings=s)
+    assert res.status == S.badLambdaParams
+    # maxIterations, LS:1175; and the counters of the oracle at that point
+    s = M.LeastSquaresSettings(); s.maxIterations = 3
+    so = oracle.default_settings(); so.maxIterations = 3
+    res, x, _ = r.solve(g["x0"], g["lower"], g["upper"], settings=s)
+    ro, xo, _ = oracle_gauss(oracle, g, g["x0"], g["lower"], g["upper"], settings=so)
+    assert res.status == S.maxIterations == ro.status and res.iterations == ro.iterations == 3 and res.fCalls == ro.fCalls
+    assert np.allclose(x, xo, rtol=1e-9)
+    # fConverged, LS:974: data that the model reproduces exactly
+    t = g["t"]
+    truth = g["truth"]
+    K = 3
+    clean = sum(truth[k] * np.exp(-(t - truth[K + k]) ** 2 / (2 * truth[2 * K + k] ** 2)) for k in range(K)) + truth[3 * K]
+    r2 = W.Resident.gauss_sum(t, clean, K=3)
+    s = M.LeastSquaresSettings(); s.maxGoodResidual = 1e-12
+    res, x, _ = r2.solve(g["x0"], g["lower"], g["upper"], settings=s)
+    assert res.status == S.fConverged and res.residual <= 1e-12 and np.allclose(x, truth, rtol=1e-5)
+
+
+def test_resident_null_step_elision_changes_nothing():
+    """Trials equal to x bit for bit are not evaluated (the callbacks are pure, least_squares.d:73-80): the same bits, counters
+    and trace with the elision switched off."""
+    g = P.gauss_sum(100000, K=5)
+    r = W.Resident.gauss_sum(g["t"], g["data"], K=5)
+    outs = []
+    for variant in (0, W.RESIDENT_NO_NULL_SKIP):
+        tr = M.Trace(4096)
+        res, x, st = r.solve(g["x0"], g["lower"], g["upper"], trace=tr, variant=variant)
+        outs.append((x.tobytes(), int(res.status), res.iterations, res.fCalls, res.residual, res.lambda_, tuple(tr.records())))
+        if variant:
+            assert st["elided_evaluations"] == 0
+        else:
+            assert st["elided_evaluations"] > 0
+    assert outs[0] == outs[1]
+
+
+def test_resident_does_not_fit_falls_back(oracle):
+    """m x (n + nd + 3) doubles beyond the chip's LDS: launch_resident answers -3 and the caller takes the launch-chain path."""
+    g = P.gauss_sum(1000000, K=5)
+    prob = W.Curve("gauss_sum", g["t"], g["data"])
+    r = W.Resident.gauss_sum(g["t"], g["data"], K=5, fallback=prob)
+    assert r.plan_rc == -3
+    res, x, st = r.solve(g["x0"], g["lower"], g["upper"])
+    assert st is None and res.status >= 0
+    assert np.allclose(x, g["truth"], rtol=5e-3, atol=1e-3)
+    with pytest.raises(W.ResidentDoesNotFit):
+        W.Resident.gauss_sum(g["t"], g["data"], K=5).solve(g["x0"], g["lower"], g["upper"])
