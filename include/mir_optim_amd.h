@@ -399,6 +399,7 @@ typedef struct mir_lsq_resident_stats {         /* written by the kernel at exit
     uint64_t rounds, passes, accepted, rejected, step_guard_rejects, jacobian_full, jacobian_broyden, qp_active_set_passes,
         elided_evaluations;
     uint64_t t_total, t_stage, t_worker, t_group, t_total_wait, t_solver, t_solve_body, t_cmd_wait;
+    uint64_t t_w_eval, t_w_fd, t_w_prod;         /* of t_worker: trial residuals, finite-difference refreshes, products + publication */
     uint32_t abort_code, grid, rows, groups;
 } mir_lsq_resident_stats;
 typedef struct mir_lsq_resident_options {

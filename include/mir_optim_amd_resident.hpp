@@ -55,7 +55,8 @@ template <class Model> size_t resident_lds_bytes(int rows)
     constexpr int NCB = resident_ncb<Model>(), NC = 16 * NCB, NBT = NCB * (NCB + 1) / 2;
     const size_t R = (size_t)(rows + 15) / 16 * 16;
     const size_t doubles = R * NC + 3 * R + R * Model::nd + 2 * (size_t)Model::n * Model::nc
-        + (size_t)mirlsq::kResWaves * (NBT * 256 + NC) + 3 * NC + (size_t)mirlsq::LdsSolveCfg<NCB>::ELEMS;
+        + (size_t)(mirlsq::res_threads(Model::n) / 64) * (NBT * 256 + NC) + 3 * NC
+        + (Model::n <= 16 ? (size_t)768 : (size_t)mirlsq::LdsSolveCfg<NCB>::ELEMS);      // n <= 16: the one-wave solve's operands and ladder
     return doubles * sizeof(double);
 }
 
@@ -194,7 +195,7 @@ int launch_resident(const mir_least_squares_settings_d* S, size_t m, double* x, 
         void* args[] = {&a};
         // cooperative: the launch is refused (hipErrorCooperativeLaunchTooLarge) instead of deadlocking when the grid cannot be
         // resident at once
-        e = hipLaunchCooperativeKernel(kern, dim3((unsigned)plan.grid), dim3(kResThreads), args, (unsigned)plan.lds_bytes, stream);
+        e = hipLaunchCooperativeKernel(kern, dim3((unsigned)plan.grid), dim3(res_threads(Model::n)), args, (unsigned)plan.lds_bytes, stream);
     }
     if (owned) {
         const hipError_t f = hipStreamSynchronize(stream);       // the kernel uses the workspace: wait before freeing it

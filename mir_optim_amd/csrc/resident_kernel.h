@@ -29,11 +29,15 @@
 #include "common.h"
 #include "solve_types.h"
 #include "solve_kernel.h"
+#include "solve_wave16.h"
 
 namespace mirlsq {
 
-constexpr int kResThreads = kSolveThreads;      // 256: workgroup 0 runs lm_solve_body, which is written for this many
-constexpr int kResWaves = kResThreads / kWave;
+// Threads of a workgroup. 256: what lm_solve_body (n > 16) is written for. The kernel also runs with 512 for n <= 16 (the one-wave
+// solve does not care, and two waves a SIMD keep the f64 vector pipe busier in the one-row-per-thread phases: measured at cfg 2,
+// trial residuals + products + refreshes 524 -> 392 us per fit) -- but two waves a SIMD leave a wave 256 registers where one has
+// 512, the solve then spills 150-240 of them into the round loop and workgroup 0's share grows by more (384 -> 700 us): 256 it is.
+__host__ __device__ constexpr int res_threads(int n) { return n <= 16 ? 256 : kSolveThreads; }
 constexpr int kResGroups = 16;                  // group leaders (first level of the reduction)
 constexpr int kResGroupMax = 16;                // members a leader sums (grid <= 256)
 constexpr int kResNMax = 32;                    // parameters: one or two 16-column blocks (the solve runs NB = 1 or 2)
@@ -130,8 +134,9 @@ __device__ __forceinline__ bool res_wait_ge(const uint32_t* p, uint32_t target, 
 // ---- the kernel ---------------------------------------------------------------------------------------------------------
 // Model (include/mir_optim_amd_resident.hpp): n, nd, nc, prepare(x, c), eval(row, c).
 template <class Model, bool BOUNDED>
-__global__ __launch_bounds__(kResThreads) void k_lm_resident(ResidentArgs a)
+__global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentArgs a)
 {
+    constexpr int kResThreads = res_threads(Model::n), kResWaves = kResThreads / kWave;
     constexpr int N = Model::n, ND = Model::nd, NCN = Model::nc;
     static_assert(N >= 1 && N <= kResNMax, "1 <= n <= 32");
     constexpr int NCB = (N + 15) / 16;
@@ -149,6 +154,11 @@ __global__ __launch_bounds__(kResThreads) void k_lm_resident(ResidentArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wg = blockIdx.x;
+    auto wave_total = [&](const double* w) {
+        double t = (w[0] + w[1]) + (w[2] + w[3]);
+        if constexpr (kResWaves == 8) t += (w[4] + w[5]) + (w[6] + w[7]);
+        return t;
+    };
     const int R = (a.rows + 15) / 16 * 16;                  // padded slice: four waves x four rows per MFMA step
     const int row0 = wg * a.rows;
     const int nrows = max(0, min(a.rows, a.m - row0));
@@ -165,11 +175,26 @@ __global__ __launch_bounds__(kResThreads) void k_lm_resident(ResidentArgs a)
     double* Xl = RED + kResWaves * REDW;                    // NC: point of an FD refresh
     double* DXl = Xl + NC;                                  // NC: dx of the speculative update (kept for the commit)
     double* INVl = DXl + NC;                                // NC: 1 / (x+ - x-) per column
-    unsigned char* solve_smem = reinterpret_cast<unsigned char*>(INVl + NC);
+    // n <= 16: the n x n part runs on ONE wave with a matrix row per lane (solve_wave16.h) and everything it reads and writes
+    // stays in LDS; above, lm_solve_body (the launch-chain path's code, 256 threads, operands and scratch in global memory)
+    constexpr bool WAVE = N <= kW16;
+    double* SOL = INVl + NC;
+    unsigned char* solve_smem = reinterpret_cast<unsigned char*>(SOL);
+    // WAVE layout of SOL: J^T J x 2 (16 x 16 each) | J^T y x 2 | x | lower | upper | 4 ladder levels: dx, trial | 4 level records
+    double* JJp[2] = {WAVE ? SOL : a.JJ[0], WAVE ? SOL + 256 : a.JJ[1]};
+    double* Jyp[2] = {WAVE ? SOL + 512 : a.Jy[0], WAVE ? SOL + 528 : a.Jy[1]};
+    double* xsp = WAVE ? SOL + 544 : a.xs;
+    double* lop = SOL + 560;
+    double* upp = SOL + 576;
+    double* dxp = WAVE ? SOL + 592 : a.dx;                   // level k at dxp + 16 k
+    double* trp = WAVE ? SOL + 656 : a.trial;
+    double* lrec = SOL + 720;                                // level k: lambda, ndd, pred, xnorm at lrec + 8 k; ints behind
+    int* lreci = reinterpret_cast<int*>(SOL + 752);          // level k: qp_status, qp_iters, flags, offered at lreci + 4 k
+    constexpr int JLD = WAVE ? kW16 : N;                     // leading dimension of the J^T J copies
 
     int iy = 0, it = 1;                                     // roles of Yb's first two vectors
     constexpr int iu = 2;
-    long long tk0 = 0, t_stage = 0, t_worker = 0, t_group = 0, t_total_wait = 0, t_solver = 0, t_solve_body = 0, t_cmd_wait = 0;
+    long long tk0 = 0, t_stage = 0, t_w_eval = 0, t_w_fd = 0, t_w_prod = 0, t_worker = 0, t_group = 0, t_total_wait = 0, t_solver = 0, t_solve_body = 0, t_cmd_wait = 0;
     const bool clk = wg == 0 && tid == 0;
     if (clk) tk0 = wall_clock64();
 
@@ -181,6 +206,16 @@ __global__ __launch_bounds__(kResThreads) void k_lm_resident(ResidentArgs a)
         Dl[e] = i < nrows ? a.rowdata[(size_t)row0 * ND + e] : 0.0;
     }
     if (tid < NC) { DXl[tid] = 0; INVl[tid] = 0; Xl[tid] = 0; }
+    if constexpr (WAVE) {
+        if (wg == 0) {
+            for (int e = tid; e < 768; e += kResThreads) SOL[e] = 0;
+            __syncthreads();
+            if (tid < kW16) {
+                lop[tid] = tid < N ? a.lower[tid] : -Lim<double>::inf();
+                upp[tid] = tid < N ? a.upper[tid] : Lim<double>::inf();
+            }
+        }
+    }
     __syncthreads();
     if (clk) t_stage = wall_clock64() - tk0;
 
@@ -198,6 +233,10 @@ __global__ __launch_bounds__(kResThreads) void k_lm_resident(ResidentArgs a)
     int status = -1;                                        // maxIterations, LS:971
     bool needJac = true, fConverged = false, x_nan = false;
     int cur = 0;                                            // which of JJ[2] / Jy[2] is the current pair
+    double null_lambda = Lim<double>::inf();                // above this damping the rounded step is provably zero (see kSolve)
+    int null_lambda_for = 0;                                // 2: null_lambda belongs to the current (J^T y, x)
+    bool lad_valid = false;                                 // n <= 16: the ladder in LDS was solved on the current J^T J, J^T y, x
+    int lad_level = 0;                                      // its level the pass being decided uses
     int phase = 0;                                          // 0: initial residual, 1: refresh products, 2: trial
     uint64_t n_rounds = 0, n_passes = 0, n_acc = 0, n_rej = 0, n_guard = 0, n_fd = 0, n_br = 0, n_qp = 0, n_elided = 0;
     uint32_t tr_count = 0;
@@ -245,7 +284,8 @@ __global__ __launch_bounds__(kResThreads) void k_lm_resident(ResidentArgs a)
             ss = wave_sum(ss);
             if (lane == 0) s_w[wave] = ss;
             __syncthreads();
-            if (tid == 0) res_st(a.partial + (size_t)wg * PL::STRIDE, (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
+            if (tid == 0) res_st(a.partial + (size_t)wg * PL::STRIDE, wave_total(s_w));
+            if (clk) { const long long t = wall_clock64(); t_w_eval += t - tw0; }
         } else if (action == kResFd) {
             // (2') central differences at the command's point, LS:1018-1049: thread p prepares point p (2j: x + h e_j, 2j + 1:
             // x - h e_j, clipped to the bounds), then one row per thread
@@ -278,7 +318,10 @@ __global__ __launch_bounds__(kResThreads) void k_lm_resident(ResidentArgs a)
                 }
             }
             __syncthreads();
+            if (clk) { const long long t = wall_clock64(); t_w_fd += t - tw0; }
         }
+        long long tp0 = 0;
+        if (clk) tp0 = wall_clock64();
         if (action == kResEvalSpec || action == kResFd) {
             // (3) products of the slice on the matrix cores. Lane (q, p) holds J[4 s + q][16 c + p]: the A and the B operand of
             // v_mfma_f64_16x16x4 at once. kResEvalSpec: the rows are FIRST updated as the Broyden pass after an acceptance of
@@ -337,7 +380,12 @@ __global__ __launch_bounds__(kResThreads) void k_lm_resident(ResidentArgs a)
             }
             __syncthreads();
             double* out = a.partial + (size_t)wg * PL::STRIDE;
-            auto four = [&](int e) { return (RED[e] + RED[REDW + e]) + (RED[2 * REDW + e] + RED[3 * REDW + e]); };
+            auto four = [&](int e) {                               // the waves' values in a fixed order
+                double t = (RED[e] + RED[REDW + e]) + (RED[2 * REDW + e] + RED[3 * REDW + e]);
+                if constexpr (kResWaves == 8)
+                    t += (RED[4 * REDW + e] + RED[5 * REDW + e]) + (RED[6 * REDW + e] + RED[7 * REDW + e]);
+                return t;
+            };
             {
                 int b = 0;
 #pragma unroll
@@ -345,9 +393,11 @@ __global__ __launch_bounds__(kResThreads) void k_lm_resident(ResidentArgs a)
 #pragma unroll
                     for (int J = 0; J <= I; ++J, ++b) {
                         const int r = tid >> 4, c = tid & 15;
-                        const double v = four(b * 256 + tid);
-                        if (I == J) { if (c <= r) res_st(out + PL::blk_base(b) + r * (r + 1) / 2 + c, v); }
-                        else res_st(out + PL::blk_base(b) + tid, v);
+                        if (tid < 256) {
+                            const double v = four(b * 256 + tid);
+                            if (I == J) { if (c <= r) res_st(out + PL::blk_base(b) + r * (r + 1) / 2 + c, v); }
+                            else res_st(out + PL::blk_base(b) + tid, v);
+                        }
                     }
             }
             if (tid < NC) res_st(out + PL::JY + tid, four(NBT * 256 + tid));
@@ -357,7 +407,7 @@ __global__ __launch_bounds__(kResThreads) void k_lm_resident(ResidentArgs a)
         res_drain();
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(a.cnt + 32 * grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (clk) { const long long t = wall_clock64(); t_worker += t - tw0; tw0 = t; }
+        if (clk) { const long long t = wall_clock64(); t_worker += t - tw0; t_w_prod += t - tp0; tw0 = t; }
 
         // =================================================================================== group leaders
         if (leader) {
@@ -410,8 +460,8 @@ __global__ __launch_bounds__(kResThreads) void k_lm_resident(ResidentArgs a)
             const double ss_total = TOT[0];
             if (len > 1) {
                 // unpack into the pair that is NOT current: J^T J full symmetric n x n, J^T y
-                double* JJn = a.JJ[cur ^ 1];
-                double* Jyn = a.Jy[cur ^ 1];
+                double* JJn = JJp[cur ^ 1];
+                double* Jyn = Jyp[cur ^ 1];
                 int b = 0;
 #pragma unroll
                 for (int I = 0; I < NCB; ++I)
@@ -419,12 +469,12 @@ __global__ __launch_bounds__(kResThreads) void k_lm_resident(ResidentArgs a)
                     for (int J = 0; J <= I; ++J, ++b) {
                         const int r = tid >> 4, c = tid & 15;
                         const int gi = 16 * I + r, gj = 16 * J + c;
-                        if (gi < N && gj < N) {
+                        if (tid < 256 && gi < N && gj < N) {
                             double v;
                             if (I == J) v = c <= r ? TOT[PL::blk_base(b) + r * (r + 1) / 2 + c] : TOT[PL::blk_base(b) + c * (c + 1) / 2 + r];
                             else v = TOT[PL::blk_base(b) + tid];
-                            JJn[(size_t)gi * N + gj] = v;
-                            if (I != J) JJn[(size_t)gj * N + gi] = v;
+                            JJn[(size_t)gi * JLD + gj] = v;
+                            if (I != J) JJn[(size_t)gj * JLD + gi] = v;
                         }
                     }
                 if (tid < N) Jyn[tid] = TOT[PL::JY + tid];
@@ -448,7 +498,7 @@ __global__ __launch_bounds__(kResThreads) void k_lm_resident(ResidentArgs a)
                     if (!(-Lim<double>::inf() < xj && xj < Lim<double>::inf())) finite = false;
                     if (!(a.lower[j] <= xj) || !(xj <= a.upper[j])) inb = false;
                 }
-                if (tid < N) a.xs[tid] = a.x[tid];
+                if (tid < N) xsp[tid] = a.x[tid];
                 __syncthreads();
                 if (!finite) { status = mir_ls_badGuess; where = kDone; }
                 else if (!inb) { status = mir_ls_badBounds; where = kDone; }
@@ -473,6 +523,7 @@ __global__ __launch_bounds__(kResThreads) void k_lm_resident(ResidentArgs a)
                             ++age;
                             next_pre |= kResPreCommitJ;
                             cur ^= 1;
+                            null_lambda_for = 0; lad_valid = false;
                             ++n_br;
                             newJac = true;
                             trace(1, iterations, lambda, residual, 0, dx_dot);
@@ -489,27 +540,86 @@ __global__ __launch_bounds__(kResThreads) void k_lm_resident(ResidentArgs a)
                     fCalls += N;                                               // LS:1049 (quirk Q5)
                     ++n_fd;
                     cur ^= 1;
+                    null_lambda_for = 0; lad_valid = false;
                     newJac = true;
                     trace(0, iterations, lambda, residual, 0, dx_dot);
                     where = kSolve;
                 }
                 if (where == kSolve) {
+                    // A pass after a rejection solves (J^T J + lambda I) dx = -J^T y again with a larger lambda. The solution of
+                    // the (bound-constrained) QP satisfies |dx| <= 2 |J^T y| / lambda (its objective is <= 0, J^T J is positive
+                    // semidefinite), so once 8 |J^T y|_2 / lambda < 2^-54 min |x_i| every component of the ROUNDED step
+                    // (dx + x) - x, LS:1096-1097, is exactly zero: the pass is a null step whatever the solve returns -- trial == x,
+                    // f(trial) is the residual we hold (pure callbacks, LS:73-80), improvement 0, rejected (LS:1125). Such passes
+                    // -- most of the ~45 that end a noisy fit, quirk Q3 -- are booked without solving.
+                    if (!newJac && null_lambda_for != 2) {
+                        if (tid < kWave) {
+                            double j2 = 0, xm = Lim<double>::inf(), dg = 0;
+                            for (int j = lane; j < N; j += kWave) {
+                                const double v = Jyp[cur][j];
+                                j2 = fma(v, v, j2);
+                                xm = fmin(xm, fabs(xsp[j]));
+                                dg += fabs(JJp[cur][(size_t)j * JLD + j]);
+                            }
+                            j2 = wave_sum(j2);
+                            dg = wave_sum(dg);
+                            xm = -wave_max(-xm);
+                            if (lane == 0) { s_w[0] = j2; s_w[1] = xm; s_w[2] = dg; }
+                        }
+                        __syncthreads();
+                        const double j2 = s_w[0], xm = s_w[1], dg = s_w[2];
+                        __syncthreads();
+                        // (and lambda > 1e-6 trace(J^T J): P is then positive definite whatever rounding did to J^T J)
+                        null_lambda = (j2 <= Lim<double>::max && dg <= Lim<double>::max && xm > 0)
+                            ? fmax(8.0 * sqrt(j2) / (0x1p-54 * xm), 1e-6 * dg) : Lim<double>::inf();
+                        null_lambda_for = 2;
+                    }
+                    if (!newJac && lambda > null_lambda && lambda >= a.set.minLambda && !(a.variant & kResVariantNoNullSkip)) {
+                        ++fCalls;                                              // LS:1112
+                        ++n_elided;
+                        ++n_rej;
+                        trace(2, iterations, lambda, residual, residual, 0.0);
+                        lambda *= a.set.lambdaIncrease * mu;
+                        mu *= 2;
+                        where = kCond;
+                        continue;
+                    }
                     // LS:1052-1110, 1141-1142 on this workgroup: gradient test, lambda_0, solveBoxQP, rounding, trial, prediction
                     long long ts0 = 0;
                     if (clk) ts0 = wall_clock64();
                     const bool from_state = !(lambda >= a.set.minLambda);
-                    if (tid == 0) a.st->lambda = lambda;
-                    __syncthreads();
-                    LmSolveArgs<double> sa{};
-                    sa.JJ = a.JJ[cur]; sa.Jy = a.Jy[cur]; sa.x = a.xs; sa.lower = a.lower; sa.upper = a.upper;
-                    sa.dx = a.dx; sa.trial = a.trial; sa.st = a.st; sa.rec = a.rec; sa.set = a.set; sa.n = N;
-                    sa.sc[0] = a.sc; sa.lam[0] = lambda; sa.f_in_lds = 1;
-                    sa.check_grad = newJac ? 1 : 0;
-                    sa.lambda_from_state = from_state ? 1 : 0;
-                    sa.lambda_from_device = 0; sa.guard = nullptr;
-                    lm_solve_body<double, NB, BOUNDED>(sa, 0, solve_smem);
-                    __syncthreads();
-                    const ChainRec<double> rec = *a.rec;
+                    ChainRec<double> rec{};
+                    if constexpr (WAVE) {
+                        // a pass after a rejection finds its step in the ladder the last solve made (same J^T J, J^T y, x; its
+                        // damping bit for bit the ladder's next value): the steps are those of the one-by-one loop
+                        const bool reuse = !newJac && lad_valid && lad_level + 1 < 4 && lrec[8 * (lad_level + 1)] == lambda
+                            && lreci[4 * (lad_level + 1) + 3] != 0 && !from_state;
+                        if (reuse) ++lad_level;
+                        else {
+                            if (wave == 0)
+                                wave16_lm_solve_lds<N, BOUNDED>(JJp[cur], Jyp[cur], xsp, lop, upp, lambda, mu, newJac ? 1 : 0, from_state ? 1 : 0,
+                                                                &a.set, dxp, trp, lrec, lreci);
+                            __syncthreads();
+                            lad_level = 0;
+                            lad_valid = true;
+                        }
+                        rec.lambda = lrec[8 * lad_level]; rec.new_dx_dot = lrec[8 * lad_level + 1]; rec.predicted = lrec[8 * lad_level + 2];
+                        rec.trial_xnorm = lrec[8 * lad_level + 3];
+                        rec.qp_status = lreci[4 * lad_level]; rec.qp_iterations = lreci[4 * lad_level + 1]; rec.flags = lreci[4 * lad_level + 2];
+                    } else {
+                        if (tid == 0) a.st->lambda = lambda;
+                        __syncthreads();
+                        LmSolveArgs<double> sa{};
+                        sa.JJ = a.JJ[cur]; sa.Jy = a.Jy[cur]; sa.x = a.xs; sa.lower = a.lower; sa.upper = a.upper;
+                        sa.dx = a.dx; sa.trial = a.trial; sa.st = a.st; sa.rec = a.rec; sa.set = a.set; sa.n = N;
+                        sa.sc[0] = a.sc; sa.lam[0] = lambda; sa.f_in_lds = 1;
+                        sa.check_grad = newJac ? 1 : 0;
+                        sa.lambda_from_state = from_state ? 1 : 0;
+                        sa.lambda_from_device = 0; sa.guard = nullptr;
+                        lm_solve_body<double, NB, BOUNDED>(sa, 0, solve_smem);
+                        __syncthreads();
+                        rec = *a.rec;
+                    }
                     if (clk) t_solve_body += wall_clock64() - ts0;
                     if (rec.flags & kFlagGradSmall) {                          // LS:1053-1062
                         if (age == 0) { status = mir_ls_gConverged; where = kDone; break; }
@@ -563,7 +673,8 @@ __global__ __launch_bounds__(kResThreads) void k_lm_resident(ResidentArgs a)
                     mu = 1;
                     ++iterations;
                     ++n_acc;
-                    if (tid < N) a.xs[tid] = a.trial[tid];
+                    null_lambda_for = 0; lad_valid = false;
+                    if (tid < N) xsp[tid] = trp[(WAVE ? 16 * lad_level : 0) + tid];
                     __syncthreads();
                     next_pre |= kResPreAccept;
                     residual = trialResidual;
@@ -587,7 +698,7 @@ __global__ __launch_bounds__(kResThreads) void k_lm_resident(ResidentArgs a)
 
             // ---- publish the command
             if (next_action == kResExit) {
-                if (tid < N) a.x[tid] = a.xs[tid];
+                if (tid < N) a.x[tid] = xsp[tid];
                 if (tid == 0) {
                     mir_least_squares_result_d r;
                     r.status = (mir_least_squares_status)status; r.iterations = iterations; r.fCalls = fCalls; r.gCalls = 0;
@@ -599,10 +710,10 @@ __global__ __launch_bounds__(kResThreads) void k_lm_resident(ResidentArgs a)
                     if (a.trace_count) *a.trace_count = tr_count;
                 }
             } else {
-                const double* pt = next_action == kResFd ? a.xs : a.trial;
+                const double* pt = next_action == kResFd ? xsp : trp + (WAVE ? 16 * lad_level : 0);
                 if (tid < kResNMax) {
                     res_st(a.cmd + tid, (unsigned long long)__double_as_longlong(tid < N ? pt[tid] : 0.0));
-                    res_st(a.cmd + kResNMax + tid, (unsigned long long)__double_as_longlong(tid < N ? a.dx[tid] : 0.0));
+                    res_st(a.cmd + kResNMax + tid, (unsigned long long)__double_as_longlong(tid < N ? dxp[(WAVE ? 16 * lad_level : 0) + tid] : 0.0));
                 }
                 if (tid == 0) res_st(a.cmd + 2 * kResNMax, (unsigned long long)__double_as_longlong(1.0 / s_ndd));   // LS:1002
             }
@@ -650,6 +761,7 @@ __global__ __launch_bounds__(kResThreads) void k_lm_resident(ResidentArgs a)
         s.rounds = n_rounds; s.passes = n_passes; s.accepted = n_acc; s.rejected = n_rej; s.step_guard_rejects = n_guard;
         s.jacobian_full = n_fd; s.jacobian_broyden = n_br; s.qp_active_set_passes = n_qp; s.elided_evaluations = n_elided;
         s.t_total = (uint64_t)(wall_clock64() - tk0); s.t_stage = (uint64_t)t_stage; s.t_worker = (uint64_t)t_worker;
+        s.t_w_eval = (uint64_t)t_w_eval; s.t_w_fd = (uint64_t)t_w_fd; s.t_w_prod = (uint64_t)t_w_prod;
         s.t_group = (uint64_t)t_group; s.t_total_wait = (uint64_t)t_total_wait; s.t_solver = (uint64_t)t_solver;
         s.t_solve_body = (uint64_t)t_solve_body; s.t_cmd_wait = (uint64_t)t_cmd_wait;
         s.abort_code = 0; s.grid = (uint32_t)G; s.rows = (uint32_t)a.rows; s.groups = (uint32_t)NG;
