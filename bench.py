@@ -304,6 +304,61 @@ def main_cfg2(args):
                      "note": "launch-latency bound: J^T J at n = 16 is 2 flop/B (SURVEY 8d) and J is 12.8 MB -- every kernel of a "
                              "round runs for microseconds; the figure of merit is us_per_round"},
     }
+    # ---- the resident-J path (include/mir_optim_amd_resident.hpp): the whole loop in ONE cooperative launch, J in the CUs' LDS.
+    # It is the product path for a problem of this size; the launch chain timed above stays on the line as `launch_chain`.
+    chain = {k: out[k] for k in ("value", "ms_per_step")}
+    chain.update({k: out["config"][k] for k in ("iterations_per_solve", "passes_per_solve", "rounds_per_solve", "us_per_round", "status",
+                                                 "residual", "time_split_ms_per_solve")})
+    chain["us_per_pass"] = dt / K / max(1.0, d["passes"] / K) * 1e6
+    chain["solve_kernel"] = out.pop("roofline")
+    rp = W.Resident.gauss_sum(g["t"], g["data"], K=5)
+    if rp.plan_rc == 0:
+        for _ in range(max(1, args.warmup)):
+            rres, rx, rst = rp.solve(g["x0"], g["lower"], g["upper"])
+        torch.cuda.synchronize()
+        riters, steps_ms = 0, []
+        t0 = time.perf_counter()
+        for _ in range(K):
+            ts = time.perf_counter()
+            rp.upload_point(g["x0"], g["lower"], g["upper"])       # x, lower, upper: 384 bytes, as the launch chain uploads them per solve
+            rp.launch()
+            rp.stream.synchronize()
+            steps_ms.append((time.perf_counter() - ts) * 1e3)
+        rdt = time.perf_counter() - t0
+        rres, rx, rst = rp.solve(g["x0"], g["lower"], g["upper"])  # the same solve once more for its result and in-kernel stamps
+        riters = rres.iterations * K
+        tick = 1e-2                                               # stats are in 10 ns ticks -> us
+        rounds_r, passes_r = rst["rounds"], rst["passes"]
+        out.update({"value": riters / rdt, "ms_per_step": rdt / K * 1e3})
+        out["config"].update({
+            "workload": f"cfg2 Gaussian-sum fit m={m} x n={n} fp64, width bounds, FD Jacobian; resident-J path: the whole LM loop in one "
+                        "cooperative launch, J / y / row data in the CUs' LDS, compile-time residual model, default settings, whole solves",
+            "path": "resident", "iterations_per_solve": rres.iterations, "passes_per_solve": passes_r, "rounds_per_solve": rounds_r,
+            "fcalls_per_solve": rres.fCalls, "status": rres.status.name, "residual": rres.residual,
+            "qp_active_set_passes_per_solve": rst["qp_active_set_passes"],
+            "us_per_round": rdt / K / max(1, rounds_r) * 1e6, "us_per_pass": rdt / K / max(1, passes_r) * 1e6,
+            "step_ms_min_median_max": [float(np.min(steps_ms)), float(np.median(steps_ms)), float(np.max(steps_ms))],
+            "grid": rst["grid"], "rows_per_workgroup": rst["rows"], "lds_bytes_per_workgroup": rp.lds_bytes,
+            "kernel_us_per_solve": rst["t_total"] * tick,
+            "time_split_us_per_solve": {"workers_trial_residuals": rst["t_w_eval"] * tick, "workers_fd_refreshes": rst["t_w_fd"] * tick,
+                                        "workers_products_and_publication": rst["t_w_prod"] * tick,
+                                        "group_leaders": rst["t_group"] * tick, "wait_for_totals": rst["t_total_wait"] * tick,
+                                        "solver_workgroup": rst["t_solver"] * tick, "of_which_n_x_n_solves": rst["t_solve_body"] * tick,
+                                        "wait_for_command": rst["t_cmd_wait"] * tick, "staging": rst["t_stage"] * tick,
+                                        "note": "stamps of workgroup 0 (s_memrealtime) inside the one launch"},
+            "jacobian_full": rst["jacobian_full"], "jacobian_broyden": rst["jacobian_broyden"], "rejected": rst["rejected"],
+            "elided_null_steps": rst["elided_evaluations"]})
+        out["config"].pop("time_split_ms_per_solve", None)
+        out["launch_chain"] = chain
+        out["roofline"] = {"kernel": "mirlsq::k_lm_resident<ResGaussSum<5>, true> (the one launch of a solve)", "bound": "latency", "achieved": None,
+                           "peak": None, "unit": "us", "frac": None, "avg_launch_ms": rst["t_total"] * tick / 1e3, "launches": 1, "traffic": None,
+                           "note": "J never leaves LDS: 16 MB of operands against 40 MB of LDS on the chip; a pass is three in-launch hand-offs "
+                                   "(members -> 16 leaders -> workgroup 0 -> everybody) and a one-wave n = 16 solve -- latency, not HBM or MFMA. "
+                                   "Figures of merit: us_per_pass, us_per_round"}
+        res, x = rres, rx
+    else:
+        out["roofline"] = chain["solve_kernel"]
+        out["config"]["path"] = f"launch chain (resident plan returned {rp.plan_rc})"
     if not args.no_cpu_baseline:
         from oracle import oracle as O
         ctx = O.GaussSumCtx(g["t"].ctypes.data, g["data"].ctypes.data)
