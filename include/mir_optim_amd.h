@@ -463,7 +463,7 @@ mir_lsq_comm* mir_lsq_comm_create_callback(int nranks, int rank, mir_lsq_allredu
  * A rank that waits longer than 120 s at the barrier gives up (the solve then returns numericError). Returns 0. */
 int mir_lsq_comm_create_local_group(int nranks, mir_lsq_comm** out_comms);
 void mir_lsq_comm_destroy(mir_lsq_comm* comm);
-/* Record / replay of a rank's exchanges (a measurement tool: bench.py --replay-rank). A rank of an
+/* Record / replay of a rank's exchanges (a measurement tool: bench.py --replay-ranks). A rank of an
  * in-process group can RECORD the totals of all its all-reduces (as doubles, concatenated in call order) into a caller-owned
  * host buffer: mir_lsq_comm_record(comm, buf, capacity_in_doubles) before the solve, mir_lsq_comm_recorded(comm) after it
  * (the doubles written; (size_t)-1 after an overflow). A REPLAY communicator then lets ONE rank run alone on exactly the global
@@ -504,6 +504,10 @@ int mir_lsq_selftest_reductions(int rounds, int mismatches[4]);
 void* mir_lsq_stream_create(void);
 void mir_lsq_stream_destroy(void* stream);
 int mir_lsq_stream_synchronize(void* stream);
+/* "mir_optim_amd <major.minor> (gfx950)". 0.2: the last argument of mir_lsq_batched_kernel_s became the options struct (it was a
+ * hipStream_t in 0.1 -- same arity, so an old caller still links: both batched entries answer -1 to an options pointer whose
+ * first word is not a plausible struct_size) and mir_optimize_least_squares_batched_s gained it; 0.3: the resident-J options /
+ * statistics of part 2 and mir_optim_amd_resident.hpp. Callers that cache function pointers across versions check this. */
 const char* mir_lsq_version(void);
 
 /* =====================================================================================================

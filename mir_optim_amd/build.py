@@ -4,8 +4,9 @@
   lib/libmir_optim_amd_workloads.so  device residual callbacks of the synthetic workloads
 
 The solver is a dozen translation units (csrc/driver.h lists them): each is compiled to an object of its own under
-build/obj/ -- in parallel, and only when it or a header is newer -- and the objects are linked. A kernel edit costs the
-one translation unit that instantiates it (launch_*.hip), not the library.
+build/obj/ -- in parallel, and only when it or one of the headers IT includes (the compiler's own dependency file, -MMD)
+is newer -- and the objects are linked. A kernel edit costs the translation units that include that kernel's header
+(usually one launch_*.hip), not the library.
 """
 import os
 import shutil
@@ -37,7 +38,17 @@ def _stale(target, sources):
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    return any(os.path.getmtime(s) > t for s in sources)
+    return any((not os.path.exists(s)) or os.path.getmtime(s) > t for s in sources)
+
+
+def _deps(obj):
+    """The files an object was compiled from, as the compiler recorded them (`-MMD -MF obj.d`): the translation unit and
+    exactly the headers it includes -- an edit of a kernel header recompiles the units that include it and no others."""
+    d = obj[:-2] + ".d"
+    if not os.path.exists(d):
+        return None
+    toks = open(d).read().replace("\\\n", " ").split()
+    return [t for t in toks[1:] if not t.endswith(":") and not t.startswith("/opt/") and not t.startswith("/usr/")]
 
 
 def _run(cmd, verbose):
@@ -46,47 +57,38 @@ def _run(cmd, verbose):
     subprocess.check_call(cmd)
 
 
+def _compile_units(units, extra, force, verbose, jobs):
+    objs, todo = [], []
+    for u in units:
+        src = os.path.join(CSRC, u)
+        obj = os.path.join(OBJDIR, os.path.splitext(u)[0] + ".o")
+        objs.append(obj)
+        deps = _deps(obj)
+        if force or deps is None or _stale(obj, [src] + deps):
+            todo.append([_hipcc()] + _FLAGS + extra + ["-MMD", "-MF", obj[:-2] + ".d", "-c", src, "-o", obj])
+    if todo:
+        with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
+            list(ex.map(lambda c: _run(c, verbose), todo))
+    return objs, bool(todo)
+
+
 def build(force=False, verbose=False, jobs=None):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc")) and not f.startswith("workloads_")]
-    inc = os.path.join(os.path.dirname(HERE), "include")
-    hdrs += [os.path.join(inc, f) for f in os.listdir(inc)]
     # the flags are part of what an object depends on (a profiling build must not reuse the product objects)
     stamp = os.path.join(OBJDIR, "flags.txt")
     if not os.path.exists(stamp) or open(stamp).read() != " ".join(_FLAGS):
         force = True
-    todo = []
-    objs = []
-    for u in SOLVER_UNITS:
-        src = os.path.join(CSRC, u)
-        obj = os.path.join(OBJDIR, os.path.splitext(u)[0] + ".o")
-        objs.append(obj)
-        if force or _stale(obj, [src] + hdrs):
-            todo.append([_hipcc()] + _FLAGS + ["-c", src, "-o", obj])
-    if todo:
-        with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
-            list(ex.map(lambda c: _run(c, verbose), todo))
-        open(stamp, "w").write(" ".join(_FLAGS))
-    if force or todo or _stale(SOLVER_LIB, objs):
-        _run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SOLVER_LIB] + objs + ["-ldl"], verbose)
-    # the caller side: residual kernels of the synthetic workloads (two units: the C entries + small kernels, the batched GEMM)
-    wobjs, wtodo = [], []
-    whdrs = [os.path.join(CSRC, f) for f in ("workloads_device.h", "workloads_gemm.h")]
-    # the resident models are compiled against the device header of the resident-J solver, like a caller's own model would be
-    rhdrs = whdrs + [os.path.join(inc, "mir_optim_amd_resident.hpp"), os.path.join(inc, "mir_optim_amd.h")] + [
-        os.path.join(CSRC, f) for f in ("resident_kernel.h", "solve_kernel.h", "solve_lds.h", "solve_types.h", "common.h")]
-    for u in WORKLOAD_UNITS:
-        src = os.path.join(CSRC, u)
-        obj = os.path.join(OBJDIR, os.path.splitext(u)[0] + ".o")
-        wobjs.append(obj)
-        if force or _stale(obj, [src] + (rhdrs if u == "workloads_resident.hip" else whdrs)):
-            wtodo.append([_hipcc()] + _FLAGS + ["-fopenmp", "-c", src, "-o", obj])   # OpenMP: host-side data generation / host residual
-    if wtodo:
-        with ThreadPoolExecutor(max_workers=3) as ex:
-            list(ex.map(lambda c: _run(c, verbose), wtodo))
-    if force or wtodo or _stale(WORKLOADS_LIB, wobjs):
-        _run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fopenmp", "-o", WORKLOADS_LIB] + wobjs, verbose)
+    objs, rebuilt = _compile_units(SOLVER_UNITS, [], force, verbose, jobs)
+    open(stamp, "w").write(" ".join(_FLAGS))
+    # the link takes the same flags as the compilations (-g, sanitizer or profiling flags from MIR_OPTIM_AMD_CXXFLAGS reach the .so)
+    if force or rebuilt or _stale(SOLVER_LIB, objs):
+        _run([_hipcc()] + _FLAGS + ["-shared", "-o", SOLVER_LIB] + objs + ["-ldl"], verbose)
+    # the caller side: residual kernels of the synthetic workloads (the C entries + small kernels, the batched GEMM, and the
+    # resident models, which are compiled against the device header of the resident-J solver like a caller's own model would be)
+    wobjs, wrebuilt = _compile_units(WORKLOAD_UNITS, ["-fopenmp"], force, verbose, 3)     # OpenMP: host-side data generation / host residual
+    if force or wrebuilt or _stale(WORKLOADS_LIB, wobjs):
+        _run([_hipcc()] + _FLAGS + ["-shared", "-fopenmp", "-o", WORKLOADS_LIB] + wobjs, verbose)
     return SOLVER_LIB, WORKLOADS_LIB
 
 

@@ -164,6 +164,6 @@ void* mir_lsq_stream_create(void)
 }
 void mir_lsq_stream_destroy(void* stream) { if (stream) (void)hipStreamDestroy(static_cast<hipStream_t>(stream)); }
 int mir_lsq_stream_synchronize(void* stream) { return hipStreamSynchronize(static_cast<hipStream_t>(stream)) == hipSuccess ? 0 : -1; }
-const char* mir_lsq_version(void) { return "mir_optim_amd 0.1 (gfx950)"; }
+const char* mir_lsq_version(void) { return "mir_optim_amd 0.3 (gfx950)"; }
 
 }  // extern "C"

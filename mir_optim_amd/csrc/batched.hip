@@ -50,6 +50,12 @@ mir_lsq_batched_options batched_options(const mir_lsq_batched_options* opt)
     o.struct_size = sizeof o;
     return o;
 }
+// A caller of the 0.1 interface passed a hipStream_t where the options pointer is now (same arity: it links). Its first word is
+// not a struct size: anything below the two leading members or absurdly large is refused instead of being copied from.
+bool batched_options_plausible(const mir_lsq_batched_options* opt)
+{
+    return !opt || (opt->struct_size >= 8 && opt->struct_size <= 1024);
+}
 
 }  // namespace
 
@@ -59,7 +65,7 @@ int mir_lsq_batched_kernel_s(const mir_least_squares_settings_s* S, size_t count
                              const float* lower, const float* upper, const float* t, size_t t_stride, const float* data,
                              mir_least_squares_result_s* results, const mir_lsq_batched_options* options)
 {
-    if (batched_model_n(model) == 0) return -1;
+    if (batched_model_n(model) == 0 || !batched_options_plausible(options)) return -1;
     if (count != 0 && !device_available()) return -2;
     const mir_lsq_batched_options o = batched_options(options);
     return batched_launch(model, S, count, m, x, lower, upper, t, t_stride, data, results, &o);
@@ -81,7 +87,7 @@ int mir_optimize_least_squares_batched_s(const mir_least_squares_settings_s* S, 
                                          const float* t, size_t t_stride, const float* data,
                                          mir_least_squares_result_s* results, const mir_lsq_batched_options* options)
 {
-    if (!S || !x || !lower || !upper || !t || !data || !results) return -1;
+    if (!S || !x || !lower || !upper || !t || !data || !results || !batched_options_plausible(options)) return -1;
     const int n = batched_model_n(model);
     if (n == 0 || (t_stride != 0 && t_stride != m)) return -1;
     for (size_t i = 0; i < count; ++i) {       // defaults of LeastSquaresResult!T, LS:132-142

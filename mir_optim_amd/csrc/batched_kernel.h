@@ -52,7 +52,13 @@ struct ModelExp3Affine {        // sum_{k<3} p_{2k} exp(-t p_{2k+1}) + p6 + p7 t
 __host__ __device__ inline float det_expf(float y)
 {
 #pragma clang fp contract(off)
-    y = fminf(fmaxf(y, -87.0f), 88.0f);
+    // the ends behave as expf's do (round-4 advice: a clamp made exp(NaN) finite, so the reference's numericError exit on a
+    // non-finite trial residual, LS:1117-1122, could not fire through this term): NaN stays NaN, overflow is +inf above
+    // ln(FLT_MAX), and below -87 -- where the result would leave the normal range, which device and host ldexpf need not treat
+    // alike -- the value is 0 (the true one is < 1.7e-38)
+    if (!(y == y)) return y;
+    if (y > 88.7228394f) return __builtin_huge_valf();
+    if (y < -87.0f) return 0.0f;
     const float k = rintf(y * 1.44269504f);
     float r = __builtin_fmaf(k, -0.693145752f, y);
     r = __builtin_fmaf(k, -1.42860677e-06f, r);

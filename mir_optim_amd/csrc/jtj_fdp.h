@@ -1,12 +1,12 @@
 // jtj_fdp.h -- finite-difference rows -> J, J^T J, J^T y with register-staged producer waves (gfx950, f64).
 //
-// Same job as k_jtj2<NCB, false, true> (jtj_kernel.h): the m x 2n row-major panel of perturbed residuals
-// Y[i][2j] = f(x + h e_j)_i, Y[i][2j+1] = f(x - h e_j)_i becomes the Jacobian (LS:1041-1047), which is written to J and
-// contracted to J^T J (LS:1065) and J^T y (LS:1052) in the same pass. The LDS-DMA ring of k_jtj2 keeps the bytes in
-// flight in LDS (64 KB per CU) and its read side tops out near 2.9 TB/s; here the bytes in flight live in REGISTERS:
+// The m x 2n row-major panel of perturbed residuals Y[i][2j] = f(x + h e_j)_i, Y[i][2j+1] = f(x - h e_j)_i becomes the
+// Jacobian (LS:1041-1047), which is written to J and contracted to J^T J (LS:1065) and J^T y (LS:1052) in the same pass.
+// (Round 1's kernel for this job kept the bytes in flight in an LDS-DMA ring, 64 KB per CU, whose read side topped out near
+// 2.9 TB/s: DESIGN_HISTORY.md.) Here the bytes in flight live in REGISTERS:
 //
-//   * a workgroup has 8 waves: 4 PRODUCERS and 4 CONSUMERS (the MFMA roles of k_jtj2, 9 accumulator blocks each at
-//     n = 128);
+//   * a workgroup has 8 waves: 4 PRODUCERS and 4 CONSUMERS (the MFMA "roles" of jtj_kernel.h: the lower block triangle dealt
+//     to four waves, 9 accumulator blocks each at n = 128);
 //   * a stage is 32 rows; producer w owns rows 8w .. 8w+7 of every stage, i.e. 16n contiguous doubles of the panel,
 //     which it reads with 2 NCB coalesced 16-byte loads per lane (the flat pair index 64 i + lane: row = f / n,
 //     column = f % n): 64 VGPRs = 16 KB per wave, 64 KB per workgroup, 128 KB per CU in flight at n = 128 -- twice the
@@ -24,7 +24,7 @@
 // nothing written back), and the m x n DIFFERENCE panel the caller's kernel has already subtracted (FD = false, DIFF = true:
 // mir_lsq_gpu_options.fbRowMajorDiff -- the plain producer applies scal(1 / twh), the consumers write J): half the panel bytes.
 //
-// Slabs are laid out exactly like k_jtj2's, so k_jtj_slab_reduce finishes the job. Rows past m are clamped on the
+// Slabs are laid out exactly like k_jtj's (jtj_kernel.h), so k_jtj_slab_reduce finishes the job. Rows past m are clamped on the
 // load side and written as zeros to LDS.
 #pragma once
 

@@ -1,5 +1,5 @@
-// jtj_ring8.h -- fused [Broyden] + J^T J + J^T y for 128 < n <= 256 (fp64, n % 16 == 0, m even): the LDS-DMA ring
-// of k_jtj2 / k_jtj3 (jtj_kernel.h) with EIGHT waves per workgroup.
+// jtj_ring8.h -- fused [Broyden] + J^T J + J^T y for 128 < n <= 256 (fp64, n % 16 == 0, m even): an LDS-DMA ring
+// (`global_load_lds_dwordx4` stages, counted vmcnt, one raw s_barrier per stage) with EIGHT waves per workgroup.
 //
 // Replaces LS:1003-1006 (Broyden), LS:1052 (gemv^T), LS:1065 (syrk) like the narrower kernels. At n = 256 the lower
 // triangle of J^T J is 136 MFMA blocks of 16 x 16 = 1088 accumulator VGPRs: eight waves ("roles") own 17 blocks each
@@ -11,8 +11,8 @@
 //   role 4       also accumulates J^T y;
 //   all roles    run their MFMA chains on stage s, which was updated one iteration earlier.
 // One raw s_barrier per stage of 16 rows; the DMA of stage s + 3 is issued right after barrier s into the slot
-// stage s - 1 has just left (4 slots of up to 32 KB). The row-update arithmetic and the order of every sum are
-// those of k_jtj2, so at n <= 128 the scheme is bit-identical to it (k_jtj3 is exactly that check).
+// stage s - 1 has just left (4 slots of up to 32 KB). (The four-wave ring kernels this scheme was first built and checked
+// against at n <= 128 were retired in round 4: DESIGN_HISTORY.md.)
 #pragma once
 
 #include <type_traits>

@@ -98,7 +98,10 @@ bool Solver<T>::setup()
     const bool small_problem = (double)m * (double)n * sizeof(T) <= 32.0 * 1024 * 1024;
     pipeline = device_cb && lowrank && !big_solve && !trace && !dbg_solve
         && small_problem && !(variant & MIR_LSQ_VARIANT_NO_PIPELINE)
-        && (!comm || comm->kind == 1 || comm->kind == 4);      // host-mediated communicators synchronise the stream inside every exchange
+        && (!comm || comm->kind == 1);      // host-mediated communicators synchronise the stream inside every exchange; a REPLAY
+                                            // communicator (kind 4) cannot serve a round enqueued ahead of time at all: its tape
+                                            // holds the exchanges the recorded solve COMMITTED (an in-process group never
+                                            // pipelines), so the speculative exchange of the final round would read past its end
     twh_h.resize(n);
     // x, lower, upper sit back to back in the workspace: one copy from the pinned block instead of three from pageable
     // memory (each of those is a staged blit kernel, ~18 us apart on the stream)
@@ -351,9 +354,6 @@ template <typename T>
 void Solver<T>::drop_spec_round()
 {
     for (size_t i = spec_events_from; i < events.size(); ++i) if (events[i].kind >= 100) events[i].kind = -1;
-    // a replay communicator has already handed out the recorded total of the dropped round's one exchange (the sweep vector;
-    // the guarded kernels behind it did not run): put it back on the tape
-    if (comm && comm->kind == 4) comm->replay_pos -= (size_t)lr_len((int)n);
 }
 
 template <typename T>

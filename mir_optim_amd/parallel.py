@@ -143,9 +143,12 @@ def record_rank_tape(make_problem, world, x0, rank=0, capacity=1 << 22, **solve_
     for t in ts:
         t.join(1200)
     wall = time.perf_counter() - t0
+    if any(t.is_alive() for t in ts):
+        # a solver thread is still inside an all-reduce on these handles: LEAK the group rather than free it under a live thread
+        raise RuntimeError("grouped solve did not finish within the join timeout (the communicators are left allocated)")
     n = L.mir_lsq_comm_recorded(comms[rank])
     close()
-    if any(t.is_alive() for t in ts) or any(err):
+    if any(err):
         raise RuntimeError(f"grouped solve failed: {err}")
     if n == C.c_size_t(-1).value:
         raise RuntimeError("tape overflow: raise `capacity`")

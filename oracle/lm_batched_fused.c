@@ -23,7 +23,9 @@
 
 static float det_expf(float y)                       /* batched_kernel.h: det_expf */
 {
-    y = fminf(fmaxf(y, -87.0f), 88.0f);
+    if (!(y == y)) return y;                         /* NaN stays NaN, +inf above ln(FLT_MAX), 0 below -87: as the kernel */
+    if (y > 88.7228394f) return HUGE_VALF;
+    if (y < -87.0f) return 0.0f;
     const float k = rintf(y * 1.44269504f);
     float r = fmaf(k, -0.693145752f, y);
     r = fmaf(k, -1.42860677e-06f, r);

@@ -32,7 +32,7 @@ def launch(mode, m_total, n, tmp_path, world=2):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
-                   LOCAL_RANK=str(r), OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   LOCAL_RANK=str(r), OMP_NUM_THREADS="2")
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), mode, str(m_total), str(n), out],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=600)[0].decode() for p in procs]
@@ -115,7 +115,7 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     prints one JSON line, last; both shards contribute; the control flow of the N > 1 path (barriers, max over ranks,
     teardown) completes."""
     root = os.path.dirname(HERE)
-    env = dict(os.environ, BENCH_M="200000", BENCH_N="64", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    env = dict(os.environ, BENCH_M="200000", BENCH_N="64", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--comm", "gloo-callback", "--survey-steps", "1"]
@@ -140,7 +140,7 @@ def test_bench_falls_back_when_rccl_is_unusable():
     both), every rank takes the same decision over the control plane and the run continues on the callback communicator --
     one JSON line that says so, instead of a crash or a hang in the driver's multi-GPU run."""
     root = os.path.dirname(HERE)
-    env = dict(os.environ, BENCH_M="100000", BENCH_N="32", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2",
+    env = dict(os.environ, BENCH_M="100000", BENCH_N="32", OMP_NUM_THREADS="2",
                BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
@@ -172,7 +172,7 @@ def test_bench_self_launches_its_ranks_from_a_bare_shell():
     parent starts two rank processes (sharing the one GPU here: BENCH_SHARE_GPU=1, callback communicator over gloo) and
     relays rank 0's line as its own LAST stdout line."""
     root = os.path.dirname(HERE)
-    env = dict(os.environ, BENCH_M="200000", BENCH_N="64", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", BENCH_SHARE_GPU="1")
+    env = dict(os.environ, BENCH_M="200000", BENCH_N="64", OMP_NUM_THREADS="2", BENCH_SHARE_GPU="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--comm", "gloo-callback"]
@@ -195,7 +195,7 @@ def test_bench_self_launch_with_rccl_on_one_gpu_takes_the_labelled_fallback():
     """`python3 bench.py --gpus 2` (default --comm rccl) on a box with ONE GPU and nothing in the environment: the ranks share
     the device, RCCL refuses the communicator, every rank switches to the callback communicator -- a labelled line, rc 0."""
     root = os.path.dirname(HERE)
-    env = dict(os.environ, BENCH_M="100000", BENCH_N="32", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    env = dict(os.environ, BENCH_M="100000", BENCH_N="32", OMP_NUM_THREADS="2")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_SHARE_GPU"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--survey-steps", "0"]
@@ -205,3 +205,31 @@ def test_bench_self_launch_with_rccl_on_one_gpu_takes_the_labelled_fallback():
     assert d["n_gpus"] == 2 and d["config"]["rccl_fallback_reason"] and "callback" in d["config"]["parallelism"]
     assert d["config"]["ranks_share_gpus"] is True and d["config"]["visible_gpus"] == 1
     assert d["config"]["status"] in ("xConverged", "furtherImprovement", "fConverged", "gConverged") and d["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra,m_env,check", [
+    ([], "80000", lambda d: d["scaling"] == "strong" and d["config"]["m_total"] == 80000),
+    (["--scaling", "weak", "--n", "256"], "12000", lambda d: d["scaling"] == "weak" and d["config"]["m_per_gpu"] == 12000
+     and d["config"]["m_total"] == 6 * 12000 and d["config"]["allreduce_per_solve"]["packed_elems"] == 256 * 257 // 2 + 256),
+])
+def test_bench_six_rank_rehearsal_on_one_gpu(extra, m_env, check):
+    """First-contact rehearsal for the driver's multi-GPU run: `python bench.py --gpus 6` from a bare shell with SIX rank
+    processes sharing the one GPU (the box admits at most six processes on its card: the driver's N = 8 is two more of the
+    same). Port, rendezvous, deadline, barriers, max over ranks and the JSON relay with more than two ranks -- strong scaling
+    (the headline's command line) and `--scaling weak --n 256` (cfg 4's), so that neither flag pair meets the launcher for the
+    first time on the 8-GPU node."""
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, BENCH_M=m_env, OMP_NUM_THREADS="2", BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_N"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "6", "--steps", "2", "--warmup", "1", "--comm", "gloo-callback",
+           "--survey-steps", "0"] + extra
+    p = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{"metric"')
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 6 and d["steps"] == 2 and d["config"]["ranks_share_gpus"] is True and check(d), d
+    assert d["config"]["status"] in ("xConverged", "furtherImprovement", "fConverged", "gConverged") and d["value"] > 0
+    assert d["value"] == pytest.approx(d["config"]["iterations_per_solve"] / (d["ms_per_step"] * 1e-3), rel=1e-9)

@@ -198,3 +198,39 @@ def test_cfg4_full_size_eight_logical_shards_on_one_gpu():
     assert np.isclose(r0.residual, ru.residual, rtol=1e-11)
     assert np.abs(xu - xstar).max() < 1e-2                       # and it is the minimiser of the generating model
     dA.free(); db.free()
+
+
+def test_record_and_replay_of_a_small_sharded_solve(oracle):
+    """mir_lsq_comm_record / _recorded / _create_replay / _replay_rewind (a measurement tool) on a problem
+    UNDER the 32 MB threshold at which single-GPU solves enqueue rounds ahead of time: a replay communicator must not pipeline
+    (its tape holds committed exchanges only) -- rank 0 alone on the global trajectory returns the bits of
+    the grouped solve, with and without MIR_LSQ_VARIANT_NO_PIPELINE, solve after solve (rewind), and an overflowing tape says so."""
+    m_total, n, world = 40000, 32, 4
+    w = P.tanh_linear(m_total, n)
+
+    def shard(r):
+        o, ml = PAR.row_shard(m_total, world, r)
+        d = P.tanh_linear(ml, n, row_offset=o, m_total=m_total)
+        return W.TanhLinear(d["A"], d["b"])
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
+    tape, rres, rx, _ = PAR.record_rank_tape(shard, world, w["x0"], settings=s, batched=True)
+    assert rres.status >= 0 and tape.size > 0
+    L = M.api.lib()
+    comm = PAR.replay_comm(world, 0, tape)
+    prob = shard(0)
+    outs = []
+    for variant in (0, M.VARIANT_NO_PIPELINE, 0):
+        assert L.mir_lsq_comm_replay_rewind(C.c_void_p(comm)) == 0
+        r1, x1 = prob.solve(w["x0"], settings=s, comm=comm, batched=True, variant=variant)
+        outs.append((x1.tobytes(), int(r1.status), r1.iterations, r1.fCalls, r1.residual, r1.lambda_))
+    assert outs[0] == outs[1] == outs[2]
+    assert outs[0] == (rx.tobytes(), int(rres.status), rres.iterations, rres.fCalls, rres.residual, rres.lambda_)
+    L.mir_lsq_comm_destroy(C.c_void_p(comm))
+    # the global solve is the unsharded oracle's
+    so = oracle.default_settings(); so.absTolerance = 1e-9
+    ctx = oracle.TanhLinearCtx(w["A"].ctypes.data, w["b"].ctypes.data)
+    ro, xo = oracle.optimize(oracle.native_fn("wlc_tanh_linear_f"), m_total, w["x0"], settings=so, fctx=C.addressof(ctx))
+    assert np.allclose(rx, xo, rtol=1e-6, atol=1e-9) and np.isclose(rres.residual, ro.residual, rtol=1e-9)
+    # a tape that is too small reports (size_t)-1
+    with pytest.raises(RuntimeError, match="overflow"):
+        PAR.record_rank_tape(shard, world, w["x0"], capacity=16, settings=s, batched=True)
