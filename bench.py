@@ -148,6 +148,9 @@ def parse():
                     help="bracket the kernels with HIP events in every k-th step of the timed region (an event record costs a "
                          "few microseconds on the stream: ~0.2 ms per cfg-3 solve when every step is instrumented)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cfg5-replicas", type=int, default=16,
+                    help="--config cfg5: also time ONE launch of this many copies of the 4096 problems (the steady-state rate of the kernel, "
+                         "where the tail of long fits is amortised); 1 = skip")
     ap.add_argument("--no-host-callback", action="store_true",
                     help="skip the reference-ABI leg (host residual callback + native thread manager, PCIe inclusive; rank 0, N = 1): "
                          "one untimed + one timed solve, a few seconds of host work")
@@ -226,6 +229,41 @@ def main_cfg5(args):
                    "mean_residual": float(raw["residual"].mean()), "parallelism": "replicas only (independent problems)"},
         "roofline": cfg5_roofline(ms, evals, args.steps, count, m, n),
     }
+    # ---- steady state (round-4 review): the 4096 fits differ 3 x in length and go to 2048 wave slots, so the launch ends with
+    # its stragglers. The same problems 16 times over (65 536 fits in one launch) amortise that tail: the kernel's rate where the
+    # dispatcher always has a next problem for a finished wave.
+    reps = max(1, args.cfg5_replicas)
+    if reps > 1:
+        big = count * reps
+        dd2, dx02 = api.DeviceBuffer(np.tile(data, (reps, 1))), api.DeviceBuffer(np.tile(x0, (reps, 1)))
+        dx2 = api.DeviceBuffer(np.tile(x0, (reps, 1)))
+        dres2 = api.DeviceBuffer(nbytes=big * 24, dtype=np.uint8, shape=(big * 24,))
+
+        def step2():
+            if L.mir_lsq_memcpy_d2d(dx2.ptr, dx02.ptr, big * n * 4, stream.handle) != 0:
+                raise SystemExit("d2d failed")
+            if L.mir_lsq_batched_kernel_s(C.byref(s), big, m, M.MODEL_EXP_DECAY_PAD8, dx2.ptr, dlo.ptr, dup.ptr, dt_.ptr, 0, dd2.ptr,
+                                          dres2.ptr, C.byref(bopt)) != 0:
+                raise SystemExit("batched kernel launch failed")
+        step2()
+        stream.synchronize()
+        k2 = max(3, args.steps // 8)
+        t0 = time.perf_counter()
+        for _ in range(k2):
+            step2()
+        stream.synchronize()
+        ms2 = (time.perf_counter() - t0) / k2 * 1e3
+        raw2 = np.frombuffer(dres2.download().tobytes(), dtype=raw.dtype)
+        same = bool((raw2["iterations"].reshape(reps, count) == raw["iterations"][None, :]).all()
+                    and (raw2["residual"].view(np.uint32).reshape(reps, count) == raw["residual"].view(np.uint32)[None, :]).all())
+        rf = out["roofline"]
+        ss = {"fits_per_launch": big, "ms_per_launch": ms2, "fits_per_s": big / (ms2 * 1e-3), "iterations_per_s": iters * reps / (ms2 * 1e-3),
+              "speedup_over_4096_fit_launches": (big / ms2) / (count / ms), "replicas_bit_identical_with_the_4096_fit_launch": same}
+        if rf.get("valu_instructions_per_launch"):
+            ss["valu_frac"] = rf["valu_instructions_per_launch"] * reps / (ms2 * 1e-3) / 1e9 / rf["peak"]
+            ss["note"] = ("valu_frac = VALU instructions (the committed count of a 4096-fit launch x replicas: the same problems execute the same "
+                          "instructions) / launch time / the issue peak; where the straggler tail is amortised")
+        out["config"]["steady_state"] = ss
     if not args.no_cpu_baseline:
         from oracle import oracle as O
 
