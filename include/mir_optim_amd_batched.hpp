@@ -90,9 +90,15 @@ int launch_batched(const mir_least_squares_settings_s* S, size_t count, size_t m
             table = opt->basis;                                // the caller's table: no allocation in this call
         } else {
             // No table from the caller: hipMalloc, and a stream synchronisation before hipFree below. (Until round 4 this was
-            // hipMallocAsync / hipFreeAsync. On ROCm 7.2 that produced, in 2 of 300 calls with a 2 MB table, wrong fits for a
-            // contiguous range of problems -- the pool's block and another allocation of the process overlapping is what it
-            // looked like -- and never with the table in ordinary memory (tests/test_gpu_batched.py::test_repeated_launches_with_a_large_basis_table_agree).)
+            // hipMallocAsync / hipFreeAsync, and 2 of 300 calls with a 2 MB table returned wrong fits for a contiguous range of
+            // problems. Root cause, reproduced WITHOUT any library code by scripts/probes/malloc_async_probe.hip on this ROCm
+            // (HIP runtime 70226015): with the pool's default release threshold (0) a synchronisation hands the freed block back
+            // to the OS, the next hipMallocAsync maps memory at the same address again, and kernels then read wrong words from
+            // it -- 84 % of a table per iteration when ordinary hipMalloc / hipFree traffic runs beside it, still some without;
+            // with hipMemPoolAttrReleaseThreshold = UINT64_MAX (the pool keeps its memory): none, in any configuration
+            // (profiles/r05/malloc_async_probe_*.txt). The runtime's, not this library's; a caller who wants stream-ordered
+            // allocation around these launches raises that threshold first. The table here stays in ordinary memory:
+            // tests/test_gpu_batched.py::test_repeated_launches_with_a_large_basis_table_agree.)
             owned = true;
             if (hipMalloc((void**)&table, bytes) != hipSuccess) return -4;
         }

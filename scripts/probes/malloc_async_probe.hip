@@ -34,12 +34,14 @@ __global__ void k_fill(uint32_t* p, size_t words, uint32_t key)
 }
 // reads every word `passes` times (a long-running consumer re-reads its table, as the batched fit does at every residual
 // evaluation) and counts words that are not the pattern
-__global__ void k_check(const uint32_t* p, size_t words, uint32_t key, int passes, unsigned long long* bad)
+static int g_flags = 0;     // argv[2]: 1 = no bystander allocations, 2 = pool release threshold = max (the pool keeps its memory over
+                            // synchronisations), 4 = plain instead of non-temporal loads in the consumer
+__global__ void k_check(const uint32_t* p, size_t words, uint32_t key, int passes, unsigned long long* bad, int plain)
 {
     unsigned long long b = 0;
     for (int s = 0; s < passes; ++s)
         for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x)
-            b += __builtin_nontemporal_load(p + i) != pat(key, (uint32_t)i);
+            b += (plain ? ((const volatile uint32_t*)p)[i] : __builtin_nontemporal_load(p + i)) != pat(key, (uint32_t)i);
     if (b) atomicAdd(bad, b);
 }
 
@@ -67,26 +69,27 @@ static Result run(long iters, bool null_stream, int mode, size_t table_bytes)
         seen.insert(t);
         hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, s, t, words, (uint32_t)it);
         // a bystander comes or goes on the side stream: ordinary allocations of 1 .. 64 MB holding their own pattern
-        if ((next() & 3) != 0 && live.size() < 6) {
+        if (g_flags & 1) {
+        } else if ((next() & 3) != 0 && live.size() < 6) {
             By b; b.words = ((size_t)1 << (18 + next() % 7)); b.key = 0x80000000u + (uint32_t)it;
             CK(hipMalloc((void**)&b.p, b.words * 4));
             hipLaunchKernelGGL(k_fill, dim3(512), dim3(256), 0, side, b.p, b.words, b.key);
             live.push_back(b);
         } else if (!live.empty()) {
             const size_t k = next() % live.size();
-            hipLaunchKernelGGL(k_check, dim3(512), dim3(256), 0, side, live[k].p, live[k].words, live[k].key, 1, bad2);
+            hipLaunchKernelGGL(k_check, dim3(512), dim3(256), 0, side, live[k].p, live[k].words, live[k].key, 1, bad2, g_flags & 4);
             CK(hipStreamSynchronize(side));
             CK(hipFree(live[k].p));
             live.erase(live.begin() + (long)k);
         }
-        hipLaunchKernelGGL(k_check, dim3(mode == 2 ? 2048 : 256), dim3(256), 0, s, t, words, (uint32_t)it, mode == 2 ? 40 : 1, bad);
+        hipLaunchKernelGGL(k_check, dim3(mode == 2 ? 2048 : 256), dim3(256), 0, s, t, words, (uint32_t)it, mode == 2 ? 40 : 1, bad, g_flags & 4);
         CK(hipFreeAsync(t, s));
         if (mode == 0) CK(hipDeviceSynchronize());
         if (mode == 2 && (it & 15) == 15) CK(hipStreamSynchronize(s));      // the host entry waits for results now and then
     }
     CK(hipDeviceSynchronize());
     for (auto& b : live) {
-        hipLaunchKernelGGL(k_check, dim3(512), dim3(256), 0, side, b.p, b.words, b.key, 1, bad2);
+        hipLaunchKernelGGL(k_check, dim3(512), dim3(256), 0, side, b.p, b.words, b.key, 1, bad2, g_flags & 4);
         CK(hipStreamSynchronize(side));
         CK(hipFree(b.p));
     }
@@ -119,8 +122,8 @@ static Result run_library_sequence(long iters)
         CK(hipMallocAsync((void**)&t, table_bytes, nullptr));
         seen.insert(t);
         hipLaunchKernelGGL(k_fill, dim3(512), dim3(256), 0, nullptr, t, t_words, (uint32_t)it);
-        hipLaunchKernelGGL(k_check, dim3(256), dim3(64), 0, nullptr, t, t_words, (uint32_t)it, 30, bad);
-        hipLaunchKernelGGL(k_check, dim3(256), dim3(64), 0, nullptr, base, in_words, 0x40000000u + (uint32_t)it, 30, bad + 1);
+        hipLaunchKernelGGL(k_check, dim3(256), dim3(64), 0, nullptr, t, t_words, (uint32_t)it, 30, bad, g_flags & 4);
+        hipLaunchKernelGGL(k_check, dim3(256), dim3(64), 0, nullptr, base, in_words, 0x40000000u + (uint32_t)it, 30, bad + 1, g_flags & 4);
         CK(hipFreeAsync(t, nullptr));
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(back.data(), base, 256, hipMemcpyDeviceToHost));
@@ -135,11 +138,19 @@ static Result run_library_sequence(long iters)
 int main(int argc, char** argv)
 {
     const long iters = argc > 1 ? std::atol(argv[1]) : 2000;
+    g_flags = argc > 2 ? std::atoi(argv[2]) : 0;
+    if (g_flags & 2) {
+        hipMemPool_t pool;
+        CK(hipDeviceGetDefaultMemPool(&pool, 0));
+        uint64_t thr = UINT64_MAX;
+        CK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr));
+    }
     int rt = 0;
     CK(hipRuntimeGetVersion(&rt));
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
-    std::printf("device %s  HIP runtime %d  iterations per configuration %ld\n", prop.gcnArchName, rt, iters);
+    std::printf("device %s  HIP runtime %d  iterations per configuration %ld  flags %d (1 no bystanders, 2 release threshold max, 4 plain loads)\n",
+                prop.gcnArchName, rt, iters, g_flags);
     unsigned long long total = 0;
     for (int mode = 0; mode < 3; ++mode)
         for (int ns = 0; ns < 2; ++ns)
