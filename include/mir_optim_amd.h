@@ -400,6 +400,7 @@ typedef struct mir_lsq_resident_stats {         /* written by the kernel at exit
         elided_evaluations;
     uint64_t t_total, t_stage, t_worker, t_group, t_total_wait, t_solver, t_solve_body, t_cmd_wait;
     uint64_t t_w_eval, t_w_fd, t_w_prod;         /* of t_worker: trial residuals, finite-difference refreshes, products + publication */
+    uint64_t t_w_mma;                            /* of t_w_prod: the matrix-core loop up to the workgroup's cross-wave hand-over */
     uint32_t abort_code, grid, rows, groups;
 } mir_lsq_resident_stats;
 typedef struct mir_lsq_resident_options {

@@ -53,8 +53,8 @@ template <class Model> constexpr int resident_ncb() { return (Model::n + 15) / 1
 template <class Model> size_t resident_lds_bytes(int rows)
 {
     constexpr int NCB = resident_ncb<Model>(), NC = 16 * NCB, NBT = NCB * (NCB + 1) / 2;
-    const size_t R = (size_t)(rows + 15) / 16 * 16;
-    const size_t doubles = R * NC + 3 * R + R * Model::nd + 2 * (size_t)Model::n * Model::nc
+    const size_t R = (size_t)(rows + 31) / 32 * 32;
+    const size_t doubles = R * (NC + 1) + 3 * R + R * Model::nd + 2 * (size_t)Model::n * Model::nc
         + (size_t)(mirlsq::res_threads(Model::n) / 64) * (NBT * 256 + NC) + 3 * NC
         + (Model::n <= 16 ? (size_t)768 : (size_t)mirlsq::LdsSolveCfg<NCB>::ELEMS);      // n <= 16: the one-wave solve's operands and ladder
     return doubles * sizeof(double);
@@ -92,7 +92,7 @@ template <class Model> ResidentCarve resident_carve(int grid)
 template <class Model> int resident_plan(size_t m, int num_cu, ResidentPlan* plan)
 {
     static_assert(Model::n >= 1 && Model::n <= mirlsq::kResNMax, "1 <= n <= 32");
-    static_assert(Model::nd >= 0 && Model::nc >= 1, "nd: doubles of per-row data, nc: per-point constants");
+    static_assert(Model::nd >= 0 && Model::nc >= 1 && Model::nc <= mirlsq::kResCMax, "nd: doubles of per-row data, nc: per-point constants (<= 64)");
     if (m == 0 || num_cu < 1) return -1;
     if (num_cu > 256) num_cu = 256;                                   // group leaders sum at most 16 members each
     int grid = (int)((m + kResidentMinRows - 1) / kResidentMinRows);

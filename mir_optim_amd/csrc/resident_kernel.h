@@ -66,7 +66,8 @@ template <int NCB> struct ResPayload {
     static constexpr int STRIDE = (LEN + 15) / 16 * 16;
 };
 
-constexpr int kResCmdWords = 2 * kResNMax + 2;   // point | dx | 1 / dx.dx | action + preops << 32
+constexpr int kResCMax = 64;                     // per-point constants of a model (Model::nc)
+constexpr int kResCmdWords = 2 * kResNMax + 2 + kResCMax;   // point | dx | 1 / dx.dx | action + preops << 32 | the point's constants
 
 struct ResidentArgs {
     LmSettingsDev<double> set;
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
     constexpr int kResThreads = res_threads(Model::n), kResWaves = kResThreads / kWave;
     constexpr int N = Model::n, ND = Model::nd, NCN = Model::nc;
     static_assert(N >= 1 && N <= kResNMax, "1 <= n <= 32");
+    static_assert(NCN >= 1 && NCN <= kResCMax, "1 <= nc <= 64");
     constexpr int NCB = (N + 15) / 16;
     constexpr int NC = 16 * NCB;
     constexpr int NB = NCB;                                 // solve_lds.h block count: 1 (n <= 16) or 2
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
         if constexpr (kResWaves == 8) t += (w[4] + w[5]) + (w[6] + w[7]);
         return t;
     };
-    const int R = (a.rows + 15) / 16 * 16;                  // padded slice: four waves x four rows per MFMA step
+    const int R = (a.rows + 31) / 32 * 32;                  // padded slice: four waves x two MFMA steps of four rows per iteration
     const int row0 = wg * a.rows;
     const int nrows = max(0, min(a.rows, a.m - row0));
     const int G = a.grid, NG = a.groups;
@@ -167,8 +169,11 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
     const bool leader = wg < NG;
     const int members = (G - grp + NG - 1) / NG;            // workgroups w < G with w % NG == grp
 
-    double* Jl = reinterpret_cast<double*>(smem_res);       // R x NC
-    double* Yb = Jl + (size_t)R * NC;                       // 3 x R: residual, trial residual, Broyden scale u
+    // J rows have stride JS = NC + 1 doubles: a thread walking ITS row (the Broyden dot product) and a wave reading 4 rows x 16
+    // columns (the matrix-core operand) are both free of bank conflicts (17 doubles = 34 banks, 33 = 66)
+    constexpr int JS = NC + 1;
+    double* Jl = reinterpret_cast<double*>(smem_res);       // R x JS
+    double* Yb = Jl + (size_t)R * JS;                       // 3 x R: residual, trial residual, Broyden scale u
     double* Dl = Yb + 3 * (size_t)R;                        // R x ND
     double* Cl = Dl + (size_t)R * ND;                       // 2 N x NCN point constants
     double* RED = Cl + 2 * N * NCN;                         // kResWaves x REDW ; later the totals (PL::LEN)
@@ -194,12 +199,12 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
 
     int iy = 0, it = 1;                                     // roles of Yb's first two vectors
     constexpr int iu = 2;
-    long long tk0 = 0, t_stage = 0, t_w_eval = 0, t_w_fd = 0, t_w_prod = 0, t_worker = 0, t_group = 0, t_total_wait = 0, t_solver = 0, t_solve_body = 0, t_cmd_wait = 0;
+    long long tk0 = 0, t_stage = 0, t_w_eval = 0, t_w_fd = 0, t_w_prod = 0, t_w_mma = 0, t_worker = 0, t_group = 0, t_total_wait = 0, t_solver = 0, t_solve_body = 0, t_cmd_wait = 0;
     const bool clk = wg == 0 && tid == 0;
     if (clk) tk0 = wall_clock64();
 
     // ---- stage the slice's row data; zero J, the vectors and the padding
-    for (int e = tid; e < R * NC; e += kResThreads) Jl[e] = 0;
+    for (int e = tid; e < R * JS; e += kResThreads) Jl[e] = 0;
     for (int e = tid; e < 3 * R; e += kResThreads) Yb[e] = 0;
     for (int e = tid; e < R * ND; e += kResThreads) {
         const int i = e / ND;
@@ -272,18 +277,34 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
         if (preops & kResPreAccept) { const int t = iy; iy = it; it = t; }     // swap(mBuffer, y), LS:1136
         int len = 1;
         if (action == kResEval || action == kResEvalSpec) {
-            // (2) f(point) on the slice's rows -> trial residual, sum of squares (LS:1113-1115; LS:953-955 at entry)
-            if (tid == 0) Model::prepare(Xl, Cl);
-            __syncthreads();
+            // (2) f(point) on the slice's rows -> trial residual, sum of squares (LS:1113-1115; LS:953-955 at entry). The point's
+            // constants (Model::prepare) came with the command: workgroup 0 prepared them once for everybody (only the entry
+            // evaluation, which no command precedes, prepares them here)
+            if (round == 1) {
+                if (tid == 0) Model::prepare(Xl, Cl);
+                __syncthreads();
+            }
+            // kResEvalSpec: the thread that evaluated row i also forms the row's Broyden scale (LS:1003-1005: mBuffer = y_old -
+            // y_new, += J dx, *= -1 / dx.dx) from ITS row of J -- a private dot product, no cross-lane sum; u is kept for the
+            // products below and for the commit
+            const bool spec_u = action == kResEvalSpec;
             double ss = 0;
             for (int i = tid; i < R; i += kResThreads) {
                 const double v = i < nrows ? Model::eval(Dl + (size_t)i * ND, Cl) : 0.0;
                 Yb[it * R + i] = v;
                 ss = fma(v, v, ss);
+                if (spec_u) {
+                    const double* Ji = Jl + (size_t)i * JS;
+                    double d0 = 0, d1 = 0;
+#pragma unroll
+                    for (int c = 0; c < N; c += 2) { d0 = fma(Ji[c], DXl[c], d0); if (c + 1 < N) d1 = fma(Ji[c + 1], DXl[c + 1], d1); }
+                    const double t = (Yb[iy * R + i] - v) + (d0 + d1);
+                    Yb[iu * R + i] = -inv_dd * t;
+                }
             }
             ss = wave_sum(ss);
             if (lane == 0) s_w[wave] = ss;
-            __syncthreads();
+            __syncthreads();                                       // (also: every row of the trial residual is in LDS for step 3)
             if (tid == 0) res_st(a.partial + (size_t)wg * PL::STRIDE, wave_total(s_w));
             if (clk) { const long long t = wall_clock64(); t_w_eval += t - tw0; }
         } else if (action == kResFd) {
@@ -304,18 +325,17 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
                 if ((tid & 1) == 0) INVl[j] = twh != 0 ? 1.0 / twh : 0.0;      // a collapsed interval: zero column, LS:1046
             }
             __syncthreads();
-            for (int i = tid; i < R; i += kResThreads) {
-                if (i < nrows) {
-                    const double* row = Dl + (size_t)i * ND;
-                    for (int j = 0; j < N; ++j) {
-                        const double fp = Model::eval(row, Cl + (size_t)(2 * j) * NCN);
-                        const double fm = Model::eval(row, Cl + (size_t)(2 * j + 1) * NCN);
-                        const double inv = INVl[j];
-                        double v = fp;                                         // copy, axpy(-1), scal(1 / twh): LS:1041-1047
-                        v += -1.0 * fm;
-                        Jl[(size_t)i * NC + j] = inv != 0 ? v * inv : 0.0;
-                    }
-                }
+            // one (row, column) item at a time, consecutive threads on consecutive rows of one column (a thread that took whole
+            // rows left a third of the workgroup idle in its last sweep: 391 rows on 256 threads)
+            for (int e = tid; e < nrows * N; e += kResThreads) {
+                const int j = e / nrows, i = e - j * nrows;
+                const double* row = Dl + (size_t)i * ND;
+                const double fp = Model::eval(row, Cl + (size_t)(2 * j) * NCN);
+                const double fm = Model::eval(row, Cl + (size_t)(2 * j + 1) * NCN);
+                const double inv = INVl[j];
+                double v = fp;                                                 // copy, axpy(-1), scal(1 / twh): LS:1041-1047
+                v += -1.0 * fm;
+                Jl[(size_t)i * JS + j] = inv != 0 ? v * inv : 0.0;
             }
             __syncthreads();
             if (clk) { const long long t = wall_clock64(); t_w_fd += t - tw0; }
@@ -325,13 +345,12 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
         if (action == kResEvalSpec || action == kResFd) {
             // (3) products of the slice on the matrix cores. Lane (q, p) holds J[4 s + q][16 c + p]: the A and the B operand of
             // v_mfma_f64_16x16x4 at once. kResEvalSpec: the rows are FIRST updated as the Broyden pass after an acceptance of
-            // this trial would (LS:1003-1006: u = -((y_old - y_new) + J dx) / dx.dx; J' = J + u dx^T) -- in registers only; u is
-            // kept for the commit -- and the products are those of J' with the trial residual.
+            // this trial would (LS:1006: J' = J + u dx^T with the row scales u of step 2) -- in registers only -- and the
+            // products are those of J' with the trial residual.
             len = PL::LEN;
             const bool spec = action == kResEvalSpec;
             const int q = lane >> 4, p = lane & 15;
             const double* yv = Yb + (size_t)(spec ? it : iy) * R;
-            const double* yo = Yb + (size_t)iy * R;
             double dxv[NCB];
 #pragma unroll
             for (int c = 0; c < NCB; ++c) dxv[c] = DXl[16 * c + p];
@@ -341,22 +360,15 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
             double jy[NCB];
 #pragma unroll
             for (int c = 0; c < NCB; ++c) jy[c] = 0;
-            for (int s = wave; s < R / 4; s += kResWaves) {
-                const int i = 4 * s + q;
+            // two k-steps per iteration (rows i0, i1): two independent chains of LDS reads, the 16-lane dot product and the MFMAs --
+            // one chain alone leaves the wave waiting on its own latencies (R / 4 is a multiple of 2 x the waves)
+            auto kstep = [&](const double (&vin)[NCB], double yi, double u) {
                 double v[NCB];
 #pragma unroll
-                for (int c = 0; c < NCB; ++c) v[c] = Jl[(size_t)i * NC + 16 * c + p];
-                const double yi = yv[i];
+                for (int c = 0; c < NCB; ++c) v[c] = vin[c];
                 if (spec) {
-                    double dot = 0;
 #pragma unroll
-                    for (int c = 0; c < NCB; ++c) dot = fma(v[c], dxv[c], dot);
-                    dot = sum16(dot);
-                    const double t = (yo[i] - yi) + dot;
-                    const double u = -inv_dd * t;
-                    if (p == 0) Yb[iu * R + i] = u;
-#pragma unroll
-                    for (int c = 0; c < NCB; ++c) v[c] = fma(u, dxv[c], v[c]);
+                    for (int c = 0; c < NCB; ++c) v[c] = fma(u, dxv[c], v[c]);        // J' = J + u dx^T, LS:1006
                 }
 #pragma unroll
                 for (int c1 = 0; c1 < NCB; ++c1)
@@ -364,6 +376,15 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
                     for (int c2 = 0; c2 <= c1; ++c2) acc[c1 * (c1 + 1) / 2 + c2] = Mma<double>::mma(v[c1], v[c2], acc[c1 * (c1 + 1) / 2 + c2]);
 #pragma unroll
                 for (int c = 0; c < NCB; ++c) jy[c] = fma(v[c], yi, jy[c]);
+            };
+            for (int s = wave; s < R / 4; s += 2 * kResWaves) {
+                const int i0 = 4 * s + q, i1 = i0 + 4 * kResWaves;
+                double v0[NCB], v1[NCB];
+#pragma unroll
+                for (int c = 0; c < NCB; ++c) { v0[c] = Jl[(size_t)i0 * JS + 16 * c + p]; v1[c] = Jl[(size_t)i1 * JS + 16 * c + p]; }
+                const double y0 = yv[i0], y1 = yv[i1], u0 = Yb[iu * R + i0], u1 = Yb[iu * R + i1];
+                kstep(v0, y0, u0);
+                kstep(v1, y1, u1);
             }
             // the four waves' accumulators through LDS, summed in a fixed order
             double* mine = RED + (size_t)wave * REDW;
@@ -379,6 +400,7 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
                 if (q == 0) mine[NBT * 256 + 16 * c + p] = t;
             }
             __syncthreads();
+            if (clk) t_w_mma += wall_clock64() - tp0;
             double* out = a.partial + (size_t)wg * PL::STRIDE;
             auto four = [&](int e) {                               // the waves' values in a fixed order
                 double t = (RED[e] + RED[REDW + e]) + (RED[2 * REDW + e] + RED[3 * REDW + e]);
@@ -716,6 +738,11 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
                     res_st(a.cmd + kResNMax + tid, (unsigned long long)__double_as_longlong(tid < N ? dxp[(WAVE ? 16 * lad_level : 0) + tid] : 0.0));
                 }
                 if (tid == 0) res_st(a.cmd + 2 * kResNMax, (unsigned long long)__double_as_longlong(1.0 / s_ndd));   // LS:1002
+                if (next_action != kResFd) {
+                    if (tid == 0) Model::prepare(pt, Cl);
+                    __syncthreads();
+                    if (tid < NCN) res_st(a.cmd + 2 * kResNMax + 2 + tid, (unsigned long long)__double_as_longlong(Cl[tid]));
+                }
             }
             if (tid == 0) res_st(a.cmd + 2 * kResNMax + 1, (unsigned long long)next_action | ((unsigned long long)next_pre << 32));
             res_drain();
@@ -744,7 +771,7 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
         if (preops & kResPreCommitJ) {
             for (int e = tid; e < R * NC; e += kResThreads) {
                 const int i = e / NC, c = e % NC;
-                Jl[e] = fma(Yb[iu * R + i], DXl[c], Jl[e]);
+                Jl[(size_t)i * JS + c] = fma(Yb[iu * R + i], DXl[c], Jl[(size_t)i * JS + c]);
             }
             preops &= ~kResPreCommitJ;
             __syncthreads();
@@ -753,6 +780,7 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
             Xl[tid] = tid < N ? __longlong_as_double((long long)s_cmd[tid]) : 0.0;
             DXl[tid] = tid < N ? __longlong_as_double((long long)s_cmd[kResNMax + tid]) : 0.0;
         }
+        if (action != kResFd && tid < NCN) Cl[tid] = __longlong_as_double((long long)s_cmd[2 * kResNMax + 2 + tid]);
         __syncthreads();
     }
 
@@ -761,7 +789,7 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
         s.rounds = n_rounds; s.passes = n_passes; s.accepted = n_acc; s.rejected = n_rej; s.step_guard_rejects = n_guard;
         s.jacobian_full = n_fd; s.jacobian_broyden = n_br; s.qp_active_set_passes = n_qp; s.elided_evaluations = n_elided;
         s.t_total = (uint64_t)(wall_clock64() - tk0); s.t_stage = (uint64_t)t_stage; s.t_worker = (uint64_t)t_worker;
-        s.t_w_eval = (uint64_t)t_w_eval; s.t_w_fd = (uint64_t)t_w_fd; s.t_w_prod = (uint64_t)t_w_prod;
+        s.t_w_eval = (uint64_t)t_w_eval; s.t_w_fd = (uint64_t)t_w_fd; s.t_w_prod = (uint64_t)t_w_prod; s.t_w_mma = (uint64_t)t_w_mma;
         s.t_group = (uint64_t)t_group; s.t_total_wait = (uint64_t)t_total_wait; s.t_solver = (uint64_t)t_solver;
         s.t_solve_body = (uint64_t)t_solve_body; s.t_cmd_wait = (uint64_t)t_cmd_wait;
         s.abort_code = 0; s.grid = (uint32_t)G; s.rows = (uint32_t)a.rows; s.groups = (uint32_t)NG;

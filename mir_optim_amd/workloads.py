@@ -134,7 +134,7 @@ class ResidentStats(C.Structure):
     _fields_ = ([(k, C.c_uint64) for k in ("rounds", "passes", "accepted", "rejected", "step_guard_rejects", "jacobian_full",
                                             "jacobian_broyden", "qp_active_set_passes", "elided_evaluations", "t_total", "t_stage",
                                             "t_worker", "t_group", "t_total_wait", "t_solver", "t_solve_body", "t_cmd_wait", "t_w_eval", "t_w_fd",
-                                            "t_w_prod")]
+                                            "t_w_prod", "t_w_mma")]
                 + [(k, C.c_uint32) for k in ("abort_code", "grid", "rows", "groups")])
 
     def as_dict(self):

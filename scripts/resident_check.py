@@ -27,7 +27,7 @@ def show(tag, res, x, st):
         print(f"   us: total {tt:.1f} stage {st['t_stage']/100:.1f} worker {st['t_worker']/100:.1f} group {st['t_group']/100:.1f} "
               f"total-wait {st['t_total_wait']/100:.1f} solver {st['t_solver']/100:.1f} (solve body {st['t_solve_body']/100:.1f}) "
               f"cmd-wait {st['t_cmd_wait']/100:.1f}  per round {tt / max(1, st['rounds']):.2f}  [worker: eval {st['t_w_eval']/100:.1f} fd {st['t_w_fd']/100:.1f} "
-              f"products+publish {st['t_w_prod']/100:.1f}]", flush=True)
+              f"products+publish {st['t_w_prod']/100:.1f} (matrix-core loop {st['t_w_mma']/100:.1f})]", flush=True)
 
 
 def gauss(m, K, bounded=None):
