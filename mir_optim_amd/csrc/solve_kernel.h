@@ -935,6 +935,43 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
     lm_solve_body<T, NB, BOUNDED>(a, (int)blockIdx.x, smem_raw);      // blockIdx.x: chain step
 }
 
+// n <= 16, f64: the same pass on ONE wave per ladder entry, every matrix a row per lane (solve_wave16.h): no LDS, no barrier,
+// no global scratch -- 17 us -> see DESIGN.md for the launch-chain path of cfg 2 (n = 16). Compiled once, for 16 rows; rows
+// n .. 15 are identity rows.
+}  // namespace mirlsq
+#include "solve_wave16.h"
+namespace mirlsq {
+template <bool BOUNDED>
+__global__ __launch_bounds__(kWave) void k_lm_solve_wave(LmSolveArgs<double> a)
+{
+    const int n = a.n, kc = blockIdx.x, lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+    if (a.guard && *a.guard == 0) return;
+    const bool el = r < n;
+    const int rc = el ? r : 0;
+    double JJrow[kW16];
+#pragma unroll
+    for (int k = 0; k < kW16; ++k) { const double v = a.JJ[(size_t)rc * n + (k < n ? k : 0)]; JJrow[k] = (el && k < n) ? v : 0.0; }
+    const double djj_l = a.JJ[(size_t)rc * n + rc], jy_l = a.Jy[rc], x_l = a.x[rc], lo_l = a.lower[rc], up_l = a.upper[rc];
+    const double djj = el ? djj_l : 0.0, Jy_r = el ? jy_l : 0.0, x_r = el ? x_l : 0.0;
+    const double lo_r = el ? lo_l : -Lim<double>::inf(), up_r = el ? up_l : Lim<double>::inf();
+    const double lambda = (kc == 0 && (a.lambda_from_state || a.lambda_from_device)) ? a.st->lambda : a.lam[kc];
+    if (a.check_grad && kc == 0) {
+        const double jy_inf = row16_max(fabs(Jy_r));
+        if (lane == 0) a.st->jy_inf = jy_inf;
+    }
+    Wave16Level lv;
+    double d, t;
+    wave16_lm_solve<kW16, BOUNDED>(JJrow, djj, Jy_r, x_r, lo_r, up_r, lambda, 1.0, a.check_grad != 0, kc == 0 && a.lambda_from_state != 0,
+                                   a.set, lv, d, t, n, true);
+    if (g == 0 && el && !(lv.flags & kFlagGradSmall)) { a.dx[(size_t)kc * n + r] = d; a.trial[(size_t)kc * n + r] = t; }
+    if (lane == 0) {
+        ChainRec<double> rec{};
+        rec.lambda = lv.lambda; rec.new_dx_dot = lv.ndd; rec.predicted = lv.pred; rec.trial_xnorm = lv.xnorm;
+        rec.qp_status = lv.qp_status; rec.qp_iterations = lv.qp_iters; rec.flags = lv.flags;
+        a.rec[kc] = rec;
+    }
+}
+
 // standalone BOXCQP (mir_solve_box_qp_gpu_*; BoxQpArgs: solve_types.h)
 template <typename T, int NB>
 __global__ __launch_bounds__(kSolveThreads) void k_box_qp(BoxQpArgs<T> a)

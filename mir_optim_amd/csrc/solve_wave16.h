@@ -40,7 +40,8 @@ __device__ __forceinline__ unsigned group_bits(bool pred, int g) { return (unsig
 // ?posvx('E','L') of the group's system (M + shift I) x = rhs: Mrow = row r of the symmetric M; rows with live == false (and
 // every row >= N) are identity rows. Returns info (group-uniform: 0, or the 1-based index of the first non-positive pivot); x_r out.
 template <int N>
-__device__ __forceinline__ int posvx_rows16(const double (&Mrow)[kW16], double shift, double d_r, double rhs_r, bool live, int r, double& x_r)
+__device__ __forceinline__ int posvx_rows16(const double (&Mrow)[kW16], double shift, double d_r, double rhs_r, bool live, int r, double& x_r,
+                                            int order = N)
 {
     // The matrix is M + shift I, row r in Mrow (no damped copy is kept: registers). d_r = Mrow[r] + shift, handed in by the
     // caller: picking it out of the register array with a run-time index would put the array in scratch memory
@@ -107,7 +108,7 @@ __device__ __forceinline__ int posvx_rows16(const double (&Mrow)[kW16], double s
     };
     double x = potrs(b_r);
     // ?porfs: the loop runs while any group refines; a group that has stopped keeps its solution
-    const double safe1 = (double)(N + 1) * safmin, safe2 = safe1 / eps;
+    const double safe1 = (double)(order + 1) * safmin, safe2 = safe1 / eps;     // order: rows of the system (<= N)
     double lstres = 3;
     bool active = true;
     for (int count = 1;; ++count) {
@@ -147,10 +148,13 @@ struct Wave16Level {
 template <int N, bool BOUNDED>
 __device__ __forceinline__ void wave16_lm_solve(const double (&JJrow)[kW16], double djj, double Jy_r, double x_r, double lo_r, double up_r,
                                                 double lambda, double mu, bool check_grad, bool from_state,
-                                                const LmSettingsDev<double>& set, Wave16Level& out, double& dx_out, double& trial_out)
+                                                const LmSettingsDev<double>& set, Wave16Level& out, double& dx_out, double& trial_out,
+                                                int n = N, bool single = false)
 {
+    // n <= N: the problem's order at run time (rows n .. N - 1 are identity rows: the launch-chain kernel k_lm_solve_wave is
+    // compiled once, for N = 16); single: no ladder, every group solves with `lambda` (one ladder entry per wave)
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-    const bool el = r < N;
+    const bool el = r < n;
     out.lambda = lambda; out.ndd = 0; out.pred = 0; out.xnorm = 0; out.qp_status = 0; out.qp_iters = 0; out.flags = 0; out.offered = g == 0;
     dx_out = 0; trial_out = x_r;
     if (check_grad) {                                            // LS:1053
@@ -171,7 +175,7 @@ __device__ __forceinline__ void wave16_lm_solve(const double (&JJrow)[kW16], dou
     {
         double l = lambda, mm = mu;
 #pragma unroll
-        for (int k = 1; k < 4; ++k) { l *= set.lambdaIncrease * mm; mm *= 2; lam_g = (g == k) ? l : lam_g; }
+        for (int k = 1; k < 4; ++k) { l *= set.lambdaIncrease * mm; mm *= 2; lam_g = (g == k && !single) ? l : lam_g; }
     }
     out.lambda = lam_g;
     const double qpl = lo_r - x_r, qpu = up_r - x_r;              // LS:1074-1077
@@ -180,7 +184,7 @@ __device__ __forceinline__ void wave16_lm_solve(const double (&JJrow)[kW16], dou
     double xq;
     int qp = 0, qp_iters = 0;
     {
-        const int info = posvx_rows16<N>(JJrow, lam_g, djj + lam_g, -Jy_r, el, r, xq);                          // QP:168-214
+        const int info = posvx_rows16<N>(JJrow, lam_g, djj + lam_g, -Jy_r, el, r, xq, n);                          // QP:168-214
         if (info != 0) qp = 1;
     }
     bool infeasible = el && !(qpl <= xq && xq <= qpu);                                       // QP:216-219 (NaN counts)
@@ -198,7 +202,7 @@ __device__ __forceinline__ void wave16_lm_solve(const double (&JJrow)[kW16], dou
             double x = __shfl(xq, r, 64);
             const double q_r = Jy_r;
             double la = 0, mul = 0;                                                          // QP:228-232
-            uint32_t maxit = set.qpMaxIterations ? set.qpMaxIterations : (uint32_t)N * 10 + 100;   // QP:224-226
+            uint32_t maxit = set.qpMaxIterations ? set.qpMaxIterations : (uint32_t)n * 10 + 100;   // QP:224-226
             int st0 = 2;                                                                      // QP:378
             for (uint32_t step = 0; step < maxit; ++step) {                                   // QP:234
                 qp_iters = (int)step + 1;
@@ -211,7 +215,7 @@ __device__ __forceinline__ void wave16_lm_solve(const double (&JJrow)[kW16], dou
                 }
                 const unsigned free_bits = (unsigned)(__ballot(fl == 0) & 0xffffull);
                 const int sN = __builtin_popcount(free_bits);
-                if (sN == N) break;                                                           // QP:265-266 (quirk Q8)
+                if (sN == n) break;                                                           // QP:265-266 (quirk Q8)
                 // right-hand side of the reduced system, QP:282-305: Kahan-Babuska-Neumaier over the bound variables, j ascending
                 double ks = q_r, kc = 0;
                 static_for<kW16>([&](auto JX) {
@@ -229,7 +233,7 @@ __device__ __forceinline__ void wave16_lm_solve(const double (&JJrow)[kW16], dou
                 const double b_r = -(ks + kc);
                 if (sN) {                                                                     // QP:307-329
                     double xs;
-                    const int info = posvx_rows16<N>(JJrow, lam0, djj + lam0, b_r, fl == 0, r, xs);
+                    const int info = posvx_rows16<N>(JJrow, lam0, djj + lam0, b_r, fl == 0, r, xs, n);
                     if (info != 0) { st0 = 1; break; }
                     x = fl == 0 ? xs : x;
                 }
