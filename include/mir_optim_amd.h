@@ -298,7 +298,7 @@ typedef struct mir_lsq_gpu_options {
                                         no separate column-fill pass: the 2n points are evaluated in one call and the
                                         J^T J kernel forms the Jacobian rows from the (+h, -h) pairs while it writes J.
                                         Read only when struct_size covers it; `fb` is still used for lambda-ladder trials */
-    void* fbRowMajorDiff;            /* optional mir_lsq_batched_function_d (f64; even n <= 128, n = 192, n = 256), context fbContext: called with the
+    void* fbRowMajorDiff;            /* optional mir_lsq_batched_function_d (f64; n <= 128, n = 192, n = 256), context fbContext: called with the
                                         p = 2n finite-difference points X = [x + h e_0, x - h e_0, x + h e_1, ...] and writes the
                                         m x n ROW-major DIFFERENCE panel D[i * n + j] = f(X_2j)_i - f(X_2j+1)_i -- the caller's
                                         kernel does the reference's copy + axpy(-1) (LS:1041, 1045) on its way out, every one of
@@ -439,7 +439,7 @@ int mir_lsq_jtj_s(size_t m, size_t n, float* J, const float* y, const float* y_o
 int mir_lsq_fd_jtj_d(size_t m, size_t n, const double* Yrm, const double* twh, const double* y, double* J,
                      double* JJ, double* Jy, void* stream, float* kernel_ms);
 /* The same from the m x n row-major DIFFERENCE panel D[i][j] = f(x + h e_j)_i - f(x - h e_j)_i (what a fbRowMajorDiff callback
- * writes; f64; even n <= 128, n = 192, n = 256, else -6): J = D * (1 / twh) column-wise (zero for twh = 0), JJ, Jy. */
+ * writes; f64; n <= 128, n = 192, n = 256, else -6): J = D * (1 / twh) column-wise (zero for twh = 0), JJ, Jy. */
 int mir_lsq_fd_diff_jtj_d(size_t m, size_t n, const double* Drm, const double* twh, const double* y, double* J,
                           double* JJ, double* Jy, void* stream, float* kernel_ms);
 

@@ -218,7 +218,108 @@ __device__ __forceinline__ void fdp_producer_plain(const JtjArgs<double>& a, dou
     }
 }
 
-template <int NCB, int ROLE, bool FD = true, bool DIFF = false>
+// FLAT variant of the plain / difference-panel producer, for sources whose rows do not start on 16-byte boundaries -- ODD n
+// (LS:911-926: the reference is generic in n) or an offset view of J. A wave's RP rows are RP n CONTIGUOUS doubles of the source
+// (RP is even, so is the index of their first double): they are read as a flat array of pairs with 16-byte BUFFER loads --
+// `buffer_load_dwordx4` needs 4-byte alignment only, and what lies past the end of the array (rows >= m, or the partner of the
+// last double when m n is odd) reads as zero --, a pair may straddle a row end, so its two doubles go to LDS separately (two
+// 8-byte stores at their own (row, column) positions). As many loads as the aligned variant; the padding columns of the LDS
+// stage are zeroed once; 1 / twh of the difference panel comes from a small LDS table (n doubles behind the two slots).
+template <int NCB, bool DIFF = false>
+__device__ __forceinline__ void fdp_producer_plain_flat(const JtjArgs<double>& a, double* smem, int lane, int w, size_t s0, size_t S)
+{
+    using C = JtjFdpCfg<NCB, false>;
+    constexpr int n = C::N;                                // padded
+    constexpr int NI = C::NI;
+    const size_t m = a.m;
+    const int nr = a.n;
+    double* invt = smem + 2 * C::SLOT_DOUBLES;             // DIFF: 1 / twh per column (0: collapsed interval, LS:1046)
+    if constexpr (DIFF) {
+        for (int c = lane; c < nr; c += kWave) { const double t = a.twh[c]; invt[c] = t == 0 ? 0.0 : 1.0 / t; }
+    }
+    // this workgroup's rows as a buffer: everything past the end of the array reads as zero
+    const size_t rowb = s0 * C::RS < m ? s0 * C::RS : m;
+    const size_t left = (m - rowb) * (size_t)nr * sizeof(double);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double*>(a.J + rowb * (size_t)nr), 0, (int)(left < 0xffffffffull ? left : 0xffffffffull), 0x00020000);
+
+    // DIFF: the scaled pairs ARE the rows of J in memory order (same row stride as the panel): the producer writes them back
+    // itself, 1 KB contiguous per instruction -- the consumers' 128-byte row segments straddle cache lines whenever a row of J
+    // does not start on a 128-byte boundary (n % 16 != 0: 0.52 ms at n = 126 against 0.43 at n = 128 for 1e6 rows)
+    __amdgpu_buffer_rsrc_t rout = rsrc;
+    if constexpr (DIFF) {
+        if (a.Jout) rout = __builtin_amdgcn_make_buffer_rsrc(a.Jout + rowb * (size_t)nr, 0, (int)(left < 0xffffffffull ? left : 0xffffffffull), 0x00020000);
+    }
+    int off0[NI], off1[NI];                                // LDS offsets (row * n + column inside the wave's region); -1: no element
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int e0 = 2 * (64 * i + lane), e1 = e0 + 1;
+        off0[i] = e0 < C::RP * nr ? (e0 / nr) * n + e0 % nr : -1;
+        off1[i] = e1 < C::RP * nr ? (e1 / nr) * n + e1 % nr : -1;
+    }
+    // the padding columns (nr .. n - 1) of this wave's rows, both slots: zero for the whole kernel
+    for (int e = lane; e < C::RP * (n - nr); e += kWave) {
+        const int r = e / (n - nr), c = nr + e % (n - nr);
+        smem[w * C::RP * n + r * n + c] = 0.0;
+        smem[C::SLOT_DOUBLES + w * C::RP * n + r * n + c] = 0.0;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    typedef unsigned int fdp_u4 __attribute__((ext_vector_type(4)));
+    fdp_u4 b[2][NI];
+    double yb[2] = {0, 0};
+    auto issue = [&](size_t s, auto B) {
+        constexpr int bb = decltype(B)::value;
+        const size_t sc = s < S ? s : S - 1;
+        const size_t row0 = (s0 + sc) * C::RS + C::RP * (size_t)w;
+        const unsigned base = (unsigned)((row0 - rowb) * (size_t)nr * sizeof(double));
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            b[bb][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(base + 16u * (unsigned)(64 * i + lane)), 0, DIFF ? 2 : 0);   // nt: the panel is read once
+        size_t yr = row0 + (lane & (C::RP - 1));
+        yr = yr < m ? yr : m - 1;
+        yb[bb] = a.y[yr];
+    };
+    auto convert = [&](size_t s, auto B) {
+        constexpr int bb = decltype(B)::value;
+        double* slot = smem + (s & 1) * C::SLOT_DOUBLES + w * C::RP * n;
+        const size_t row0 = (s0 + s) * C::RS + C::RP * (size_t)w;
+        const unsigned base = (unsigned)((row0 - rowb) * (size_t)nr * sizeof(double));
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            double v0 = __hiloint2double((int)b[bb][i].y, (int)b[bb][i].x), v1 = __hiloint2double((int)b[bb][i].w, (int)b[bb][i].z);
+            if constexpr (DIFF) {
+                const double i0 = invt[off0[i] >= 0 ? off0[i] % n : 0], i1 = invt[off1[i] >= 0 ? off1[i] % n : 0];
+                v0 = i0 == 0 ? 0.0 : v0 * i0;               // scal(1 / twh, Jj), LS:1047 (LS:1046: zero column)
+                v1 = i1 == 0 ? 0.0 : v1 * i1;
+                if (a.Jout && off0[i] >= 0) {               // rows >= m lie past the buffer's end: the store is dropped
+                    const fdp_u4 o = {(unsigned)__double2loint(v0), (unsigned)__double2hiint(v0), (unsigned)__double2loint(v1), (unsigned)__double2hiint(v1)};
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rout, (int)(base + 16u * (unsigned)(64 * i + lane)), 0, 2);
+                }
+            }
+            if (off0[i] >= 0) slot[off0[i]] = v0;
+            if (off1[i] >= 0) slot[off1[i]] = v1;
+        }
+        if (lane < C::RP) smem[(s & 1) * C::SLOT_DOUBLES + C::RS * n + C::RP * w + lane] = (row0 + lane < m) ? yb[bb] : 0.0;
+    };
+    if (S > 0) {
+        issue(0, IntC<0>{});
+        issue(1, IntC<1>{});
+        for (size_t t = 0; t < S; t += 2) {
+            static_for<2>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                if (t + u < S) {
+                    convert(t + u, U);
+                    issue(t + u + 2, U);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+            });
+        }
+    }
+}
+
+template <int NCB, int ROLE, bool FD = true, bool DIFF = false, bool PRODUCER_WRITES_J = false>
 __device__ __forceinline__ void fdp_consumer(const JtjArgs<double>& a, const double* smem, int lane, size_t s0, size_t S)
 {
     using T = double;
@@ -248,7 +349,7 @@ __device__ __forceinline__ void fdp_consumer(const JtjArgs<double>& a, const dou
             if constexpr (ROLE == 0) g.y = slot[C::RS * n + 4 * gi + q];
         };
         auto side = [&](int gi, const Grp& g) {
-            if constexpr ((FD || DIFF) && ROLE >= 2) {
+            if constexpr ((FD || DIFF) && ROLE >= 2 && !PRODUCER_WRITES_J) {
                 // the Jacobian rows leave through roles 2 and 3 (column blocks c = ROLE (mod 2))
                 const size_t row = row0 + 4 * gi + q;
                 if (row < m && a.Jout) {                   // Jout == nullptr: the caller keeps the panel itself as J (unscaled)
@@ -304,10 +405,11 @@ __device__ __forceinline__ void fdp_consumer(const JtjArgs<double>& a, const dou
     }
 }
 
-template <int NCB, bool FD = true, bool DIFF = false>
+template <int NCB, bool FD = true, bool DIFF = false, bool ELEM = false>
 __global__ __launch_bounds__(kJtjFdpThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_jtj_fdp(JtjArgs<double> a)
 {
     static_assert(!(FD && DIFF), "DIFF uses the plain stage layout");
+    static_assert(!(FD && ELEM), "the pair panel's rows always start on 16-byte boundaries");
     using C = JtjFdpCfg<NCB, FD>;
     extern __shared__ __attribute__((aligned(16))) unsigned char fdp_smem[];
     double* smem = reinterpret_cast<double*>(fdp_smem);
@@ -320,11 +422,13 @@ __global__ __launch_bounds__(kJtjFdpThreads) __attribute__((amdgpu_waves_per_eu(
     const size_t s1 = s0 + per < Stot ? s0 + per : Stot;
     const size_t S = s1 - s0;
 
-    if (wave == 0) fdp_consumer<NCB, 0, FD, DIFF>(a, smem, lane, s0, S);
-    else if (wave == 1) fdp_consumer<NCB, 1, FD, DIFF>(a, smem, lane, s0, S);
-    else if (wave == 2) fdp_consumer<NCB, 2, FD, DIFF>(a, smem, lane, s0, S);
-    else if (wave == 3) fdp_consumer<NCB, 3, FD, DIFF>(a, smem, lane, s0, S);
+    constexpr bool PW = DIFF && ELEM;                      // the flat producer of the difference panel writes J itself
+    if (wave == 0) fdp_consumer<NCB, 0, FD, DIFF, PW>(a, smem, lane, s0, S);
+    else if (wave == 1) fdp_consumer<NCB, 1, FD, DIFF, PW>(a, smem, lane, s0, S);
+    else if (wave == 2) fdp_consumer<NCB, 2, FD, DIFF, PW>(a, smem, lane, s0, S);
+    else if (wave == 3) fdp_consumer<NCB, 3, FD, DIFF, PW>(a, smem, lane, s0, S);
     else if constexpr (FD) fdp_producer<NCB>(a, smem, lane, wave - 4, s0, S);
+    else if constexpr (ELEM) fdp_producer_plain_flat<NCB, DIFF>(a, smem, lane, wave - 4, s0, S);
     else fdp_producer_plain<NCB, DIFF>(a, smem, lane, wave - 4, s0, S);
 }
 

@@ -3,7 +3,7 @@
 //
 // Kernel by shape, LS = /root/reference/source/mir/optim/least_squares.d:
 //   f64, n <= 128               k_jtj_fdp<NCB, true>    finite-difference panel -> J, J^T J, J^T y   (LS:1041-1047, 1052, 1065)
-//   f64, n <= 128, n even       k_jtj_fdp<NCB, false>   J^T J + J^T y of a given J                   (LS:1052, 1065)
+//   f64, n <= 128               k_jtj_fdp<NCB, false>   J^T J + J^T y of a given J (odd n: 8-byte loads) (LS:1052, 1065)
 //   f64, 128 < n <= 256, n % 32 == 0           k_jtj_fdp8   finite-difference panel -> J, J^T J, J^T y
 //   f64, 128 < n <= 256 (n % 16 == 0, m even)  k_jtj8   eight-wave LDS-DMA ring, J^T J of a given J
 //   f32, n <= 128, n % 4 == 0   k_jtj_pc32
@@ -66,7 +66,7 @@ struct JtjPlan {
     bool wide = false;      // n > 128 and not ring8: 64-column tile-pair jobs (jtj_wide.h), any n
     bool ring8 = false;     // 128 < n <= 256, f64, n % 16 == 0, m even: eight-wave LDS-DMA ring (jtj_ring8.h)
     bool fdp = false;       // f64, n <= 128, any m: producer / consumer kernel (jtj_fdp.h) for the finite-difference J^T J
-    bool fdp_plain = false; // ... and, n even, for the plain J^T J
+    bool fdp_plain = false; // ... and for the plain J^T J / the difference panel (odd n: the element-wise producer)
     bool fdp8 = false;      // f64, 128 < n <= 256, n % 32 == 0, any m: eight producer + consumer waves (jtj_fdp8.h), FD J^T J only
     int fdp8_nblk = 0, fdp8_slab_len = 0;
     bool pc32 = false;      // f32, n <= 128, n % 4 == 0, any m: producer / consumer kernel on v_mfma_f32_16x16x4 (jtj_pc32.h), plain J^T J
@@ -119,7 +119,7 @@ JtjPlan jtj_plan(size_t m, int n, int num_cu)
         p.pc32_nblk = (int)(want < cap ? (want ? want : 1) : cap);
     }
     p.fdp = sizeof(T) == 8 && n <= 128;
-    p.fdp_plain = p.fdp && n % 2 == 0;
+    p.fdp_plain = p.fdp;                // any n: odd n (rows not on 16-byte boundaries) takes the element-wise producer
     // the register-streaming kernel k_jtj: f64 with odd n, f32 with n % 4 != 0, and every Broyden REWRITE at n <= 128
     {
         const int rpb = 4 * (int)(sizeof(T) / 4);
@@ -162,7 +162,7 @@ inline size_t jtj_slab_elems(const JtjPlan& a)
 
 // does jtj_run honour a JtjUnpack for this plan? (the tile-pair jobs have a reduction of their own; jtj_run_fd* always do)
 inline bool jtj_plain_unpacks(const JtjPlan& p) { return !p.wide; }
-// can the m x n DIFFERENCE panel be consumed for this shape? (f64; n <= 128, n even: fdp_plain; n = 192, 256: k_jtj_fdp8)
+// can the m x n DIFFERENCE panel be consumed for this shape? (f64; n <= 128: fdp_plain; n = 192, 256: k_jtj_fdp8)
 inline bool jtj_fd_diff_ok(const JtjPlan& p, int n) { return p.fdp_plain || (p.fdp8 && n % 64 == 0); }
 
 // ---- launch entry points (launch_jtj.hip; instantiated for double and float). Every kernel they launch is counted in

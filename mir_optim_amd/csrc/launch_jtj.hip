@@ -60,6 +60,18 @@ template <int NCB, bool FD, bool DIFF>
 hipError_t fdp_one(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t s)
 {
     using FC = JtjFdpCfg<NCB, FD>;
+    if constexpr (!FD) {
+        // plain J / difference panel: rows of n doubles. Odd n, or a source that is not 16-byte aligned (an offset view handed to
+        // a unit entry): the flat producer (the same 16-byte loads, 8-byte aligned, over the wave's contiguous rows)
+        // ... and the difference panel whenever a row of J does not start on a 128-byte boundary (n % 16 != 0): the flat
+        // producer writes J back in memory order instead of the consumers' row segments
+        if (a.n % 2 != 0 || reinterpret_cast<uintptr_t>(a.J) % 16 != 0 || (DIFF && a.n % 16 != 0)) {
+            constexpr size_t lds = (size_t)FC::LDS_BYTES + FC::N * sizeof(double);       // + the 1 / twh table of the flat producer
+            MIRLSQ_ENSURE_LDS((k_jtj_fdp<NCB, FD, DIFF, true>), lds);
+            MIRLSQ_LAUNCH((k_jtj_fdp<NCB, FD, DIFF, true>), dim3(p.nblk), dim3(FC::THREADS), lds, s, a);
+            return hipGetLastError();
+        }
+    }
     MIRLSQ_ENSURE_LDS((k_jtj_fdp<NCB, FD, DIFF>), (size_t)FC::LDS_BYTES);
     MIRLSQ_LAUNCH((k_jtj_fdp<NCB, FD, DIFF>), dim3(p.nblk), dim3(FC::THREADS), FC::LDS_BYTES, s, a);
     return hipGetLastError();

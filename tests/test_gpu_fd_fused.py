@@ -50,7 +50,8 @@ def test_fd_jtj_exact_integers(m, n):
     assert np.array_equal(JJ, JJ.T)
 
 
-@pytest.mark.parametrize("m,n", [(4096, 128), (5000, 16), (30, 32), (10002, 64), (7778, 80), (12344, 96), (6, 112), (50000, 128)])
+@pytest.mark.parametrize("m,n", [(4096, 128), (5000, 16), (30, 32), (10002, 64), (7778, 80), (12344, 96), (6, 112), (50000, 128),
+                                 (4097, 127), (5000, 99), (2000, 9), (12345, 65), (3, 1)])
 def test_plain_and_fused_producer_consumer_kernels_agree_on_exact_integers(m, n):
     """The plain J^T J (k_jtj_fdp<., false>) of the J the fused finite-difference kernel wrote: bit-exact on exact-integer
     inputs, like the fused kernel itself."""
@@ -195,7 +196,8 @@ def test_collapsed_interval_gives_zero_column_through_the_fused_path():
 
 @pytest.mark.parametrize("m,n", [(4096, 128), (5000, 16), (30, 32), (2, 48), (10002, 64), (7778, 80), (6, 112), (100000, 128),
                                  (4097, 128), (1, 16), (12345, 90), (5000, 100), (33, 2),
-                                 (4096, 256), (5001, 192), (50000, 256), (1, 256), (17, 192)])
+                                 (4096, 256), (5001, 192), (50000, 256), (1, 256), (17, 192),
+                                 (4097, 127), (5000, 99), (333, 1), (2000, 9), (12345, 65), (50001, 127), (7, 33)])   # odd n: 8-byte loads
 def test_fd_diff_panel_gives_the_pair_panel_jacobian_bit_for_bit(m, n):
     """D = Y+ + (-1) Y- formed by the caller (LS:1041, 1045), scal(1 / twh) by the kernel (LS:1047): the same J as from the pair
     panel, bit for bit, incl. a clipped and a collapsed interval; J^T J / J^T y exact on exact-integer inputs."""

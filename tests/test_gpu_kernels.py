@@ -59,10 +59,10 @@ def test_jtj_wide_n_matches_numpy(m, n):
     assert np.array_equal(JJ, Ji.T @ Ji) and np.array_equal(Jy, Ji.T @ yi)
 
 
-def test_jtj_exact_integers():
-    """small integers: every partial sum is exact, so the result must be bit-exact."""
+@pytest.mark.parametrize("m,n", [(3001, 96), (3001, 97), (40000, 127), (777, 1), (5000, 31)])
+def test_jtj_exact_integers(m, n):
+    """small integers: every partial sum is exact, so the result must be bit-exact (odd n: the element-wise producer of jtj_fdp.h)."""
     rng = np.random.default_rng(5)
-    m, n = 3001, 96
     J = rng.integers(-8, 9, size=(m, n)).astype(np.float64)
     y = rng.integers(-8, 9, size=m).astype(np.float64)
     JJ, Jy, _, _ = M.jtj(J, y)
