@@ -294,7 +294,7 @@ typedef struct mir_lsq_gpu_options {
                                         device-to-host copy per pass) */
     void* fbRowMajor;                /* optional mir_lsq_batched_function_{d,s} that writes Y as m x p ROW-major
                                         (point k's residual of row i at Y[i * p + k]), context fbContext. With it the
-                                        finite-difference refresh of f64 problems with n <= 128 (and n = 160, 192, 224, 256) needs
+                                        finite-difference refresh of f64 problems with n <= 256 needs
                                         no separate column-fill pass: the 2n points are evaluated in one call and the
                                         J^T J kernel forms the Jacobian rows from the (+h, -h) pairs while it writes J.
                                         Read only when struct_size covers it; `fb` is still used for lambda-ladder trials */
@@ -432,7 +432,7 @@ int mir_lsq_jtj_d(size_t m, size_t n, double* J, const double* y, const double* 
                   int broyden, double* JJ, double* Jy, void* stream, float* kernel_ms);
 int mir_lsq_jtj_s(size_t m, size_t n, float* J, const float* y, const float* y_old, const float* dx,
                   int broyden, float* JJ, float* Jy, void* stream, float* kernel_ms);
-/* Finite-difference fill fused into the J^T J kernel (f64; n <= 128, or 128 < n <= 256 with n % 32 == 0; else -6). Yrm: m x 2n
+/* Finite-difference fill fused into the J^T J kernel (f64; n <= 256; else -6). Yrm: m x 2n
  * row-major, Yrm[i][2j] = f(x + h e_j)_i, Yrm[i][2j+1] = f(x - h e_j)_i; twh[j] = (x_j + h) - (x_j - h) after clipping
  * (0 = collapsed interval: zero column, LS:1046). Writes J (m x n row-major, (Y+ - Y-) * (1 / twh) as LS:1041-1047),
  * JJ = J^T J (full symmetric) and Jy = J^T y. */

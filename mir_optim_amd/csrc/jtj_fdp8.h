@@ -1,4 +1,5 @@
-// jtj_fdp8.h -- finite-difference rows -> J, J^T J, J^T y for 128 < n <= 256 (f64, n % 32 == 0, any m): cfg 4's per-GPU shape.
+// jtj_fdp8.h -- finite-difference rows -> J, J^T J, J^T y for 128 < n <= 256 (f64, any n and m; compiled for N = 160, 192, 224,
+// 256 = n rounded up to a multiple of 32, padding columns are zero columns): cfg 4's per-GPU shape.
 //
 // Same job as k_jtj_fdp (jtj_fdp.h): the m x 2n row-major panel of perturbed residuals Y[i][2j] = f(x + h e_j)_i,
 // Y[i][2j+1] = f(x - h e_j)_i becomes the Jacobian (LS:1041-1047), which is written to J and contracted to J^T J
@@ -55,7 +56,11 @@ __device__ __forceinline__ void jtj_fdp8_body(const JtjArgs<double>& a, double* 
     constexpr int NPR = DIFF ? N / 2 : N;                  // 16-byte loads per panel row
     const int q = lane >> 4, p = lane & 15;
     const size_t m = a.m;
-    const fdp_v2d* __restrict__ Y = reinterpret_cast<const fdp_v2d*>(a.J);   // m x N pairs (DIFF: m x N / 2 column pairs)
+    const fdp_v2d* __restrict__ Y = reinterpret_cast<const fdp_v2d*>(a.J);   // m x n pairs (DIFF: m x N / 2 column pairs)
+    // The problem's n may be smaller than the padded N = 16 NCB of this instantiation (pair panel only: any 128 < n <= 256 runs
+    // the next even NCB; LS:911-926 is generic in n): nr is the row stride of the panel (in pairs) and of J; pairs of padding
+    // columns read a valid address and behave like collapsed intervals (zeros in LDS, nothing written to J).
+    const int nr = DIFF ? N : a.n;
 
     // ---- producer side: load i of this lane is pair (row prow[i] of the wave's two rows, column pcol[i])
     //      (DIFF: columns 2 pcol[i], 2 pcol[i] + 1)
@@ -67,7 +72,9 @@ __device__ __forceinline__ void jtj_fdp8_body(const JtjArgs<double>& a, double* 
         const int f = 64 * i + lane;
         prow[i] = f / NPR;
         pcol[i] = f % NPR;
-        const T t = a.twh[DIFF ? 2 * pcol[i] : pcol[i]];
+        const bool padc = !DIFF && pcol[i] >= nr;
+        const T t = padc ? T(0) : a.twh[DIFF ? 2 * pcol[i] : pcol[i]];
+        if (padc) pcol[i] |= 0x10000;                      // bit 16: a padding column (address 0 of the row is read instead)
         zc[i] = t == 0;                                    // collapsed interval: zero column (LS:1046)
         inv[i] = zc[i] ? 0.0 : 1.0 / t;                    // LS:1047
         if constexpr (DIFF) {
@@ -83,7 +90,7 @@ __device__ __forceinline__ void jtj_fdp8_body(const JtjArgs<double>& a, double* 
         for (int i = 0; i < NI; ++i) {
             size_t row = row0 + prow[i];
             row = row < m ? row : m - 1;
-            b[i] = __builtin_nontemporal_load(&Y[row * (size_t)NPR + pcol[i]]);   // the panel is read once
+            b[i] = __builtin_nontemporal_load(&Y[row * (size_t)(DIFF ? NPR : nr) + ((pcol[i] & 0x10000) ? 0 : pcol[i])]);   // the panel is read once
         }
         size_t yr = row0 + (lane & (C::RP - 1));
         yr = yr < m ? yr : m - 1;
@@ -107,8 +114,8 @@ __device__ __forceinline__ void jtj_fdp8_body(const JtjArgs<double>& a, double* 
                 d += -1.0 * b[i].y;                        // axpy(-1, mBuffer, Jj)   LS:1045
                 T v = zc[i] ? 0.0 : d * inv[i];            // scal(1 / twh, Jj)       LS:1047
                 v = rok ? v : 0.0;                         // rows past m contribute nothing
-                slot[(C::RP * ROLE + prow[i]) * C::LDJ + pcol[i]] = v;
-                if (rok) __builtin_nontemporal_store(v, &a.Jout[row * (size_t)N + pcol[i]]);
+                slot[(C::RP * ROLE + prow[i]) * C::LDJ + (pcol[i] & 0xffff)] = v;
+                if (rok && !(pcol[i] & 0x10000)) __builtin_nontemporal_store(v, &a.Jout[row * (size_t)nr + pcol[i]]);
             }
         }
         if (lane < C::RP) slot[C::RS * C::LDJ + C::RP * ROLE + lane] = (row0 + lane < m) ? yb : 0.0;

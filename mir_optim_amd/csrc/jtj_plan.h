@@ -4,7 +4,7 @@
 // Kernel by shape, LS = /root/reference/source/mir/optim/least_squares.d:
 //   f64, n <= 128               k_jtj_fdp<NCB, true>    finite-difference panel -> J, J^T J, J^T y   (LS:1041-1047, 1052, 1065)
 //   f64, n <= 128               k_jtj_fdp<NCB, false>   J^T J + J^T y of a given J (odd n: 8-byte loads) (LS:1052, 1065)
-//   f64, 128 < n <= 256, n % 32 == 0           k_jtj_fdp8   finite-difference panel -> J, J^T J, J^T y
+//   f64, 128 < n <= 256 (any n, m)             k_jtj_fdp8   finite-difference panel -> J, J^T J, J^T y
 //   f64, 128 < n <= 256 (n % 16 == 0, m even)  k_jtj8   eight-wave LDS-DMA ring, J^T J of a given J
 //   f32, n <= 128, n % 4 == 0   k_jtj_pc32
 //   everything else             k_jtj (n <= 128, register streaming) / k_jtj_wide (any n: 64-column tile pairs)
@@ -67,8 +67,8 @@ struct JtjPlan {
     bool ring8 = false;     // 128 < n <= 256, f64, n % 16 == 0, m even: eight-wave LDS-DMA ring (jtj_ring8.h)
     bool fdp = false;       // f64, n <= 128, any m: producer / consumer kernel (jtj_fdp.h) for the finite-difference J^T J
     bool fdp_plain = false; // ... and for the plain J^T J / the difference panel (odd n: the element-wise producer)
-    bool fdp8 = false;      // f64, 128 < n <= 256, n % 32 == 0, any m: eight producer + consumer waves (jtj_fdp8.h), FD J^T J only
-    int fdp8_nblk = 0, fdp8_slab_len = 0;
+    bool fdp8 = false;      // f64, 128 < n <= 256, any n and m: eight producer + consumer waves (jtj_fdp8.h), FD J^T J only
+    int fdp8_nblk = 0, fdp8_slab_len = 0, fdp8_ncb = 0;     // fdp8_ncb: the even block count the kernel is compiled for (>= ncb)
     bool pc32 = false;      // f32, n <= 128, n % 4 == 0, any m: producer / consumer kernel on v_mfma_f32_16x16x4 (jtj_pc32.h), plain J^T J
     int pc32_nblk = 0;
     int njobs = 1;
@@ -83,12 +83,14 @@ JtjPlan jtj_plan(size_t m, int n, int num_cu)
     p.ncb = (n + 15) / 16;
     const int nacc = p.ncb * (p.ncb + 1) / 2;
     p.slab_len = (nacc * 4 + p.ncb) * kWave;
-    if (sizeof(T) == 8 && n > 128 && n <= 256 && n % 32 == 0) {
+    if (sizeof(T) == 8 && n > 128 && n <= 256) {
+        // any n: the kernel is compiled for n rounded up to a multiple of 32 (an even number of 16-column blocks)
         p.fdp8 = true;
+        p.fdp8_ncb = 2 * ((n + 31) / 32);
         const size_t stot = (m + 15) / 16;
         const size_t want = (stot + 7) / 8;                    // at least ~8 stages per workgroup
         p.fdp8_nblk = (int)(want < (size_t)num_cu ? (want ? want : 1) : (size_t)num_cu);   // one workgroup per CU
-        p.fdp8_slab_len = p.slab_len;
+        p.fdp8_slab_len = (p.fdp8_ncb * (p.fdp8_ncb + 1) / 2 * 4 + p.fdp8_ncb) * kWave;
     }
     if (sizeof(T) == 8 && n > 128 && n <= 256 && n % 16 == 0 && m % 2 == 0) {
         p.ring8 = true;

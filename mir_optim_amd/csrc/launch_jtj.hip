@@ -23,10 +23,12 @@ namespace {
 
 // ---- slab reduction shared by every one-job kernel: -> packed[ n(n+1)/2 + n ]
 template <typename T>
-hipError_t reduce_slabs(const JtjPlan& p, const JtjArgs<T>& a, T* packed, hipStream_t s, const JtjUnpack<T>& u, int nslabs, int slab_len)
+hipError_t reduce_slabs(const JtjPlan& p, const JtjArgs<T>& a, T* packed, hipStream_t s, const JtjUnpack<T>& u, int nslabs, int slab_len,
+                        int ncb = 0)
 {
+    // ncb: the block count the slabs were laid out for (a kernel compiled for a padded n: > p.ncb; rows / columns >= n are skipped)
     const int rb = (slab_len + 31) / 32;
-    MIRLSQ_LAUNCH(k_jtj_slab_reduce<T>, dim3(rb), dim3(1024), 0, s, a.slabs, nslabs, slab_len, p.ncb, a.n, packed, u.JJ, u.Jy);
+    MIRLSQ_LAUNCH(k_jtj_slab_reduce<T>, dim3(rb), dim3(1024), 0, s, a.slabs, nslabs, slab_len, ncb ? ncb : p.ncb, a.n, packed, u.JJ, u.Jy);
     return hipGetLastError();
 }
 
@@ -186,12 +188,13 @@ hipError_t fdp8_launch(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
 {
     if constexpr (sizeof(T) == 8) {
         if constexpr (DIFF) {                              // two columns per 16-byte load: whole loads per row need n % 64 == 0
-            switch (p.ncb) {
+            if (a.n % 64 != 0) return hipErrorInvalidValue;
+            switch (p.fdp8_ncb) {
             case 12: return fdp8_one<12, true>(p, a, s);
             case 16: return fdp8_one<16, true>(p, a, s);
             }
         } else {
-            switch (p.ncb) {
+            switch (p.fdp8_ncb) {                          // the pair panel: any n, compiled for n rounded up to a multiple of 32
             case 10: return fdp8_one<10>(p, a, s);
             case 12: return fdp8_one<12>(p, a, s);
             case 14: return fdp8_one<14>(p, a, s);
@@ -235,7 +238,7 @@ hipError_t jtj_run_fd(const JtjPlan& p, const JtjArgs<T>& a, T* packed, hipStrea
     if (p.fdp8) {
         const hipError_t e = fdp8_launch<T>(p, a, s);
         if (e != hipSuccess) return e;
-        return reduce_slabs<T>(p, a, packed, s, u, p.fdp8_nblk, p.fdp8_slab_len);
+        return reduce_slabs<T>(p, a, packed, s, u, p.fdp8_nblk, p.fdp8_slab_len, p.fdp8_ncb);
     }
     if (!p.fdp) return hipErrorInvalidValue;
     const hipError_t e = fdp_launch<T, true>(p, a, s);
@@ -249,7 +252,7 @@ hipError_t jtj_run_fd_diff(const JtjPlan& p, const JtjArgs<T>& a, T* packed, hip
     if (p.fdp8 && a.n % 64 == 0) {
         const hipError_t e = fdp8_launch<T, true>(p, a, s);
         if (e != hipSuccess) return e;
-        return reduce_slabs<T>(p, a, packed, s, u, p.fdp8_nblk, p.fdp8_slab_len);
+        return reduce_slabs<T>(p, a, packed, s, u, p.fdp8_nblk, p.fdp8_slab_len, p.fdp8_ncb);
     }
     if (!p.fdp_plain) return hipErrorInvalidValue;
     const hipError_t e = fdp_launch<T, false, true>(p, a, s);

@@ -32,7 +32,9 @@ def ref_fill(Yrm, twh):
                                  (6, 112), (100000, 128), (4097, 128), (10001, 64), (1, 16), (33, 32), (7777, 112),
                                  (5000, 100), (3001, 7), (2048, 17), (999, 33), (6000, 127), (40, 1), (12345, 90),
                                  # 128 < n <= 256, n % 32 == 0: k_jtj_fdp8 (eight producer + consumer waves, jtj_fdp8.h)
-                                 (4096, 256), (5001, 160), (33, 192), (10003, 224), (50000, 256), (1, 256), (17, 160)])
+                                 (4096, 256), (5001, 160), (33, 192), (10003, 224), (50000, 256), (1, 256), (17, 160),
+                                 # ... and any other n there: the kernel of n rounded up to a multiple of 32, zero padding columns
+                                 (4096, 200), (5001, 250), (33, 129), (10003, 161), (20000, 255), (1, 193), (777, 240)])
 def test_fd_jtj_exact_integers(m, n):
     rng = np.random.default_rng(m + n)
     Yrm = rng.integers(-8, 9, size=(m, 2 * n)).astype(np.float64)
