@@ -223,3 +223,36 @@ def test_resident_does_not_fit_falls_back(oracle):
     assert np.allclose(x, g["truth"], rtol=5e-3, atol=1e-3)
     with pytest.raises(W.ResidentDoesNotFit):
         W.Resident.gauss_sum(g["t"], g["data"], K=5).solve(g["x0"], g["lower"], g["upper"])
+
+
+def test_two_host_threads_run_resident_solves_concurrently(oracle):
+    """Re-entrancy (SURVEY 8b "Threading"): two host threads, each with its own problem, stream and workspace, launch resident
+    solves at the same time, several times over -- small slices (both grids can be resident together) and cfg-2-sized ones (a CU's
+    LDS holds one workgroup: the second cooperative launch waits for the first). Every solve returns the bits of the same solve
+    run alone."""
+    import threading
+    probs = []
+    for m, K in ((6000, 3), (100000, 5)):
+        g = P.gauss_sum(m, K=K)
+        probs.append((g, W.Resident.gauss_sum(g["t"], g["data"], K=K), W.Resident.gauss_sum(g["t"], g["data"], K=K)))
+    for g, ra, rb in probs:
+        ref_res, ref_x, _ = ra.solve(g["x0"], g["lower"], g["upper"])
+        out, err = {}, []
+
+        def work(tag, r):
+            try:
+                got = []
+                for _ in range(4):
+                    res, x, st = r.solve(g["x0"], g["lower"], g["upper"])
+                    got.append((x.tobytes(), int(res.status), res.iterations, res.fCalls, res.residual, st["abort_code"]))
+                out[tag] = got
+            except BaseException as e:      # noqa: BLE001
+                err.append(e)
+        ts = [threading.Thread(target=work, args=(k, r)) for k, r in (("a", ra), ("b", rb))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(300)
+        assert not any(t.is_alive() for t in ts) and not err, err
+        want = (ref_x.tobytes(), int(ref_res.status), ref_res.iterations, ref_res.fCalls, ref_res.residual, 0)
+        assert all(q == want for q in out["a"] + out["b"])
