@@ -274,7 +274,7 @@ struct Solver {
     // ---- solver_jacobian.hip
     bool broyden_lowrank(const T* y_dev, const T* yold_dev);
     bool plain_products(const T* y_vec);
-    bool unpack_in_reduce(bool fd) const { return !comm && (fd || jtj_plain_unpacks(plan)); }
+    bool unpack_in_reduce(bool fd, bool broyden = false) const { return !comm && (fd || jtj_plain_unpacks(plan, broyden)); }
     JtjUnpack<T> unpack_target() { JtjUnpack<T> u; u.JJ = B.JJ; u.Jy = B.Jy; return u; }
     bool finish_products(bool direct);
     bool jacobian_products(bool broyden, const T* y_dev, const T* yold_dev);

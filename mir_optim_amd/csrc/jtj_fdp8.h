@@ -44,9 +44,14 @@ template <int NCB> struct JtjFdp8Cfg {
 
 // DIFF: a.J is the m x N row-major DIFFERENCE panel D[i][j] = f(x + h e_j)_i - f(x - h e_j)_i (mir_lsq_gpu_options.fbRowMajorDiff):
 // a 16-byte load is two columns of one row, half as many loads per stage; the producer applies scal(1 / twh) only.
-template <int NCB, int ROLE, bool DIFF = false>
+// PLAIN: a.J is J itself (m x n row-major, any n <= N and any m): the plain J^T J + J^T y of a given Jacobian (resynchronisation
+// after a flush, analytic g) for the shapes the eight-wave ring does not take (n % 16 != 0, odd m). A wave's two rows of a stage
+// are 2 n contiguous doubles, read as a flat array of pairs with 16-byte BUFFER loads (4-byte alignment suffices; past the end of
+// the array reads as zero), each double stored to its own (row, column) of the LDS stage; nothing is written back.
+template <int NCB, int ROLE, bool DIFF = false, bool PLAIN = false>
 __device__ __forceinline__ void jtj_fdp8_body(const JtjArgs<double>& a, double* smem, int lane, size_t s0, size_t S)
 {
+    static_assert(!(DIFF && PLAIN), "one source at a time");
     using T = double;
     using Acc = typename Mma<T>::Acc;
     using C = JtjFdp8Cfg<NCB>;
@@ -60,15 +65,38 @@ __device__ __forceinline__ void jtj_fdp8_body(const JtjArgs<double>& a, double* 
     // The problem's n may be smaller than the padded N = 16 NCB of this instantiation (pair panel only: any 128 < n <= 256 runs
     // the next even NCB; LS:911-926 is generic in n): nr is the row stride of the panel (in pairs) and of J; pairs of padding
     // columns read a valid address and behave like collapsed intervals (zeros in LDS, nothing written to J).
-    const int nr = DIFF ? N : a.n;
+    const int nr = DIFF ? N : a.n;                         // (PLAIN: the row stride of J)
 
     // ---- producer side: load i of this lane is pair (row prow[i] of the wave's two rows, column pcol[i])
     //      (DIFF: columns 2 pcol[i], 2 pcol[i] + 1)
     int prow[NI], pcol[NI];
     T inv[NI], inv1[DIFF ? NI : 1];
     bool zc[NI];
+    // PLAIN: pair-load i of this lane covers doubles e0 = 2 (64 i + lane), e0 + 1 of the wave's 2 n contiguous doubles
+    constexpr int NIP = (N + 63) / 64;
+    int off0[PLAIN ? NIP : 1], off1[PLAIN ? NIP : 1];      // LDS offsets inside the slot (-1: no element)
+    typedef unsigned int fdp8_u4 __attribute__((ext_vector_type(4)));
+    fdp8_u4 bp[PLAIN ? NIP : 1];
+    const size_t rowb = s0 * C::RS < m ? s0 * C::RS : m;
+    const size_t left = PLAIN ? (m - rowb) * (size_t)nr * sizeof(T) : 0;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(a.J + (PLAIN ? rowb * (size_t)nr : 0)), 0, (int)(left < 0xffffffffull ? left : 0xffffffffull), 0x00020000);
+    if constexpr (PLAIN) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
+        for (int i = 0; i < NIP; ++i) {
+            const int e0 = 2 * (64 * i + lane), e1 = e0 + 1;
+            off0[i] = e0 < C::RP * nr ? (C::RP * ROLE + e0 / nr) * C::LDJ + e0 % nr : -1;
+            off1[i] = e1 < C::RP * nr ? (C::RP * ROLE + e1 / nr) * C::LDJ + e1 % nr : -1;
+        }
+        // the padding columns (nr .. N - 1) of this wave's rows, both slots: zero for the whole kernel
+        for (int e = lane; e < C::RP * (N - nr); e += kWave) {
+            const int o = (C::RP * ROLE + e / (N - nr)) * C::LDJ + nr + e % (N - nr);
+            smem[o] = 0.0;
+            smem[C::SLOT_DOUBLES + o] = 0.0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < (PLAIN ? 0 : NI); ++i) {
         const int f = 64 * i + lane;
         prow[i] = f / NPR;
         pcol[i] = f % NPR;
@@ -86,8 +114,13 @@ __device__ __forceinline__ void jtj_fdp8_body(const JtjArgs<double>& a, double* 
     T yb = 0;
     auto issue = [&](size_t t) {
         const size_t row0 = (s0 + t) * C::RS + C::RP * (size_t)ROLE;
+        if constexpr (PLAIN) {
+            const unsigned base = (unsigned)((row0 - rowb) * (size_t)nr * sizeof(T));
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
+            for (int i = 0; i < NIP; ++i) bp[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(base + 16u * (unsigned)(64 * i + lane)), 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < (PLAIN ? 0 : NI); ++i) {
             size_t row = row0 + prow[i];
             row = row < m ? row : m - 1;
             b[i] = __builtin_nontemporal_load(&Y[row * (size_t)(DIFF ? NPR : nr) + ((pcol[i] & 0x10000) ? 0 : pcol[i])]);   // the panel is read once
@@ -99,8 +132,15 @@ __device__ __forceinline__ void jtj_fdp8_body(const JtjArgs<double>& a, double* 
     auto convert = [&](size_t t) {
         T* slot = smem + (t & 1) * C::SLOT_DOUBLES;
         const size_t row0 = (s0 + t) * C::RS + C::RP * (size_t)ROLE;
+        if constexpr (PLAIN) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
+            for (int i = 0; i < NIP; ++i) {
+                if (off0[i] >= 0) slot[off0[i]] = __hiloint2double((int)bp[i].y, (int)bp[i].x);
+                if (off1[i] >= 0) slot[off1[i]] = __hiloint2double((int)bp[i].w, (int)bp[i].z);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < (PLAIN ? 0 : NI); ++i) {
             const size_t row = row0 + prow[i];
             const bool rok = row < m;
             if constexpr (DIFF) {
@@ -182,7 +222,7 @@ __device__ __forceinline__ void jtj_fdp8_body(const JtjArgs<double>& a, double* 
         }
 }
 
-template <int NCB, bool DIFF = false>
+template <int NCB, bool DIFF = false, bool PLAIN = false>
 __global__ __launch_bounds__(JtjFdp8Cfg<NCB>::THREADS, 1) void k_jtj_fdp8(JtjArgs<double> a)
 {
     using C = JtjFdp8Cfg<NCB>;
@@ -196,14 +236,14 @@ __global__ __launch_bounds__(JtjFdp8Cfg<NCB>::THREADS, 1) void k_jtj_fdp8(JtjArg
     const size_t s1 = s0 + per < Stot ? s0 + per : Stot;
     const size_t S = s1 - s0;
     switch (wave) {
-    case 0: jtj_fdp8_body<NCB, 0, DIFF>(a, smem, lane, s0, S); break;
-    case 1: jtj_fdp8_body<NCB, 1, DIFF>(a, smem, lane, s0, S); break;
-    case 2: jtj_fdp8_body<NCB, 2, DIFF>(a, smem, lane, s0, S); break;
-    case 3: jtj_fdp8_body<NCB, 3, DIFF>(a, smem, lane, s0, S); break;
-    case 4: jtj_fdp8_body<NCB, 4, DIFF>(a, smem, lane, s0, S); break;
-    case 5: jtj_fdp8_body<NCB, 5, DIFF>(a, smem, lane, s0, S); break;
-    case 6: jtj_fdp8_body<NCB, 6, DIFF>(a, smem, lane, s0, S); break;
-    default: jtj_fdp8_body<NCB, 7, DIFF>(a, smem, lane, s0, S); break;
+    case 0: jtj_fdp8_body<NCB, 0, DIFF, PLAIN>(a, smem, lane, s0, S); break;
+    case 1: jtj_fdp8_body<NCB, 1, DIFF, PLAIN>(a, smem, lane, s0, S); break;
+    case 2: jtj_fdp8_body<NCB, 2, DIFF, PLAIN>(a, smem, lane, s0, S); break;
+    case 3: jtj_fdp8_body<NCB, 3, DIFF, PLAIN>(a, smem, lane, s0, S); break;
+    case 4: jtj_fdp8_body<NCB, 4, DIFF, PLAIN>(a, smem, lane, s0, S); break;
+    case 5: jtj_fdp8_body<NCB, 5, DIFF, PLAIN>(a, smem, lane, s0, S); break;
+    case 6: jtj_fdp8_body<NCB, 6, DIFF, PLAIN>(a, smem, lane, s0, S); break;
+    default: jtj_fdp8_body<NCB, 7, DIFF, PLAIN>(a, smem, lane, s0, S); break;
     }
 }
 

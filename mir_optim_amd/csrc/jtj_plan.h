@@ -6,6 +6,7 @@
 //   f64, n <= 128               k_jtj_fdp<NCB, false>   J^T J + J^T y of a given J (odd n: 8-byte loads) (LS:1052, 1065)
 //   f64, 128 < n <= 256 (any n, m)             k_jtj_fdp8   finite-difference panel -> J, J^T J, J^T y
 //   f64, 128 < n <= 256 (n % 16 == 0, m even)  k_jtj8   eight-wave LDS-DMA ring, J^T J of a given J
+//   f64, 128 < n <= 256, the other n and m     k_jtj_fdp8<., false, true>   J^T J of a given J (flat buffer loads)
 //   f32, n <= 128, n % 4 == 0   k_jtj_pc32
 //   everything else             k_jtj (n <= 128, register streaming) / k_jtj_wide (any n: 64-column tile pairs)
 // MIR_LSQ_VARIANT_BROYDEN_REWRITE runs the Broyden pass as the literal restatement of LS:1003-1006 (J rewritten):
@@ -163,7 +164,7 @@ inline size_t jtj_slab_elems(const JtjPlan& a)
 }
 
 // does jtj_run honour a JtjUnpack for this plan? (the tile-pair jobs have a reduction of their own; jtj_run_fd* always do)
-inline bool jtj_plain_unpacks(const JtjPlan& p) { return !p.wide; }
+inline bool jtj_plain_unpacks(const JtjPlan& p, bool broyden = false) { return !p.wide || (p.fdp8 && !broyden); }
 // can the m x n DIFFERENCE panel be consumed for this shape? (f64; n <= 128: fdp_plain; n = 192, 256: k_jtj_fdp8)
 inline bool jtj_fd_diff_ok(const JtjPlan& p, int n) { return p.fdp_plain || (p.fdp8 && n % 64 == 0); }
 

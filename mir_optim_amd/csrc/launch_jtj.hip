@@ -176,13 +176,27 @@ hipError_t run_wide(const JtjPlan& p, const JtjArgs<T>& a, bool broyden, T* pack
 }
 
 // ---- k_jtj_fdp8: the finite-difference J^T J for 128 < n <= 256 (jtj_fdp8.h)
-template <int NCB, bool DIFF = false>
+template <int NCB, bool DIFF = false, bool PLAIN = false>
 hipError_t fdp8_one(const JtjPlan& p, const JtjArgs<double>& a, hipStream_t s)
 {
     using FC = JtjFdp8Cfg<NCB>;
-    MIRLSQ_ENSURE_LDS((k_jtj_fdp8<NCB, DIFF>), (size_t)FC::LDS_BYTES);
-    MIRLSQ_LAUNCH((k_jtj_fdp8<NCB, DIFF>), dim3(p.fdp8_nblk), dim3(FC::THREADS), FC::LDS_BYTES, s, a);
+    MIRLSQ_ENSURE_LDS((k_jtj_fdp8<NCB, DIFF, PLAIN>), (size_t)FC::LDS_BYTES);
+    MIRLSQ_LAUNCH((k_jtj_fdp8<NCB, DIFF, PLAIN>), dim3(p.fdp8_nblk), dim3(FC::THREADS), FC::LDS_BYTES, s, a);
     return hipGetLastError();
+}
+// the plain J^T J of a given J for the shapes the eight-wave ring does not take (n % 16 != 0, odd m)
+template <typename T>
+hipError_t fdp8_plain_launch(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
+{
+    if constexpr (sizeof(T) == 8) {
+        switch (p.fdp8_ncb) {
+        case 10: return fdp8_one<10, false, true>(p, a, s);
+        case 12: return fdp8_one<12, false, true>(p, a, s);
+        case 14: return fdp8_one<14, false, true>(p, a, s);
+        case 16: return fdp8_one<16, false, true>(p, a, s);
+        }
+    }
+    return hipErrorInvalidValue;
 }
 template <typename T, bool DIFF = false>
 hipError_t fdp8_launch(const JtjPlan& p, const JtjArgs<T>& a, hipStream_t s)
@@ -221,6 +235,11 @@ hipError_t jtj_run(const JtjPlan& p, const JtjArgs<T>& a, bool broyden, T* packe
         e = ring8_launch<T>(p, a, broyden, s);
         if (e != hipSuccess) return e;
         return reduce_slabs<T>(p, a, packed, s, u, p.nblk, p.slab_len);
+    }
+    if (p.wide && p.fdp8 && !broyden) {                    // 128 < n <= 256 off the ring's grid: the plain flavour of k_jtj_fdp8
+        e = fdp8_plain_launch<T>(p, a, s);
+        if (e != hipSuccess) return e;
+        return reduce_slabs<T>(p, a, packed, s, u, p.fdp8_nblk, p.fdp8_slab_len, p.fdp8_ncb);
     }
     if (p.wide) return run_wide<T>(p, a, broyden, packed, s);
     if (!broyden && p.fdp_plain) {

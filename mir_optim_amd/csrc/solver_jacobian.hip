@@ -94,7 +94,7 @@ bool Solver<T>::jacobian_products(bool broyden, const T* y_dev, const T* yold_de
         ev_end();
         return finish_products(direct);
     }
-    const bool direct = unpack_in_reduce(false);
+    const bool direct = unpack_in_reduce(false, broyden);
     ev_begin(broyden ? 1 : 0);
     if (!ok(jtj_run<T>(plan, a, broyden, B.packed, stream, direct ? unpack_target() : JtjUnpack<T>{}), "jtj kernel")) return false;
     ev_end();

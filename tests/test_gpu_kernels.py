@@ -59,7 +59,9 @@ def test_jtj_wide_n_matches_numpy(m, n):
     assert np.array_equal(JJ, Ji.T @ Ji) and np.array_equal(Jy, Ji.T @ yi)
 
 
-@pytest.mark.parametrize("m,n", [(3001, 96), (3001, 97), (40000, 127), (777, 1), (5000, 31)])
+@pytest.mark.parametrize("m,n", [(3001, 96), (3001, 97), (40000, 127), (777, 1), (5000, 31),
+                                 # 128 < n <= 256 off the eight-wave ring's grid (n % 16 != 0 or odd m): the plain flavour of k_jtj_fdp8
+                                 (3000, 200), (4001, 250), (5000, 129), (4001, 256), (2000, 161), (1, 255), (30001, 208)])
 def test_jtj_exact_integers(m, n):
     """small integers: every partial sum is exact, so the result must be bit-exact (odd n: the element-wise producer of jtj_fdp.h)."""
     rng = np.random.default_rng(5)
