@@ -53,7 +53,8 @@ template <class Model> constexpr int resident_ncb() { return (Model::n + 15) / 1
 template <class Model> size_t resident_lds_bytes(int rows)
 {
     constexpr int NCB = resident_ncb<Model>(), NC = 16 * NCB, NBT = NCB * (NCB + 1) / 2;
-    const size_t R = (size_t)(rows + 31) / 32 * 32;
+    constexpr size_t RPAD = 8 * (mirlsq::res_threads(Model::n) / 64);
+    const size_t R = ((size_t)rows + RPAD - 1) / RPAD * RPAD;
     const size_t doubles = R * (NC + 1) + 3 * R + R * Model::nd + 2 * (size_t)Model::n * Model::nc
         + (size_t)(mirlsq::res_threads(Model::n) / 64) * (NBT * 256 + NC) + 3 * NC
         + (Model::n <= 16 ? (size_t)768 : (size_t)mirlsq::LdsSolveCfg<NCB>::ELEMS);      // n <= 16: the one-wave solve's operands and ladder

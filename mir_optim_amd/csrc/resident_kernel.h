@@ -161,7 +161,8 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
         if constexpr (kResWaves == 8) t += (w[4] + w[5]) + (w[6] + w[7]);
         return t;
     };
-    const int R = (a.rows + 31) / 32 * 32;                  // padded slice: four waves x two MFMA steps of four rows per iteration
+    constexpr int RPAD = 8 * kResWaves;                     // every wave takes two MFMA steps of four rows per iteration
+    const int R = (a.rows + RPAD - 1) / RPAD * RPAD;        // padded slice
     const int row0 = wg * a.rows;
     const int nrows = max(0, min(a.rows, a.m - row0));
     const int G = a.grid, NG = a.groups;
