@@ -36,7 +36,8 @@ namespace mirlsq {
 // Threads of a workgroup. 256: what lm_solve_body (n > 16) is written for. The kernel also runs with 512 for n <= 16 (the one-wave
 // solve does not care, and two waves a SIMD keep the f64 vector pipe busier in the one-row-per-thread phases: measured at cfg 2,
 // trial residuals + products + refreshes 524 -> 392 us per fit) -- but two waves a SIMD leave a wave 256 registers where one has
-// 512, the solve then spills 150-240 of them into the round loop and workgroup 0's share grows by more (384 -> 700 us): 256 it is.
+// 512, the solve then spills 150-240 of them into the round loop and workgroup 0's share grows by more (384 -> 700 us; with the
+// solve out of line -- __noinline__, operands in LDS -- the workers go 338 -> 289 us and workgroup 0 396 -> 908): 256 it is.
 __host__ __device__ constexpr int res_threads(int n) { return n <= 16 ? 256 : kSolveThreads; }
 constexpr int kResGroups = 16;                  // group leaders (first level of the reduction)
 constexpr int kResGroupMax = 16;                // members a leader sums (grid <= 256)
