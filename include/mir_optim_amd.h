@@ -393,14 +393,18 @@ int mir_lsq_batched_kernel_s(const mir_least_squares_settings_s* settings, size_
  * cfg 2). The residual model is a compile-time type of the caller's, as on the batched path. Options and statistics of
  * that launch; every pointer is a DEVICE pointer. */
 enum { MIR_LSQ_RESIDENT_NO_NULL_SKIP = 1u,     /* variant bit: evaluate f also for trials equal to x bit for bit */
-       MIR_LSQ_RESIDENT_UNBOUNDED = 2u };       /* variant bit: the caller asserts that every lower / upper entry is infinite
+       MIR_LSQ_RESIDENT_UNBOUNDED = 2u,         /* variant bit: the caller asserts that every lower / upper entry is infinite
                                                   (the BOXCQP active-set loop is compiled out of workgroup 0's solve) */
+       MIR_LSQ_RESIDENT_NO_LOOKAHEAD = 4u };    /* variant bit: every trial gets a round of its own (no sums of squares of the
+                                                  next damping levels evaluated along; same results bit for bit, for A/B runs) */
 typedef struct mir_lsq_resident_stats {         /* written by the kernel at exit; times in 10 ns ticks of workgroup 0 */
     uint64_t rounds, passes, accepted, rejected, step_guard_rejects, jacobian_full, jacobian_broyden, qp_active_set_passes,
         elided_evaluations;
     uint64_t t_total, t_stage, t_worker, t_group, t_total_wait, t_solver, t_solve_body, t_cmd_wait;
     uint64_t t_w_eval, t_w_fd, t_w_prod;         /* of t_worker: trial residuals, finite-difference refreshes, products + publication */
     uint64_t t_w_mma;                            /* of t_w_prod: the matrix-core loop up to the workgroup's cross-wave hand-over */
+    uint64_t lookahead_rejections;               /* rejected passes decided from a sum of squares evaluated along an earlier round */
+    uint64_t t_look;                             /* of t_solver: those decisions (own rows + collecting the others' sums) */
     uint32_t abort_code, grid, rows, groups;
 } mir_lsq_resident_stats;
 typedef struct mir_lsq_resident_options {

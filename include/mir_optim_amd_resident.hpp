@@ -46,7 +46,7 @@ struct ResidentPlan {
 
 constexpr size_t kResidentLdsLimit = 160 * 1024 - 2048;      // the kernel's static LDS (solve reductions, command) comes on top
 constexpr int kResidentMinRows = 64;                          // below this a slice is not worth a workgroup
-constexpr size_t kResidentSyncBytes = (2 * mirlsq::kResGroups + 2) * 128;    // counters, flags, seq, abort: zeroed before every launch
+constexpr size_t kResidentSyncBytes = (2 * mirlsq::kResGroups + 3) * 128;    // counters, flags, seq, abort, look-ahead counter: zeroed before every launch
 
 template <class Model> constexpr int resident_ncb() { return (Model::n + 15) / 16; }
 
@@ -64,7 +64,7 @@ template <class Model> size_t resident_lds_bytes(int rows)
 namespace detail {
 inline size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct ResidentCarve {
-    size_t sync, cmd, partial, gtotal, jj0, jj1, jy0, jy1, xs, dx, trial, st, rec, pm, a, fg, vec, ivec, total;
+    size_t sync, cmd, look, partial, gtotal, jj0, jj1, jy0, jy1, xs, dx, trial, st, rec, pm, a, fg, vec, ivec, total;
 };
 template <class Model> ResidentCarve resident_carve(int grid)
 {
@@ -74,7 +74,8 @@ template <class Model> ResidentCarve resident_carve(int grid)
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += up(bytes, 256); return o; };
     c.sync = take(kResidentSyncBytes);
-    c.cmd = take(mirlsq::kResCmdWords * 8);
+    c.cmd = take(mirlsq::kResCmdWordsAll * 8);
+    c.look = take((size_t)grid * 4 * 8);
     c.partial = take((size_t)grid * PL::STRIDE * 8);
     c.gtotal = take((size_t)mirlsq::kResGroups * PL::STRIDE * 8);
     c.jj0 = take(n * n * 8); c.jj1 = take(n * n * 8);
@@ -167,6 +168,8 @@ int launch_resident(const mir_least_squares_settings_d* S, size_t m, double* x, 
     a.flag = a.cnt + 32 * kResGroups;
     a.seq = a.flag + 32 * kResGroups;
     a.abort = a.seq + 32;
+    a.lcnt = a.abort + 32;
+    a.look = reinterpret_cast<double*>(ws + c.look);
     a.cmd = reinterpret_cast<unsigned long long*>(ws + c.cmd);
     a.partial = reinterpret_cast<double*>(ws + c.partial);
     a.gtotal = reinterpret_cast<double*>(ws + c.gtotal);

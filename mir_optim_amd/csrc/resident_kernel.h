@@ -46,7 +46,8 @@ constexpr double kResSpinSeconds = 20.0;
 
 enum : uint32_t { kResEval = 1, kResEvalSpec = 2, kResFd = 3, kResExit = 4 };          // command actions
 enum : uint32_t { kResPreAccept = 1, kResPreCommitJ = 2 };                             // what to do with the previous trial first
-enum : uint32_t { kResVariantNoNullSkip = MIR_LSQ_RESIDENT_NO_NULL_SKIP, kResVariantUnbounded = MIR_LSQ_RESIDENT_UNBOUNDED };
+enum : uint32_t { kResVariantNoNullSkip = MIR_LSQ_RESIDENT_NO_NULL_SKIP, kResVariantUnbounded = MIR_LSQ_RESIDENT_UNBOUNDED,
+                  kResVariantNoLookahead = MIR_LSQ_RESIDENT_NO_LOOKAHEAD };
 
 using ResidentStats = mir_lsq_resident_stats;     // written by workgroup 0 at exit (times: 10 ns ticks)
 
@@ -69,6 +70,11 @@ template <int NCB> struct ResPayload {
 
 constexpr int kResCMax = 64;                     // per-point constants of a model (Model::nc)
 constexpr int kResCmdWords = 2 * kResNMax + 2 + kResCMax;   // point | dx | 1 / dx.dx | action + preops << 32 | the point's constants
+// Look-ahead (n <= 16, section "look-ahead" in the kernel): behind the command, the constants of up to kResLookMax FURTHER ladder
+// levels' trial points; bits 16-17 of the action word say how many. Workers evaluate their sums of squares AFTER they have
+// published the round's payload -- while the leaders and workgroup 0 are busy and they would wait -- into look[wg][level].
+constexpr int kResLookMax = 3;
+constexpr int kResCmdWordsAll = kResCmdWords + kResLookMax * kResCMax;
 
 struct ResidentArgs {
     LmSettingsDev<double> set;
@@ -86,7 +92,9 @@ struct ResidentArgs {
     uint32_t* flag;                     // groups flags, 32 words apart
     uint32_t* seq;                      // command sequence number
     uint32_t* abort;
-    unsigned long long* cmd;            // kResCmdWords
+    uint32_t* lcnt;                     // look-ahead sums published (one add per workgroup and round that carries any)
+    double* look;                       // grid x 4: the workgroups' look-ahead sums of squares
+    unsigned long long* cmd;            // kResCmdWordsAll
     double* JJ[2];                      // n x n each: current / speculative
     double* Jy[2];
     double* xs;                         // n: the solver's x
@@ -154,6 +162,8 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
     __shared__ int s_ok;
     __shared__ double s_w[kResWaves];
     __shared__ unsigned long long s_cmd[kResCmdWords];
+    __shared__ double s_lw[kResLookMax][kResWaves];         // look-ahead: the waves' sums of squares per level
+    __shared__ double s_look[kResGroups + 4];               // ... group sums | [kResGroups + k]: this workgroup's level sums, the total
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wg = blockIdx.x;
@@ -198,6 +208,9 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
     double* lrec = SOL + 720;                                // level k: lambda, ndd, pred, xnorm at lrec + 8 k; ints behind
     int* lreci = reinterpret_cast<int*>(SOL + 752);          // level k: qp_status, qp_iters, flags, offered at lreci + 4 k
     constexpr int JLD = WAVE ? kW16 : N;                     // leading dimension of the J^T J copies
+    // look-ahead needs the ladder of the one-wave solve, room for 1 + kResLookMax constant sets in Cl (2 N of them) and one
+    // thread per constant when the command is read
+    constexpr bool LOOK = WAVE && N >= 2 && kResLookMax * NCN <= kResThreads;
 
     int iy = 0, it = 1;                                     // roles of Yb's first two vectors
     constexpr int iu = 2;
@@ -245,7 +258,12 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
     bool lad_valid = false;                                 // n <= 16: the ladder in LDS was solved on the current J^T J, J^T y, x
     int lad_level = 0;                                      // its level the pass being decided uses
     int phase = 0;                                          // 0: initial residual, 1: refresh products, 2: trial
-    uint64_t n_rounds = 0, n_passes = 0, n_acc = 0, n_rej = 0, n_guard = 0, n_fd = 0, n_br = 0, n_qp = 0, n_elided = 0;
+    uint32_t nlook = 0;                                     // everybody: look-ahead levels of the command being executed
+    int look_n = 0, look_base = 0;                          // workgroup 0: levels look_base + 1 ... + look_n of the ladder were sent along
+    uint32_t look_target = 0;                               // ... value of *lcnt when every other workgroup has published them
+    bool look_fetched = false;
+    uint64_t n_rounds = 0, n_passes = 0, n_acc = 0, n_rej = 0, n_guard = 0, n_fd = 0, n_br = 0, n_qp = 0, n_elided = 0, n_look = 0;
+    long long t_look = 0;
     uint32_t tr_count = 0;
     auto trace = [&](int ev, uint32_t iters, double lam, double res, double tres, double dd) {
         if (tid == 0 && a.trace) {
@@ -266,6 +284,27 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
             *a.result = r;
             if (a.stats) a.stats->abort_code = code;
         }
+    };
+
+    // Sums of squares of f at `count` further points (constant sets first, first + 1, ... of Cl) over the slice's rows: the SAME
+    // per-thread order, wave sum and wave order as the trial evaluation of step (2), so a level's sum has the bits a round of its
+    // own would produce. Result in s_look[kResGroups + k], k < count.
+    auto look_sums = [&](int first, int count) {
+        double q0 = 0, q1 = 0, q2 = 0;
+        for (int i = tid; i < R; i += kResThreads) {
+            if (i < nrows) {                                                   // (padding rows add fma(0, 0, s) = s)
+                const double* row = Dl + (size_t)i * ND;
+                const double v0 = Model::eval(row, Cl + (size_t)first * NCN);
+                q0 = fma(v0, v0, q0);
+                if (count > 1) { const double v1 = Model::eval(row, Cl + (size_t)(first + 1) * NCN); q1 = fma(v1, v1, q1); }
+                if (count > 2) { const double v2 = Model::eval(row, Cl + (size_t)(first + 2) * NCN); q2 = fma(v2, v2, q2); }
+            }
+        }
+        q0 = wave_sum(q0); q1 = wave_sum(q1); q2 = wave_sum(q2);
+        if (lane == 0) { s_lw[0][wave] = q0; s_lw[1][wave] = q1; s_lw[2][wave] = q2; }
+        __syncthreads();
+        if (tid < count) s_look[kResGroups + tid] = wave_total(s_lw[tid]);
+        __syncthreads();
     };
 
     for (;;) {
@@ -459,6 +498,21 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
         }
         if (clk) { const long long t = wall_clock64(); t_group += t - tw0; tw0 = t; }
 
+        // =================================================================================== look-ahead (everybody but workgroup 0)
+        // A rejected trial is followed by the SAME system with a larger damping, and the one-wave solve has already produced the
+        // next levels of that ladder (solve_wave16.h). Their trial points came with the command: evaluate their sums of squares
+        // now -- the leaders and workgroup 0 are at work for ~10 us, this workgroup would wait for the next command -- so that
+        // workgroup 0 can book a rejected level WITHOUT a round of its own (LS:1112-1130 need nothing but the number).
+        if constexpr (LOOK) {
+            if (nlook > 0 && wg != 0) {
+                look_sums(1, (int)nlook);
+                if (tid < (int)nlook) res_st(a.look + (size_t)wg * 4 + tid, s_look[kResGroups + tid]);
+                res_drain();
+                __syncthreads();
+                if (tid == 0) __hip_atomic_fetch_add(a.lcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+
         // =================================================================================== workgroup 0: the solver
         if (wg == 0) {
             if (wave == 0) {
@@ -626,6 +680,7 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
                             __syncthreads();
                             lad_level = 0;
                             lad_valid = true;
+                            look_n = 0;
                         }
                         rec.lambda = lrec[8 * lad_level]; rec.new_dx_dot = lrec[8 * lad_level + 1]; rec.predicted = lrec[8 * lad_level + 2];
                         rec.trial_xnorm = lrec[8 * lad_level + 3];
@@ -675,6 +730,60 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
                         where = kCond;
                         continue;
                     }
+                    if constexpr (LOOK) {
+                        if (look_n > 0 && lad_valid && lad_level > look_base && lad_level <= look_base + look_n) {
+                            // this level's trial point went out with the last command: its sum of squares is there (or about
+                            // to be). Own rows now; the others' in the order the leaders and the totals use (members of a group
+                            // by rank, groups by number), so the number is the one a round would have produced.
+                            long long tl0 = 0;
+                            if (clk) tl0 = wall_clock64();
+                            const int k = lad_level - look_base;               // 1 ... look_n
+                            look_sums(k, 1);
+                            if (!look_fetched) {
+                                if (wave == 0) {
+                                    const bool good = res_wait_ge(a.lcnt, look_target, a.abort);
+                                    if (lane == 0) s_ok = good ? 1 : 0;
+                                }
+                                __syncthreads();
+                                if (!s_ok) { fail_out(4); return; }
+                                look_fetched = true;
+                            }
+                            if (tid < NG) {
+                                const int mem = (G - tid + NG - 1) / NG;
+                                double v[kResGroupMax];
+#pragma unroll
+                                for (int j = 0; j < kResGroupMax; ++j) {
+                                    const int w = tid + NG * (j < mem ? j : mem - 1);
+                                    v[j] = w == 0 ? s_look[kResGroups] : res_ld(a.look + (size_t)w * 4 + (k - 1));
+                                }
+                                double sg = v[0];
+#pragma unroll
+                                for (int j = 1; j < kResGroupMax; ++j) sg = j < mem ? sg + v[j] : sg;
+                                s_look[tid] = sg;
+                            }
+                            __syncthreads();
+                            if (tid == 0) {
+                                double tt = s_look[0];
+                                for (int g = 1; g < NG; ++g) tt += s_look[g];
+                                s_look[kResGroups + 3] = tt;
+                            }
+                            __syncthreads();
+                            const double ahead = s_look[kResGroups + 3];
+                            __syncthreads();
+                            if (clk) t_look += wall_clock64() - tl0;
+                            if (ahead <= Lim<double>::inf() && !(residual - ahead > 0)) {      // LS:1117, 1125-1130
+                                trace(2, iterations, s_lam_used, residual, ahead, s_ndd);
+                                ++n_rej;
+                                ++n_look;
+                                lambda *= a.set.lambdaIncrease * mu;
+                                mu *= 2;
+                                where = kCond;
+                                continue;
+                            }
+                            // an improvement (or not a number): the round below evaluates the level again, with the products an
+                            // accepted step needs
+                        }
+                    }
                     x_nan = (rec.flags & kFlagXNaN) != 0;                      // becomes x if accepted
                     next_action = age < maxAge ? kResEvalSpec : kResEval;
                     phase = 2;
@@ -721,6 +830,7 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
             if (next_action == 0) next_action = kResExit;
 
             // ---- publish the command
+            int nl = 0;                                                        // look-ahead levels sent along
             if (next_action == kResExit) {
                 if (tid < N) a.x[tid] = xsp[tid];
                 if (tid == 0) {
@@ -734,6 +844,19 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
                     if (a.trace_count) *a.trace_count = tr_count;
                 }
             } else {
+                // further ladder levels to evaluate along (plain ones only: offered, solved, an ordinary step)
+                if constexpr (LOOK) {
+                    if (next_action != kResFd && lad_valid && !(a.variant & kResVariantNoLookahead)) {
+                        for (int l = lad_level + 1; l < 4 && nl < kResLookMax; ++l) {
+                            if (lreci[4 * l + 3] == 0 || lreci[4 * l] != 0) break;
+                            if (lreci[4 * l + 2] & (kFlagDxNaN | kFlagStepTooLong | kFlagNullStep | kFlagGradSmall | kFlagXNaN)) break;
+                            if (!(lrec[8 * l] <= a.set.maxLambda)) break;
+                            ++nl;
+                        }
+                    }
+                }
+                look_n = nl; look_base = lad_level; look_fetched = false;
+                if (nl > 0) look_target += (uint32_t)(G - 1);
                 const double* pt = next_action == kResFd ? xsp : trp + (WAVE ? 16 * lad_level : 0);
                 if (tid < kResNMax) {
                     res_st(a.cmd + tid, (unsigned long long)__double_as_longlong(tid < N ? pt[tid] : 0.0));
@@ -742,11 +865,18 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
                 if (tid == 0) res_st(a.cmd + 2 * kResNMax, (unsigned long long)__double_as_longlong(1.0 / s_ndd));   // LS:1002
                 if (next_action != kResFd) {
                     if (tid == 0) Model::prepare(pt, Cl);
+                    if constexpr (LOOK) {
+                        if (tid >= 1 && tid <= nl) Model::prepare(trp + 16 * (lad_level + tid), Cl + (size_t)tid * NCN);
+                    }
                     __syncthreads();
                     if (tid < NCN) res_st(a.cmd + 2 * kResNMax + 2 + tid, (unsigned long long)__double_as_longlong(Cl[tid]));
+                    if constexpr (LOOK) {
+                        if (tid < nl * NCN) res_st(a.cmd + kResCmdWords + tid, (unsigned long long)__double_as_longlong(Cl[NCN + tid]));
+                    }
                 }
             }
-            if (tid == 0) res_st(a.cmd + 2 * kResNMax + 1, (unsigned long long)next_action | ((unsigned long long)next_pre << 32));
+            if (tid == 0)
+                res_st(a.cmd + 2 * kResNMax + 1, (unsigned long long)(next_action | ((uint32_t)nl << 16)) | ((unsigned long long)next_pre << 32));
             res_drain();
             __syncthreads();
             if (tid == 0) res_st(a.seq, round);
@@ -762,8 +892,13 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
         __syncthreads();
         if (!s_ok) { fail_out(3); return; }
         if (tid < kResCmdWords) s_cmd[tid] = res_ld(a.cmd + tid);
+        unsigned long long lw = 0;                                             // a look-ahead constant (used if the command says so)
+        if constexpr (LOOK) {
+            if (tid < kResLookMax * NCN) lw = res_ld(a.cmd + kResCmdWords + tid);
+        }
         __syncthreads();
-        action = (uint32_t)(s_cmd[2 * kResNMax + 1] & 0xffffffffull);
+        action = (uint32_t)(s_cmd[2 * kResNMax + 1] & 0xffffull);
+        nlook = LOOK ? (uint32_t)((s_cmd[2 * kResNMax + 1] >> 16) & 3ull) : 0u;
         preops = (uint32_t)(s_cmd[2 * kResNMax + 1] >> 32);
         if (clk) { const long long t = wall_clock64(); t_cmd_wait += t - tw0; }
         if (action == kResExit) break;
@@ -783,6 +918,9 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
             DXl[tid] = tid < N ? __longlong_as_double((long long)s_cmd[kResNMax + tid]) : 0.0;
         }
         if (action != kResFd && tid < NCN) Cl[tid] = __longlong_as_double((long long)s_cmd[2 * kResNMax + 2 + tid]);
+        if constexpr (LOOK) {
+            if (tid < (int)nlook * NCN) Cl[NCN + tid] = __longlong_as_double((long long)lw);
+        }
         __syncthreads();
     }
 
@@ -794,6 +932,7 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
         s.t_w_eval = (uint64_t)t_w_eval; s.t_w_fd = (uint64_t)t_w_fd; s.t_w_prod = (uint64_t)t_w_prod; s.t_w_mma = (uint64_t)t_w_mma;
         s.t_group = (uint64_t)t_group; s.t_total_wait = (uint64_t)t_total_wait; s.t_solver = (uint64_t)t_solver;
         s.t_solve_body = (uint64_t)t_solve_body; s.t_cmd_wait = (uint64_t)t_cmd_wait;
+        s.lookahead_rejections = n_look; s.t_look = (uint64_t)t_look;
         s.abort_code = 0; s.grid = (uint32_t)G; s.rows = (uint32_t)a.rows; s.groups = (uint32_t)NG;
         *a.stats = s;
     }

@@ -30,6 +30,9 @@ def case(seed):
     if os.environ.get("FUZZ_WIDE") == "1":              # the paths above n = 256: tile-pair J^T J, the any-n solve, the wide sweep / rewrite
         n = int(rng.choice([257, 264, 300, 320, 384, 500, 512, 513, 520]))
         m = int(n + rng.integers(0, 300)) if rng.random() < 0.6 else int(n + rng.integers(300, 1500))
+    if os.environ.get("FUZZ_WIDE") == "2":              # above the read-only Broyden sweep's n = 512: J rewritten, everything through the any-n kernels
+        n = int(rng.choice([527, 600, 768, 1000, 1024, 1025, 1100]))
+        m = int(n + rng.integers(0, 200)) if rng.random() < 0.6 else int(n + rng.integers(200, 900))
     A = (2 * rng.random((m, n)) - 1) * np.sqrt(3.0 / n)
     xs = 2 * rng.random(n) - 1
     b = np.tanh(A @ xs) + 10.0 ** rng.integers(-6, -1) * (2 * rng.random(m) - 1)
@@ -49,7 +52,7 @@ def case(seed):
         lo = xs - 0.05 - 0.1 * rng.random(n); up = xs + 0.02 + 0.1 * rng.random(n)
     up = np.maximum(up, lo)
     x0 = np.clip(x0, lo, up)
-    s = dict(maxIterations=int(rng.choice([1, 2, 5, 12, 40] if os.environ.get("FUZZ_WIDE") != "1" else [1, 2, 4, 6, 12])), absTolerance=float(rng.choice([1e-3, 1e-6, 1e-9])),
+    s = dict(maxIterations=int(rng.choice([1, 2, 5, 12, 40] if os.environ.get("FUZZ_WIDE") not in ("1", "2") else [1, 2, 4, 6, 12])), absTolerance=float(rng.choice([1e-3, 1e-6, 1e-9])),
              maxAge=int(rng.choice([0, 0, 1, 3])), gradTolerance=float(rng.choice([2.2e-16, 1e-8, 1e-3])))
     return dict(A=A, b=b, x0=x0, lo=lo, up=up, m=m, n=n, s=s, bounded=kind >= 1)
 
@@ -141,7 +144,7 @@ def main():
     tally = {"same": 0, "trajectory": 0, "MISMATCH": 0}
     # (no OpenBLAS in this process: its thread pool and the GPU runtime do not share a process well -- tests/test_gpu_fullsize.py runs it in one of its own)
     wide_blas = False
-    wide = os.environ.get("FUZZ_WIDE") == "1"
+    wide = os.environ.get("FUZZ_WIDE") in ("1", "2")
     if wide:
         O.lib().lmo_set_omp_threads(8)      # the oracle's tanh-linear residual goes OpenMP above 200 000 elements; a GPU box shows every host core but shares 16
     for k in range(cases):
