@@ -386,7 +386,7 @@ def main_cfg2(args):
                                         "wait_for_command": rst["t_cmd_wait"] * tick, "staging": rst["t_stage"] * tick,
                                         "note": "stamps of workgroup 0 (s_memrealtime) inside the one launch"},
             "jacobian_full": rst["jacobian_full"], "jacobian_broyden": rst["jacobian_broyden"], "rejected": rst["rejected"],
-            "elided_null_steps": rst["elided_evaluations"]})
+            "elided_null_steps": rst["elided_evaluations"], "rejections_decided_by_lookahead": rst["lookahead_rejections"]})
         out["config"].pop("time_split_ms_per_solve", None)
         out["launch_chain"] = chain
         out["roofline"] = {"kernel": "mirlsq::k_lm_resident<ResGaussSum<5>, true> (the one launch of a solve)", "bound": "latency", "achieved": None,

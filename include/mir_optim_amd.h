@@ -395,8 +395,10 @@ int mir_lsq_batched_kernel_s(const mir_least_squares_settings_s* settings, size_
 enum { MIR_LSQ_RESIDENT_NO_NULL_SKIP = 1u,     /* variant bit: evaluate f also for trials equal to x bit for bit */
        MIR_LSQ_RESIDENT_UNBOUNDED = 2u,         /* variant bit: the caller asserts that every lower / upper entry is infinite
                                                   (the BOXCQP active-set loop is compiled out of workgroup 0's solve) */
-       MIR_LSQ_RESIDENT_NO_LOOKAHEAD = 4u };    /* variant bit: every trial gets a round of its own (no sums of squares of the
+       MIR_LSQ_RESIDENT_NO_LOOKAHEAD = 4u,      /* variant bit: every trial gets a round of its own (no sums of squares of the
                                                   next damping levels evaluated along; same results bit for bit, for A/B runs) */
+       MIR_LSQ_RESIDENT_NO_STAMPS = 8u          /* variant bit: mir_lsq_resident_stats carries the counters only, every t_* is 0 (the
+                                                  clock reads of workgroup 0 cost a few per cent of a latency-bound fit) */ };
 typedef struct mir_lsq_resident_stats {         /* written by the kernel at exit; times in 10 ns ticks of workgroup 0 */
     uint64_t rounds, passes, accepted, rejected, step_guard_rejects, jacobian_full, jacobian_broyden, qp_active_set_passes,
         elided_evaluations;
@@ -405,6 +407,7 @@ typedef struct mir_lsq_resident_stats {         /* written by the kernel at exit
     uint64_t t_w_mma;                            /* of t_w_prod: the matrix-core loop up to the workgroup's cross-wave hand-over */
     uint64_t lookahead_rejections;               /* rejected passes decided from a sum of squares evaluated along an earlier round */
     uint64_t t_look;                             /* of t_solver: those decisions (own rows + collecting the others' sums) */
+    uint64_t t_unpack, t_publish;                /* of t_solver: totals of the 16 groups -> LDS; the next command (constants, stores, drain) */
     uint32_t abort_code, grid, rows, groups;
 } mir_lsq_resident_stats;
 typedef struct mir_lsq_resident_options {

@@ -47,7 +47,7 @@ constexpr double kResSpinSeconds = 20.0;
 enum : uint32_t { kResEval = 1, kResEvalSpec = 2, kResFd = 3, kResExit = 4 };          // command actions
 enum : uint32_t { kResPreAccept = 1, kResPreCommitJ = 2 };                             // what to do with the previous trial first
 enum : uint32_t { kResVariantNoNullSkip = MIR_LSQ_RESIDENT_NO_NULL_SKIP, kResVariantUnbounded = MIR_LSQ_RESIDENT_UNBOUNDED,
-                  kResVariantNoLookahead = MIR_LSQ_RESIDENT_NO_LOOKAHEAD };
+                  kResVariantNoLookahead = MIR_LSQ_RESIDENT_NO_LOOKAHEAD, kResVariantNoStamps = MIR_LSQ_RESIDENT_NO_STAMPS };
 
 using ResidentStats = mir_lsq_resident_stats;     // written by workgroup 0 at exit (times: 10 ns ticks)
 
@@ -215,8 +215,9 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
     int iy = 0, it = 1;                                     // roles of Yb's first two vectors
     constexpr int iu = 2;
     long long tk0 = 0, t_stage = 0, t_w_eval = 0, t_w_fd = 0, t_w_prod = 0, t_w_mma = 0, t_worker = 0, t_group = 0, t_total_wait = 0, t_solver = 0, t_solve_body = 0, t_cmd_wait = 0;
-    const bool clk = wg == 0 && tid == 0;
-    if (clk) tk0 = wall_clock64();
+    const bool stamper = wg == 0 && tid == 0;
+    const bool clk = stamper && a.stats && !(a.variant & kResVariantNoStamps);     // s_memrealtime is not free: ~20 reads a round
+    if (stamper) tk0 = wall_clock64();
 
     // ---- stage the slice's row data; zero J, the vectors and the padding
     for (int e = tid; e < R * JS; e += kResThreads) Jl[e] = 0;
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
     uint32_t look_target = 0;                               // ... value of *lcnt when every other workgroup has published them
     bool look_fetched = false;
     uint64_t n_rounds = 0, n_passes = 0, n_acc = 0, n_rej = 0, n_guard = 0, n_fd = 0, n_br = 0, n_qp = 0, n_elided = 0, n_look = 0;
-    long long t_look = 0;
+    long long t_look = 0, t_unpack = 0, t_publish = 0;
     uint32_t tr_count = 0;
     auto trace = [&](int ev, uint32_t iters, double lam, double res, double tres, double dd) {
         if (tid == 0 && a.trace) {
@@ -559,6 +560,7 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
             }
             __syncthreads();
 
+            if (clk) t_unpack += wall_clock64() - tw0;
             // ---- the loop of LS:972-1175, resumed where the last command left it
             uint32_t next_action = 0, next_pre = 0;
             enum { kTop, kAfterJac, kSolve, kAfterTrial, kCond, kDone } where;
@@ -830,6 +832,8 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
             if (next_action == 0) next_action = kResExit;
 
             // ---- publish the command
+            long long tpub0 = 0;
+            if (clk) tpub0 = wall_clock64();
             int nl = 0;                                                        // look-ahead levels sent along
             if (next_action == kResExit) {
                 if (tid < N) a.x[tid] = xsp[tid];
@@ -881,7 +885,7 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
             __syncthreads();
             if (tid == 0) res_st(a.seq, round);
             ++n_rounds;
-            if (clk) { const long long t = wall_clock64(); t_solver += t - tw0; tw0 = t; }
+            if (clk) { const long long t = wall_clock64(); t_solver += t - tw0; t_publish += t - tpub0; tw0 = t; }
         }
 
         // =================================================================================== everybody: the next command
@@ -924,7 +928,7 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
         __syncthreads();
     }
 
-    if (clk && a.stats) {
+    if (stamper && a.stats) {
         ResidentStats s{};
         s.rounds = n_rounds; s.passes = n_passes; s.accepted = n_acc; s.rejected = n_rej; s.step_guard_rejects = n_guard;
         s.jacobian_full = n_fd; s.jacobian_broyden = n_br; s.qp_active_set_passes = n_qp; s.elided_evaluations = n_elided;
@@ -932,7 +936,7 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
         s.t_w_eval = (uint64_t)t_w_eval; s.t_w_fd = (uint64_t)t_w_fd; s.t_w_prod = (uint64_t)t_w_prod; s.t_w_mma = (uint64_t)t_w_mma;
         s.t_group = (uint64_t)t_group; s.t_total_wait = (uint64_t)t_total_wait; s.t_solver = (uint64_t)t_solver;
         s.t_solve_body = (uint64_t)t_solve_body; s.t_cmd_wait = (uint64_t)t_cmd_wait;
-        s.lookahead_rejections = n_look; s.t_look = (uint64_t)t_look;
+        s.lookahead_rejections = n_look; s.t_look = (uint64_t)t_look; s.t_unpack = (uint64_t)t_unpack; s.t_publish = (uint64_t)t_publish;
         s.abort_code = 0; s.grid = (uint32_t)G; s.rows = (uint32_t)a.rows; s.groups = (uint32_t)NG;
         *a.stats = s;
     }

@@ -134,7 +134,7 @@ class ResidentStats(C.Structure):
     _fields_ = ([(k, C.c_uint64) for k in ("rounds", "passes", "accepted", "rejected", "step_guard_rejects", "jacobian_full",
                                             "jacobian_broyden", "qp_active_set_passes", "elided_evaluations", "t_total", "t_stage",
                                             "t_worker", "t_group", "t_total_wait", "t_solver", "t_solve_body", "t_cmd_wait", "t_w_eval", "t_w_fd",
-                                            "t_w_prod", "t_w_mma", "lookahead_rejections", "t_look")]
+                                            "t_w_prod", "t_w_mma", "lookahead_rejections", "t_look", "t_unpack", "t_publish")]
                 + [(k, C.c_uint32) for k in ("abort_code", "grid", "rows", "groups")])
 
     def as_dict(self):
@@ -154,6 +154,7 @@ class ResidentOptions(C.Structure):
 RESIDENT_NO_NULL_SKIP = 1
 RESIDENT_UNBOUNDED = 2
 RESIDENT_NO_LOOKAHEAD = 4
+RESIDENT_NO_STAMPS = 8
 RESIDENT_MODELS = {"gauss5": 0, "tanh32": 1, "gauss3": 2, "exp_decay1": 3}
 
 

@@ -22,7 +22,9 @@ print(c["model"], "m", c["m"], c["s"], "bounded", c["bounded"], "wgs", c["wgs"])
 r = W.Resident(c["model"], c["rows"], max_workgroups=c["wgs"])
 tr = M.Trace(8192)
 res, x, st = r.solve(c["x0"], c["lo"], c["up"], settings=sg, trace=tr)
-print("resident:", res)
+print("resident:", res, "look-ahead rejections", st["lookahead_rejections"])
+res_n, x_n, st_n = r.solve(c["x0"], c["lo"], c["up"], settings=sg, variant=W.RESIDENT_NO_LOOKAHEAD)
+print("resident, no look-ahead:", res_n, "same bits" if (np.array_equal(x, x_n) and res.residual == res_n.residual and res.fCalls == res_n.fCalls) else "DIFFERENT")
 ev = []
 ro, xo = O.optimize(O.native_fn(c["ofn"]), c["m"], c["x0"], lower=c["lo"], upper=c["up"], settings=so, fctx=C.addressof(c["octx"]), trace=lambda *a: ev.append(a))
 print("oracle  :", ro.status, ro.iterations, ro.fCalls, repr(ro.residual))

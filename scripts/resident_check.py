@@ -22,7 +22,7 @@ def show(tag, res, x, st):
     if st:
         tt = st["t_total"] / 100.0
         print(f"   rounds {st['rounds']} passes {st['passes']} acc {st['accepted']} rej {st['rejected']} fd {st['jacobian_full']} "
-              f"broyden {st['jacobian_broyden']} qp {st['qp_active_set_passes']} elided {st['elided_evaluations']} abort {st['abort_code']} "
+              f"broyden {st['jacobian_broyden']} qp {st['qp_active_set_passes']} elided {st['elided_evaluations']} look-ahead {st['lookahead_rejections']} ({st['t_look']/100:.1f} us) abort {st['abort_code']} "
               f"grid {st['grid']} rows {st['rows']}", flush=True)
         print(f"   us: total {tt:.1f} stage {st['t_stage']/100:.1f} worker {st['t_worker']/100:.1f} group {st['t_group']/100:.1f} "
               f"total-wait {st['t_total_wait']/100:.1f} solver {st['t_solver']/100:.1f} (solve body {st['t_solve_body']/100:.1f}) "

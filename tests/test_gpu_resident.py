@@ -44,8 +44,10 @@ def test_cfg2_gauss_sum_full_size_resident(oracle):
     assert st["rejected"] == sum(1 for q in recs if q[0] == 2) and st["jacobian_full"] == sum(1 for q in recs if q[0] == 0)
     assert st["jacobian_broyden"] == sum(1 for q in recs if q[0] == 1)
     assert res.fCalls == 1 + 16 * st["jacobian_full"] + st["accepted"] + st["rejected"]         # LS:953, 1049 (Q5), 1112
-    # one round per executed pass that needs a residual, one more per refresh: elided null steps cost none
-    assert st["rounds"] == 1 + st["jacobian_full"] + st["accepted"] + st["rejected"] - st["elided_evaluations"]
+    # one round per executed pass that needs a residual, one more per refresh: elided null steps cost none, and neither do
+    # rejections decided from a sum of squares evaluated along an earlier round
+    assert st["rounds"] == 1 + st["jacobian_full"] + st["accepted"] + st["rejected"] - st["elided_evaluations"] - st["lookahead_rejections"]
+    assert st["lookahead_rejections"] >= 3
 
 
 def test_cfg2_binding_width_bounds_resident(oracle):
@@ -210,6 +212,33 @@ def test_resident_null_step_elision_changes_nothing():
         else:
             assert st["elided_evaluations"] > 0
     assert outs[0] == outs[1]
+
+
+def test_resident_lookahead_changes_nothing():
+    """The sums of squares of the next damping levels, evaluated along a round and used to book rejected passes without a round
+    of their own, are the numbers those rounds would have produced: the same bits, counters and trace with the look-ahead
+    switched off -- unbounded, with binding bounds (levels behind an infeasible first one are not offered), on ragged grids."""
+    for m, K, wgs, bind in ((100000, 5, 0, False), (100000, 5, 0, True), (20011, 3, 37, False), (777, 3, 3, False), (600, 3, 1, False)):
+        g = P.gauss_sum(m, K=K)
+        lower, upper, x0 = g["lower"].copy(), g["upper"].copy(), g["x0"]
+        if bind:
+            lower[2 * K] = 0.045; lower[2 * K + 3] = 0.05
+            upper[0] = 0.95; upper[3] = 0.85
+            x0 = np.clip(x0, lower, upper)
+        r = W.Resident.gauss_sum(g["t"], g["data"], K=K, max_workgroups=wgs)
+        outs, looks, rounds = [], [], []
+        for variant in (0, W.RESIDENT_NO_LOOKAHEAD):
+            tr = M.Trace(4096)
+            res, x, st = r.solve(x0, lower, upper, trace=tr, variant=variant)
+            assert st["abort_code"] == 0
+            outs.append((x.tobytes(), int(res.status), res.iterations, res.fCalls, res.residual, res.lambda_, tuple(tr.records())))
+            looks.append(st["lookahead_rejections"]); rounds.append(st["rounds"])
+        assert outs[0] == outs[1], (m, K, wgs, bind)
+        assert looks[1] == 0 and rounds[1] - rounds[0] == looks[0]
+    # (cfg 2 itself: at least a handful of rounds saved)
+    g = P.gauss_sum(100000, K=5)
+    _, _, st = W.Resident.gauss_sum(g["t"], g["data"], K=5).solve(g["x0"], g["lower"], g["upper"])
+    assert st["lookahead_rejections"] >= 3
 
 
 def test_resident_does_not_fit_falls_back(oracle):
