@@ -97,13 +97,15 @@ if __name__ == "__main__":
 
 
 def build_user_model_example(force=False, verbose=False):
-    """tests/user_model/: a caller's own residual model compiled against include/mir_optim_amd_batched.hpp (the device header
-    of the batched fit) into a library of its own -- what a user of that header does. Built here so that it travels prebuilt."""
+    """tests/user_model/: a caller's own residual models compiled against include/mir_optim_amd_batched.hpp and
+    include/mir_optim_amd_resident.hpp (the device headers of the batched fit and of the resident-J path) into a library of its own -- what a user of that header does. Built here so that it travels prebuilt."""
     root = os.path.dirname(HERE)
     src = os.path.join(root, "tests", "user_model", "user_model.hip")
     out = os.path.join(root, "tests", "user_model", "libuser_model.so")
     deps = [src, os.path.join(root, "include", "mir_optim_amd_batched.hpp"), os.path.join(root, "include", "mir_optim_amd.h"),
-            os.path.join(CSRC, "batched_kernel.h"), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "solve_types.h")]
+            os.path.join(CSRC, "batched_kernel.h"), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "solve_types.h"),
+            os.path.join(root, "include", "mir_optim_amd_resident.hpp"), os.path.join(CSRC, "resident_kernel.h"),
+            os.path.join(CSRC, "solve_wave16.h"), os.path.join(CSRC, "solve_kernel.h"), os.path.join(CSRC, "solve_lds.h")]
     if force or _stale(out, deps):
         _run([_hipcc()] + _FLAGS + ["-shared", "-I", os.path.join(root, "include"), "-o", out, src], verbose)
     return out

@@ -53,7 +53,74 @@ def make(count, m, noise=0.01):
 
 def test_user_model_example_compiles_against_the_public_header_and_exports_its_entry():
     L = user_lib()          # hipcc cross-compiles without a GPU
-    assert L.user_fit_damped_cosine
+    assert L.user_fit_damped_cosine and L.user_fit_logistic_resident and L.user_logistic_workspace_bytes
+
+
+def logistic(t, x):
+    """the expression of LogisticGrowth in tests/user_model/user_model.hip"""
+    return x[0] / (1.0 + np.exp(-x[1] * (t - x[2]))) + x[3] + x[4] * t
+
+
+@pytest.mark.gpu
+def test_user_model_on_the_resident_path_matches_the_oracle(oracle):
+    """A caller's own model through include/mir_optim_amd_resident.hpp (launch_resident<Model>, one cooperative launch per fit):
+    a five-parameter logistic growth curve, m = 60 000, bounded (one bound binding at the minimiser), against the oracle
+    minimising the same expression in numpy: same status class, x to 1e-6, residual to 1e-9; the caller's workspace and the
+    one the call allocates give the same bits; a problem too large for the chip's LDS is refused with -3."""
+    from mir_optim_amd import workloads as W
+    UL = user_lib()
+    UL.user_fit_logistic_resident.restype = C.c_int
+    UL.user_fit_logistic_resident.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 7
+    UL.user_logistic_workspace_bytes.restype = C.c_size_t
+    UL.user_logistic_workspace_bytes.argtypes = [C.c_size_t]
+    m, n = 60000, 5
+    t = np.linspace(0.0, 10.0, m)
+    truth = np.array([2.0, 1.3, 4.5, 0.3, 0.05])
+    u = P.splitmix64_uniform(4242, m)
+    data = logistic(t, truth) + 0.02 * (2 * u - 1)
+    x0 = np.array([1.5, 1.0, 4.0, 0.0, 0.0])
+    lower = np.array([0.0, 0.0, 0.0, -1.0, 0.06])          # the slope's lower bound sits above its true value: binding
+    upper = np.array([10.0, 10.0, 10.0, 1.0, 1.0])
+    x0 = np.clip(x0, lower, upper)
+    rows = np.ascontiguousarray(np.stack([t, data], axis=1))
+    st = api.Stream()
+    d_rows, d_x, d_lo, d_up = api.DeviceBuffer(rows), api.DeviceBuffer(x0), api.DeviceBuffer(lower), api.DeviceBuffer(upper)
+    d_res = api.DeviceBuffer(nbytes=32, dtype=np.uint8, shape=(32,))
+    d_stats = api.DeviceBuffer(nbytes=C.sizeof(W.ResidentStats), dtype=np.uint8, shape=(C.sizeof(W.ResidentStats),))
+    ws_bytes = UL.user_logistic_workspace_bytes(m)
+    assert ws_bytes > 0
+    d_ws = api.DeviceBuffer(nbytes=ws_bytes, dtype=np.uint8, shape=(ws_bytes,))
+    s = M.LeastSquaresSettings()
+    outs = []
+    for own_ws in (True, False):
+        api.lib().mir_lsq_memcpy_h2d(d_x.ptr, x0.ctypes.data, x0.nbytes, st.handle)
+        o = W.ResidentOptions()
+        o.struct_size = C.sizeof(W.ResidentOptions); o.stream = st.handle; o.stats = d_stats.ptr
+        if own_ws:
+            o.workspace = d_ws.ptr; o.workspace_bytes = ws_bytes
+        code = C.c_int(0)
+        rc = UL.user_fit_logistic_resident(C.addressof(s), m, d_x.ptr, d_lo.ptr, d_up.ptr, d_rows.ptr, d_res.ptr, C.addressof(o), C.addressof(code))
+        assert rc == 0
+        st.synchronize()
+        raw = api._Rd.from_buffer_copy(d_res.download().tobytes())
+        stats = W.ResidentStats.from_buffer_copy(d_stats.download().tobytes()).as_dict()
+        outs.append((api.LeastSquaresResult(raw), d_x.download()[:n].copy(), stats))
+    (res, x, stats), (res2, x2, _) = outs
+    assert x.tobytes() == x2.tobytes() and res.residual == res2.residual and res.fCalls == res2.fCalls
+    assert stats["abort_code"] == 0 and stats["grid"] == 256 and stats["qp_active_set_passes"] >= 1
+
+    def f(xv, y):
+        y[:] = logistic(t, np.asarray(xv)) - data
+    ro, xo = oracle.optimize(f, m, x0, lower=lower, upper=upper)
+    assert res.status >= 0 and ro.status >= 0
+    assert np.allclose(x, xo, rtol=1e-6, atol=1e-9), np.abs(x - xo).max()
+    assert np.isclose(res.residual, ro.residual, rtol=1e-9)
+    assert x[4] == lower[4] == xo[4]
+    # too many rows for the chip's LDS: refused, nothing launched
+    assert UL.user_logistic_workspace_bytes(4_000_000) == 0
+    big = api.DeviceBuffer(nbytes=4_000_000 * 16, dtype=np.uint8, shape=(4_000_000 * 16,))
+    o = W.ResidentOptions(); o.struct_size = C.sizeof(W.ResidentOptions); o.stream = st.handle
+    assert UL.user_fit_logistic_resident(C.addressof(s), 4_000_000, d_x.ptr, d_lo.ptr, d_up.ptr, big.ptr, d_res.ptr, C.addressof(o), None) == -3
 
 
 @pytest.mark.gpu
