@@ -193,6 +193,8 @@ enum {
     MIR_LSQ_VARIANT_NO_NULL_SKIP = 1u << 5,      /* evaluate f also for trials equal to x bit for bit */
     MIR_LSQ_VARIANT_SOLVE_BOUNDED = 1u << 6,     /* always the solve kernel with the BOXCQP loop compiled in */
     MIR_LSQ_VARIANT_SOLVE_GENERIC = 1u << 10,    /* the any-n solve kernel (solve_big.h) also for n <= 256 */
+    MIR_LSQ_VARIANT_SOLVE_ONE_WORKGROUP = 1u << 11, /* n > 256: the any-n solve on ONE workgroup per damping level, without the
+                                                    helper workgroups that share its factorisation (solve_coop.h) */
     MIR_LSQ_VARIANT_FD_HOST_COLUMNS = 1u << 13,  /* host-callback finite differences column by column (per-slot staging vectors,
                                                     a strided column write and a stream synchronisation per task, under a
                                                     lock) instead of through the pinned point-major panel */

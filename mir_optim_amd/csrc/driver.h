@@ -60,6 +60,7 @@ struct mir_lsq_workspace {
     hipStream_t copy_stream[kCopyStreams] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t copy_event[kCopyStreams] = {nullptr, nullptr, nullptr, nullptr};
     int num_cu = 256;
+    uint32_t solve_epoch = 0;  // solve launches with helper workgroups so far (solve_coop.h: the sync words carry it)
 };
 
 namespace mirlsq {

@@ -14,11 +14,13 @@
 
 #include "common.h"
 #include "solve_kernel.h"
+#include "solve_coop.h"
 
 namespace mirlsq {
 
 constexpr int kBigThreads = 512;
 constexpr int kBigWaves = kBigThreads / kWave;
+constexpr int kBigRowsMaxN = 2 * kBigThreads;  // ?potrs with one or two rows per thread and the diagonal blocks' inverses in LDS
 
 // ---------------------------------------------------------------- workgroup collectives over strided partials
 template <typename T, typename WaveOp, typename Op>
@@ -49,27 +51,39 @@ __device__ inline int big_or(int v, int* ired /* >= kBigWaves */)
 }
 
 template <typename T>
-struct BigLds {                 // static LDS of the big-n kernels
+struct BigLds {                 // LDS of the big-n kernels (dynamic: 150 KB in double)
+    T red[kBigWaves];           // (first: with span at LDS offset 0, hipcc 7.2 fails to select a null check of its generic address
+    int ired[kBigWaves + 4];    //  in the float build -- "V_CMP_NE_U32 0, $src_shared_base")
     T span[kBigThreads * 17];   // S of the current chunk (row per thread after the MFMA stage)
+    T dinv[(kBigThreads / 16) * 272];   // n <= kBigThreads: inverses of the 16 x 16 diagonal blocks of the factor (potrs_big_rows);
+                                // kBigThreads < n <= kBigRowsMaxN: span AND dinv together hold the 64 inverses (span is free
+                                // between factorisations) -- the two arrays must stay adjacent
     T blk[16 * 17];             // the current diagonal block L_kk
     T rd[16];                   // its reciprocal pivots
     T xk[32];                   // published solution block of a triangular-solve step (two slots: potrs_big_rows alternates)
-    T dinv[(kBigThreads / 16) * 272];   // n <= kBigThreads: inverses of the 16 x 16 diagonal blocks of the factor (potrs_big_rows)
-    T red[kBigWaves];
-    int ired[kBigWaves + 4];
+    T xs[kBigRowsMaxN + 16];    // n <= kBigRowsMaxN: the vector of a matrix-vector sweep (above: span)
 };
+static_assert(offsetof(BigLds<double>, dinv) == offsetof(BigLds<double>, span) + sizeof(double) * kBigThreads * 17, "span and dinv adjacent");
 
 // ---------------------------------------------------------------- ?potrf 'L', left-looking by 16-column panels
 // A: n x n full symmetric (lda), F: the factor (ldf), both column-major in global memory. Collective; returns info.
 template <typename T>
-__device__ __noinline__ int potrf_big(int n, const T* A_, int lda, T* F_, int ldf, BigLds<T>& sm, long long* dbg = nullptr)
+__device__ __noinline__ int potrf_big(int n, const T* A_, int lda, T* F_, int ldf, BigLds<T>& sm, long long* dbg = nullptr,
+                                      CoopCtx* cc = nullptr, T* cS_ = nullptr)
 {
+    // helpers (solve_coop.h, kCoopPotrfT): while this workgroup factors the four panels of a 64-column block, the helpers form the
+    // next block's update from the columns that are final (blocks <= B - 2 for block B): step 1 below then only covers the
+    // panels of blocks B - 1 and B (<= 7 of them). The factor travels through agent-scope stores; the helpers' part comes back
+    // through one of two n x 64 buffers at cS.
+    const bool coop = cc && cc->W > 1 && cS_ && !cc->failed;
+    bool pending = false;                                       // a kCoopPotrfT job is out
     // address spaces spelled out: through the generic pointers of an out-of-line function every access is a FLAT instruction, which
     // counts on lgkmcnt as well (16 outstanding at most, shared with the LDS reads) -- no ring of loads survives that
     const gbl_cptr<T> A = as_global(A_);
     const gbl_ptr<T> F = as_global_w(F_);
     const lds_ptr<T> span = as_lds(sm.span), blk = as_lds(sm.blk), rd = as_lds(sm.rd);
     long long ph[4] = {0, 0, 0, 0};       // DEBUG_SOLVE: time in steps 1, 2, 3 summed over the panels (thread 0)
+    long long ph_job = 0;                 // ... of step 1: publishing / collecting the helpers' jobs
     using Acc = typename Mma<T>::Acc;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
@@ -78,6 +92,25 @@ __device__ __noinline__ int potrf_big(int n, const T* A_, int lda, T* F_, int ld
     __syncthreads();
     for (int k = 0; k < nblk; ++k) {
         const int c0 = 16 * k;
+        const int B = k / kCoopPanels;                          // the look-ahead block of this panel
+        if (coop && k % kCoopPanels == 0) {
+            if (dbg && tid == 0) ph[3] = wall_clock64();
+            if (pending) {
+                coop_collect(*cc, kCoopPotrfT);
+                pending = false;
+                if (cc->failed) return n + 2;                   // (reported as a failed factorisation: numericError upstream)
+            }
+            if (B >= 1 && kCoopBlockCols * (B + 1) < n) {       // block B + 1: the columns of blocks <= B - 1 are final now
+                const unsigned long long d[6] = {(unsigned long long)(uintptr_t)F_, (unsigned long long)(uintptr_t)(cS_ + (size_t)((B + 1) & 1) * n * kCoopBlockCols),
+                                                 (unsigned long long)(unsigned)n | ((unsigned long long)(unsigned)ldf << 32), (unsigned long long)(B + 1), 0ull, 0ull};
+                coop_publish(*cc, kCoopPotrfT | kCoopRelease, d);      // (the factor is stored with ordinary stores: written back here)
+                pending = true;
+            }
+            if (dbg && tid == 0) { const long long t = wall_clock64(); ph[0] += t - ph[3]; ph_job += t - ph[3]; }
+        }
+        const int jstart = coop ? (B >= 1 ? kCoopPanels * (B - 1) : 0) : 0;     // step 1 covers panels jstart .. k - 1
+        const bool useT = coop && B >= 2;                            // ... the helpers' buffer the columns before them
+        const gbl_cptr<T> Tk = as_global(cS_ + (useT ? (size_t)(B & 1) * n * kCoopBlockCols + 16 * (k % kCoopPanels) : 0));
         for (int base = (c0 / kBigThreads) * kBigThreads; base < n; base += kBigThreads) {
             if (dbg && tid == 0) ph[3] = wall_clock64();
             // the panel's entries of A (row i, 16 columns) do not depend on step 1: their loads fly while the matrix cores work
@@ -92,7 +125,12 @@ __device__ __noinline__ int potrf_big(int n, const T* A_, int lda, T* F_, int ld
             //      base instead of a 64-bit multiply per address. The stage stayed at 400-450 us at n = 512 -- 2 x the matrix-core time
             //      of its busiest SIMD -- with every one of them, so the plain loop stays; what is left is spread over ring fills
             //      per panel and the two waves of a SIMD taking turns.)
-            if (k > 0 && base + 64 * wave + 63 >= c0) {
+            T tv[16];
+            if (useT) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) tv[c] = coop_ld(Tk + (size_t)(i >= c0 ? ic : n - 1) * kCoopBlockCols + c);
+            }
+            if (k > jstart && base + 64 * wave + 63 >= c0) {
                 Acc acc[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) acc[u] = Acc{0, 0, 0, 0};
@@ -100,7 +138,7 @@ __device__ __noinline__ int potrf_big(int n, const T* A_, int lda, T* F_, int ld
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { const int r = base + 64 * wave + 16 * u + lr; rowa[u] = r < n ? r : n - 1; }
                 const int rowb = c0 + lr < n ? c0 + lr : n - 1;
-                for (int j = 0; j < k; ++j) {
+                for (int j = jstart; j < k; ++j) {
                     T fa[4][4], fb[4];
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4) {
@@ -128,7 +166,8 @@ __device__ __noinline__ int potrf_big(int n, const T* A_, int lda, T* F_, int ld
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 const T v = pa[c];
-                const T sv = (k > 0 && i >= c0) ? span[tid * 17 + c] : T(0);
+                T sv = (k > jstart && i >= c0) ? span[tid * 17 + c] : T(0);
+                if (useT && i >= c0) sv += tv[c];
                 p[c] = (active && c0 + c < n) ? v - sv : ((i == c0 + c) ? T(1) : T(0));   // identity padding past n
             }
             const bool diag_chunk = base <= c0 && c0 < base + kBigThreads;
@@ -160,7 +199,10 @@ __device__ __noinline__ int potrf_big(int n, const T* A_, int lda, T* F_, int ld
                 }
                 __syncthreads();
                 const int info = sm.ired[kBigWaves];
-                if (info != 0) return info;                     // uniform
+                if (info != 0) {                                // uniform
+                    if (pending) coop_collect(*cc, kCoopPotrfT);
+                    return info;
+                }
             }
             if (dbg && tid == 0) { const long long t = wall_clock64(); ph[1] += t - ph[3]; ph[3] = t; }
             // ---- 3. the rows below the diagonal block solve against L_kk; store the panel
@@ -177,13 +219,16 @@ __device__ __noinline__ int potrf_big(int n, const T* A_, int lda, T* F_, int ld
             if (active) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c)
-                    if (c0 + c < n && i >= c0 + c) F[i + (size_t)(c0 + c) * ldf] = p[c];
+                    if (c0 + c < n && i >= c0 + c) {
+                        F[i + (size_t)(c0 + c) * ldf] = p[c];
+                    }
             }
             __syncthreads();                                    // span reusable; the panel rows are visible
             if (dbg && tid == 0) { const long long t = wall_clock64(); ph[2] += t - ph[3]; }
         }
     }
-    if (dbg && tid == 0) { dbg[16] = ph[0]; dbg[17] = ph[1]; dbg[18] = ph[2]; }
+    if (pending) coop_collect(*cc, kCoopPotrfT);             // (never: the last block publishes nothing)
+    if (dbg && tid == 0) { dbg[16] = ph[0]; dbg[17] = ph[1]; dbg[18] = ph[2]; dbg[19] = ph_job; }
     return 0;
 }
 
@@ -276,84 +321,139 @@ __device__ __noinline__ void potrs_big(int n, const T* F, int ldf, T* z, BigLds<
 // entries were loaded a step ahead (they do not depend on the solution). inv(L_kk): sm.dinv, filled once per factorisation
 // (invert_diag_blocks). 245 -> ~80 us a call at n = 512 (potrs_big: a substitution chain, two barriers and two exposed L2 round trips
 // per block step; it stays the routine for n > kBigThreads).
-template <typename T>
+template <typename T, int RPT>
 __device__ __noinline__ void potrs_big_rows(int n, const T* F_, int ldf, T* xv_, BigLds<T>& sm)
 {
+    // RPT rows per thread: row tid + kBigThreads r (RPT = 2: kBigThreads < n <= kBigRowsMaxN, 64 inverses in span + dinv)
     const gbl_cptr<T> F = as_global(F_);
     const gbl_ptr<T> xv = as_global_w(xv_);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = tid, ic = i < n ? i : n - 1;
     const int nb = (n + 15) / 16;
-    const lds_ptr<T> Dinv = as_lds(sm.dinv), xk = as_lds(sm.xk);
+    lds_ptr<T> Dinv;
+    if constexpr (RPT == 1) Dinv = as_lds(sm.dinv); else Dinv = as_lds(sm.span);
+    const lds_ptr<T> xk = as_lds(sm.xk);
     __syncthreads();
-    T z = i < n ? xv[i] : T(0);
-    T lnext[16];
+    int ir[RPT], irc[RPT];
+    T z[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) { ir[r] = tid + kBigThreads * r; irc[r] = ir[r] < n ? ir[r] : n - 1; z[r] = ir[r] < n ? xv[ir[r]] : T(0); }
+    T lnext[RPT][16];
     // (a wave none of whose rows takes part in a step skips that step's loads -- half of them on average: eight waves' 16 loads a
     //  step are 0.85 us of the CU's vector-memory address rate)
     auto load_row = [&](int kb) {                              // L[i][16 kb .. 16 kb + 15], used by rows i >= 16 kb + 16
-        if (64 * wave + 63 >= 16 * kb + 16) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) lnext[c] = F[ic + (size_t)(16 * kb + c < n ? 16 * kb + c : n - 1) * ldf];
-        }
+        for (int r = 0; r < RPT; ++r)
+            if (kBigThreads * r + 64 * wave + 63 >= 16 * kb + 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) lnext[r][c] = F[irc[r] + (size_t)(16 * kb + c < n ? 16 * kb + c : n - 1) * ldf];
+            }
     };
     auto load_col = [&](int kb) {                              // L[16 kb .. 16 kb + 15][i], used by rows i < 16 kb
-        if (64 * wave < 16 * kb) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) lnext[c] = F[(16 * kb + c < n ? 16 * kb + c : n - 1) + (size_t)ic * ldf];
-        }
+        for (int r = 0; r < RPT; ++r)
+            if (kBigThreads * r + 64 * wave < 16 * kb) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) lnext[r][c] = F[(16 * kb + c < n ? 16 * kb + c : n - 1) + (size_t)irc[r] * ldf];
+            }
     };
 #pragma unroll
-    for (int c = 0; c < 16; ++c) lnext[c] = 0;
+    for (int r = 0; r < RPT; ++r)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) lnext[r][c] = 0;
+    // the 16 owners of rows 16 kb .. 16 kb + 15 (one DPP row of one wave, row slot rs) form x_kb = op(inv(L_kk)) z_kb
+    auto diag = [&](int kb, bool transposed) {
+        const int c0 = 16 * kb, rs = c0 / kBigThreads, w0 = (c0 % kBigThreads) >> 6;
+        if (wave == w0) {
+            const int l0 = c0 & 63, r = lane & 15;
+            T zz = z[0];
+#pragma unroll
+            for (int q = 1; q < RPT; ++q) zz = (rs == q) ? z[q] : zz;
+            T dv[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) dv[c] = transposed ? Dinv[kb * 272 + c + 17 * r] : Dinv[kb * 272 + r + 17 * c];
+            T xn = 0;
+            static_for<16>([&](auto cc) { constexpr int c = decltype(cc)::value; xn += dv[c] * dpp_row_bcast<c>(zz); });
+            if (lane >= l0 && lane < l0 + 16) {
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) z[q] = (rs == q) ? xn : z[q];
+                xk[(kb & 1) * 16 + r] = xn;
+            }
+        }
+    };
     // ---- forward: L z = b
     load_row(0);
     for (int kb = 0; kb < nb; ++kb) {
         const int c0 = 16 * kb;
-        T lrow[16];
+        T lrow[RPT][16];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) lrow[c] = lnext[c];
+        for (int r = 0; r < RPT; ++r)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) lrow[r][c] = lnext[r][c];
         if (kb + 1 < nb) load_row(kb + 1); else load_col(nb - 1);
-        if (wave == (c0 >> 6)) {
-            const int l0 = c0 & 63, r = lane & 15;
-            T dv[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) dv[c] = Dinv[kb * 272 + r + 17 * c];                         // entries above the diagonal are 0
-            T xn = 0;
-            static_for<16>([&](auto cc) { constexpr int c = decltype(cc)::value; xn += dv[c] * dpp_row_bcast<c>(z); });
-            if (lane >= l0 && lane < l0 + 16) { z = xn; xk[(kb & 1) * 16 + r] = xn; }
-        }
+        diag(kb, false);
         __syncthreads();
-        if (i >= c0 + 16 && i < n) {
-            T acc = 0;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) acc += lrow[c] * ((c0 + c < n) ? xk[(kb & 1) * 16 + c] : T(0));
-            z -= acc;
-        }
+        for (int r = 0; r < RPT; ++r)
+            if (ir[r] >= c0 + 16 && ir[r] < n) {
+                T acc = 0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) acc += lrow[r][c] * ((c0 + c < n) ? xk[(kb & 1) * 16 + c] : T(0));
+                z[r] -= acc;
+            }
     }
     // ---- backward: L^T x = z
     for (int kb = nb - 1; kb >= 0; --kb) {
         const int c0 = 16 * kb;
-        T lcol[16];
+        T lcol[RPT][16];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) lcol[c] = lnext[c];
+        for (int r = 0; r < RPT; ++r)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) lcol[r][c] = lnext[r][c];
         if (kb > 0) load_col(kb - 1);
-        if (wave == (c0 >> 6)) {
-            const int l0 = c0 & 63, r = lane & 15;
-            T dv[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) dv[c] = Dinv[kb * 272 + c + 17 * r];                         // (inv L_kk)^T (r, c) = inv(c, r)
-            T xn = 0;
-            static_for<16>([&](auto cc) { constexpr int c = decltype(cc)::value; xn += dv[c] * dpp_row_bcast<c>(z); });
-            if (lane >= l0 && lane < l0 + 16) { z = xn; xk[(kb & 1) * 16 + r] = xn; }
-        }
+        diag(kb, true);
         __syncthreads();
-        if (i < c0) {
-            T acc = 0;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) acc += lcol[c] * ((c0 + c < n) ? xk[(kb & 1) * 16 + c] : T(0));
-            z -= acc;
-        }
+        for (int r = 0; r < RPT; ++r)
+            if (ir[r] < c0) {
+                T acc = 0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) acc += lcol[r][c] * ((c0 + c < n) ? xk[(kb & 1) * 16 + c] : T(0));
+                z[r] -= acc;
+            }
     }
-    if (i < n) xv[i] = z;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r)
+        if (ir[r] < n) xv[ir[r]] = z[r];
+    __syncthreads();
+}
+
+// inverses of the 16 x 16 diagonal blocks of the factor, any number of blocks (one thread per (block, column), strided)
+template <typename T>
+__device__ __noinline__ void invert_diag_blocks_big(int n, const T* F_, int ldf, T* Dinv_)
+{
+    const gbl_cptr<T> F = as_global(F_);
+    const lds_ptr<T> Dinv = as_lds(Dinv_);
+    const int nb = (n + 15) / 16;
+    for (int e = threadIdx.x; e < 16 * nb; e += kBigThreads) {
+        const int k = e >> 4, c = e & 15;
+        const int base = 16 * k;
+        T x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            T sacc = (r == c) ? T(1) : T(0);
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (q < r) {
+                    const int ir = base + r < n ? base + r : n - 1, iq = base + q < n ? base + q : n - 1;
+                    sacc -= F[ir + (size_t)iq * ldf] * x[q];
+                }
+            const int ir = base + r < n ? base + r : n - 1;
+            const T dr = F[ir + (size_t)ir * ldf];
+            x[r] = (base + r < n) ? ((r >= c) ? sacc / dr : T(0)) : ((r == c) ? T(1) : T(0));   // identity past n
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Dinv[k * 272 + r + 17 * c] = x[r];
+    }
     __syncthreads();
 }
 
@@ -362,8 +462,26 @@ __device__ __noinline__ void potrs_big_rows(int n, const T* F_, int ldf, T* xv_,
 // the compiler can keep in flight) and x comes from LDS. (Before: one wave per row with a wave reduction per row -- 64 dependent
 // round trips a wave, 115 us per residual at n = 512.)
 template <typename T>
-__device__ __noinline__ void residual_big(int n, const T* A_, int lda, const T* b, const T* x, T* r, T* w, T* xs_ /* LDS, >= n */)
+__device__ __noinline__ void residual_big(int n, const T* A_, int lda, const T* b, const T* x, T* r, T* w, T* xs_ /* LDS, >= n */,
+                                          CoopCtx* cc = nullptr, T* part = nullptr)
 {
+    if (cc && cc->W > 1 && part && !cc->failed) {
+        // helpers: the columns in W contiguous ranges, one per workgroup (solve_coop.h, kCoopSymv); a row's W partial sums are
+        // added in peer order
+        const unsigned long long d[6] = {(unsigned long long)(uintptr_t)A_, (unsigned long long)(uintptr_t)x, (unsigned long long)(uintptr_t)part,
+                                         (unsigned long long)(unsigned)n | ((unsigned long long)(unsigned)lda << 32), 1ull, 0ull};
+        coop_publish(*cc, kCoopSymv | kCoopFence, d);
+        coop_symv<T>(d, 0, cc->W, xs_);
+        coop_collect(*cc, kCoopSymv | kCoopFence);
+        for (int i = threadIdx.x; i < n; i += kBigThreads) {
+            T ra = 0, wa = 0;
+            for (int p = 0; p < cc->W; ++p) { ra += part[(size_t)(2 * p) * n + i]; wa += part[(size_t)(2 * p + 1) * n + i]; }
+            r[i] = b[i] - ra;
+            w[i] = dabs(b[i]) + wa;
+        }
+        __syncthreads();
+        return;
+    }
     const gbl_cptr<T> A = as_global(A_);
     const lds_ptr<T> xs = as_lds(xs_);
     __syncthreads();
@@ -399,9 +517,25 @@ __device__ __noinline__ void residual_big(int n, const T* A_, int lda, const T* 
     __syncthreads();
 }
 
+// which ?potrs: one / two rows per thread with the diagonal blocks' inverses in LDS, or (0) the block-step routine.
+// (Two rows per thread: double only -- the float build of that instance trips an instruction-selection error of hipcc 7.2,
+//  "V_CMP_NE_U32 0, $src_shared_base"; so does a lambda around these calls. float above n = 512 keeps the block-step routine.)
+template <typename T> __device__ __forceinline__ int potrs_rows_per_thread(int n)
+{
+    return n <= kBigThreads ? 1 : ((sizeof(T) == 8 && n <= kBigRowsMaxN) ? 2 : 0);
+}
+template <typename T>
+__device__ __forceinline__ void potrs_any(int rows, int n, const T* F, int ldf, T* v, BigLds<T>& sm)
+{
+    if (rows == 1) potrs_big_rows<T, 1>(n, F, ldf, v, sm);
+    else if (rows == 2) { if constexpr (sizeof(T) == 8) potrs_big_rows<T, 2>(n, F, ldf, v, sm); }
+    else potrs_big<T>(n, F, ldf, v, sm);
+}
+
 // ---------------------------------------------------------------- ?posvx('E','L'), nrhs = 1 (same semantics as posvx_device)
 template <typename T>
-__device__ __noinline__ int posvx_big(int n, T* A, int lda, T* F, int ldf, T* s, T* b, T* x, T* r, T* w, BigLds<T>& sm, long long* dbg = nullptr)
+__device__ __noinline__ int posvx_big(int n, T* A, int lda, T* F, int ldf, T* s, T* b, T* x, T* r, T* w, BigLds<T>& sm, long long* dbg = nullptr,
+                                      CoopCtx* cc = nullptr, T* cS = nullptr)
 {
     MIRLSQ_STAMP(dbg, 2);
     const int tid = threadIdx.x;
@@ -429,19 +563,25 @@ __device__ __noinline__ int posvx_big(int n, T* A, int lda, T* F, int ldf, T* s,
     }
     __syncthreads();
     MIRLSQ_STAMP(dbg, 3);
-    const int info = potrf_big<T>(n, A, lda, F, ldf, sm, dbg);
+    const int info = potrf_big<T>(n, A, lda, F, ldf, sm, dbg, cc, cS);
     if (info != 0) return info;
     MIRLSQ_STAMP(dbg, 4);
-    const bool rows = n <= kBigThreads;                         // uniform: one row per thread, inverse diagonal blocks in LDS
-    if (rows) invert_diag_blocks<T, kBigThreads / 16>(n, F, ldf, sm.dinv);
+    // uniform: one or two rows per thread and the inverses of the diagonal blocks in LDS (n <= 1024), else the block-step routine
+    // (two rows per thread: double only -- the float build of that instance trips an instruction-selection error of hipcc 7.2,
+    //  "V_CMP_NE_U32 0, $src_shared_base"; float above n = 512 keeps the block-step routine)
+    const int rows = potrs_rows_per_thread<T>(n);
+    // (no select between two LDS arrays here or below: hipcc 7.2 fails to select the address-space cast of one in the float build)
+    if (rows == 1) invert_diag_blocks_big<T>(n, F, ldf, sm.dinv);
+    else if (rows == 2) invert_diag_blocks_big<T>(n, F, ldf, sm.span);
     for (int i = tid; i < n; i += kBigThreads) x[i] = b[i];
-    if (rows) potrs_big_rows<T>(n, F, ldf, x, sm); else potrs_big<T>(n, F, ldf, x, sm);
+    potrs_any<T>(rows, n, F, ldf, x, sm);
     MIRLSQ_STAMP(dbg, 5);
     // ?porfs, ITMAX = 5
     const T safe1 = T(n + 1) * safmin, safe2 = safe1 / eps;
     T lstres = 3;
     for (int count = 1;; ++count) {
-        residual_big<T>(n, A, lda, b, x, r, w, sm.span);
+        if (n <= kBigRowsMaxN) residual_big<T>(n, A, lda, b, x, r, w, sm.xs, cc, cS ? cS + (size_t)n * 128 : nullptr);
+        else residual_big<T>(n, A, lda, b, x, r, w, sm.span, cc, cS ? cS + (size_t)n * 128 : nullptr);
         if (count == 1) MIRLSQ_STAMP(dbg, 11);
         T qv = 0;
         for (int i = tid; i < n; i += kBigThreads) {
@@ -451,7 +591,7 @@ __device__ __noinline__ int posvx_big(int n, T* A, int lda, T* F, int ldf, T* s,
         const T berr = big_max(qv, sm.red);
         if (count == 1) MIRLSQ_STAMP(dbg, 12);
         if (berr > eps && 2 * berr <= lstres && count <= 5) {
-            if (rows) potrs_big_rows<T>(n, F, ldf, r, sm); else potrs_big<T>(n, F, ldf, r, sm);
+            potrs_any<T>(rows, n, F, ldf, r, sm);
             for (int i = tid; i < n; i += kBigThreads) x[i] += r[i];
             lstres = berr;
             __syncthreads();
@@ -469,7 +609,8 @@ __device__ __noinline__ int posvx_big(int n, T* A, int lda, T* F, int ldf, T* s,
 // A (n x n) must hold the matrix of the unconstrained system on entry (it is overwritten); Pm stays intact.
 template <typename T>
 __device__ __noinline__ int box_qp_big(int n, const T* Pm, const T* q, const T* l, const T* u, T* x, bool unconstrainedSolution,
-                                       T relTol, T absTol, uint32_t maxIterations, SolveScratch<T>& sc, BigLds<T>& sm, int* iters)
+                                       T relTol, T absTol, uint32_t maxIterations, SolveScratch<T>& sc, BigLds<T>& sm, int* iters,
+                                       CoopCtx* cc = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     T* s = sc.vec;
@@ -488,7 +629,7 @@ __device__ __noinline__ int box_qp_big(int n, const T* Pm, const T* q, const T* 
     if (!unconstrainedSolution) {                                   // QP:168-214
         for (int i = tid; i < n; i += kBigThreads) b[i] = -q[i];
         __syncthreads();
-        const int info = posvx_big<T>(n, sc.A, n, sc.Fg, ldf, s, b, x, r, w, sm, sc.dbg);
+        const int info = posvx_big<T>(n, sc.A, n, sc.Fg, ldf, s, b, x, r, w, sm, sc.dbg, cc, sc.cS);
         if (info != 0) return 1;
     }
     {                                                               // QP:216-219
@@ -549,7 +690,7 @@ __device__ __noinline__ int box_qp_big(int n, const T* Pm, const T* q, const T* 
         }
         __syncthreads();
         if (sN) {                                                   // QP:307-325
-            const int info = posvx_big<T>(sN, sc.A, sN, sc.Fg, sN | 1, s, b, sX, r, w, sm);
+            const int info = posvx_big<T>(sN, sc.A, sN, sc.Fg, sN | 1, s, b, sX, r, w, sm, nullptr, cc, sc.cS);
             if (info != 0) return 1;
         }
         for (int ii = tid; ii < sN; ii += kBigThreads) x[SI[ii]] = sX[ii];   // QP:327-329
@@ -581,12 +722,9 @@ __device__ __noinline__ int box_qp_big(int n, const T* Pm, const T* q, const T* 
 
 // ---------------------------------------------------------------- one LM pass, n x n part, any n
 template <typename T>
-__global__ __launch_bounds__(kBigThreads) void k_lm_solve_big(LmSolveArgs<T> a)
+__device__ __forceinline__ void lm_solve_big_main(const LmSolveArgs<T>& a, int kc, BigLds<T>& sm, CoopCtx* cc)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];     // sizeof(BigLds<T>) > 64 KB: dynamic
-    BigLds<T>& sm = *reinterpret_cast<BigLds<T>*>(big_smem);
     const int n = a.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kc = blockIdx.x;
     SolveScratch<T> sc = a.sc[kc];
     T* dx_out = a.dx + (size_t)kc * n;
     T* trial_out = a.trial + (size_t)kc * n;
@@ -595,7 +733,6 @@ __global__ __launch_bounds__(kBigThreads) void k_lm_solve_big(LmSolveArgs<T> a)
     T* tv = sc.vec + 9 * (size_t)n;                  // JJ dx for the predicted reduction
     T* xq = sc.vec + 10 * (size_t)n;
 
-    if (a.guard && *a.guard == 0) return;
     MIRLSQ_STAMP(sc.dbg, 0);
     if (sc.dbg && threadIdx.x == 0) sc.dbg[9] = clock64();
     T jy_inf = 0;
@@ -634,10 +771,18 @@ __global__ __launch_bounds__(kBigThreads) void k_lm_solve_big(LmSolveArgs<T> a)
     }
     // step bounds LS:1074-1077; Pm = A = JJ + lambda I, LS:1078-1079
     for (int i = tid; i < n; i += kBigThreads) { qpl[i] = a.lower[i] - a.x[i]; qpu[i] = a.upper[i] - a.x[i]; }
+    if (cc && !cc->failed) {
+        // helpers: the two copies of J^T J over all workgroups of the entry (0.36 ms on one at n = 1024)
+        const unsigned long long d[6] = {(unsigned long long)(uintptr_t)a.JJ, (unsigned long long)(uintptr_t)sc.Pm, (unsigned long long)(uintptr_t)sc.A,
+                                         (unsigned long long)n * (unsigned long long)n, 0ull, 0ull};
+        coop_publish(*cc, kCoopCopy2 | kCoopFence, d);
+        coop_copy2<T>(d, 0, cc->W);
+        coop_collect(*cc, kCoopCopy2 | kCoopFence);
+    }
     {
         // 16 loads in flight a thread; the damping goes onto the diagonal in a pass of its own (an `idx % (n + 1)` per element was
         // a 64-bit division per element: 205 us of this kernel at n = 512)
-        const size_t nn = (size_t)n * n;
+        const size_t nn = (cc && !cc->failed) ? 0 : (size_t)n * n;
         for (size_t base = tid; base < nn; base += (size_t)16 * kBigThreads) {
             T v[16];
 #pragma unroll
@@ -659,7 +804,7 @@ __global__ __launch_bounds__(kBigThreads) void k_lm_solve_big(LmSolveArgs<T> a)
     MIRLSQ_STAMP(sc.dbg, 1);
     int qp_iters = 0;
     const int qp = box_qp_big<T>(n, sc.Pm, a.Jy, qpl, qpu, xq, false, a.set.qpRelTolerance, a.set.qpAbsTolerance,
-                                 a.set.qpMaxIterations, sc, sm, &qp_iters);   // LS:1080
+                                 a.set.qpMaxIterations, sc, sm, &qp_iters, cc);   // LS:1080
     MIRLSQ_STAMP(sc.dbg, 7);
 
     int flags = 0;
@@ -690,9 +835,22 @@ __global__ __launch_bounds__(kBigThreads) void k_lm_solve_big(LmSolveArgs<T> a)
         // (JJ dx)_i with one row per thread: JJ is symmetric, entry (i, k) is read as JJ[k n + i] -- consecutive rows in consecutive
         // lanes --, dx from LDS, 16 loads in flight (before: a wave per row and a wave reduction per row, 160 us at n = 512)
         __syncthreads();
+        if (cc && !cc->failed) {
+            T* part = sc.cS + (size_t)n * 128;
+            const unsigned long long d[6] = {(unsigned long long)(uintptr_t)a.JJ, (unsigned long long)(uintptr_t)dx_out, (unsigned long long)(uintptr_t)part,
+                                             (unsigned long long)(unsigned)n | ((unsigned long long)(unsigned)n << 32), 0ull, 0ull};
+            coop_publish(*cc, kCoopSymv | kCoopFence, d);
+            coop_symv<T>(d, 0, cc->W, sm.span);
+            coop_collect(*cc, kCoopSymv | kCoopFence);
+            for (int i = tid; i < n; i += kBigThreads) {
+                T acc = 0;
+                for (int p = 0; p < cc->W; ++p) acc += part[(size_t)(2 * p) * n + i];
+                tv[i] = acc;
+            }
+        }
         for (int i = tid; i < n; i += kBigThreads) sm.span[i] = dx_out[i];
         __syncthreads();
-        for (int i0 = 0; i0 < n; i0 += kBigThreads) {
+        for (int i0 = 0; !(cc && !cc->failed) && i0 < n; i0 += kBigThreads) {
             const int i = i0 + tid, ic = i < n ? i : n - 1;
             T acc = 0;
             for (int k0 = 0; k0 < n; k0 += 16) {
@@ -722,6 +880,30 @@ __global__ __launch_bounds__(kBigThreads) void k_lm_solve_big(LmSolveArgs<T> a)
         r.lambda = lambda; r.new_dx_dot = ndd; r.predicted = pred; r.trial_xnorm = xn;
         r.qp_status = qp; r.qp_iterations = qp_iters; r.flags = flags;
         a.rec[kc] = r;
+    }
+}
+
+// One workgroup per ladder entry, or -- a.coop_w > 1 -- that workgroup plus coop_w - 1 helpers (solve_coop.h): block
+// kc * coop_w is entry kc's main workgroup, the coop_w - 1 behind it serve its jobs until it says kCoopExit.
+template <typename T>
+__global__ __launch_bounds__(kBigThreads) void k_lm_solve_big(LmSolveArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];     // sizeof(BigLds<T>) > 64 KB: dynamic
+    BigLds<T>& sm = *reinterpret_cast<BigLds<T>*>(big_smem);
+    __shared__ int s_cflag;
+    __shared__ unsigned long long s_cdesc[8];
+    const int W = a.coop_w > 1 ? a.coop_w : 1;
+    const int kc = (int)blockIdx.x / W, peer = (int)blockIdx.x % W;
+    if (a.guard && *a.guard == 0) return;                        // (every workgroup of the launch reads the same word)
+    if (peer > 0) {
+        coop_helper_loop<T>(a.sc[kc].coop, W, peer, a.coop_epoch, sm.span);
+        return;
+    }
+    CoopCtx cc{a.sc[kc].coop, W, 0, a.coop_epoch, 0u, 0, &s_cflag, s_cdesc};
+    lm_solve_big_main<T>(a, kc, sm, W > 1 ? &cc : nullptr);
+    if (W > 1) {
+        const unsigned long long d[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+        coop_publish(cc, kCoopExit, d);
     }
 }
 

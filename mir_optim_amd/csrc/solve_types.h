@@ -61,7 +61,23 @@ struct SolveScratch {    // global scratch, all L2 resident
     T* vec;     // 12 n-vectors: s, b, r, w, la, mu, sX, qpl, qpu, q, xq, spare
     int32_t* ivec;  // 2 n: SI, flags
     long long* dbg; // optional phase stamps (diagnostic builds of the host pass a buffer; else nullptr)
+    unsigned long long* coop;   // n > kSolveMaxN: the sync words of the entry's helper workgroups (solve_coop.h), zero at creation
+    T* cS;                      // ... and their scratch: two n x 64 look-ahead blocks of ?potrf + 2 x 16 n-vectors of partial products
 };
+
+// helper workgroups of the any-n solve (solve_coop.h): sync words per ladder entry (64-bit; one 128-byte line per word that is
+// polled), peers per entry for a given n, and the entry's scratch behind cS (two n x 64 look-ahead blocks + 2 x kCoopMaxPeers n-vectors)
+constexpr int kCoopMaxPeers = 16;
+constexpr int kCoopLine = 16;
+constexpr int kCoopWords = kCoopLine * (kCoopMaxPeers + 3);
+__host__ __device__ inline int coop_peers(int n)
+{
+    if (n <= kSolveMaxN) return 1;
+    const int nb = (n + 15) / 16;
+    const int w = (nb + 3) / 4;                     // about four 16-row blocks a peer's eight waves at the start of ?potrf
+    return w < 2 ? 2 : (w > kCoopMaxPeers ? kCoopMaxPeers : w);
+}
+__host__ __device__ inline size_t coop_scratch_elems(int n) { return n > kSolveMaxN ? (size_t)n * 128 + (size_t)2 * kCoopMaxPeers * n : 0; }
 
 constexpr int kLdsBlk = 272;     // solve_lds.h: 16 x 17 elements per LDS block
 __host__ __device__ constexpr int lds_solve_elems(int nb) { return nb * (nb + 1) * kLdsBlk + 48 * nb + 2; }
@@ -101,6 +117,8 @@ struct LmSolveArgs {
     int lambda_from_state; // step 0 takes st->lambda and applies the lambda_0 rule LS:1067-1072
     int lambda_from_device; // step 0 takes st->lambda as it is (a round enqueued before the host has seen the previous decision)
     const int32_t* guard;  // optional: the kernel does nothing when *guard == 0 (rounds enqueued ahead of time)
+    int coop_w;            // k_lm_solve_big: workgroups per ladder entry (main + helpers, solve_coop.h); 0 / 1: none
+    uint32_t coop_epoch;   // ... the number of this launch among the workspace's solve launches (> 0, increasing)
 };
 
 // standalone BOXCQP (mir_solve_box_qp_gpu_*)

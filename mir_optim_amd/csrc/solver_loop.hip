@@ -290,6 +290,9 @@ bool Solver<T>::enqueue_solve(int ks, const T* lam, bool check_grad, bool lambda
     a.lambda_from_device = spec_enqueue ? 1 : 0;
     a.guard = spec_enqueue ? &B.st->spec_ok : nullptr;
     if (!dbg_solve) a.sc[0].dbg = nullptr;
+    // n > 256: every ladder entry's workgroup gets helpers (solve_coop.h)
+    a.coop_w = (big_solve && n > (uint32_t)kSolveMaxN && !(variant & MIR_LSQ_VARIANT_SOLVE_ONE_WORKGROUP)) ? coop_peers((int)n) : 1;
+    a.coop_epoch = a.coop_w > 1 ? ++ws->solve_epoch : 0;
     ev_begin(2);
     {
         HpScope hp(this, 4);
@@ -511,7 +514,7 @@ typename Solver<T>::Result Solver<T>::run()
                 if (n <= 128)
                     std::fprintf(stderr, "[solve dbg] lds_potrf, wave 0 (shader cycles, summed over the panels): diagonal update + factor %lld  wait %lld  rows below %lld  wait %lld\n", h[20], h[21], h[22], h[23]);
                 if (n > 128)
-                    std::fprintf(stderr, "[solve dbg] potrf_panel steps (10ns ticks, summed over the panels): earlier panels on MFMA %lld  diagonal rows %lld  other rows + store %lld\n", h[16], h[17], h[18]);
+                    std::fprintf(stderr, "[solve dbg] potrf_panel steps (10ns ticks, summed over the panels): earlier panels on MFMA %lld (of which publishing / waiting for the helpers' look-ahead jobs %lld)  diagonal rows %lld  other rows + store %lld\n", h[16], h[19], h[17], h[18]);
             }
         }
 

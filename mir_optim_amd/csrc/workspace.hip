@@ -65,6 +65,8 @@ Buffers<T> carve(void* base, size_t m, size_t n, int num_cu)
         b.sc[k].vec = (T*)take(12 * n, sizeof(T));
         b.sc[k].ivec = (int32_t*)take(2 * n, sizeof(int32_t));
         b.sc[k].dbg = nullptr;
+        b.sc[k].coop = (unsigned long long*)take(n > (size_t)kSolveMaxN ? kCoopWords : 0, sizeof(unsigned long long));
+        b.sc[k].cS = (T*)take(coop_scratch_elems((int)n), sizeof(T));
     }
     b.sc[0].dbg = (long long*)take(32, sizeof(long long));
     b.bytes = off;
@@ -83,6 +85,17 @@ mir_lsq_workspace* workspace_create(size_t m, size_t n)
         std::fprintf(stderr, "[mir_optim_amd] hipMalloc(%zu bytes) failed\n", ws->dev_bytes);
         delete ws;
         return nullptr;
+    }
+    // the helpers' sync words start from zero ONCE: every later value carries the number of its launch (solve_coop.h)
+    if (n > (size_t)kSolveMaxN) {
+        const Buffers<T> bb = carve<T>(ws->dev, m, n, ws->num_cu);
+        for (int k = 0; k < kChainMax; ++k)
+            if (hipMemset(bb.sc[k].coop, 0, kCoopWords * sizeof(unsigned long long)) != hipSuccess) {
+                std::fprintf(stderr, "[mir_optim_amd] workspace: hipMemset failed\n");
+                workspace_destroy(ws);
+                return nullptr;
+            }
+        (void)hipDeviceSynchronize();
     }
     // the m-sized side buffers of the solve loop are part of the workspace (no allocation inside a solve): the pending
     // Broyden columns (kLrMax x m) and the trial residuals of the lambda ladder (kChainMax x m)

@@ -11,7 +11,8 @@ from mir_optim_amd import workloads as W
 HBM, MFMA = 8000.0, {8: 78.6, 4: 157.3}
 shapes = [(1_000_000, 128, np.float64, "tuned reference shape"), (1_000_000, 128, np.float32, "f32 through the general solver"),
           (1_000_000, 127, np.float64, "odd n"), (1_000_000, 96, np.float64, "n % 32 != 0"), (250_000, 512, np.float64, "n > 256"),
-          (1_000_000, 256, np.float64, "cfg 4's per-GPU shape"), (1_000_000, 64, np.float32, "f32, n = 64")]
+          (1_000_000, 256, np.float64, "cfg 4's per-GPU shape"), (1_000_000, 64, np.float32, "f32, n = 64"),
+          (100_000, 1024, np.float64, "n = 1024: above the read-only Broyden sweep, everything through the any-n kernels")]
 if len(sys.argv) > 1:
     shapes = [s for s in shapes if str(s[1]) in sys.argv[1:] or s[2].__name__ in sys.argv[1:]]
 for m, n, dt, note in shapes:

@@ -164,3 +164,60 @@ def test_whole_path_above_256_float32_reference_abi(oracle, m, n):
     assert res.residual < 0.05 * float(np.sum((np.tanh(A32 @ x0) - b32) ** 2))   # it did minimise
     assert np.abs(np.asarray(x, dtype=np.float64) - np.asarray(xo, dtype=np.float64)).max() <= 5e-3 * max(1.0, float(np.abs(xo).max()))
     assert abs(res.residual - ro.residual) <= 5e-3 * abs(ro.residual) + 1e-6
+
+
+@pytest.mark.parametrize("m,n,bounded", [(3000, 300, True), (4000, 520, False), (2500, 1024, True), (3000, 1100, False)])
+def test_helper_workgroups_change_nothing_but_time(m, n, bounded):
+    """Above n = 256 every damping level's workgroup has helpers (csrc/solve_coop.h): the look-ahead blocks of ?potrf, the
+    residual / prediction products and the copies of J^T J are shared out. With them and without
+    (VARIANT_SOLVE_ONE_WORKGROUP): the same status, iterations and minimiser (the W partial sums of a product are added in a
+    different order than one workgroup's loop: x to 2e-8 absolute, the residual to 1e-11), up to n = 1100 (above 1024 ?potrs is the
+    block-step routine again) and with the BOXCQP active-set loop running reduced systems through the same jobs."""
+    w = P.tanh_linear(m, n)
+    lo = np.full(n, -np.inf); up = np.full(n, np.inf)
+    x0 = w["x0"]
+    if bounded:
+        lo = w["xstar"] - 0.5; up = w["xstar"] + 0.5
+        lo[::7] = w["xstar"][::7] + 0.02
+        x0 = np.clip(x0, lo, up)
+    prob = W.TanhLinear(w["A"], w["b"])
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-7
+    outs = []
+    for variant in (0, M.VARIANT_SOLVE_ONE_WORKGROUP):
+        st = M.Stats()
+        res, x = prob.solve(x0, lo, up, settings=s, stats=st, batched=True, variant=variant)
+        assert int(res.status) >= 0, res
+        outs.append((res, x, st.qp_active_set_passes if hasattr(st, "qp_active_set_passes") else 0))
+    (ra, xa, _), (rb, xb, _) = outs
+    assert ra.status == rb.status and ra.iterations == rb.iterations
+    assert np.allclose(xa, xb, rtol=0, atol=2e-8), np.abs(xa - xb).max()          # (|x| ~ 1; both stopped by absTolerance = 1e-7)
+    assert np.isclose(ra.residual, rb.residual, rtol=1e-11)
+    if bounded:
+        assert np.array_equal((xa == lo) | (xa == up), (xb == lo) | (xb == up)) and ((xa == lo) | (xa == up)).sum() >= n // 8
+
+
+def test_two_host_threads_solve_above_256_concurrently():
+    """Two host threads, each with its own workspace and stream, run n = 520 fits at the same time: the helper workgroups of
+    their solve launches share the chip (every launch is main + helpers per damping level); each thread gets the bits of the
+    same fit run alone."""
+    import threading
+    m, n = 3000, 520
+    w = P.tanh_linear(m, n)
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-7
+    probs = [W.TanhLinear(w["A"], w["b"]) for _ in range(2)]
+    ref_res, ref_x = probs[0].solve(w["x0"], settings=s, batched=True)
+    out, err = {}, []
+
+    def work(k):
+        try:
+            for _ in range(3):
+                out[k] = probs[k].solve(w["x0"], settings=s, batched=True)
+        except Exception as e:       # noqa: BLE001
+            err.append(e)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not err, err
+    for k in range(2):
+        res, x = out[k]
+        assert res.status == ref_res.status and res.iterations == ref_res.iterations and res.fCalls == ref_res.fCalls
+        assert x.tobytes() == ref_x.tobytes() and res.residual == ref_res.residual
