@@ -9,7 +9,10 @@
 // element per thread and stops at 256, this file does not. It favours plain loops over tuning: the factorisation is
 // the left-looking panel scheme of potrf_panel (MFMA 16x16x4 for the contribution of the earlier panels) walked over
 // 512-row chunks, the triangular solves go block by block with one barrier per block. One CU does n^3 / 3 flops here,
-// which is of the order of what the whole GPU spends on J^T J (m n^2) when m is a few hundred times n.
+// which is of the order of what the whole GPU spends on J^T J (m n^2) when m is a few hundred times n -- so from round 5 on
+// the ladder entry's workgroup has HELPER workgroups in the same launch (solve_coop.h): they form the look-ahead blocks of
+// ?potrf's update, share the n^2 matrix-vector sweeps and the copies of J^T J; everything serial stays here. ?potrs runs one
+// or two rows per thread with the inverses of the diagonal blocks in LDS up to n = 1024.
 #pragma once
 
 #include "common.h"

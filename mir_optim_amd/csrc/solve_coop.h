@@ -306,6 +306,10 @@ __device__ inline void coop_symv(const unsigned long long* d, int p, int W, T* x
 
 // helper workgroups' life: jobs until kCoopExit. Out of line and with a context of its own (nothing here escapes into the
 // main workgroup's call tree). xs: LDS scratch of >= ceil(n / W) + 16 elements.
+// (Out of line ON PURPOSE: inlined into k_lm_solve_big -- the context then shared a stack slot with main's, every access to it a
+// scratch / FLAT one -- the build of hipcc 7.2 deadlocked: progress markers in global memory showed waves 1-7 of a helper going
+// round this loop freely, through its workgroup barriers, while wave 0 polled for the next job and never stored its done word.
+// As a function of its own the same source behaves.)
 template <typename T>
 __device__ __noinline__ void coop_helper_loop(unsigned long long* w, int W, int p, uint32_t epoch, T* xs)
 {
