@@ -292,6 +292,9 @@ bool Solver<T>::enqueue_solve(int ks, const T* lam, bool check_grad, bool lambda
     if (!dbg_solve) a.sc[0].dbg = nullptr;
     // n > 256: every ladder entry's workgroup gets helpers (solve_coop.h)
     a.coop_w = (big_solve && n > (uint32_t)kSolveMaxN && !(variant & MIR_LSQ_VARIANT_SOLVE_ONE_WORKGROUP)) ? coop_peers((int)n) : 1;
+    // an entry's workgroups hold a CU each (150 KB of LDS) and wait for one another: never more of them than half the device
+    // (a partitioned or masked GPU), or a group could never be resident at once
+    if (a.coop_w > ws->num_cu / 2) a.coop_w = ws->num_cu / 2 >= 2 ? ws->num_cu / 2 : 1;
     a.coop_epoch = a.coop_w > 1 ? ++ws->solve_epoch : 0;
     ev_begin(2);
     {
