@@ -241,6 +241,19 @@ def test_resident_lookahead_changes_nothing():
     assert st["lookahead_rejections"] >= 3
 
 
+def test_resident_without_clock_stamps():
+    """MIR_LSQ_RESIDENT_NO_STAMPS: the statistics carry the counters only (every t_* but t_total is 0); the fit is the same."""
+    g = P.gauss_sum(20000, K=3)
+    r = W.Resident.gauss_sum(g["t"], g["data"], K=3)
+    res, x, st = r.solve(g["x0"], g["lower"], g["upper"])
+    res2, x2, st2 = r.solve(g["x0"], g["lower"], g["upper"], variant=W.RESIDENT_NO_STAMPS)
+    assert x.tobytes() == x2.tobytes() and res.residual == res2.residual and res.fCalls == res2.fCalls
+    for k in ("rounds", "passes", "accepted", "rejected", "jacobian_full", "jacobian_broyden", "elided_evaluations", "lookahead_rejections"):
+        assert st[k] == st2[k]
+    assert st["t_solver"] > 0 and st["t_worker"] > 0 and st2["t_total"] > 0
+    assert all(st2[k] == 0 for k in st2 if k.startswith("t_") and k != "t_total")
+
+
 def test_resident_does_not_fit_falls_back(oracle):
     """m x (n + nd + 3) doubles beyond the chip's LDS: launch_resident answers -3 and the caller takes the launch-chain path."""
     g = P.gauss_sum(1000000, K=5)
