@@ -127,7 +127,9 @@ __device__ __noinline__ int potrf_big(int n, const T* A_, int lda, T* F_, int ld
             //      three-buffer ring of potrf_panel, 16-byte loads of row pairs, a branch-free loop body, per-lane offsets on a scalar
             //      base instead of a 64-bit multiply per address. The stage stayed at 400-450 us at n = 512 -- 2 x the matrix-core time
             //      of its busiest SIMD -- with every one of them, so the plain loop stays; what is left is spread over ring fills
-            //      per panel and the two waves of a SIMD taking turns.)
+            //      per panel and the two waves of a SIMD taking turns. Round 5, with the helpers leaving <= 3 panels to this loop: the
+            //      first two panels' loads issued together ahead of the first matrix-core instruction made the stage SLOWER, 0.71 ->
+            //      0.95 ms at n = 1024 -- 60 more live registers in a 512-thread workgroup.)
             T tv[16];
             if (useT) {
 #pragma unroll
