@@ -42,7 +42,7 @@ def test_boxcqp_any_n_matches_oracle(oracle, n):
     assert int(st) == 0 and it == 0 and np.allclose(x, xu, rtol=1e-9, atol=1e-12)
 
 
-@pytest.mark.parametrize("m,n", [(5000, 300), (7001, 384), (6000, 512)])
+@pytest.mark.parametrize("m,n", [(5000, 300), (7001, 384), (6000, 512), (4000, 1024)])
 def test_whole_path_above_256_matches_oracle(oracle, m, n):
     w = P.tanh_linear(m, n)
     prob = W.TanhLinear(w["A"], w["b"])
