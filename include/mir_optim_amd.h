@@ -201,6 +201,9 @@ enum {
     MIR_LSQ_VARIANT_NO_PIPELINE = 1u << 22,      /* never enqueue the library part of the next Broyden round behind a device-side
                                                     guard before the current decision is known (small problems -- J up to
                                                     32 MB -- do by default; bit-identical results either way) */
+    MIR_LSQ_VARIANT_DEBUG_HELPERS_ABSENT = 1u << 12, /* diagnostic: the helper workgroups of the any-n solve are NOT launched although
+                                                    its kernel expects them -- the first job times out (5 s) and the solve must end
+                                                    with numericError instead of hanging (tests) */
     MIR_LSQ_VARIANT_DEBUG_SOLVE = 1u << 7,       /* diagnostic: print phase stamps of the solve kernel (stderr) */
     MIR_LSQ_VARIANT_HOST_PROFILE = 1u << 8,      /* diagnostic: print host wall time per category of runtime call (stderr) */
     MIR_LSQ_VARIANT_LR_CAP_SHIFT = 16            /* bits 16..20 (a field, not a switch): fold the pending Broyden terms into J

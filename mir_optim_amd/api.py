@@ -33,7 +33,7 @@ __all__ = [
     "MODEL_EXP_DECAY", "MODEL_EXP3_AFFINE", "MODEL_EXP_DECAY_PAD8", "ResultS", "Trace", "TraceRecord", "Spline", "FitSplineResult", "fitSpline",
     "fit_spline_residuals", "variant_lr_cap",
     "VARIANT_BROYDEN_REWRITE", "VARIANT_FD_SEPARATE_FILL", "VARIANT_NO_SPECULATION", "VARIANT_NO_NULL_SKIP",
-    "VARIANT_SOLVE_BOUNDED", "VARIANT_DEBUG_SOLVE", "VARIANT_HOST_PROFILE", "VARIANT_SOLVE_GENERIC", "VARIANT_SOLVE_ONE_WORKGROUP", "VARIANT_FD_HOST_COLUMNS",
+    "VARIANT_SOLVE_BOUNDED", "VARIANT_DEBUG_SOLVE", "VARIANT_HOST_PROFILE", "VARIANT_SOLVE_GENERIC", "VARIANT_SOLVE_ONE_WORKGROUP", "VARIANT_DEBUG_HELPERS_ABSENT", "VARIANT_FD_HOST_COLUMNS",
     "VARIANT_NO_PIPELINE", "BatchedOptions",
 ]
 
@@ -55,6 +55,7 @@ VARIANT_DEBUG_SOLVE = 1 << 7
 VARIANT_HOST_PROFILE = 1 << 8
 VARIANT_SOLVE_GENERIC = 1 << 10
 VARIANT_SOLVE_ONE_WORKGROUP = 1 << 11
+VARIANT_DEBUG_HELPERS_ABSENT = 1 << 12
 VARIANT_FD_HOST_COLUMNS = 1 << 13
 VARIANT_NO_PIPELINE = 1 << 22
 

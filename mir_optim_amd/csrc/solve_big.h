@@ -478,14 +478,16 @@ __device__ __noinline__ void residual_big(int n, const T* A_, int lda, const T* 
         coop_publish(*cc, kCoopSymv | kCoopFence, d);
         coop_symv<T>(d, 0, cc->W, xs_);
         coop_collect(*cc, kCoopSymv | kCoopFence);
-        for (int i = threadIdx.x; i < n; i += kBigThreads) {
-            T ra = 0, wa = 0;
-            for (int p = 0; p < cc->W; ++p) { ra += part[(size_t)(2 * p) * n + i]; wa += part[(size_t)(2 * p + 1) * n + i]; }
-            r[i] = b[i] - ra;
-            w[i] = dabs(b[i]) + wa;
+        if (!cc->failed) {                                      // (a helper that timed out: the sweep below, on this workgroup alone)
+            for (int i = threadIdx.x; i < n; i += kBigThreads) {
+                T ra = 0, wa = 0;
+                for (int p = 0; p < cc->W; ++p) { ra += part[(size_t)(2 * p) * n + i]; wa += part[(size_t)(2 * p + 1) * n + i]; }
+                r[i] = b[i] - ra;
+                w[i] = dabs(b[i]) + wa;
+            }
+            __syncthreads();
+            return;
         }
-        __syncthreads();
-        return;
     }
     const gbl_cptr<T> A = as_global(A_);
     const lds_ptr<T> xs = as_lds(xs_);
@@ -847,15 +849,16 @@ __device__ __forceinline__ void lm_solve_big_main(const LmSolveArgs<T>& a, int k
             coop_publish(*cc, kCoopSymv | kCoopFence, d);
             coop_symv<T>(d, 0, cc->W, sm.span);
             coop_collect(*cc, kCoopSymv | kCoopFence);
-            for (int i = tid; i < n; i += kBigThreads) {
-                T acc = 0;
-                for (int p = 0; p < cc->W; ++p) acc += part[(size_t)(2 * p) * n + i];
-                tv[i] = acc;
-            }
+            if (!cc->failed)
+                for (int i = tid; i < n; i += kBigThreads) {
+                    T acc = 0;
+                    for (int p = 0; p < cc->W; ++p) acc += part[(size_t)(2 * p) * n + i];
+                    tv[i] = acc;
+                }
         }
         for (int i = tid; i < n; i += kBigThreads) sm.span[i] = dx_out[i];
         __syncthreads();
-        for (int i0 = 0; !(cc && !cc->failed) && i0 < n; i0 += kBigThreads) {
+        for (int i0 = 0; !(cc && !cc->failed) && i0 < n; i0 += kBigThreads) {     // (no helpers, or one timed out: here)
             const int i = i0 + tid, ic = i < n ? i : n - 1;
             T acc = 0;
             for (int k0 = 0; k0 < n; k0 += 16) {
@@ -883,7 +886,9 @@ __device__ __forceinline__ void lm_solve_big_main(const LmSolveArgs<T>& a, int k
     if (tid == 0) {
         ChainRec<T> r{};
         r.lambda = lambda; r.new_dx_dot = ndd; r.predicted = pred; r.trial_xnorm = xn;
-        r.qp_status = qp; r.qp_iterations = qp_iters; r.flags = flags;
+        // a helper that did not answer within kCoopSpinSeconds: the pass is reported as failed (numericError upstream) even where
+        // this workgroup finished the piece on its own -- a stall of seconds is not a state to keep computing in
+        r.qp_status = (cc && cc->failed) ? 1 : qp; r.qp_iterations = qp_iters; r.flags = flags;
         a.rec[kc] = r;
     }
 }

@@ -119,6 +119,7 @@ struct LmSolveArgs {
     const int32_t* guard;  // optional: the kernel does nothing when *guard == 0 (rounds enqueued ahead of time)
     int coop_w;            // k_lm_solve_big: workgroups per ladder entry (main + helpers, solve_coop.h); 0 / 1: none
     uint32_t coop_epoch;   // ... the number of this launch among the workspace's solve launches (> 0, increasing)
+    int coop_absent;       // diagnostic (MIR_LSQ_VARIANT_DEBUG_HELPERS_ABSENT): launch the main workgroups only
 };
 
 // standalone BOXCQP (mir_solve_box_qp_gpu_*)

@@ -296,6 +296,7 @@ bool Solver<T>::enqueue_solve(int ks, const T* lam, bool check_grad, bool lambda
     // (a partitioned or masked GPU), or a group could never be resident at once
     if (a.coop_w > ws->num_cu / 2) a.coop_w = ws->num_cu / 2 >= 2 ? ws->num_cu / 2 : 1;
     a.coop_epoch = a.coop_w > 1 ? ++ws->solve_epoch : 0;
+    a.coop_absent = (variant & MIR_LSQ_VARIANT_DEBUG_HELPERS_ABSENT) ? 1 : 0;
     ev_begin(2);
     {
         HpScope hp(this, 4);

@@ -95,7 +95,7 @@ mir_lsq_workspace* workspace_create(size_t m, size_t n)
                 workspace_destroy(ws);
                 return nullptr;
             }
-        (void)hipDeviceSynchronize();
+        (void)hipStreamSynchronize(nullptr);                      // (the memsets ran on the null stream)
     }
     // the m-sized side buffers of the solve loop are part of the workspace (no allocation inside a solve): the pending
     // Broyden columns (kLrMax x m) and the trial residuals of the lambda ladder (kChainMax x m)

@@ -221,3 +221,19 @@ def test_two_host_threads_solve_above_256_concurrently():
         res, x = out[k]
         assert res.status == ref_res.status and res.iterations == ref_res.iterations and res.fCalls == ref_res.fCalls
         assert x.tobytes() == ref_x.tobytes() and res.residual == ref_res.residual
+
+
+def test_absent_helpers_end_in_numeric_error_not_in_a_hang():
+    """The any-n solve waits for its helper workgroups with bounded spins (csrc/solve_coop.h, 5 s). With the helpers NOT launched
+    (VARIANT_DEBUG_HELPERS_ABSENT; one damping level per pass) the first job times out and the solve returns numericError."""
+    import time
+    w = P.tanh_linear(1500, 300)
+    prob = W.TanhLinear(w["A"], w["b"])
+    t0 = time.perf_counter()
+    res, x = prob.solve(w["x0"], batched=True, variant=M.VARIANT_DEBUG_HELPERS_ABSENT | M.VARIANT_NO_SPECULATION)
+    dt = time.perf_counter() - t0
+    assert res.status == M.LeastSquaresStatus.numericError, res
+    assert 4.0 < dt < 30.0, dt
+    # and the workspace is usable afterwards: the stale words of the failed launch satisfy nobody
+    res2, x2 = prob.solve(w["x0"], batched=True)
+    assert int(res2.status) >= 0
