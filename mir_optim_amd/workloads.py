@@ -183,10 +183,10 @@ class Resident:
             self.d_rows = api.DeviceBuffer(rowdata)
             self.d_ws = api.DeviceBuffer(nbytes=self.workspace_bytes, dtype=np.uint8, shape=(self.workspace_bytes,))
             self.d_x = api.DeviceBuffer(nbytes=8 * 3 * self.n, dtype=np.float64, shape=(3 * self.n,))     # x | lower | upper
-            self.d_res = api.DeviceBuffer(nbytes=32, dtype=np.uint8, shape=(32,))
-            self.d_stats = api.DeviceBuffer(nbytes=C.sizeof(ResidentStats), dtype=np.uint8, shape=(C.sizeof(ResidentStats),))
+            # result record | trace count | statistics in ONE allocation: one copy back per solve
+            self._out_bytes = 64 + C.sizeof(ResidentStats)
+            self.d_out = api.DeviceBuffer(nbytes=self._out_bytes, dtype=np.uint8, shape=(self._out_bytes,))
             self.d_trace = None
-            self.d_tcount = api.DeviceBuffer(nbytes=8, dtype=np.uint32, shape=(2,))
 
     @classmethod
     def gauss_sum(cls, t, data, K=5, **kw):
@@ -220,12 +220,12 @@ class Resident:
                 self.d_trace = api.DeviceBuffer(nbytes=40 * trace_capacity, dtype=np.uint8, shape=(40 * trace_capacity,))
             o.trace_records = self.d_trace.ptr
             o.trace_capacity = trace_capacity
-        o.trace_count = self.d_tcount.ptr
-        o.stats = self.d_stats.ptr
+        o.trace_count = self.d_out.ptr + 32
+        o.stats = self.d_out.ptr + 64
         st = C.c_int(0)
         rc = api.workloads_lib().wl_resident_launch_d(
             C.c_int(self.model), C.byref(s), C.c_size_t(self.m), C.c_void_p(self.d_x.ptr), C.c_void_p(self.d_x.ptr + 8 * n),
-            C.c_void_p(self.d_x.ptr + 16 * n), C.c_void_p(self.d_rows.ptr), C.c_void_p(self.d_res.ptr), C.byref(o), C.byref(st))
+            C.c_void_p(self.d_x.ptr + 16 * n), C.c_void_p(self.d_rows.ptr), C.c_void_p(self.d_out.ptr), C.byref(o), C.byref(st))
         self.last_status_out = st.value
         return rc
 
@@ -246,11 +246,12 @@ class Resident:
                 return api.LeastSquaresResult(raw), np.array(x0, dtype=np.float64), None
             raise RuntimeError(f"launch_resident failed with {rc}")
         self.stream.synchronize()
-        raw = api._Rd.from_buffer_copy(self.d_res.download().tobytes())
+        out = self.d_out.download().tobytes()
+        raw = api._Rd.from_buffer_copy(out[:32])
         x = self.d_x.download()[:n].copy()
-        stats = ResidentStats.from_buffer_copy(self.d_stats.download().tobytes())
+        stats = ResidentStats.from_buffer_copy(out[64:64 + C.sizeof(ResidentStats)])
         if trace is not None:
-            cnt = int(self.d_tcount.download()[0])
+            cnt = int(np.frombuffer(out[32:36], dtype=np.uint32)[0])
             trace.header.count = cnt
             k = min(cnt, cap)
             if k:

@@ -121,7 +121,7 @@ def main():
                   flush=True)
         elif k % 50 == 0:
             print(f"... case {k}: {cat} ({c['model']} m {c['m']} grid {st['grid']})", flush=True)
-        for b in (r.d_rows, r.d_ws, r.d_x, r.d_res, r.d_stats, r.d_tcount):
+        for b in (r.d_rows, r.d_ws, r.d_x, r.d_out):
             b.free()
     print("summary:", tally)
 
