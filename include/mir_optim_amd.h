@@ -402,6 +402,9 @@ enum { MIR_LSQ_RESIDENT_NO_NULL_SKIP = 1u,     /* variant bit: evaluate f also f
                                                   (the BOXCQP active-set loop is compiled out of workgroup 0's solve) */
        MIR_LSQ_RESIDENT_NO_LOOKAHEAD = 4u,      /* variant bit: every trial gets a round of its own (no sums of squares of the
                                                   next damping levels evaluated along; same results bit for bit, for A/B runs) */
+       MIR_LSQ_RESIDENT_DEBUG_DROP_WORKGROUP = 16u, /* diagnostic (tests): the last workgroup leaves before the first round; the
+                                                  others' waits are bounded (1 s in this mode, 20 s otherwise) and the launch
+                                                  must end with numericError and mir_lsq_resident_stats.abort_code != 0 */
        MIR_LSQ_RESIDENT_NO_STAMPS = 8u          /* variant bit: mir_lsq_resident_stats carries the counters only, every t_* is 0 (the
                                                   clock reads of workgroup 0 cost a few per cent of a latency-bound fit) */ };
 typedef struct mir_lsq_resident_stats {         /* written by the kernel at exit; times in 10 ns ticks of workgroup 0 */

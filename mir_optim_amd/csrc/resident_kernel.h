@@ -47,7 +47,8 @@ constexpr double kResSpinSeconds = 20.0;
 enum : uint32_t { kResEval = 1, kResEvalSpec = 2, kResFd = 3, kResExit = 4 };          // command actions
 enum : uint32_t { kResPreAccept = 1, kResPreCommitJ = 2 };                             // what to do with the previous trial first
 enum : uint32_t { kResVariantNoNullSkip = MIR_LSQ_RESIDENT_NO_NULL_SKIP, kResVariantUnbounded = MIR_LSQ_RESIDENT_UNBOUNDED,
-                  kResVariantNoLookahead = MIR_LSQ_RESIDENT_NO_LOOKAHEAD, kResVariantNoStamps = MIR_LSQ_RESIDENT_NO_STAMPS };
+                  kResVariantNoLookahead = MIR_LSQ_RESIDENT_NO_LOOKAHEAD, kResVariantNoStamps = MIR_LSQ_RESIDENT_NO_STAMPS,
+                  kResVariantDebugDrop = MIR_LSQ_RESIDENT_DEBUG_DROP_WORKGROUP };
 
 using ResidentStats = mir_lsq_resident_stats;     // written by workgroup 0 at exit (times: 10 ns ticks)
 
@@ -126,7 +127,7 @@ __device__ __forceinline__ void res_drain() { asm volatile("s_waitcnt vmcnt(0)" 
 
 // ONE wave (wave 0) waits until *p >= target; the caller puts a workgroup barrier behind it. Returns false after
 // kResSpinSeconds or when another workgroup has raised `abort`.
-__device__ __forceinline__ bool res_wait_ge(const uint32_t* p, uint32_t target, const uint32_t* abort)
+__device__ __forceinline__ bool res_wait_ge(const uint32_t* p, uint32_t target, const uint32_t* abort, double seconds = kResSpinSeconds)
 {
     long long t0 = 0;
     for (uint32_t spins = 0;; ++spins) {
@@ -136,7 +137,7 @@ __device__ __forceinline__ bool res_wait_ge(const uint32_t* p, uint32_t target, 
             if (res_ld(abort) != 0) return false;
             const long long now = wall_clock64();
             if (t0 == 0) t0 = now;
-            else if ((double)(now - t0) > kResSpinSeconds * 1e8) return false;
+            else if ((double)(now - t0) > seconds * 1e8) return false;
         }
     }
 }
@@ -239,6 +240,10 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
     }
     __syncthreads();
     if (clk) t_stage = wall_clock64() - tk0;
+    // diagnostic (tests): the last workgroup leaves before the first round -- everybody else must give up (bounded spins, 1 s in
+    // this mode) and the launch must end with numericError + an abort code, not hang
+    const double spin_s = (a.variant & kResVariantDebugDrop) ? 1.0 : kResSpinSeconds;
+    if ((a.variant & kResVariantDebugDrop) && a.grid > 1 && wg == a.grid - 1) return;
 
     // ---- the command being executed (the first one comes from the arguments: evaluate f at x0)
     uint32_t action = kResEval, preops = 0;
@@ -476,7 +481,7 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
         // =================================================================================== group leaders
         if (leader) {
             if (wave == 0) {
-                const bool good = res_wait_ge(a.cnt + 32 * grp, (uint32_t)members * round, a.abort);
+                const bool good = res_wait_ge(a.cnt + 32 * grp, (uint32_t)members * round, a.abort, spin_s);
                 if (lane == 0) s_ok = good ? 1 : 0;
             }
             __syncthreads();
@@ -518,7 +523,7 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
         if (wg == 0) {
             if (wave == 0) {
                 bool good = true;
-                if (lane < NG) good = res_wait_ge(a.flag + 32 * lane, round, a.abort);
+                if (lane < NG) good = res_wait_ge(a.flag + 32 * lane, round, a.abort, spin_s);
                 good = __all(good);
                 if (lane == 0) s_ok = good ? 1 : 0;
             }
@@ -743,7 +748,7 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
                             look_sums(k, 1);
                             if (!look_fetched) {
                                 if (wave == 0) {
-                                    const bool good = res_wait_ge(a.lcnt, look_target, a.abort);
+                                    const bool good = res_wait_ge(a.lcnt, look_target, a.abort, spin_s);
                                     if (lane == 0) s_ok = good ? 1 : 0;
                                 }
                                 __syncthreads();
@@ -890,7 +895,7 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
 
         // =================================================================================== everybody: the next command
         if (wave == 0) {
-            const bool good = res_wait_ge(a.seq, round, a.abort);
+            const bool good = res_wait_ge(a.seq, round, a.abort, spin_s);
             if (lane == 0) s_ok = good ? 1 : 0;
         }
         __syncthreads();

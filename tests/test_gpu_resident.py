@@ -254,6 +254,20 @@ def test_resident_without_clock_stamps():
     assert all(st2[k] == 0 for k in st2 if k.startswith("t_") and k != "t_total")
 
 
+def test_a_missing_workgroup_ends_in_numeric_error_not_in_a_hang():
+    """Every in-launch wait is bounded: with one workgroup leaving before the first round (DEBUG_DROP_WORKGROUP) the others
+    give up, raise the abort word and the launch returns numericError with an abort code; the next launch is clean."""
+    import time
+    g = P.gauss_sum(20000, K=3)
+    r = W.Resident.gauss_sum(g["t"], g["data"], K=3)
+    t0 = time.perf_counter()
+    res, x, st = r.solve(g["x0"], g["lower"], g["upper"], variant=W.RESIDENT_DEBUG_DROP_WORKGROUP)
+    dt = time.perf_counter() - t0
+    assert res.status == M.LeastSquaresStatus.numericError and 0.5 < dt < 20.0, (res, dt)
+    res2, x2, st2 = r.solve(g["x0"], g["lower"], g["upper"])
+    assert int(res2.status) >= 0 and st2["abort_code"] == 0 and np.allclose(x2, g["truth"], rtol=5e-3, atol=1e-3)
+
+
 def test_resident_does_not_fit_falls_back(oracle):
     """m x (n + nd + 3) doubles beyond the chip's LDS: launch_resident answers -3 and the caller takes the launch-chain path."""
     g = P.gauss_sum(1000000, K=5)
