@@ -405,6 +405,9 @@ enum { MIR_LSQ_RESIDENT_NO_NULL_SKIP = 1u,     /* variant bit: evaluate f also f
        MIR_LSQ_RESIDENT_DEBUG_DROP_WORKGROUP = 16u, /* diagnostic (tests): the last workgroup leaves before the first round; the
                                                   others' waits are bounded (1 s in this mode, 20 s otherwise) and the launch
                                                   must end with numericError and mir_lsq_resident_stats.abort_code != 0 */
+       MIR_LSQ_RESIDENT_ANALYTIC_JACOBIAN = 32u, /* the model's own derivative (Model::jac) instead of finite differences at every
+                                                  refresh: the reference's optional g callback (gCalls, age limit 3 by default).
+                                                  launch_resident answers -1 for a model without jac */
        MIR_LSQ_RESIDENT_NO_STAMPS = 8u          /* variant bit: mir_lsq_resident_stats carries the counters only, every t_* is 0 (the
                                                   clock reads of workgroup 0 cost a few per cent of a latency-bound fit) */ };
 typedef struct mir_lsq_resident_stats {         /* written by the kernel at exit; times in 10 ns ticks of workgroup 0 */

@@ -17,6 +17,10 @@
 //         __device__ static void   prepare(const double* x, double* c);          // c[0 .. nc) from x[0 .. n): once per point
 //         __device__ static double eval(const double* row, const double* c);     // the RESIDUAL of one row at that point
 //     };
+// Optional, the reference's g callback (least_squares.d:80): the analytic Jacobian of a row,
+//         __device__ static void   jac(const double* row, const double* c, double* Ji);  // Ji[0 .. n) = d residual / d x_j
+// used instead of finite differences when options->variant has MIR_LSQ_RESIDENT_ANALYTIC_JACOBIAN (gCalls counts the refreshes,
+// the default age limit is 3 as for a caller with a Jacobian, least_squares.d:945).
 // prepare / eval must be pure (the reference declares its callbacks pure) and free of thread-dependent control flow;
 // `row` and `c` point into LDS. A model with nothing to hoist sets nc = n and copies x.
 //
@@ -137,6 +141,7 @@ int launch_resident(const mir_least_squares_settings_d* S, size_t m, double* x, 
     using namespace mirlsq;
     if (!S || !x || !lower || !upper || !result || (Model::nd > 0 && !rowdata) || m == 0 || m > 0x7fffffffu) return -1;
     if (const int bad = resident_check_settings(S)) { if (status_out) *status_out = bad; return -1; }
+    if (opt && (opt->variant & MIR_LSQ_RESIDENT_ANALYTIC_JACOBIAN) && !mirlsq::res_has_jac<Model>::value) return -1;
     int dev = 0, num_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess
         || hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cu < 1)

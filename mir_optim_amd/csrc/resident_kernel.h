@@ -48,7 +48,13 @@ enum : uint32_t { kResEval = 1, kResEvalSpec = 2, kResFd = 3, kResExit = 4 };   
 enum : uint32_t { kResPreAccept = 1, kResPreCommitJ = 2 };                             // what to do with the previous trial first
 enum : uint32_t { kResVariantNoNullSkip = MIR_LSQ_RESIDENT_NO_NULL_SKIP, kResVariantUnbounded = MIR_LSQ_RESIDENT_UNBOUNDED,
                   kResVariantNoLookahead = MIR_LSQ_RESIDENT_NO_LOOKAHEAD, kResVariantNoStamps = MIR_LSQ_RESIDENT_NO_STAMPS,
-                  kResVariantDebugDrop = MIR_LSQ_RESIDENT_DEBUG_DROP_WORKGROUP };
+                  kResVariantDebugDrop = MIR_LSQ_RESIDENT_DEBUG_DROP_WORKGROUP, kResVariantAnalytic = MIR_LSQ_RESIDENT_ANALYTIC_JACOBIAN };
+
+// a model MAY provide the analytic Jacobian of a row -- the reference's optional g callback (least_squares.d:80, 1010-1014):
+//     __device__ static void jac(const double* row, const double* c, double* Ji);     // Ji[0 .. n): d residual_i / d x_j
+template <class Model, class = void> struct res_has_jac : std::false_type {};
+template <class Model>
+struct res_has_jac<Model, std::void_t<decltype(Model::jac((const double*)nullptr, (const double*)nullptr, (double*)nullptr))>> : std::true_type {};
 
 using ResidentStats = mir_lsq_resident_stats;     // written by workgroup 0 at exit (times: 10 ns ticks)
 
@@ -255,7 +261,12 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
     // ---- solver state (workgroup 0; every thread carries the same values)
     double lambda = 0, mu = 1, residual = 0, dx_dot = 0, s_ndd = 0, s_pred = 0, s_xnorm = 0, s_lam_used = 0;
     uint32_t age = 0, iterations = 0, fCalls = 0;
-    const uint32_t maxAge = a.maxAge ? a.maxAge : 2u * N;   // LS:945 (no analytic Jacobian on this path)
+    // MIR_LSQ_RESIDENT_ANALYTIC_JACOBIAN: refreshes call Model::jac instead of differencing (g of LS:1010-1014: gCalls, and the
+    // default age limit of a caller WITH a Jacobian, LS:945)
+    constexpr bool HAS_JAC = res_has_jac<Model>::value;
+    const bool use_g = HAS_JAC && (a.variant & kResVariantAnalytic) != 0;
+    uint32_t gCalls = 0;
+    const uint32_t maxAge = a.maxAge ? a.maxAge : (use_g ? 3u : 2u * N);   // LS:945
     int status = -1;                                        // maxIterations, LS:971
     bool needJac = true, fConverged = false, x_nan = false;
     int cur = 0;                                            // which of JJ[2] / Jy[2] is the current pair
@@ -354,6 +365,15 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
             __syncthreads();                                       // (also: every row of the trial residual is in LDS for step 3)
             if (tid == 0) res_st(a.partial + (size_t)wg * PL::STRIDE, wave_total(s_w));
             if (clk) { const long long t = wall_clock64(); t_w_eval += t - tw0; }
+        } else if (action == kResFd && use_g) {
+            // (2'') g(x, J), LS:1010-1014: one row per thread from the model's own derivative
+            if constexpr (HAS_JAC) {
+                if (tid == 0) Model::prepare(Xl, Cl);
+                __syncthreads();
+                for (int i = tid; i < nrows; i += kResThreads) Model::jac(Dl + (size_t)i * ND, Cl, Jl + (size_t)i * JS);
+                __syncthreads();
+            }
+            if (clk) { const long long t = wall_clock64(); t_w_fd += t - tw0; }
         } else if (action == kResFd) {
             // (2') central differences at the command's point, LS:1018-1049: thread p prepares point p (2j: x + h e_j, 2j + 1:
             // x - h e_j, clipped to the bounds), then one row per thread
@@ -622,7 +642,8 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
                     } else where = kSolve;
                 }
                 if (where == kAfterJac) {
-                    fCalls += N;                                               // LS:1049 (quirk Q5)
+                    if (use_g) ++gCalls;                                       // LS:1013
+                    else fCalls += N;                                          // LS:1049 (quirk Q5)
                     ++n_fd;
                     cur ^= 1;
                     null_lambda_for = 0; lad_valid = false;
@@ -844,10 +865,10 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
                 if (tid < N) a.x[tid] = xsp[tid];
                 if (tid == 0) {
                     mir_least_squares_result_d r;
-                    r.status = (mir_least_squares_status)status; r.iterations = iterations; r.fCalls = fCalls; r.gCalls = 0;
+                    r.status = (mir_least_squares_status)status; r.iterations = iterations; r.fCalls = fCalls; r.gCalls = gCalls;
                     r.residual = residual; r.lambda = lambda;
                     if (status == mir_ls_badGuess || status == mir_ls_badBounds) {           // LS:132-142: nothing was computed
-                        r.iterations = 0; r.fCalls = 0; r.residual = Lim<double>::inf(); r.lambda = 0;
+                        r.iterations = 0; r.fCalls = 0; r.gCalls = 0; r.residual = Lim<double>::inf(); r.lambda = 0;
                     }
                     *a.result = r;
                     if (a.trace_count) *a.trace_count = tr_count;

@@ -46,6 +46,16 @@ template <int N> struct ResTanhLinear {
         for (int k = 0; k < N; k += 2) { s0 = fma(row[k], c[k], s0); if (k + 1 < N) s1 = fma(row[k + 1], c[k + 1], s1); }
         return dtanh(s0 + s1) - row[N];
     }
+    // d/dx_j (tanh(a . x) - b) = (1 - tanh^2(a . x)) a_j
+    __device__ static inline void jac(const double* row, const double* c, double* Ji)
+    {
+        double s0 = 0, s1 = 0;
+#pragma unroll
+        for (int k = 0; k < N; k += 2) { s0 = fma(row[k], c[k], s0); if (k + 1 < N) s1 = fma(row[k + 1], c[k + 1], s1); }
+        const double t = dtanh(s0 + s1), d = 1 - t * t;
+#pragma unroll
+        for (int k = 0; k < N; ++k) Ji[k] = d * row[k];
+    }
 };
 
 // exponential decay p0 exp(-t / p1) + p2 (reference unittest T5's family, least_squares.d:366-411): a bounded three-parameter fit

@@ -155,6 +155,7 @@ RESIDENT_NO_NULL_SKIP = 1
 RESIDENT_UNBOUNDED = 2
 RESIDENT_NO_LOOKAHEAD = 4
 RESIDENT_NO_STAMPS = 8
+RESIDENT_ANALYTIC_JACOBIAN = 32
 RESIDENT_DEBUG_DROP_WORKGROUP = 16
 RESIDENT_MODELS = {"gauss5": 0, "tanh32": 1, "gauss3": 2, "exp_decay1": 3}
 

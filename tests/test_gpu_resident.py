@@ -254,6 +254,36 @@ def test_resident_without_clock_stamps():
     assert all(st2[k] == 0 for k in st2 if k.startswith("t_") and k != "t_total")
 
 
+def test_resident_analytic_jacobian_matches_oracle_with_g(oracle):
+    """The reference's optional g callback (least_squares.d:80, 1010-1014) on the resident path: a model with `jac`
+    (tanh-linear: (1 - tanh^2(a.x)) a) and MIR_LSQ_RESIDENT_ANALYTIC_JACOBIAN -- refreshes count in gCalls, not in fCalls, the
+    default age limit is 3 (LS:945); against the oracle with the same analytic Jacobian: same counters, trace equal up to the
+    first noise-decided pass, same minimiser. A model without `jac` is refused (-1)."""
+    w = P.tanh_linear(20000, 32)
+    r = W.Resident.tanh_linear(w["A"], w["b"])
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
+    so = oracle.default_settings(); so.absTolerance = 1e-9
+    ctx = oracle.TanhLinearCtx(w["A"].ctypes.data, w["b"].ctypes.data)
+    ev = []
+    ro, xo = oracle.optimize(oracle.native_fn("wlc_tanh_linear_f"), w["m"], w["x0"], g=oracle.native_fn("wlc_tanh_linear_g"), settings=so,
+                             fctx=C.addressof(ctx), gctx=C.addressof(ctx), trace=lambda *a: ev.append(a))
+    tr = M.Trace(1024)
+    res, x, st = r.solve(w["x0"], settings=s, trace=tr, variant=W.RESIDENT_ANALYTIC_JACOBIAN)
+    assert res.status >= 0 and ro.status >= 0 and st["abort_code"] == 0
+    assert res.gCalls == ro.gCalls >= 2 and res.gCalls == st["jacobian_full"]
+    assert np.allclose(x, xo, rtol=1e-6, atol=1e-9) and np.isclose(res.residual, ro.residual, rtol=1e-9)
+    k_end = assert_traces_agree_until_noise(tr.records(), ev, min_passes=8)
+    assert (res.iterations, res.fCalls) == (ro.iterations, ro.fCalls) or k_end < len(ev)
+    # finite differences on the same model: more residual calls, no g calls
+    res_fd, x_fd, _ = r.solve(w["x0"], settings=s)
+    assert res_fd.gCalls == 0 and res_fd.fCalls > res.fCalls and np.allclose(x_fd, x, rtol=1e-6, atol=1e-9)
+    # a model without jac
+    g = P.gauss_sum(6000, K=3)
+    rg = W.Resident.gauss_sum(g["t"], g["data"], K=3)
+    rg.upload_point(g["x0"], g["lower"], g["upper"])
+    assert rg.launch(None, 0, W.RESIDENT_ANALYTIC_JACOBIAN) == -1
+
+
 def test_a_missing_workgroup_ends_in_numeric_error_not_in_a_hang():
     """Every in-launch wait is bounded: with one workgroup leaving before the first round (DEBUG_DROP_WORKGROUP) the others
     give up, raise the abort word and the launch returns numericError with an abort code; the next launch is clean."""
