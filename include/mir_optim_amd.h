@@ -356,6 +356,9 @@ enum { MIR_LSQ_MODEL_EXP_DECAY = 0, MIR_LSQ_MODEL_EXP3_AFFINE = 1,
                                                 (BASELINE cfg 5: the exponential decay padded to n = 8 with terms linear in
                                                 their parameters: well conditioned in fp32) */
 /* Per-call options of the batched entries (nothing about them is process-wide). NULL = all defaults. */
+enum { MIR_LSQ_BATCHED_ANALYTIC_JACOBIAN = 2 };   /* variant bit (launch_batched<Model> with a model that has `grad`): the model's own
+                                             derivative instead of finite differences -- the reference's optional g callback:
+                                             gCalls counts the refreshes, the default age limit is 3 (least_squares.d:945, 1010) */
 enum { MIR_LSQ_BATCHED_NO_LADDER = 1 };   /* variant bit: every damped solve is made for ONE lambda, as the reference's loop does
                                              (boxcqp.d:194 per LS:1080); by default a solve covers lambda and the three values
                                              the rejection rule would give it next (four 16-lane groups of the wave), with

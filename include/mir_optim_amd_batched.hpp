@@ -16,6 +16,8 @@
 //         __device__ static float eval(float t, const float* b, const float* x)             // model value at t; x[n..8) = 0
 //         { return x[0] * __expf(-t * x[1]) * __cosf(x[2] * t) + x[3]; }
 //     };
+// Optional, the reference's g callback: `__device__ static void grad(float t, const float* b, const float* x, float* g)` -- g[j] =
+// d eval / d x_j, j < n -- used instead of finite differences when options->variant has MIR_LSQ_BATCHED_ANALYTIC_JACOBIAN.
 // The residual of row i is eval(t_i, basis_i, x) - data_i. eval must be pure (as the reference's callbacks are declared)
 // and free of lane-dependent control flow. A problem needs (n + 2) m floats of LDS ((n + 2) m * 4 <= 160 KB - 512).
 // Reproducibility: the kernel's own arithmetic is a fixed sequence of IEEE operations (contraction off, every fused multiply-add
@@ -58,6 +60,7 @@ int launch_batched(const mir_least_squares_settings_s* S, size_t count, size_t m
     using namespace mirlsq;
     static_assert(Model::n >= 1 && Model::n <= kBatchedNMax, "1 <= n <= 8: one matrix row per lane of a group of eight");
     static_assert(Model::nb >= 0, "nb: number of per-row basis values");
+    if (opt && (opt->variant & MIR_LSQ_BATCHED_ANALYTIC_JACOBIAN) && !batched_has_grad<Model>::value) return -1;
     static_assert(sizeof(BatchedResult) == sizeof(mir_least_squares_result_s), "the kernel writes the C result records in place");
     if (!S || !x || !lower || !upper || !t || !data || !results || (t_stride != 0 && t_stride != m)) return -1;
     if (count == 0) return 0;

@@ -121,6 +121,13 @@ struct BatchedArgs {
     uint32_t variant;      // kBatchedNoLadder: one damping value per solve (A/B and the test of the ladder against it)
 };
 constexpr uint32_t kBatchedNoLadder = 1u;
+constexpr uint32_t kBatchedAnalytic = 2u;      // MIR_LSQ_BATCHED_ANALYTIC_JACOBIAN: Model::grad instead of finite differences
+
+// a model MAY provide the derivative of its value with respect to the parameters -- the reference's optional g callback
+// (least_squares.d:80, 1010-1014):   __device__ static void grad(float t, const float* b, const float* x, float* gi /* n */);
+template <class Model, class = void> struct batched_has_grad : std::false_type {};
+template <class Model>
+struct batched_has_grad<Model, std::void_t<decltype(Model::grad(0.0f, (const float*)nullptr, (const float*)nullptr, (float*)nullptr))>> : std::true_type {};
 
 // one row of the basis table: 16-byte loads when the model has four values
 template <int NB> struct BasisRow {
@@ -398,7 +405,9 @@ __global__ __launch_bounds__(64, Model::n <= 4 ? 4 : 2) void k_lm_batched(Batche
     if (m == 0 || !finite) ret.status = -31;           // badGuess
     else if (!inb) ret.status = -32;                   // badBounds
     else {
-        const uint32_t maxAge = a.maxAge ? a.maxAge : 2 * N;               // LS:945 (no analytic Jacobian here)
+        constexpr bool HAS_GRAD = batched_has_grad<Model>::value;
+        const bool use_g = HAS_GRAD && (a.variant & kBatchedAnalytic) != 0;  // g of LS:1010-1014 (the launcher refuses it without grad)
+        const uint32_t maxAge = a.maxAge ? a.maxAge : (use_g ? 3u : 2u * N);     // LS:945
         { MIRLSQ_T0(); ret.residual = feval(x, yv); MIRLSQ_T1(0); }       // LS:953-955
         ++ret.fCalls;
         bool fConverged = ret.residual <= S.maxGoodResidual;
@@ -443,6 +452,21 @@ __global__ __launch_bounds__(64, Model::n <= 4 ? 4 : 2) void k_lm_batched(Batche
 #pragma unroll
                         for (int j = 0; j < N; ++j) Ji[j] = __builtin_fmaf(u, dx[j], Ji[j]);
                     }
+                } else if (use_g) {                                        // g(x, J), LS:1010-1014
+                    age = 0;
+                    if constexpr (HAS_GRAD) {
+                        for (int i = lane; i < m; i += kWave) {
+                            BasisRow<NB> b;
+                            b.load(bp, i);
+                            float gi[NMAX];
+#pragma unroll
+                            for (int j = 0; j < NMAX; ++j) gi[j] = 0;
+                            Model::grad(tp[i], b.v, x, gi);
+#pragma unroll
+                            for (int j = 0; j < N; ++j) Jl[(size_t)i * N + j] = gi[j];
+                        }
+                    }
+                    ++ret.gCalls;                                          // LS:1013
                 } else {                                                   // FD LS:1016-1050
                     age = 0;
                     // the n central differences of a row share its t, d and basis: rows outside, columns inside

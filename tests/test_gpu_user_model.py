@@ -56,6 +56,57 @@ def test_user_model_example_compiles_against_the_public_header_and_exports_its_e
     assert L.user_fit_damped_cosine and L.user_fit_logistic_resident and L.user_logistic_workspace_bytes
 
 
+def model_grad(t, x):
+    """d model / d x_j: the expression of DampedCosine::grad, float32"""
+    t = t.astype(np.float32); x = x.astype(np.float32)
+    e = np.exp(-x[1] * t); ph = x[2] * t + x[3]; c = np.cos(ph); s_ = np.sin(ph)
+    return np.stack([e * c, -t * x[0] * e * c, -t * x[0] * e * s_, -x[0] * e * s_, np.ones_like(t), np.sqrt(t)], axis=1)
+
+
+@pytest.mark.gpu
+def test_user_model_with_its_own_gradient(oracle):
+    """The reference's optional g callback on the batched path: the model carries `grad` and the launch asks for it
+    (MIR_LSQ_BATCHED_ANALYTIC_JACOBIAN): refreshes count in gCalls, none of the 2n residual evaluations of a finite-difference
+    refresh is made; every problem against the float oracle given the same analytic Jacobian. A model without grad is refused."""
+    count, m = 96, 384
+    t, data, truth, x0 = make(count, m)
+    UL = user_lib()
+    s = M.LeastSquaresSettings(np.float32)
+    lo = np.full(N, -np.inf, dtype=np.float32); up = np.full(N, np.inf, dtype=np.float32)
+    dt_, dd, dx = api.DeviceBuffer(t), api.DeviceBuffer(data), api.DeviceBuffer(x0)
+    dlo, dup = api.DeviceBuffer(lo), api.DeviceBuffer(up)
+    dres = api.DeviceBuffer(nbytes=count * 24, dtype=np.uint8, shape=(count * 24,))
+    st = api.Stream()
+    rdt = np.dtype([("status", "<i4"), ("iterations", "<u4"), ("fCalls", "<u4"), ("gCalls", "<u4"), ("residual", "<f4"), ("lambda", "<f4")])
+    outs = {}
+    for variant in (2, 0):                                  # MIR_LSQ_BATCHED_ANALYTIC_JACOBIAN, finite differences
+        api.lib().mir_lsq_memcpy_h2d(dx.ptr, x0.ctypes.data, x0.nbytes, st.handle)
+        opt = api.BatchedOptions(stream=st.handle, variant=variant)
+        assert UL.user_fit_damped_cosine(C.addressof(s), count, m, dx.ptr, dlo.ptr, dup.ptr, dt_.ptr, 0, dd.ptr, dres.ptr, C.addressof(opt)) == 0
+        st.synchronize()
+        outs[variant] = (np.frombuffer(dres.download().tobytes(), dtype=rdt).copy(), dx.download().reshape(count, N).copy())
+    raw, x = outs[2]
+    raw_fd, x_fd = outs[0]
+    assert (raw["status"] >= 0).all() and (raw["gCalls"] >= 1).all() and (raw_fd["gCalls"] == 0).all()
+    assert raw["fCalls"].sum() < raw_fd["fCalls"].sum()
+    so = oracle.default_settings(np.float32)
+    for k in range(0, count, 4):
+        d = data[k]
+
+        def f(xv, y, d=d):
+            y[:] = model(t, np.asarray(xv, dtype=np.float32)) - d
+
+        def g(xv, J):
+            J[:, :] = model_grad(t, np.asarray(xv, dtype=np.float32))
+        ro, xo = oracle.optimize(f, m, x0[k], g=g, settings=so, dtype=np.float32)
+        assert ro.status >= 0 and ro.gCalls >= 1
+        assert abs(raw["residual"][k] - ro.residual) / ro.residual < 1e-3, k
+        assert np.max(np.abs(model(t, x[k]) - model(t, xo))) < 2e-3, k
+    # analytic and finite-difference fits of the same problems land on the same curves
+    for k in range(count):
+        assert np.max(np.abs(model(t, x[k]) - model(t, x_fd[k]))) < 2e-3, k
+
+
 def logistic(t, x):
     """the expression of LogisticGrowth in tests/user_model/user_model.hip"""
     return x[0] / (1.0 + np.exp(-x[1] * (t - x[2]))) + x[3] + x[4] * t

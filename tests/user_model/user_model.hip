@@ -14,6 +14,17 @@ struct DampedCosine {
     {
         return x[0] * expf(-x[1] * t) * cosf(x[2] * t + x[3]) + x[4] + x[5] * b[0];
     }
+    // the reference's optional g callback: d eval / d x_j (used with MIR_LSQ_BATCHED_ANALYTIC_JACOBIAN)
+    __device__ static void grad(float t, const float* b, const float* x, float* g)
+    {
+        const float e = expf(-x[1] * t), ph = x[2] * t + x[3], c = cosf(ph), s = sinf(ph);
+        g[0] = e * c;
+        g[1] = -t * x[0] * e * c;
+        g[2] = -t * x[0] * e * s;
+        g[3] = -x[0] * e * s;
+        g[4] = 1.0f;
+        g[5] = b[0];
+    }
 };
 
 // every pointer is a DEVICE pointer (the contract of mir_lsq_batched_kernel_s)
