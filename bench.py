@@ -389,8 +389,19 @@ def main_cfg2(args):
             "elided_null_steps": rst["elided_evaluations"], "rejections_decided_by_lookahead": rst["lookahead_rejections"]})
         out["config"].pop("time_split_ms_per_solve", None)
         out["launch_chain"] = chain
+        # HBM bytes of one launch from the committed rocprofv3 --pmc passes of this command (FETCH_SIZE doubled: the gfx950 correction)
+        traffic, traffic_src, valu_busy = None, None, None
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "cfg2_pmc.json")), key=_round_no):
+            try:
+                pm = next(v for k, v in json.load(open(f))["kernels"].items() if "k_lm_resident" in k)
+                traffic, traffic_src, valu_busy = pm.get("hbm_bytes_per_launch"), os.path.relpath(f, ROOT), pm.get("valu_util")
+            except (StopIteration, KeyError, ValueError):
+                pass
         out["roofline"] = {"kernel": "mirlsq::k_lm_resident<ResGaussSum<5>, true> (the one launch of a solve)", "bound": "latency", "achieved": None,
-                           "peak": None, "unit": "us", "frac": None, "avg_launch_ms": rst["t_total"] * tick / 1e3, "launches": 1, "traffic": None,
+                           "peak": None, "unit": "us", "frac": None, "avg_launch_ms": rst["t_total"] * tick / 1e3, "launches": 1, "traffic": traffic,
+                           "traffic_source": traffic_src, "valu_busy_pmc": valu_busy,
+                           "algorithmic_bytes_per_launch": float(m * 2 * 8 + 3 * n * 8),
                            "note": "J never leaves LDS: 16 MB of operands against 40 MB of LDS on the chip; a pass is three in-launch hand-offs "
                                    "(members -> 16 leaders -> workgroup 0 -> everybody) and a one-wave n = 16 solve -- latency, not HBM or MFMA. "
                                    "Figures of merit: us_per_pass, us_per_round"}
