@@ -198,9 +198,11 @@ enum {
     MIR_LSQ_VARIANT_FD_HOST_COLUMNS = 1u << 13,  /* host-callback finite differences column by column (per-slot staging vectors,
                                                     a strided column write and a stream synchronisation per task, under a
                                                     lock) instead of through the pinned point-major panel */
-    MIR_LSQ_VARIANT_NO_PIPELINE = 1u << 22,      /* never enqueue the library part of the next Broyden round behind a device-side
-                                                    guard before the current decision is known (small problems -- J up to
-                                                    32 MB -- do by default; bit-identical results either way) */
+    MIR_LSQ_VARIANT_NO_PIPELINE = 1u << 22,      /* no FUSED rounds (by default, with device callbacks and n <= 256: the next pass's
+                                                    Broyden sweep runs speculatively behind a round's trial residual and carries
+                                                    the trial's sum of squares -- one all-reduce for both -- and ONE kernel decides
+                                                    the trial, applies the pass's n x n side and solves the next system): every
+                                                    round kernel by kernel, decision first; bit-identical results either way */
     MIR_LSQ_VARIANT_DEBUG_HELPERS_ABSENT = 1u << 12, /* diagnostic: the helper workgroups of the any-n solve are NOT launched although
                                                     its kernel expects them -- the first job times out (5 s) and the solve must end
                                                     with numericError instead of hanging (tests) */
@@ -231,7 +233,9 @@ typedef struct mir_lsq_stats {
                                         fCalls counts them like the reference does */
     /* row-shard exchanges of this call (counted whenever a communicator is attached, also with one rank):
      * [0] packed [J^T J lower | J^T y] after a full refresh or a resynchronisation: n(n+1)/2 + n elements each
-     * [1] sweep vector of a Broyden pass: 2n + 34 elements each     [2] sums of squares of residual vectors */
+     * [1] sweep vector of a Broyden pass + the sum of squares of the trial residual it was run behind (fused rounds: the ONE
+     *     exchange of the round; one-by-one rounds leave that entry unused): 2n + 35 elements each
+     * [2] sums of squares of residual vectors that did not ride on a sweep (entry, re-solve rounds, one-by-one rounds) */
     uint64_t allreduce_calls[3];
     uint64_t allreduce_elems[3];
     uint64_t broyden_flushes;        /* times the pending rank-one terms were folded into J */
@@ -257,6 +261,10 @@ typedef struct mir_lsq_stats {
     uint64_t fd_host_columns;
     double host_f_ms;                /* host-callback mode: wall time inside the caller's f for the entry and trial evaluations */
     uint64_t host_f_calls;
+    uint64_t fused_rounds;           /* rounds whose tail was fused (speculative sweep + trial sum, one exchange, one kernel for
+                                        decision + n x n side + next solve); fused_passes: of those, the ones whose trial was
+                                        accepted with a Broyden pass next -- the pass run ahead was the reference's next pass */
+    uint64_t fused_passes;
 } mir_lsq_stats;
 /* Versioning of mir_lsq_stats: the library writes min(stats_size, sizeof(mir_lsq_stats)) bytes. A caller whose options
  * struct has no stats_size member (struct_size < 96), or leaves it 0, gets the layout of its era: 120 bytes (through

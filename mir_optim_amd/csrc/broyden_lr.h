@@ -35,6 +35,39 @@ template <> struct LrPair<float> { using type = float2; };
 
 
 
+// May a Broyden pass follow the trial of ladder record r if it is accepted? (The speculative sweep and the decision of the
+// fused round evaluate the same expression on the same record.) No after a QP failure, a NaN, the step guard, a null step
+// or the gradient test (LS:1053-1106), and no when the x-convergence test LS:1164-1173 fires: it forces a full refresh.
+template <typename T>
+__device__ __forceinline__ bool lr_spec_go(const ChainRec<T>& r, T absTolerance, T relTolerance)
+{
+    const T dxn = dsqrt(r.new_dx_dot);
+    return r.qp_status == 0 && !(r.flags & (kFlagDxNaN | kFlagXNaN | kFlagStepTooLong | kFlagNullStep | kFlagGradSmall))
+        && (dxn > absTolerance && r.trial_xnorm > dxn * relTolerance);
+}
+
+// ||y||^2 over the 4-row groups [gb, ge) of one wave, lane group q taking row 4 g + q: every lane of the group forms the same
+// sum, in row order, one fma per row; the caller adds the four groups (xor 16, xor 32). Rows past m count as zero.
+template <typename T>
+__device__ __forceinline__ T lr_wave_sumsq(const T* __restrict__ y, size_t m, size_t gb, size_t ge, int q)
+{
+    T yy = 0;
+    for (size_t g0 = gb; g0 < ge; g0 += 8) {
+        T v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const size_t row = 4 * (g0 + e) + q;
+            v[e] = (g0 + e < ge && row < m) ? y[row] : T(0);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (g0 + e < ge) yy = dfma(v[e], v[e], yy);
+    }
+    yy += wave_shfl_xor(yy, 16);
+    yy += wave_shfl_xor(yy, 32);
+    return yy;
+}
+
 // (four workgroups per CU up to n = 128)
 template <typename T, int NCP, bool VEC>
 __global__ __launch_bounds__(256, (NCP <= 4 ? 4 : 1)) void k_broyden_lr(const LrArgs<T> a)
@@ -46,7 +79,22 @@ __global__ __launch_bounds__(256, (NCP <= 4 ? 4 : 1)) void k_broyden_lr(const Lr
     const int q = lane >> 4, p = lane & 15;
     const int n = a.n, k = a.k;
     const size_t m = a.m;
-    if (a.guard && *a.guard == 0) return;
+    // the rows of this wave: a contiguous range of 4-row groups (k_lr_sumsq walks the same ranges)
+    const size_t G = (m + 3) / 4;
+    const size_t nw = (size_t)gridDim.x * 4, wid = (size_t)blockIdx.x * 4 + wave;
+    const size_t per = (G + nw - 1) / nw;
+    const size_t gb = wid * per;
+    const size_t ge = gb + per < G ? gb + per : G;
+    if (a.spec_rec && !lr_spec_go(a.spec_rec[0], a.absTolerance, a.relTolerance)) {
+        // speculative sweep whose trial cannot be followed by a Broyden pass: ||y||^2 only, zeros for the rest
+        const T yy = lr_wave_sumsq(a.y, m, gb, ge, q);
+        if (q == 0 && p == 0) red[wave][0] = yy;
+        __syncthreads();
+        const int len = lr_len(n);
+        T* out = a.partials + (size_t)blockIdx.x * len;
+        for (int e = threadIdx.x; e < len; e += blockDim.x) out[e] = e == lr_yy(n) ? (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]) : T(0);
+        return;
+    }
 
     // coef[l] = D_l . dx for the pending columns (wave w takes l = w, w + 4, ...)
     for (int l = wave; l < k; l += 4) {
@@ -78,13 +126,8 @@ __global__ __launch_bounds__(256, (NCP <= 4 ? 4 : 1)) void k_broyden_lr(const Lr
     T va0[NCP], va1[NCP], ga0[NCP], ga1[NCP];
 #pragma unroll
     for (int c = 0; c < NCP; ++c) { va0[c] = 0; va1[c] = 0; ga0[c] = 0; ga1[c] = 0; }
-    T wl = 0, hl = 0, uu = 0, uy = 0;
+    T wl = 0, hl = 0, uu = 0, uy = 0, yy = 0;
 
-    const size_t G = (m + 3) / 4;
-    const size_t nw = (size_t)gridDim.x * 4, wid = (size_t)blockIdx.x * 4 + wave;
-    const size_t per = (G + nw - 1) / nw;
-    const size_t gb = wid * per;
-    const size_t ge = gb + per < G ? gb + per : G;
     // UNR row groups per trip: their loads are issued together, then the groups are taken in order (the same per-lane order of
     // sums as one group per trip: same bits). Narrow problems (n <= 64: one or two 16-byte loads a lane and group) are small
     // in bytes as well -- cfg 2's J is 12.8 MB, 8 groups a wave -- and ran at one memory latency PER GROUP (12 us for a 2 us
@@ -139,6 +182,7 @@ __global__ __launch_bounds__(256, (NCP <= 4 ? 4 : 1)) void k_broyden_lr(const Lr
                 hl += ul * yn;
                 uu += u * u;
                 uy += u * yn;
+                yy = dfma(yn, yn, yy);                             // (the operation and the order of lr_wave_sumsq)
             }
         }
     }
@@ -147,7 +191,7 @@ __global__ __launch_bounds__(256, (NCP <= 4 ? 4 : 1)) void k_broyden_lr(const Lr
     auto qsum = [](T v) { v += wave_shfl_xor(v, 16); v += wave_shfl_xor(v, 32); return v; };
 #pragma unroll
     for (int c = 0; c < NCP; ++c) { va0[c] = qsum(va0[c]); va1[c] = qsum(va1[c]); ga0[c] = qsum(ga0[c]); ga1[c] = qsum(ga1[c]); }
-    wl = qsum(wl); hl = qsum(hl); uu = qsum(uu); uy = qsum(uy);
+    wl = qsum(wl); hl = qsum(hl); uu = qsum(uu); uy = qsum(uy); yy = qsum(yy);
     if (q == 0) {
 #pragma unroll
         for (int c = 0; c < NCP; ++c) {
@@ -156,7 +200,7 @@ __global__ __launch_bounds__(256, (NCP <= 4 ? 4 : 1)) void k_broyden_lr(const Lr
         }
         red[wave][2 * n + p] = wl;
         red[wave][2 * n + kLrMax + p] = hl;
-        if (p == 0) { red[wave][2 * n + 2 * kLrMax] = uu; red[wave][2 * n + 2 * kLrMax + 1] = uy; }
+        if (p == 0) { red[wave][2 * n + 2 * kLrMax] = uu; red[wave][2 * n + 2 * kLrMax + 1] = uy; red[wave][lr_yy(n)] = yy; }
     }
     __syncthreads();
     const int len = lr_len(n);
@@ -167,10 +211,8 @@ __global__ __launch_bounds__(256, (NCP <= 4 ? 4 : 1)) void k_broyden_lr(const Lr
 // sum the per-block partial vectors in a fixed order: blockDim = 1024 = 32 entries x 32 block ranges (a thread walks
 // nparts / 32 partials with 8 loads in flight: the 8-range version spent 9 us on 16 dependent L2 round trips per thread)
 template <typename T>
-__global__ __launch_bounds__(32 * kReduceRanges) void k_lr_reduce(const T* __restrict__ partials, int nparts, int len, T* __restrict__ out,
-                                                                  const int32_t* guard = nullptr)
+__global__ __launch_bounds__(32 * kReduceRanges) void k_lr_reduce(const T* __restrict__ partials, int nparts, int len, T* __restrict__ out)
 {
-    if (guard && *guard == 0) return;
     __shared__ T part[kReduceRanges][33];
     const int es = threadIdx.x & 31, sp = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + es;
@@ -191,14 +233,60 @@ __global__ __launch_bounds__(32 * kReduceRanges) void k_lr_reduce(const T* __res
     }
 }
 
+// the same sum for ONE entry (stride 1 between the partials), by a workgroup of any size >= kReduceRanges threads: ranges in
+// sequence, then the range totals in sequence -- the bits k_lr_reduce gives that entry. Collective; every thread gets the sum.
+template <typename T>
+__device__ inline T lr_reduce_scalar(const T* __restrict__ partials, int nparts, T* part /* kReduceRanges, LDS */)
+{
+    if ((int)threadIdx.x < kReduceRanges) {
+        const int per = (nparts + kReduceRanges - 1) / kReduceRanges;
+        const int b0 = (int)threadIdx.x * per, b1 = (b0 + per < nparts) ? b0 + per : nparts;
+        T s = 0;
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) s += partials[b];
+        part[threadIdx.x] = s;
+    }
+    __syncthreads();
+    T tot = part[0];
+#pragma unroll
+    for (int r = 1; r < kReduceRanges; ++r) tot += part[r];
+    __syncthreads();                                         // part may be reused
+    return tot;
+}
+
+// ||v_k||^2, k = blockIdx.y, without a sweep: the row walk of k_broyden_lr over the vector alone (lr_wave_sumsq), one partial per
+// workgroup at partials + k pstride + blockIdx.x -- summed by lr_reduce_scalar (k_decide_chain on one GPU, k_lr_sumsq_final
+// before an all-reduce) the trial's sum of squares has the bits of entry lr_yy(n) of a reduced sweep
+template <typename T>
+__global__ __launch_bounds__(256) void k_lr_sumsq(const T* __restrict__ v0, size_t m, size_t vstride, T* __restrict__ partials0, int pstride)
+{
+    __shared__ T red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const T* __restrict__ v = v0 + (size_t)blockIdx.y * vstride;
+    const size_t G = (m + 3) / 4;
+    const size_t nw = (size_t)gridDim.x * 4, wid = (size_t)blockIdx.x * 4 + wave;
+    const size_t per = (G + nw - 1) / nw;
+    const size_t gb = wid * per;
+    const size_t ge = gb + per < G ? gb + per : G;
+    const T yy = lr_wave_sumsq(v, m, gb, ge, lane >> 4);
+    if (lane == 0) red[wave] = yy;
+    __syncthreads();
+    if (threadIdx.x == 0) partials0[(size_t)blockIdx.y * pstride + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_lr_sumsq_final(const T* __restrict__ partials0, int pstride, int nparts, T* __restrict__ out)
+{
+    __shared__ T part[kReduceRanges];
+    const T tot = lr_reduce_scalar(partials0 + (size_t)blockIdx.x * pstride, nparts, part);
+    if (threadIdx.x == 0) out[blockIdx.x] = tot;
+}
+
 // n x n side of a pass: JJ += v dx^T + dx v^T + uu dx dx^T (block i < n: row i), Jy and |Jy|_inf (LS:1052-1053),
 // D_k = dx (block n). `lr` is the (all-reduced) vector of k_lr_reduce.
 template <typename T>
 __global__ __launch_bounds__(256) void k_lr_finish(const T* __restrict__ lr, T* __restrict__ D, const T* __restrict__ dx,
-                                                   int k, int n, T* __restrict__ JJ, T* __restrict__ Jy, LmState<T>* st,
-                                                   const int32_t* guard = nullptr)
+                                                   int k, int n, T* __restrict__ JJ, T* __restrict__ Jy, LmState<T>* st)
 {
-    if (guard && *guard == 0) return;
     __shared__ T v[kLrMaxN];
     __shared__ T red[4];
     const T* __restrict__ w = lr + 2 * n;
@@ -236,6 +324,35 @@ __global__ __launch_bounds__(256) void k_lr_finish(const T* __restrict__ lr, T* 
         for (int wv = 1; wv < (int)(blockDim.x >> 6); ++wv) r = red[wv] > r ? red[wv] : r;
         st->jy_inf = r;
     }
+}
+
+// k_lr_finish by ONE workgroup (any size), for the head of the fused round's kernel (k_lm_solve with a.fused, n <= kSolveMaxN):
+// the same expressions entry by entry -- the same bits. |Jy|_inf is left to the solve body's gradient test, which forms it
+// anyway. v: n elements of LDS. Collective; ends with a barrier (JJ, Jy, D_k are visible to the whole workgroup).
+template <typename T>
+__device__ inline void lr_finish_block(const T* __restrict__ lr, T* __restrict__ D, const T* __restrict__ dx, int k, int n,
+                                       T* __restrict__ JJ, T* __restrict__ Jy, T* v)
+{
+    const T* __restrict__ w = lr + 2 * n;
+    const T* __restrict__ h = w + kLrMax;
+    const T uu = lr[2 * n + 2 * kLrMax], uy = lr[2 * n + 2 * kLrMax + 1];
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        T s = lr[j];
+        for (int l = 0; l < k; ++l) s += D[(size_t)l * n + j] * w[l];
+        v[j] = s;
+        T g = lr[n + j];
+        for (int l = 0; l < k; ++l) g += D[(size_t)l * n + j] * h[l];
+        g += dx[j] * uy;
+        Jy[j] = g;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+        const int i = e / n, j = e - i * n;
+        const int r = i >= j ? i : j, c = i >= j ? j : i;
+        JJ[e] += lr_jj_term(v[r], v[c], dx[r], dx[c], uu);
+    }
+    for (int j = threadIdx.x; j < n; j += blockDim.x) D[(size_t)k * n + j] = dx[j];
+    __syncthreads();
 }
 
 // fold the k pending terms into J: J[i,:] += u_0[i] dx_0 + ... + u_{k-1}[i] dx_{k-1}, in update order

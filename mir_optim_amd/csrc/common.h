@@ -30,8 +30,10 @@ inline thread_local uint64_t tl_launches = 0;
 
 // ---- pending rank-one Broyden terms (broyden_lr.h): sizes shared by the sweep, its reduction and the n x n finish
 constexpr int kLrMax = 16;
-// [ v0 (n) | g0 (n) | w (kLrMax) | h (kLrMax) | uu | uy ]
-__host__ __device__ constexpr int lr_len(int n) { return 2 * n + 2 * kLrMax + 2; }
+// [ v0 (n) | g0 (n) | w (kLrMax) | h (kLrMax) | uu | uy | yy ]   yy = ||y_new||^2: the trial's sum of squares (LS:1115) rides on
+// the sweep that is run speculatively behind the trial residual, one all-reduce for both (lr_yy(n) = its index)
+__host__ __device__ constexpr int lr_len(int n) { return 2 * n + 2 * kLrMax + 3; }
+__host__ __device__ constexpr int lr_yy(int n) { return 2 * n + 2 * kLrMax + 2; }
 constexpr int kLrMaxN = 512;     // widest problem of the read-only Broyden sweep (16 column-pair chunks of 32 a lane); above, J is rewritten
 constexpr int kReduceRanges = 32;
 // one entry of the symmetric rank-two update J_k^T J_k = J_{k-1}^T J_{k-1} + v dx^T + dx v^T + uu dx dx^T, r >= c (k_lr_finish)
@@ -259,6 +261,9 @@ __device__ inline void rsqrt_sqrt(float a, float& rinv, float& d)
     rinv = 1.0f / d;
 }
 
+// one rounding, whatever the compiler's contraction setting: sums that two kernels must form bit for bit alike
+__device__ inline double dfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ inline float dfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ inline double dsqrt(double v) { return sqrt(v); }
 __device__ inline float dsqrt(float v) { return sqrtf(v); }
 __device__ inline double dabs(double v) { return fabs(v); }

@@ -145,7 +145,7 @@ struct Solver {
     FB fbr = nullptr;          // batched residual callback writing Y row-major (m x p): the pair panel of the fused FD kernels
     FB fbd = nullptr;          // batched residual callback writing the m x n row-major DIFFERENCE panel (fbRowMajorDiff)
     int fd_fused = 0;          // 1: the (+h, -h) pair panel, 2: the difference panel of this refresh is in ws->ypanel and J has not been filled yet
-    int sums_pending = 0;      // > 0: the trial sums of this round are still stage-1 partials (k_decide_chain finishes them)
+    int sums_pending = 0;      // > 0: the trial sums of this round are still k_lr_sumsq's stage-1 partials (k_decide_chain finishes them)
     uint32_t fd_batch;
     bool device_cb;
     bool time_kernels;
@@ -185,15 +185,13 @@ struct Solver {
     // at before the callbacks are launched, and when every entry is a null step nothing is evaluated
     bool has_bounds = true;    // some lower / upper entry is finite (set in run()); MIR_LSQ_VARIANT_SOLVE_BOUNDED forces the full kernel
     bool tail_null = false;
-    // ---- rounds enqueued ahead of time (pipelining of the host): while the GPU runs round r, the host already enqueues
-    // the round that follows IF r is accepted without any exit test firing -- Broyden sweep, solve -- behind a device-side
-    // guard (LmState::spec_ok, set by k_decide_chain of round r). If r ends differently the guarded kernels return at once
-    // and the host enqueues the right round as before. Results are bit-identical with and without it (tests/test_gpu_lm.py);
-    // what disappears is the launch latency between accepted rounds. On for small problems (J up to 32 MB) unless
-    // MIR_LSQ_VARIANT_NO_PIPELINE.
-    bool spec_enqueue = false;     // set while the kernels of such a round are being enqueued
-    bool pipeline = true;          // allowed at all for this solve (see setup())
-    size_t spec_events_from = 0;   // events of the round enqueued ahead of time start here
+    // ---- the fused round (solver_loop.hip, setup() and enqueue_fused_tail()): behind a round's one trial residual the next
+    // pass's Broyden sweep runs speculatively and carries the trial's sum of squares; one kernel then decides the trial and, if
+    // it is accepted without any exit test firing, applies the pass's n x n side and solves the next system. Results are
+    // bit-identical with the one-by-one rounds (MIR_LSQ_VARIANT_NO_PIPELINE; tests/test_gpu_lm.py).
+    bool fused = false;            // allowed at all for this solve (see setup())
+    bool spec_enqueue = false;     // set while the kernels of the pass run ahead are being enqueued (their events are tagged)
+    size_t spec_events_from = 0;   // events of the pass run ahead start here
     bool big_solve = false;    // n > 256 (or MIR_LSQ_VARIANT_SOLVE_GENERIC): the any-n solve kernel
 
     LmState<T>* st_h;      // pinned mirror of the decision point being processed (one of st_slot[])
@@ -259,15 +257,18 @@ struct Solver {
     void teardown();
     bool eval_f(const T* x_dev, const T* x_host, T* y_dev);
     int sumsq_blocks() const;
-    bool sumsq(const T* v, int slot, int count = 1, size_t vstride = 0, bool defer_final = false);
+    bool sumsq(const T* v, int slot);
+    bool trial_sums(const T* v, int count, size_t vstride);
     bool allreduce(T* buf, size_t count, int kind);
     void trace_emit(int event, uint32_t iterations, T lambda, T residual, T trial_residual, T dx_dot);
     bool trace_round(int ks, T residual_before, uint32_t iterations_before);
     bool wait_state(uint32_t expect);
     bool read_state(const T* vec_dev);
+    LmSolveArgs<T> solve_args(int ks, const T* lam, bool check_grad, bool lambda_from_state);
     bool enqueue_solve(int ks, const T* lam, bool check_grad, bool lambda_from_state);
-    bool enqueue_decide(int ks, bool check_grad, bool lambda_from_state, bool next_round_enqueued_ahead, const T* sum_v = nullptr);
-    bool enqueue_spec_round();
+    DecideArgs<T> decide_args(int ks, bool check_grad, bool lambda_from_state);
+    bool enqueue_decide(int ks, bool check_grad, bool lambda_from_state, const T* sum_v = nullptr);
+    bool enqueue_fused_tail(const T* ytr, bool check_grad, bool lambda_from_state);
     void commit_spec_round();
     void drop_spec_round();
     Result run();

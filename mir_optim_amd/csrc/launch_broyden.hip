@@ -59,24 +59,40 @@ hipError_t lr_flush(T* J, const T* U, const T* D, int k, size_t m, int n, int nu
 }
 
 template <typename T>
-hipError_t lr_reduce(const T* partials, int nblk, int n, T* out, const int32_t* guard, hipStream_t s)
+hipError_t lr_reduce(const T* partials, int nblk, int n, T* out, hipStream_t s)
 {
     const int len = lr_len(n);
-    MIRLSQ_LAUNCH(k_lr_reduce<T>, dim3((len + 31) / 32), dim3(32 * kReduceRanges), 0, s, partials, nblk, len, out, guard);
+    MIRLSQ_LAUNCH(k_lr_reduce<T>, dim3((len + 31) / 32), dim3(32 * kReduceRanges), 0, s, partials, nblk, len, out);
     return hipGetLastError();
 }
 
 template <typename T>
-hipError_t lr_finish(const T* lr, T* D, const T* dx, int k, int n, T* JJ, T* Jy, LmState<T>* st, const int32_t* guard, hipStream_t s)
+hipError_t lr_finish(const T* lr, T* D, const T* dx, int k, int n, T* JJ, T* Jy, LmState<T>* st, hipStream_t s)
 {
-    MIRLSQ_LAUNCH(k_lr_finish<T>, dim3(n + 1), dim3(256), 0, s, lr, D, dx, k, n, JJ, Jy, st, guard);
+    MIRLSQ_LAUNCH(k_lr_finish<T>, dim3(n + 1), dim3(256), 0, s, lr, D, dx, k, n, JJ, Jy, st);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t lr_sumsq(const T* v, size_t m, int count, size_t vstride, T* partials, int pstride, int nblk, hipStream_t s)
+{
+    if (count < 1 || nblk < 1 || nblk > pstride) return hipErrorInvalidValue;
+    MIRLSQ_LAUNCH(k_lr_sumsq<T>, dim3(nblk, count), dim3(256), 0, s, v, m, vstride, partials, pstride);
+    return hipGetLastError();
+}
+template <typename T>
+hipError_t lr_sumsq_final(const T* partials, int pstride, int nblk, int count, T* out, hipStream_t s)
+{
+    MIRLSQ_LAUNCH(k_lr_sumsq_final<T>, dim3(count), dim3(256), 0, s, partials, pstride, nblk, out);
     return hipGetLastError();
 }
 
 #define MIRLSQ_INSTANTIATE(T)                                                                                             \
     template hipError_t lr_sweep<T>(const LrArgs<T>&, int, hipStream_t);                                                  \
-    template hipError_t lr_reduce<T>(const T*, int, int, T*, const int32_t*, hipStream_t);                                \
-    template hipError_t lr_finish<T>(const T*, T*, const T*, int, int, T*, T*, LmState<T>*, const int32_t*, hipStream_t); \
+    template hipError_t lr_reduce<T>(const T*, int, int, T*, hipStream_t);                                                \
+    template hipError_t lr_finish<T>(const T*, T*, const T*, int, int, T*, T*, LmState<T>*, hipStream_t);                 \
+    template hipError_t lr_sumsq<T>(const T*, size_t, int, size_t, T*, int, int, hipStream_t);                            \
+    template hipError_t lr_sumsq_final<T>(const T*, int, int, int, T*, hipStream_t);                                      \
     template hipError_t lr_flush<T>(T*, const T*, const T*, int, size_t, int, int, hipStream_t);
 MIRLSQ_INSTANTIATE(double)
 MIRLSQ_INSTANTIATE(float)

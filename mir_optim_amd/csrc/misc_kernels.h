@@ -8,6 +8,7 @@
 //                     speculative trials                                -> k_decide_chain
 #pragma once
 
+#include "broyden_lr.h"
 #include "common.h"
 #include "solve_types.h"
 
@@ -188,43 +189,17 @@ __global__ __launch_bounds__(256) void k_fd_fill_col(const T* __restrict__ yp, c
 //      sums[k] = ||f(trial_k)||^2 (already all-reduced). Later chain entries are simply discarded: they were
 //      computed on the assumption that every earlier entry is rejected, which is exactly when the reference would
 //      have computed them. One block of kSolveThreads.
+// Collective over the workgroup (any size >= kReduceRanges threads when nparts > 0); returns LmState::spec_ok as it was
+// decided -- 1: the fused round's kernel goes on with the Broyden finish and the next solve (solve_kernel.h).
 template <typename T>
-struct DecideArgs {
-    T* sums;            // ks trial sums of squares; entries of null steps are filled in here (= the current residual)
-    const ChainRec<T>* rec;
-    LmState<T>* st;
-    LmSettingsDev<T> set;
-    T* x;               // n: current point, overwritten by the accepted trial (LS:1135)
-    const T* trial;     // ks x n
-    const T* dx_chain;  // ks x n
-    T* dx_acc;          // n: accepted step, kept for the next Broyden update (LS:1004-1006)
-    int n, ks, check_grad, lambda_from_state;
-    LmState<T>* host_st;  // pinned mirror (device-mapped) or nullptr
-    T* host_x;            // pinned, n: receives the accepted point
-    uint32_t seq;         // sequence number of this decision point
-    const int32_t* guard; // optional: the kernel does nothing when *guard == 0 (rounds enqueued ahead of time)
-    int spec_static;      // the host has enqueued (or will enqueue) the NEXT round behind st->spec_ok: decide whether it may run
-    uint32_t maxIterations;
-    const T* partials;    // nparts > 0: sums[k] is still the nparts stage-1 partials at partials + k pstride (no all-reduce
-    int nparts, pstride;  // sits between the stages: single GPU) -- this kernel runs stage 2 itself, one launch less per round
-};
-
-template <typename T>
-__device__ inline void decide_chain_body(const DecideArgs<T>& a)
+__device__ inline int decide_chain_body(const DecideArgs<T>& a)
 {
     __shared__ int acc_s;
     __shared__ LmState<T> s_pub;
-    {   // the guard is the flag this kernel rewrites further down: one thread reads it, everybody takes that value
-        __shared__ int go;
-        if (threadIdx.x == 0) go = !(a.guard && *a.guard == 0);
-        __syncthreads();
-        if (!go) return;
-    }
-    static_assert(kSolveThreads == 256, "sumsq_final_block is written for 256 threads");
     if (a.nparts > 0) {
-        __shared__ T red[4];
+        __shared__ T part[kReduceRanges];
         for (int k = 0; k < a.ks; ++k) {
-            const T tot = sumsq_final_block(a.partials + (size_t)k * a.pstride, a.nparts, red);
+            const T tot = lr_reduce_scalar(a.partials + (size_t)k * a.pstride, a.nparts, part);
             if (threadIdx.x == 0) a.sums[k] = tot;           // read back by thread 0 below (and by the host's trace)
         }
     }
@@ -282,14 +257,15 @@ __device__ inline void decide_chain_body(const DecideArgs<T>& a)
             dec = kDecideAccept;
             break;
         }
-        // May the round the host has enqueued ahead of time run? Only when this one ended in a plain acceptance and none of
-        // the reference's exit / refresh tests fires before the next pass (LS:974, 979, 990, 1144, 1164-1173, 1175): then the
-        // next pass is a Broyden update + one solve, which is exactly what was enqueued.
+        // Fused round (spec_static): may the kernel go on with the Broyden finish and the next solve? Only when this round
+        // ended in a plain acceptance of its one trial and none of the reference's exit / refresh tests fires before the next
+        // pass (LS:974, 979, 990, 1144, 1164-1173, 1175; lambda >= minLambda: no lambda_0 rule, LS:1067): then the next pass is
+        // a Broyden update + one solve -- the sweep behind the trial residual has prepared exactly that (lr_spec_go, the same
+        // expression on the same record, says whether it ran in full).
         int spec = 0;
-        if (a.spec_static && dec == kDecideAccept) {
-            const T dxn = dsqrt(s.dx_dot);
+        if (a.spec_static && dec == kDecideAccept && acc == 0) {
             spec = !(s.residual <= a.set.maxGoodResidual) && s.iterations < a.maxIterations && (s.lambda <= a.set.maxLambda)
-                && !(s.flags & kFlagXNaN) && (dxn > a.set.absTolerance && s.trial_xnorm > dxn * a.set.relTolerance);
+                && (s.lambda >= a.set.minLambda) && lr_spec_go(a.rec[0], a.set.absTolerance, a.set.relTolerance);
         }
         s.spec_ok = spec;
         s.decision = dec; s.accepted_k = acc; s.consumed = consumed; s.fcalls = fcalls;
@@ -314,12 +290,15 @@ __device__ inline void decide_chain_body(const DecideArgs<T>& a)
         __syncthreads();
         if (threadIdx.x == 0) publish_state(s_pub, a.host_st, a.seq);
     }
+    const int spec = s_pub.spec_ok;
+    __syncthreads();                     // x, dx_acc and the state are visible to the whole workgroup; s_pub may be reused
+    return spec;
 }
 
 template <typename T>
 __global__ __launch_bounds__(kSolveThreads) void k_decide_chain(DecideArgs<T> a)
 {
-    decide_chain_body(a);
+    (void)decide_chain_body(a);
 }
 
 // ---- LS:984-989: forced refresh resets mu

@@ -722,7 +722,7 @@ __global__ __launch_bounds__(res_threads(Model::n)) void k_lm_resident(ResidentA
                         sa.sc[0] = a.sc; sa.lam[0] = lambda; sa.f_in_lds = 1;
                         sa.check_grad = newJac ? 1 : 0;
                         sa.lambda_from_state = from_state ? 1 : 0;
-                        sa.lambda_from_device = 0; sa.guard = nullptr;
+                        sa.lambda_from_device = 0;
                         lm_solve_body<double, NB, BOUNDED>(sa, 0, solve_smem);
                         __syncthreads();
                         rec = *a.rec;

@@ -904,7 +904,6 @@ __global__ __launch_bounds__(kBigThreads) void k_lm_solve_big(LmSolveArgs<T> a)
     __shared__ unsigned long long s_cdesc[8];
     const int W = a.coop_w > 1 ? a.coop_w : 1;
     const int kc = (int)blockIdx.x / W, peer = (int)blockIdx.x % W;
-    if (a.guard && *a.guard == 0) return;                        // (every workgroup of the launch reads the same word)
     if (peer > 0) {
         coop_helper_loop<T>(a.sc[kc].coop, W, peer, a.coop_epoch, sm.span);
         return;

@@ -20,6 +20,7 @@
 #pragma once
 
 #include "common.h"
+#include "misc_kernels.h"
 #include "solve_types.h"
 
 namespace mirlsq {
@@ -724,7 +725,6 @@ __device__ __forceinline__ void lm_solve_body(const LmSolveArgs<T>& a, const int
     T* qpu = sc.vec + 8 * (size_t)n;
     T* xq = sc.vec + 10 * (size_t)n;
 
-    if (a.guard && *a.guard == 0) return;
     MIRLSQ_STAMP(sc.dbg, 0);
     if (sc.dbg && threadIdx.x == 0) sc.dbg[9] = clock64();
     // the LDS path: the loads of J^T J go out now and are collected inside ?posvx, behind this prologue (solve_lds.h)
@@ -928,10 +928,29 @@ __device__ __forceinline__ void lm_solve_body(const LmSolveArgs<T>& a, const int
     }
 }
 
+// Head of a FUSED round (a.fused; LmSolveArgs): the decision of the previous round's trial (LS:1112-1161; its sum of squares came
+// in with the all-reduced sweep vector), published to the host at once, and -- if a Broyden pass follows -- that pass's n x n
+// side (LS:1003-1006, 1052, 1065 as k_lr_finish forms them). false: the kernel is done (no pass follows, the host takes over).
+// fin_v: n elements of LDS scratch (the LDS solve's dynamic region is free until the body starts: at n = 128 it leaves 4 KB of a
+// CU's 160 KB for every static variable of the kernel).
+template <typename T>
+__device__ __forceinline__ bool lm_round_head(const LmSolveArgs<T>& a, T* fin_v)
+{
+    if (!decide_chain_body(a.dec)) return false;
+    lr_finish_block(a.fin_lr, a.fin_D, a.dec.dx_acc, a.fin_k, a.n, a.fin_JJ, a.fin_Jy, fin_v);
+    return true;
+}
+
 template <typename T, int NB, bool BOUNDED = true>
 __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if (a.fused) {
+        T* fin_v;
+        if constexpr (NB > 0) fin_v = reinterpret_cast<T*>(smem_raw);
+        else { __shared__ T fin_static[kSolveMaxN]; fin_v = fin_static; }
+        if (!lm_round_head(a, fin_v)) return;
+    }
     lm_solve_body<T, NB, BOUNDED>(a, (int)blockIdx.x, smem_raw);      // blockIdx.x: chain step
 }
 
@@ -945,7 +964,10 @@ template <bool BOUNDED>
 __global__ __launch_bounds__(kWave) void k_lm_solve_wave(LmSolveArgs<double> a)
 {
     const int n = a.n, kc = blockIdx.x, lane = threadIdx.x, r = lane & 15, g = lane >> 4;
-    if (a.guard && *a.guard == 0) return;
+    if (a.fused) {
+        __shared__ double fin_v[kW16];
+        if (!lm_round_head(a, fin_v)) return;
+    }
     const bool el = r < n;
     const int rc = el ? r : 0;
     double JJrow[kW16];

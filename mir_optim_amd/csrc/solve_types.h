@@ -25,8 +25,8 @@ struct LmState {
     uint32_t rejects, guards, qp_active;
     uint32_t null_tail;        // the last consumed trial of the round was a null step (trial == x): the next ones probably are too
     uint32_t seq;              // host mirror only: number of the decision point this image belongs to (written last)
-    int32_t spec_ok;           // set by the decision kernel: the round enqueued ahead of time behind this flag is the one the
-                               // reference would run next (accepted step, no exit test fired): its kernels may execute
+    int32_t spec_ok;           // set by the decision at the head of a fused round: the Broyden pass the round's sweep prepared is the
+                               // one the reference runs next (accepted step, no exit test fired) -- the kernel went on with it
 };
 
 // One solve of the lambda ladder (chain step k): everything the acceptance logic needs about it.
@@ -97,6 +97,27 @@ __host__ __device__ inline size_t solve_lds_bytes(int n, int elem)
     return nb ? (size_t)lds_solve_elems(nb) * elem : 0;
 }
 
+// the decision of a round (k_decide_chain / the head of a fused round; misc_kernels.h)
+template <typename T>
+struct DecideArgs {
+    T* sums;            // ks trial sums of squares; entries of null steps are filled in here (= the current residual)
+    const ChainRec<T>* rec;
+    LmState<T>* st;
+    LmSettingsDev<T> set;
+    T* x;               // n: current point, overwritten by the accepted trial (LS:1135)
+    const T* trial;     // ks x n
+    const T* dx_chain;  // ks x n
+    T* dx_acc;          // n: accepted step, kept for the next Broyden update (LS:1004-1006)
+    int n, ks, check_grad, lambda_from_state;
+    LmState<T>* host_st;  // pinned mirror (device-mapped) or nullptr
+    T* host_x;            // pinned, n: receives the accepted point
+    uint32_t seq;         // sequence number of this decision point
+    int spec_static;      // the decision is the head of a fused round (k_lm_solve with a.fused): decide whether the kernel goes on
+    uint32_t maxIterations;
+    const T* partials;    // nparts > 0: sums[k] is still the nparts stage-1 partials of k_lr_sumsq at partials + k pstride (no
+    int nparts, pstride;  // all-reduce sits between the stages: single GPU) -- this kernel runs stage 2 itself (lr_reduce_scalar)
+};
+
 template <typename T>
 struct LmSolveArgs {
     const T* JJ;       // n x n full symmetric, undamped
@@ -115,8 +136,18 @@ struct LmSolveArgs {
     int f_in_lds;
     int check_grad;        // a new Jy was just computed: apply the gradient test LS:1053 first (chain of 1)
     int lambda_from_state; // step 0 takes st->lambda and applies the lambda_0 rule LS:1067-1072
-    int lambda_from_device; // step 0 takes st->lambda as it is (a round enqueued before the host has seen the previous decision)
-    const int32_t* guard;  // optional: the kernel does nothing when *guard == 0 (rounds enqueued ahead of time)
+    int lambda_from_device; // step 0 takes st->lambda as it is (the fused round: written by the decision at the kernel's head)
+    // FUSED ROUND (fused != 0; one ladder entry, n <= kSolveMaxN): the kernel first DECIDES the previous round's trial (dec;
+    // its sum of squares is entry lr_yy(n) of the all-reduced sweep vector fin_lr) and publishes the decision; if that is a plain
+    // acceptance after which a Broyden pass follows, it applies the pass's n x n side (k_lr_finish's arithmetic: J^T J, J^T y,
+    // D[fin_k] = dx) from the rest of fin_lr and goes on with the solve -- decision, finish and solve in ONE launch.
+    int fused;
+    DecideArgs<T> dec;
+    const T* fin_lr;
+    T* fin_D;
+    T* fin_JJ;
+    T* fin_Jy;
+    int fin_k;
     int coop_w;            // k_lm_solve_big: workgroups per ladder entry (main + helpers, solve_coop.h); 0 / 1: none
     uint32_t coop_epoch;   // ... the number of this launch among the workspace's solve launches (> 0, increasing)
     int coop_absent;       // diagnostic (MIR_LSQ_VARIANT_DEBUG_HELPERS_ABSENT): launch the main workgroups only

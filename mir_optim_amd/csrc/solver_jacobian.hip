@@ -29,23 +29,20 @@ bool Solver<T>::broyden_lowrank(const T* y_dev, const T* yold_dev)
         if (!plain_products(yold_dev)) return false;
         if (stats) stats->jtj_resyncs++;
     }
-    // spec_enqueue: the pass is enqueued behind the device-side guard before the host knows whether it will be needed; the
-    // host-side bookkeeping (lr_k, statistics) is done when the round is committed (commit_spec_round)
-    const int32_t* guard = spec_enqueue ? &B.st->spec_ok : nullptr;
+    // (the pass of a fused round is enqueued by enqueue_fused_tail, solver_loop.hip: the same kernels, the sweep ahead of the
+    // decision and the n x n side inside the solve's launch)
     LrArgs<T> a{};
     a.J = B.J; a.U = U; a.D = B.lrD; a.dx = B.dx_acc; a.dx_dot = &B.st->dx_dot; a.y = y_dev; a.y_old = yold_dev;
-    a.partials = B.lrpart; a.m = m; a.n = (int)n; a.k = lr_k; a.guard = guard;
+    a.partials = B.lrpart; a.m = m; a.n = (int)n; a.k = lr_k;
     const int nblk = lr_blocks(m, ws->num_cu), len = lr_len((int)n);
     ev_begin(1);
     if (!ok(lr_sweep<T>(a, nblk, stream), "broyden sweep")) return false;
     ev_end();
-    if (!ok(lr_reduce<T>(B.lrpart, nblk, (int)n, B.lrvec, guard, stream), "broyden reduce")) return false;
+    if (!ok(lr_reduce<T>(B.lrpart, nblk, (int)n, B.lrvec, stream), "broyden reduce")) return false;
     if (comm && !allreduce(B.lrvec, (size_t)len, 1)) return false;
-    if (!ok(lr_finish<T>(B.lrvec, B.lrD, B.dx_acc, lr_k, (int)n, B.JJ, B.Jy, B.st, guard, stream), "broyden finish")) return false;
-    if (!spec_enqueue) {
-        if (stats) stats->broyden_lr_columns += (uint64_t)lr_k;
-        ++lr_k;
-    }
+    if (!ok(lr_finish<T>(B.lrvec, B.lrD, B.dx_acc, lr_k, (int)n, B.JJ, B.Jy, B.st, stream), "broyden finish")) return false;
+    if (stats) stats->broyden_lr_columns += (uint64_t)lr_k;
+    ++lr_k;
     return true;
 }
 

@@ -14,7 +14,7 @@ void Solver<T>::ev_begin(int kind)
     if (!time_kernels) return;
     HpScope hp(this, 0);
     EventPair p{};
-    p.kind = spec_enqueue ? kind + 100 : kind;       // rounds enqueued ahead of time: counted only once they are committed
+    p.kind = spec_enqueue ? kind + 100 : kind;       // the pass a fused round runs ahead: counted only once it is committed
     // events come from the workspace's pool (created on first use, reused by every later solve on this workspace)
     if (ws->event_pool.size() < 2 * (events.size() + 1)) {
         hipEvent_t ea, eb;
@@ -90,18 +90,13 @@ bool Solver<T>::setup()
     fr = B.ytmp;
     big_solve = n > (uint32_t)kSolveMaxN || (variant & MIR_LSQ_VARIANT_SOLVE_GENERIC) != 0;
     if (n > (uint32_t)kLrMaxN) lowrank = false;    // the read-only Broyden sweep keeps n <= kLrMaxN = 512; above, J is rewritten
-    // Rounds enqueued ahead of time: measured on one MI355X they do not pay at cfg 3 (7.08 ms per solve with, 7.02 without: the
-    // stream is busy > 97 % of a solve anyway) but do for SMALL problems (J up to 32 MB: every kernel of a round is a few
-    // microseconds and the host's decision latency is a visible share of it): cfg 2 63.5 -> 61.8 us per round. So: on for
-    // those, MIR_LSQ_VARIANT_NO_PIPELINE turns it off. (Re-measured in round 4 with the threshold at 1 GB: cfg 3 1001 / 1002 it/s
-    // with, 1020 / 1009 without; a strong-scaled rank's 125 000 x 128 on the global trajectory 1.365 vs 1.375 ms: still nothing.)
-    const bool small_problem = (double)m * (double)n * sizeof(T) <= 32.0 * 1024 * 1024;
-    pipeline = device_cb && lowrank && !big_solve && !trace && !dbg_solve
-        && small_problem && !(variant & MIR_LSQ_VARIANT_NO_PIPELINE)
-        && (!comm || comm->kind == 1);      // host-mediated communicators synchronise the stream inside every exchange; a REPLAY
-                                            // communicator (kind 4) cannot serve a round enqueued ahead of time at all: its tape
-                                            // holds the exchanges the recorded solve COMMITTED (an in-process group never
-                                            // pipelines), so the speculative exchange of the final round would read past its end
+    // The FUSED round (enqueue_fused_tail): behind a round's one trial residual the Broyden sweep of the NEXT pass is run
+    // speculatively (it needs the step and the two residual vectors, not the decision) and carries the trial's sum of squares,
+    // ONE all-reduce serves LS:1115 and LS:1052 / 1065, and ONE kernel decides the trial, applies the pass's n x n side and
+    // solves the next system: 3 launches and 1 collective per accepted Broyden pass instead of 7 and 2. Device callbacks, the
+    // read-only sweep (n <= kLrMaxN) and the one-workgroup solves (n <= kSolveMaxN) only; a trace or the solve's phase stamps
+    // keep the one-by-one rounds (MIR_LSQ_VARIANT_NO_PIPELINE selects them too): the same bits either way.
+    fused = device_cb && lowrank && !big_solve && !trace && !dbg_solve && !(variant & MIR_LSQ_VARIANT_NO_PIPELINE);
     twh_h.resize(n);
     // x, lower, upper sit back to back in the workspace: one copy from the pinned block instead of three from pageable
     // memory (each of those is a staged blit kernel, ~18 us apart on the stream)
@@ -124,7 +119,7 @@ void Solver<T>::teardown()
                              "longest single call %.3f\n", hp_ms[0], hp_ms[1], hp_ms[2], hp_ms[3], hp_ms[4], hp_ms[5]);
     if (stats) {
         for (auto& e : events) {
-            if (e.kind < 0 || e.kind >= 100) continue;       // a round enqueued ahead of time whose guard stayed closed
+            if (e.kind < 0 || e.kind >= 100) continue;       // a fused round's pass run ahead that was not the next pass
             float ms = 0;
             (void)hipEventElapsedTime(&ms, e.a, e.b);
             if (e.kind == 0) { stats->jtj_ms += ms; stats->jtj_launches++; }
@@ -164,8 +159,7 @@ bool Solver<T>::eval_f(const T* x_dev, const T* x_host, T* y_dev)
         && ok(hipStreamSynchronize(stream), "sync");
 }
 
-// ---- ||v_k||^2 for k < count vectors (stride vstride) -> B.sum[slot + k] on device (all-reduced over row shards)
-//      defer_final (single GPU, trial sums): stage 2 is left to k_decide_chain (sums_pending = the partial count)
+// ---- ||v||^2 -> B.sum[slot] on device (all-reduced over row shards): the residual at entry, LS:955
 template <typename T>
 int Solver<T>::sumsq_blocks() const
 {
@@ -174,14 +168,27 @@ int Solver<T>::sumsq_blocks() const
     return nb < 1 ? 1 : nb;
 }
 template <typename T>
-bool Solver<T>::sumsq(const T* v, int slot, int count, size_t vstride, bool defer_final)
+bool Solver<T>::sumsq(const T* v, int slot)
 {
     const int nb = sumsq_blocks();
-    MIRLSQ_LAUNCH(k_sumsq_partial<T>, dim3(nb, count), dim3(256), 0, stream, v, m, B.partials, vstride, kPartials);
-    if (defer_final && !comm) { sums_pending = nb; return ok(hipGetLastError(), "sumsq"); }
-    MIRLSQ_LAUNCH(k_sumsq_final<T>, dim3(count), dim3(256), 0, stream, B.partials, nb, B.sum + slot, kPartials);
-    if (comm && !allreduce(B.sum + slot, (size_t)count, 2)) return false;
+    MIRLSQ_LAUNCH(k_sumsq_partial<T>, dim3(nb), dim3(256), 0, stream, v, m, B.partials, (size_t)0, kPartials);
+    MIRLSQ_LAUNCH(k_sumsq_final<T>, dim3(1), dim3(256), 0, stream, B.partials, nb, B.sum + slot, kPartials);
+    if (comm && !allreduce(B.sum + slot, 1, 2)) return false;
     return ok(hipGetLastError(), "sumsq");
+}
+
+// ---- ||v_k||^2 of the ks TRIAL residual vectors -> B.sum[1 + k]: the row walk and summation order of the Broyden sweep
+//      (k_lr_sumsq), so that a trial's sum has the same bits whether it rode on a speculative sweep (fused round) or not.
+//      Single GPU: stage 2 is left to k_decide_chain (sums_pending = the partial count).
+template <typename T>
+bool Solver<T>::trial_sums(const T* v, int count, size_t vstride)
+{
+    static_assert(kPartials >= kLrMaxBlocks, "one partial per workgroup of the sweep's grid");
+    const int nb = lr_blocks(m, ws->num_cu);
+    if (!ok(lr_sumsq<T>(v, m, count, vstride, B.partials, kPartials, nb, stream), "trial sums")) return false;
+    if (!comm) { sums_pending = nb; return true; }
+    if (!ok(lr_sumsq_final<T>(B.partials, kPartials, nb, count, B.sum + 1, stream), "trial sums, stage 2")) return false;
+    return allreduce(B.sum + 1, (size_t)count, 2);
 }
 
 // ---- row-shard exchange: sum `count` elements over the ranks, in place, ordered on the stream. kind: 0 packed
@@ -278,7 +285,7 @@ bool Solver<T>::read_state(const T* vec_dev)
 
 // the n x n part of a round (LS:1053-1110, 1141-1142) for ks ladder entries
 template <typename T>
-bool Solver<T>::enqueue_solve(int ks, const T* lam, bool check_grad, bool lambda_from_state)
+LmSolveArgs<T> Solver<T>::solve_args(int ks, const T* lam, bool check_grad, bool lambda_from_state)
 {
     LmSolveArgs<T> a{};
     a.JJ = B.JJ; a.Jy = B.Jy; a.x = B.x; a.lower = B.lower; a.upper = B.upper;
@@ -287,8 +294,6 @@ bool Solver<T>::enqueue_solve(int ks, const T* lam, bool check_grad, bool lambda
     a.f_in_lds = solve_nb((int)n, (int)sizeof(T)) > 0;
     a.check_grad = check_grad ? 1 : 0;
     a.lambda_from_state = lambda_from_state ? 1 : 0;
-    a.lambda_from_device = spec_enqueue ? 1 : 0;
-    a.guard = spec_enqueue ? &B.st->spec_ok : nullptr;
     if (!dbg_solve) a.sc[0].dbg = nullptr;
     // n > 256: every ladder entry's workgroup gets helpers (solve_coop.h)
     a.coop_w = (big_solve && n > (uint32_t)kSolveMaxN && !(variant & MIR_LSQ_VARIANT_SOLVE_ONE_WORKGROUP)) ? coop_peers((int)n) : 1;
@@ -297,6 +302,12 @@ bool Solver<T>::enqueue_solve(int ks, const T* lam, bool check_grad, bool lambda
     if (a.coop_w > ws->num_cu / 2) a.coop_w = ws->num_cu / 2 >= 2 ? ws->num_cu / 2 : 1;
     a.coop_epoch = a.coop_w > 1 ? ++ws->solve_epoch : 0;
     a.coop_absent = (variant & MIR_LSQ_VARIANT_DEBUG_HELPERS_ABSENT) ? 1 : 0;
+    return a;
+}
+template <typename T>
+bool Solver<T>::enqueue_solve(int ks, const T* lam, bool check_grad, bool lambda_from_state)
+{
+    const LmSolveArgs<T> a = solve_args(ks, lam, check_grad, lambda_from_state);
     ev_begin(2);
     {
         HpScope hp(this, 4);
@@ -307,44 +318,76 @@ bool Solver<T>::enqueue_solve(int ks, const T* lam, bool check_grad, bool lambda
     return true;
 }
 
-// the decision of a round (LS:1080-1161) for ks trials whose sums of squares are in B.sum + 1; publishes decision point ++seq
-//      sum_v != nullptr: the ks trial residual vectors at sum_v + k m still have to be summed (sumsq() runs first; on a
-//      single GPU its second stage is left to the decision kernel)
+// the decision of a round (LS:1080-1161) for ks trials; publishes decision point ++seq
 template <typename T>
-bool Solver<T>::enqueue_decide(int ks, bool check_grad, bool lambda_from_state, bool next_round_enqueued_ahead, const T* sum_v)
+DecideArgs<T> Solver<T>::decide_args(int ks, bool check_grad, bool lambda_from_state)
 {
-    if (sum_v && !sumsq(sum_v, 1, ks, m, true)) return false;
     DecideArgs<T> d{};
     d.sums = B.sum + 1; d.rec = B.rec; d.st = B.st; d.set = sd; d.x = B.x; d.trial = B.trial; d.dx_chain = B.dx;
     d.dx_acc = B.dx_acc; d.n = (int)n; d.ks = ks; d.check_grad = check_grad ? 1 : 0;
     d.lambda_from_state = lambda_from_state ? 1 : 0;
     ++seq;
     d.host_st = st_slot_d[seq & 1]; d.host_x = x_slot_d[seq & 1]; d.seq = seq;
-    d.guard = spec_enqueue ? &B.st->spec_ok : nullptr;
-    d.spec_static = next_round_enqueued_ahead ? 1 : 0;
     d.maxIterations = S->maxIterations;
     d.partials = B.partials; d.nparts = sums_pending; d.pstride = kPartials;
     sums_pending = 0;
+    return d;
+}
+//      sum_v != nullptr: the ks trial residual vectors at sum_v + k m still have to be summed (trial_sums() runs first; on a
+//      single GPU its second stage is left to the decision kernel); else their sums of squares are in B.sum + 1
+template <typename T>
+bool Solver<T>::enqueue_decide(int ks, bool check_grad, bool lambda_from_state, const T* sum_v)
+{
+    if (sum_v && !trial_sums(sum_v, ks, m)) return false;
+    const DecideArgs<T> d = decide_args(ks, check_grad, lambda_from_state);
     MIRLSQ_LAUNCH(k_decide_chain<T>, dim3(1), dim3(kSolveThreads), 0, stream, d);
     return ok(hipGetLastError(), "decide kernel");
 }
 
-// Enqueue, behind the guard, the LIBRARY part of the round that follows an ACCEPTED round with one trial: the Broyden
-// sweep with the roles the residual buffers will have after the rotation (y_new = fr, y_old = y) and the solve with
-// lambda taken from the device state. The caller's residual callback is NOT enqueued ahead of time: it cannot be guarded
-// (a full sweep over the caller's data per miss -- measured at cfg 3: two misses per solve cost more than the launch
-// latency the scheme hides); the host enqueues it, the sum of squares and the decision once the round is committed,
-// while the GPU is busy with the sweep and the solve. The host-side bookkeeping waits for commit_spec_round().
+// The tail of a FUSED round (see setup()), behind the round's one trial residual ytr = f(trial):
+//   k_broyden_lr   SPECULATIVELY, as if the trial were accepted: y_new = ytr, y_old = y, the step and its dx.dx from ladder
+//                  entry 0 (what the decision would copy into dx_acc / the state) -- plus ||ytr||^2 (entry lr_yy); when the
+//                  entry's record already rules a Broyden pass out the kernel only forms that sum
+//   k_lr_reduce    -> B.lrvec;  ONE all-reduce of [sweep | sum of squares] (LS:1115 and LS:1052 / 1065 of the next pass)
+//   k_lm_solve     with a.fused: decision of this round (published at once), the pass's n x n side, the next pass's solve
+// A rejected trial discards the sweep (column lr_k of U is rewritten by the next one). Host-side bookkeeping of the pass that
+// may have been run ahead waits for commit_spec_round().
 template <typename T>
-bool Solver<T>::enqueue_spec_round()
+bool Solver<T>::enqueue_fused_tail(const T* ytr, bool check_grad, bool lambda_from_state)
 {
-    spec_enqueue = true;
     spec_events_from = events.size();
-    const bool good = broyden_lowrank(fr, y) && enqueue_solve(1, nullptr, true, false);
+    if (stats) stats->fused_rounds++;
+    LrArgs<T> a{};
+    a.J = B.J; a.U = static_cast<T*>(ws->ulr); a.D = B.lrD; a.dx = B.dx; a.dx_dot = &B.rec[0].new_dx_dot; a.y = ytr; a.y_old = y;
+    a.partials = B.lrpart; a.m = m; a.n = (int)n; a.k = lr_k;
+    a.spec_rec = B.rec; a.absTolerance = sd.absTolerance; a.relTolerance = sd.relTolerance;
+    const int nblk = lr_blocks(m, ws->num_cu), len = lr_len((int)n);
+    spec_enqueue = true;                                 // (the events of the pass run ahead count once it is committed)
+    ev_begin(1);
+    const bool swept = ok(lr_sweep<T>(a, nblk, stream), "broyden sweep");
+    ev_end();
+    spec_enqueue = false;
+    if (!swept || !ok(lr_reduce<T>(B.lrpart, nblk, (int)n, B.lrvec, stream), "broyden reduce")) return false;
+    if (comm && !allreduce(B.lrvec, (size_t)len, 1)) return false;
+    LmSolveArgs<T> sa = solve_args(1, nullptr, true, false);
+    sa.lambda_from_device = 1;
+    sa.fused = 1;
+    sa.dec = decide_args(1, check_grad, lambda_from_state);
+    sa.dec.sums = B.lrvec + lr_yy((int)n);
+    sa.dec.spec_static = 1;
+    sa.fin_lr = B.lrvec; sa.fin_D = B.lrD; sa.fin_JJ = B.JJ; sa.fin_Jy = B.Jy; sa.fin_k = lr_k;
+    spec_enqueue = true;
+    ev_begin(2);
+    bool good;
+    {
+        HpScope hp(this, 4);
+        good = ok(launch_lm_solve<T>(sa, 1, has_bounds, false, stream), "fused round launch");
+    }
+    ev_end();
     spec_enqueue = false;
     return good;
 }
-// the round enqueued ahead of time is the one the reference runs next: do now what the host does when it enqueues a
+// the pass run ahead by the fused round is the one the reference runs next: do now what the host does when it enqueues a
 // Broyden round itself
 template <typename T>
 void Solver<T>::commit_spec_round()
@@ -352,8 +395,8 @@ void Solver<T>::commit_spec_round()
     for (size_t i = spec_events_from; i < events.size(); ++i) if (events[i].kind >= 100) events[i].kind -= 100;
     if (stats) {
         stats->jacobian_broyden++;
+        stats->fused_passes++;
         stats->broyden_lr_columns += (uint64_t)lr_k;
-        if (comm) { stats->allreduce_calls[1]++; stats->allreduce_elems[1] += (uint64_t)lr_len((int)n); }
     }
     ++lr_k;
 }
@@ -406,7 +449,7 @@ typename Solver<T>::Result Solver<T>::run()
     bool fConverged = ret.residual <= S->maxGoodResidual;                // LS:956
     bool needJacobian = true;                                            // LS:959
     bool last_rejected = false;
-    bool spec_live = false;            // the round at the top of the loop is already enqueued (guard open)
+    bool spec_live = false;            // the Jacobian side and the solve of the round at the top of the loop have run already (fused round)
     bool spec_predict = true;          // the last first trial after a Jacobian update was accepted
     const bool speculate = device_cb && !no_speculation;        // ladder trials: one fb call, or ks calls of f
     uint32_t age = maxAge;
@@ -437,10 +480,10 @@ typename Solver<T>::Result Solver<T>::run()
         T* ytr = fr;
         bool solve_enqueued = false;
         if (spec_live) {
-            // this round is already in the stream (enqueue_spec_round of the previous iteration) and its guard is open
+            // the Jacobian side and the solve of this round have run in the previous round's fused kernel
             spec_live = false;
             if (!needJacobian || !(age < maxAge) || lr_k >= lr_cap) {
-                std::fprintf(stderr, "[mir_optim_amd] internal error: the round enqueued ahead of time is not the next round\n");
+                std::fprintf(stderr, "[mir_optim_amd] internal error: the pass run ahead by the fused round is not the next pass\n");
                 fail = true;
                 break;
             }
@@ -557,19 +600,17 @@ typename Solver<T>::Result Solver<T>::run()
             if (!no_f && !eval_f(B.trial, trial_h, ytr)) { fail = true; break; }
         }
 
-        // Can the round after this one be enqueued before this one's decision is known? Only the common case is covered:
-        // one trial now, and -- if it is accepted and no exit test fires (decided on the device, k_decide_chain) -- a
-        // Broyden pass next that needs neither a full refresh (age) nor a flush of the pending terms (lr_k).
-        const bool decide_static = pipeline && spec_predict && ks == 1 && !skip_eval && age < maxAge && lr_k < lr_cap;
-        if (!enqueue_decide(ks, newJacobian, lambda_from_state, decide_static, skip_eval ? nullptr : ytr)) { fail = true; break; }
+        // Fused round: one trial now, and -- if it is accepted and no exit test fires (decided on the device) -- a Broyden pass
+        // next that needs neither a full refresh (age) nor a flush of the pending terms (lr_k). One-bit predictor: only while
+        // first trials are being accepted (the rejection tail of a noisy fit would waste a sweep per miss).
+        const bool fuse = fused && spec_predict && ks == 1 && !skip_eval && age < maxAge && lr_k < lr_cap;
+        if (fuse ? !enqueue_fused_tail(ytr, newJacobian, lambda_from_state)
+                 : !enqueue_decide(ks, newJacobian, lambda_from_state, skip_eval ? nullptr : ytr)) { fail = true; break; }
         const uint32_t round_seq = seq;
-        if (decide_static && !enqueue_spec_round()) { fail = true; break; }
         if (!wait_state(round_seq)) { fail = true; break; }
-        if (decide_static) {
+        if (fuse) {
             if (st_h->spec_ok) spec_live = true; else drop_spec_round();
         }
-        // one-bit predictor: enqueue ahead only while first trials are being accepted (the rejection tail of a noisy fit
-        // would waste a guarded round per miss)
         if (ks == 1 && newJacobian) spec_predict = st_h->decision == kDecideAccept;
 
         if (trace && !trace_round(ks, ret.residual, ret.iterations)) { fail = true; break; }

@@ -100,12 +100,32 @@ def test_rccl_communicator_world_size_1(oracle):
         r1, x1 = prob.solve(w["x0"], settings=s, comm=comm, stats=st, batched=True)
         r0, x0 = prob.solve(w["x0"], settings=s, batched=True)
         assert r1.status >= 0 and np.array_equal(x1, x0) and r1.iterations == r0.iterations   # sum over one rank = identity
-        # every exchange of the solve went through ncclAllReduce with the documented payloads (n = 128: 8384 / 290 / 1+)
+        # every exchange of the solve went through ncclAllReduce with the documented payloads (n = 128: 8384 / 291 / 1+)
         assert st.allreduce_calls[0] == st.jacobian_full + st.jtj_resyncs >= 1
         assert st.allreduce_elems[0] == st.allreduce_calls[0] * PAR.packed_length(n)
-        assert st.allreduce_calls[1] == st.jacobian_broyden >= 1 and st.allreduce_elems[1] == st.allreduce_calls[1] * (2 * n + 34)
-        assert st.allreduce_calls[2] >= r1.iterations + 1 and st.allreduce_elems[2] >= st.allreduce_calls[2]
-    assert PAR.packed_length(128) == 8384 and 2 * 128 + 34 == 290
+        # COLLECTIVE BUDGET (the three reductions LS:1052, 1065, 1115): a fused round exchanges [sweep | trial sum] ONCE; only a
+        # Broyden pass that no fused round had prepared pays a sweep exchange of its own, only a trial that did not ride on a
+        # sweep (and the entry residual) a scalar one
+        assert st.fused_rounds >= st.fused_passes >= 1 and st.jacobian_broyden >= st.fused_passes
+        assert st.allreduce_calls[1] == st.fused_rounds + (st.jacobian_broyden - st.fused_passes)
+        assert st.allreduce_elems[1] == st.allreduce_calls[1] * (2 * n + 35)
+        assert st.allreduce_calls[2] == 1 + (st.trial_callback_calls - st.fused_rounds) and st.allreduce_elems[2] >= st.allreduce_calls[2]
+    # cfg 3's own trajectory at the bench's tolerance (refresh, 4 Broyden passes, confirming refresh; 6 trials): 1 + 2 + 6 = 9
+    # exchanges per solve (13 with one-by-one rounds)
+    w = P.tanh_linear(30000, 128)
+    prob = W.TanhLinear(w["A"], w["b"])
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-5
+    counts = {}
+    for variant in (0, M.VARIANT_NO_PIPELINE):
+        st = M.Stats()
+        r1, x1 = prob.solve(w["x0"], settings=s, comm=comm, stats=st, batched=True, variant=variant)
+        counts[variant] = (sum(st.allreduce_calls), st.trial_callback_calls, st.jacobian_full, st.jacobian_broyden, x1.tobytes(), r1.residual)
+        if not variant:
+            assert st.fused_passes == st.jacobian_broyden            # every Broyden pass of this trajectory rode on a fused round
+    assert counts[0][1:] == counts[M.VARIANT_NO_PIPELINE][1:]
+    trials, full, broyden = counts[0][1:4]
+    assert (counts[0][0], counts[M.VARIANT_NO_PIPELINE][0]) == (1 + full + trials, 1 + full + broyden + trials), (counts[0][:4], counts[M.VARIANT_NO_PIPELINE][:4])
+    assert PAR.packed_length(128) == 8384 and 2 * 128 + 35 == 291
     M.api.lib().mir_lsq_comm_destroy(comm)
 
 

@@ -170,7 +170,12 @@ def test_fused_fd_solve_matches_fill_pass(m, n, bounded):
     assert sf.jtj_fd_launches == sf.jacobian_full >= 1 and sp.jtj_fd_launches == 0
     assert (rf.fCalls, rf.gCalls) == (rp.fCalls, rp.gCalls) or first_differs_late(tf, tp)
     assert int(rf.status) >= 0 and int(rp.status) >= 0
-    assert np.allclose(xf, xp, rtol=1e-6, atol=1e-9), np.abs(xf - xp).max()
+    if [a[0] for a in tf] == [b[0] for b in tp]:
+        assert np.allclose(xf, xp, rtol=1e-6, atol=1e-9), np.abs(xf - xp).max()
+    else:
+        # two end games (the two J differ in the last bits, a noise-decided acceptance branches, one run makes a pass more): each
+        # stops within the tolerance of the minimiser, so they agree NORM-wise to 1e-6 -- a component of 0.15 need not to 1e-7
+        assert np.abs(xf - xp).max() <= 1e-6 * np.abs(xp).max(), np.abs(xf - xp).max()
     assert np.isclose(rf.residual, rp.residual, rtol=1e-9)
     assert_same_trajectory(tf, tp, (m, n, bounded))
 

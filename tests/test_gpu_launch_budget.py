@@ -1,13 +1,14 @@
 """Launches per round and the statistics that report them.
 
-Single GPU, the product sequence:
-    refresh round   k_fd_points | fused FD J^T J | slab reduce (writes J^T J, J^T y) | solve (|J^T y|_inf in its prologue) |
-                    sums of squares (stage 1) | decision (stage 2 + the ladder walk)                                    = 6
-    Broyden round   sweep | reduce | finish | solve | sums | decision                                                   = 6
+Single GPU, the product sequence (FUSED rounds: the tail behind a round's one trial residual is speculative sweep | reduce |
+ONE kernel for decision + the pass's n x n side + the next solve, so the round that follows starts at its trial residual):
+    refresh round   k_fd_points | fused FD J^T J | slab reduce (writes J^T J, J^T y) | solve | tail                     = 7
+    Broyden round   (sweep, reduce, finish and solve ran in the previous round's tail) tail                             = 3
     re-solve round  solve | sums | decision (or solve | decision when every trial is a null step)                      <= 3
-With a communicator the all-reduce sits between a reduction and its consumer: k_unpack_grad and k_sumsq_final come back (7).
-(The "last workgroup finishes" tails and the finish-in-solve variant that round 3 built, measured and retired are gone from
-the library: profiles/r03/ab_tails.txt keeps the evidence.)
+One-by-one rounds (MIR_LSQ_VARIANT_NO_PIPELINE; also what a trace selects):
+    refresh round   k_fd_points | fused FD J^T J | slab reduce | solve | sums of squares (stage 1) | decision (stage 2 + walk) = 6
+    Broyden round   sweep | reduce | finish | solve | sums | decision                                                   = 6
+With a communicator the all-reduce sits between a reduction and its consumer: k_unpack_grad and k_lr_sumsq_final come back.
 Reference loop: least_squares.d:972-1175 (the reductions are LS:1052, 1065, 1115)."""
 import ctypes as C
 import threading
@@ -37,8 +38,7 @@ def test_bounded_gauss_sum_launch_counts():
     g = P.gauss_sum(100000, K=5)
     prob = W.Curve("gauss_sum", g["t"], g["data"])
     st = M.Stats()
-    # (no rounds enqueued ahead of time: this small problem would pipeline by default, and a guarded round that is
-    # dropped still counts its launches)
+    # (one-by-one rounds: the budget of the kernels taken apart)
     r, x = prob.solve(g["x0"], l=g["lower"], u=g["upper"], batched=True, stats=st, variant=M.VARIANT_NO_PIPELINE)
     assert r.status >= 0
     assert st.rounds[0] == st.jacobian_full and st.rounds[1] == st.jacobian_broyden
@@ -55,14 +55,28 @@ def test_launch_budget_cfg3_shape():
     w = P.tanh_linear(50000, 128)
     prob = W.TanhLinear(w["A"], w["b"])
     s = M.LeastSquaresSettings(); s.absTolerance = 1e-5
-    st = M.Stats()
-    r, x = prob.solve(w["x0"], settings=s, batched=True, stats=st)
-    assert r.status == M.LeastSquaresStatus.xConverged
-    assert st.rounds[0] == st.jacobian_full >= 2 and st.rounds[1] == st.jacobian_broyden >= 2
-    assert st.round_launches[1] == 6 * st.rounds[1]          # sweep, reduce, finish, solve, sums, decision
-    # FD points, k_jtj_fdp, slab reduce, solve, sums, decision (+ k_reset_mu in a refresh that LS:984-989 forces)
-    assert 6 * st.rounds[0] <= st.round_launches[0] <= 6 * st.rounds[0] + 1
-    assert st.library_launches == sum(st.round_launches) + 3  # + the sum of squares at entry (LS:955: two stages) and the state set-up
+    outs = []
+    for variant in (M.VARIANT_NO_PIPELINE, 0):
+        st = M.Stats()
+        r, x = prob.solve(w["x0"], settings=s, batched=True, stats=st, variant=variant)
+        assert r.status == M.LeastSquaresStatus.xConverged
+        assert st.rounds[0] == st.jacobian_full >= 2 and st.rounds[1] == st.jacobian_broyden >= 2
+        if variant:
+            assert st.fused_rounds == 0
+            assert st.round_launches[1] == 6 * st.rounds[1]          # sweep, reduce, finish, solve, sums, decision
+            # FD points, k_jtj_fdp, slab reduce, solve, sums, decision (+ k_reset_mu in a refresh that LS:984-989 forces)
+            assert 6 * st.rounds[0] <= st.round_launches[0] <= 6 * st.rounds[0] + 1
+        else:
+            # a round with one trial fuses its tail while first trials are being accepted; a Broyden pass that a fused tail
+            # prepared costs its round 3 launches (speculative sweep, reduce, decision + finish + solve), one that follows a
+            # refused prediction starts with its own sweep, reduce, finish, solve
+            own = st.jacobian_broyden - st.fused_passes
+            assert st.fused_rounds >= st.fused_passes >= st.jacobian_broyden - 1
+            assert 3 * st.fused_passes + 6 * own <= st.round_launches[1] <= 3 * st.fused_passes + 7 * own
+            assert 6 * st.rounds[0] <= st.round_launches[0] <= 7 * st.rounds[0] + 1
+        assert st.library_launches == sum(st.round_launches) + 3  # + the sum of squares at entry (LS:955: two stages) and the state set-up
+        outs.append((key(r, x), counters(st)))
+    assert outs[0] == outs[1]
 
 
 def test_one_rank_communicator_keeps_the_reductions_apart():
@@ -72,14 +86,21 @@ def test_one_rank_communicator_keeps_the_reductions_apart():
     w = P.tanh_linear(30000, n)
     prob = W.TanhLinear(w["A"], w["b"])
     s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
-    comms, close = PAR.local_group(1)
-    st = M.Stats()
-    r1, x1 = prob.solve(w["x0"], settings=s, comm=comms[0], stats=st, batched=True)
-    close()
     r0, x0 = prob.solve(w["x0"], settings=s, batched=True)
-    assert key(r1, x1) == key(r0, x0)
-    # Broyden round with a communicator: sweep | reduce | AR | finish | solve | sums x 2 | AR | decision = 7 launches
-    assert st.round_launches[1] == 7 * st.rounds[1]
+    for variant in (M.VARIANT_NO_PIPELINE, 0):
+        comms, close = PAR.local_group(1)
+        st = M.Stats()
+        r1, x1 = prob.solve(w["x0"], settings=s, comm=comms[0], stats=st, batched=True, variant=variant)
+        close()
+        assert key(r1, x1) == key(r0, x0)
+        if variant:
+            # Broyden round with a communicator: sweep | reduce | AR | finish | solve | sums x 2 | AR | decision = 7 launches
+            assert st.round_launches[1] == 7 * st.rounds[1]
+        else:
+            # fused: the Broyden rounds a fused tail prepared cost 3 launches and ONE exchange (sweep | reduce | AR | decision +
+            # finish + solve); one that follows a refused prediction starts with its own sweep, reduce, finish, solve (+ 4)
+            own = st.jacobian_broyden - st.fused_passes
+            assert st.fused_passes >= 1 and 3 * st.fused_passes + 6 * own <= st.round_launches[1] <= 3 * st.fused_passes + 8 * own
 
 
 def test_eight_shards_agree_bitwise_run_after_run():

@@ -86,15 +86,15 @@ def test_eight_logical_shards_equal_the_unsharded_oracle(oracle, m_total, n, wor
     assert int(r0.status) >= 0 and ro.status >= 0
     assert np.allclose(x0, xo, rtol=1e-6, atol=1e-9), np.abs(x0 - xo).max()
     assert np.isclose(r0.residual, ro.residual, rtol=1e-9)
-    # payloads of the three exchanges: packed n(n+1)/2 + n, sweep vector 2n + 34, residual sums
+    # payloads of the three exchanges: packed n(n+1)/2 + n, sweep vector + trial sum 2n + 35, residual sums
     st = stats[0]
     assert st.allreduce_calls[0] >= 1 and st.allreduce_elems[0] == st.allreduce_calls[0] * (n * (n + 1) // 2 + n)
     if n <= 256 and st.jacobian_broyden:
-        assert st.allreduce_elems[1] == st.allreduce_calls[1] * (2 * n + 34)
-    assert st.allreduce_calls[2] >= st.accepted + 1 and st.allreduce_elems[2] >= st.allreduce_calls[2]
+        assert st.allreduce_elems[1] == st.allreduce_calls[1] * (2 * n + 35)
+    assert st.allreduce_calls[1] + st.allreduce_calls[2] >= st.accepted + 1 and st.allreduce_elems[2] >= st.allreduce_calls[2]
     if n == 128:
         assert PAR.packed_length(n) == 8384 and st.allreduce_elems[0] % 8384 == 0
-        assert st.allreduce_calls[1] == 0 or st.allreduce_elems[1] // st.allreduce_calls[1] == 290
+        assert st.allreduce_calls[1] == 0 or st.allreduce_elems[1] // st.allreduce_calls[1] == 291
 
 
 def test_sharded_bounded_problem_runs_boxcqp_on_every_rank(oracle):
@@ -135,7 +135,7 @@ def test_one_rank_group_goes_through_every_collective():
     r0, x0 = prob.solve(w["x0"], settings=s, batched=True)
     assert np.array_equal(x1, x0) and (r1.status, r1.iterations, r1.residual) == (r0.status, r0.iterations, r0.residual)
     assert st.allreduce_calls[0] == st.jacobian_full + st.jtj_resyncs and st.allreduce_elems[0] == st.allreduce_calls[0] * 8384
-    assert st.allreduce_calls[1] == st.jacobian_broyden and st.allreduce_elems[1] == 290 * st.allreduce_calls[1]
+    assert st.allreduce_calls[1] == st.fused_rounds + st.jacobian_broyden - st.fused_passes and st.allreduce_elems[1] == 291 * st.allreduce_calls[1]
     assert st.allreduce_calls[2] >= 1
 
 
@@ -190,7 +190,7 @@ def test_cfg4_full_size_eight_logical_shards_on_one_gpu():
         assert np.array_equal(x, xs) and (r.status, r.iterations, r.fCalls, r.residual) == (r0.status, r0.iterations, r0.fCalls, r0.residual)
     st = stats[0]
     assert st.allreduce_calls[0] == st.jacobian_full + st.jtj_resyncs and st.allreduce_elems[0] == st.allreduce_calls[0] * PAR.packed_length(256)
-    assert PAR.packed_length(256) == 33152 and st.allreduce_elems[1] == st.allreduce_calls[1] * (2 * 256 + 34)
+    assert PAR.packed_length(256) == 33152 and st.allreduce_elems[1] == st.allreduce_calls[1] * (2 * 256 + 35)
     whole = W.TanhLinearView(dA, db, 0, m_total, n)
     ru, xu = whole.solve(x0, settings=s, batched=True)
     assert int(r0.status) >= 0 and r0.status == ru.status and r0.iterations == ru.iterations
@@ -201,10 +201,12 @@ def test_cfg4_full_size_eight_logical_shards_on_one_gpu():
 
 
 def test_record_and_replay_of_a_small_sharded_solve(oracle):
-    """mir_lsq_comm_record / _recorded / _create_replay / _replay_rewind (a measurement tool) on a problem
-    UNDER the 32 MB threshold at which single-GPU solves enqueue rounds ahead of time: a replay communicator must not pipeline
-    (its tape holds committed exchanges only) -- rank 0 alone on the global trajectory returns the bits of
-    the grouped solve, with and without MIR_LSQ_VARIANT_NO_PIPELINE, solve after solve (rewind), and an overflowing tape says so."""
+    """mir_lsq_comm_record / _recorded / _create_replay / _replay_rewind (a measurement tool): rank 0
+    alone on the global trajectory returns the bits of the grouped solve, solve after solve (rewind), and an overflowing
+    tape says so. A tape belongs to the round structure it was recorded with: the fused rounds exchange [sweep | trial sum]
+    ONCE per trial, the one-by-one rounds (MIR_LSQ_VARIANT_NO_PIPELINE) the trial's sum and the sweep apart -- so each variant
+    records and replays its own tape, and BOTH trajectories are the same bits (the exchanges of a fused round are
+    unconditional: nothing speculative is ever missing from a tape)."""
     m_total, n, world = 40000, 32, 4
     w = P.tanh_linear(m_total, n)
 
@@ -213,19 +215,22 @@ def test_record_and_replay_of_a_small_sharded_solve(oracle):
         d = P.tanh_linear(ml, n, row_offset=o, m_total=m_total)
         return W.TanhLinear(d["A"], d["b"])
     s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
-    tape, rres, rx, _ = PAR.record_rank_tape(shard, world, w["x0"], settings=s, batched=True)
-    assert rres.status >= 0 and tape.size > 0
     L = M.api.lib()
-    comm = PAR.replay_comm(world, 0, tape)
     prob = shard(0)
-    outs = []
-    for variant in (0, M.VARIANT_NO_PIPELINE, 0):
-        assert L.mir_lsq_comm_replay_rewind(C.c_void_p(comm)) == 0
-        r1, x1 = prob.solve(w["x0"], settings=s, comm=comm, batched=True, variant=variant)
-        outs.append((x1.tobytes(), int(r1.status), r1.iterations, r1.fCalls, r1.residual, r1.lambda_))
-    assert outs[0] == outs[1] == outs[2]
-    assert outs[0] == (rx.tobytes(), int(rres.status), rres.iterations, rres.fCalls, rres.residual, rres.lambda_)
-    L.mir_lsq_comm_destroy(C.c_void_p(comm))
+    outs, tapes = [], []
+    for variant in (0, M.VARIANT_NO_PIPELINE):
+        tape, rres, rx, _ = PAR.record_rank_tape(shard, world, w["x0"], settings=s, batched=True, variant=variant)
+        assert rres.status >= 0 and tape.size > 0
+        tapes.append(tape.size)
+        comm = PAR.replay_comm(world, 0, tape)
+        for rep in range(2):
+            assert L.mir_lsq_comm_replay_rewind(C.c_void_p(comm)) == 0
+            r1, x1 = prob.solve(w["x0"], settings=s, comm=comm, batched=True, variant=variant)
+            outs.append((x1.tobytes(), int(r1.status), r1.iterations, r1.fCalls, r1.residual, r1.lambda_))
+        assert outs[-1] == outs[-2] == (rx.tobytes(), int(rres.status), rres.iterations, rres.fCalls, rres.residual, rres.lambda_)
+        L.mir_lsq_comm_destroy(C.c_void_p(comm))
+    assert outs[0] == outs[2]                     # fused and one-by-one rounds: the same bits under sharding
+    assert tapes[0] != tapes[1]
     # the global solve is the unsharded oracle's
     so = oracle.default_settings(); so.absTolerance = 1e-9
     ctx = oracle.TanhLinearCtx(w["A"].ctypes.data, w["b"].ctypes.data)
