@@ -121,6 +121,15 @@ __device__ inline void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier that orders LDS accesses only: outstanding GLOBAL stores are not waited for (a __syncthreads() drains them:
+// 1-2 us when a workgroup has just written tens of values per thread that nobody in it reads back soon).
+__device__ inline void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // sum over each quad of lanes (4 l .. 4 l + 3), every lane receives the total: DPP quad_perm [1,0,3,2] then [2,3,0,1]
 template <int CTRL> __device__ inline int dpp_quad(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
 template <int CTRL> __device__ inline double dpp_quad(double v)

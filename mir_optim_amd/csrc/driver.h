@@ -264,6 +264,7 @@ struct Solver {
     bool trace_round(int ks, T residual_before, uint32_t iterations_before);
     bool wait_state(uint32_t expect);
     bool read_state(const T* vec_dev);
+    void print_solve_dbg(bool fused_round);
     LmSolveArgs<T> solve_args(int ks, const T* lam, bool check_grad, bool lambda_from_state);
     bool enqueue_solve(int ks, const T* lam, bool check_grad, bool lambda_from_state);
     DecideArgs<T> decide_args(int ks, bool check_grad, bool lambda_from_state);

@@ -191,8 +191,12 @@ __global__ __launch_bounds__(256) void k_fd_fill_col(const T* __restrict__ yp, c
 //      have computed them. One block of kSolveThreads.
 // Collective over the workgroup (any size >= kReduceRanges threads when nparts > 0); returns LmState::spec_ok as it was
 // decided -- 1: the fused round's kernel goes on with the Broyden finish and the next solve (solve_kernel.h).
+// One trial and no more parameters than threads (the fused round): entry 0 of the trial point and of the step, loaded by the
+// caller BEFORE the decision is known, so that their memory latency runs beside the decision's own loads.
+template <typename T> struct DecidePre { T xv, dv; };
+
 template <typename T>
-__device__ inline int decide_chain_body(const DecideArgs<T>& a)
+__device__ inline int decide_chain_body(const DecideArgs<T>& a, const DecidePre<T>* pre = nullptr, long long* dbg = nullptr)
 {
     __shared__ int acc_s;
     __shared__ LmState<T> s_pub;
@@ -205,6 +209,7 @@ __device__ inline int decide_chain_body(const DecideArgs<T>& a)
     }
     if (threadIdx.x == 0) {
         LmState<T> s = *a.st;
+        if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg[29] = wall_clock64(); }
         int dec = kDecideReject, acc = -1;
         uint32_t consumed = 0, fcalls = 0, rejects = 0, guards = 0, qpact = 0, null_tail = 0;
         for (int k = 0; k < a.ks; ++k) {
@@ -274,22 +279,36 @@ __device__ inline int decide_chain_body(const DecideArgs<T>& a)
         *a.st = s;
         s_pub = s;
         acc_s = acc;
+        // the image of the state goes to the pinned mirror now (sequence number 0: not valid yet), beside the accepted point below
+        if (a.host_st) { LmState<T> t = s; t.seq = 0; *a.host_st = t; }
     }
-    __syncthreads();
+    lds_barrier();                       // (acc_s, s_pub; thread 0's stores to memory are drained by the barriers further down)
     const int acc = acc_s;
     if (acc >= 0) {
-        for (int i = threadIdx.x; i < a.n; i += blockDim.x) {
-            const T xv = a.trial[(size_t)acc * a.n + i];
-            a.x[i] = xv;                                                      // LS:1135
-            if (a.host_x) a.host_x[i] = xv;
-            a.dx_acc[i] = a.dx_chain[(size_t)acc * a.n + i];
+        if (pre) {                                                            // (acc == 0: there is one trial)
+            if ((int)threadIdx.x < a.n) {
+                a.x[threadIdx.x] = pre->xv;                                   // LS:1135
+                if (a.host_x) a.host_x[threadIdx.x] = pre->xv;
+                a.dx_acc[threadIdx.x] = pre->dv;
+            }
+        } else {
+            for (int i = threadIdx.x; i < a.n; i += blockDim.x) {
+                const T xv = a.trial[(size_t)acc * a.n + i];
+                a.x[i] = xv;                                                  // LS:1135
+                if (a.host_x) a.host_x[i] = xv;
+                a.dx_acc[i] = a.dx_chain[(size_t)acc * a.n + i];
+            }
         }
     }
+    if (dbg && threadIdx.x == 0) dbg[30] = wall_clock64();
     if (a.host_st) {
-        __threadfence_system();          // the accepted point is in host memory before the state that announces it
+        // ONE system-scope fence per thread: the accepted point and the image are in host memory before the sequence number
+        // that announces them (the host polls that word; nothing waits for it here)
+        __threadfence_system();
         __syncthreads();
-        if (threadIdx.x == 0) publish_state(s_pub, a.host_st, a.seq);
+        if (threadIdx.x == 0) *reinterpret_cast<volatile uint32_t*>(&a.host_st->seq) = a.seq;
     }
+    if (dbg && threadIdx.x == 0) dbg[31] = wall_clock64();
     const int spec = s_pub.spec_ok;
     __syncthreads();                     // x, dx_acc and the state are visible to the whole workgroup; s_pub may be reused
     return spec;

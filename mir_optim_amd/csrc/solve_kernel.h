@@ -709,8 +709,11 @@ __device__ __forceinline__ int box_qp_device(int n, const T* Pm, const T* q, con
 // The body of k_lm_solve as a device function: ladder entry kc of `a`, collective over a workgroup of kSolveThreads threads;
 // smem_raw: LdsSolveCfg<NB>::ELEMS elements of LDS when NB > 0. Also called by the resident-J cooperative solver
 // (resident_kernel.h), whose workgroup 0 runs the n x n part of every pass inside the one launch.
+// `pre` / preissued: the fused round's kernel has the values of J^T J in registers already (loaded at ITS entry, the Broyden pass's
+// rank-two term added on the way -- lm_round_head); otherwise the body issues the loads itself.
 template <typename T, int NB, bool BOUNDED = true>
-__device__ __forceinline__ void lm_solve_body(const LmSolveArgs<T>& a, const int kc, unsigned char* smem_raw)
+__device__ __forceinline__ void lm_solve_body(const LmSolveArgs<T>& a, const int kc, unsigned char* smem_raw,
+                                              LdsPreload<T, (NB > 0 ? NB : 1)>& pre, const bool preissued)
 {
     __shared__ T red[8];
     __shared__ int ired[12];
@@ -728,8 +731,7 @@ __device__ __forceinline__ void lm_solve_body(const LmSolveArgs<T>& a, const int
     MIRLSQ_STAMP(sc.dbg, 0);
     if (sc.dbg && threadIdx.x == 0) sc.dbg[9] = clock64();
     // the LDS path: the loads of J^T J go out now and are collected inside ?posvx, behind this prologue (solve_lds.h)
-    LdsPreload<T, (NB > 0 ? NB : 1)> pre;
-    if constexpr (NB > 0) lds_load_issue<T, NB>(n, a.JJ, n, pre);
+    if constexpr (NB > 0) { if (!preissued) lds_load_issue<T, NB>(n, a.JJ, n, pre); }
     T jy_inf = 0;
     if (a.check_grad) {
         jy_inf = block_max(tid < n ? dabs(a.Jy[tid]) : T(0), red);       // |Jy[iamax(Jy)]|, LS:1053
@@ -928,16 +930,102 @@ __device__ __forceinline__ void lm_solve_body(const LmSolveArgs<T>& a, const int
     }
 }
 
+template <typename T, int NB, bool BOUNDED = true>
+__device__ __forceinline__ void lm_solve_body(const LmSolveArgs<T>& a, const int kc, unsigned char* smem_raw)
+{
+    LdsPreload<T, (NB > 0 ? NB : 1)> pre;
+    lm_solve_body<T, NB, BOUNDED>(a, kc, smem_raw, pre, false);
+}
+
 // Head of a FUSED round (a.fused; LmSolveArgs): the decision of the previous round's trial (LS:1112-1161; its sum of squares came
 // in with the all-reduced sweep vector), published to the host at once, and -- if a Broyden pass follows -- that pass's n x n
 // side (LS:1003-1006, 1052, 1065 as k_lr_finish forms them). false: the kernel is done (no pass follows, the host takes over).
-// fin_v: n elements of LDS scratch (the LDS solve's dynamic region is free until the body starts: at n = 128 it leaves 4 KB of a
+// fin_v: 2 n elements of LDS scratch (the LDS solve's dynamic region is free until the body starts: at n = 128 it leaves 4 KB of a
 // CU's 160 KB for every static variable of the kernel).
-template <typename T>
-__device__ __forceinline__ bool lm_round_head(const LmSolveArgs<T>& a, T* fin_v)
+// NB > 0 (n <= 128, the LDS solve): `pre` holds J^T J, loaded at kernel entry so that the memory latency runs behind the
+// decision; the pass's rank-two term is added IN THESE REGISTERS (entry by entry k_lr_finish's expression: the same bits), the
+// updated matrix goes back to memory (both triangles) for the passes to come, and the body commits the registers to LDS --
+// one trip through memory where a separate finish costs a read-modify-write AND the body's read (7.5 us at n = 128 -> 1.5).
+template <typename T, int NB>
+__device__ __forceinline__ bool lm_round_head(const LmSolveArgs<T>& a, T* fin_v, LdsPreload<T, (NB > 0 ? NB : 1)>& pre)
 {
-    if (!decide_chain_body(a.dec)) return false;
-    lr_finish_block(a.fin_lr, a.fin_D, a.dec.dx_acc, a.fin_k, a.n, a.fin_JJ, a.fin_Jy, fin_v);
+    MIRLSQ_STAMP(a.sc[0].dbg, 26);
+    const int n = a.n, tid = threadIdx.x;
+    // Everything the head reads from memory is requested NOW, before the decision is known (one trial: entry 0 of the ladder;
+    // the sweep vector and the pending steps do not depend on the decision): ONE memory latency for the whole head instead of
+    // a chain of five (decision -> point and step -> sweep vector -> pending steps -> J^T J).
+    const bool el = tid < n;
+    const int t0 = el ? tid : 0;
+    DecidePre<T> dp;
+    dp.xv = a.dec.trial[t0];
+    dp.dv = a.dec.dx_chain[t0];
+    const T* __restrict__ lr = a.fin_lr;
+    const int k = a.fin_k;
+    const T lv = lr[t0], lg = lr[n + t0];
+    const T uu = lr[2 * n + 2 * kLrMax], uy = lr[2 * n + 2 * kLrMax + 1];
+    T dl[kLrMax], wl[kLrMax], hl[kLrMax];
+#pragma unroll
+    for (int l = 0; l < kLrMax; ++l) {
+        const bool on = l < k;
+        dl[l] = a.fin_D[(size_t)(on ? l : 0) * n + t0];
+        wl[l] = lr[2 * n + (on ? l : 0)];
+        hl[l] = lr[2 * n + kLrMax + (on ? l : 0)];
+    }
+    if (!decide_chain_body(a.dec, &dp, a.sc[0].dbg)) return false;
+    MIRLSQ_STAMP(a.sc[0].dbg, 27);
+    // the vectors of k_lr_finish (its expressions, its order: the same bits): v = J_{k-1}^T u, J^T y, D_k = dx
+    {
+        T s = lv, g = lg;
+#pragma unroll
+        for (int l = 0; l < kLrMax; ++l) if (l < k) s += dl[l] * wl[l];
+#pragma unroll
+        for (int l = 0; l < kLrMax; ++l) if (l < k) g += dl[l] * hl[l];
+        g += dp.dv * uy;
+        if (el) {
+            fin_v[tid] = s;
+            fin_v[n + tid] = dp.dv;
+            a.fin_Jy[tid] = g;
+            a.fin_D[(size_t)k * n + tid] = dp.dv;
+        }
+    }
+    lds_barrier();                                           // (fin_v; the stores to memory drain behind the arithmetic below)
+    const T* v = fin_v;
+    const T* dxs = fin_v + n;
+    if constexpr (NB > 0) {
+        T* __restrict__ JJ = a.fin_JJ;
+        const int c = tid & 15, r = tid >> 4;
+        // a thread's entries are (16 I + r, 16 J + c): 2 NB values of v and of the step cover them all -- read once, then the NB
+        // (NB + 1) / 2 terms are register arithmetic (one LDS round trip per ENTRY was 2 of this phase's 4.4 us at n = 128)
+        T vi[NB], di[NB], vj[NB], dj[NB];
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            const int gi = 16 * I + r, gj = 16 * I + c;
+            vi[I] = v[gi < n ? gi : 0]; di[I] = dxs[gi < n ? gi : 0];
+            vj[I] = v[gj < n ? gj : 0]; dj[I] = dxs[gj < n ? gj : 0];
+        }
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int J = 0; J <= I; ++J) {
+                const int gi = 16 * I + r, gj = 16 * J + c;
+                if (gi < n && gj < n) {
+                    const bool up = gi < gj;                 // (only inside a diagonal block)
+                    const T vh = up ? vj[J] : vi[I], vl = up ? vi[I] : vj[J], dh = up ? dj[J] : di[I], dl = up ? di[I] : dj[J];
+                    const T t = pre.v[I * (I + 1) / 2 + J] + lr_jj_term(vh, vl, dh, dl, uu);
+                    pre.v[I * (I + 1) / 2 + J] = t;
+                    JJ[(size_t)gi * n + gj] = t;
+                    if (I != J) JJ[(size_t)gj * n + gi] = t;
+                }
+            }
+        if (el) pre.diag += lr_jj_term(v[tid], v[tid], dxs[tid], dxs[tid], uu);
+    } else {
+        lr_finish_matrix(a.fin_JJ, n, v, dxs, uu);
+    }
+    // fin_v is free. The stores of J^T J, J^T y and D_k are NOT waited for: a thread reads back what it wrote itself (J^T y,
+    // program order), the matrix is read from memory again only behind the solve's own barriers (the prediction), D_k by later
+    // kernels. (NB = 0: the body copies J^T J from memory at once -- a full barrier.)
+    if constexpr (NB > 0) lds_barrier(); else __syncthreads();
+    MIRLSQ_STAMP(a.sc[0].dbg, 28);
     return true;
 }
 
@@ -945,13 +1033,14 @@ template <typename T, int NB, bool BOUNDED = true>
 __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    LdsPreload<T, (NB > 0 ? NB : 1)> pre;
     if (a.fused) {
         T* fin_v;
-        if constexpr (NB > 0) fin_v = reinterpret_cast<T*>(smem_raw);
-        else { __shared__ T fin_static[kSolveMaxN]; fin_v = fin_static; }
-        if (!lm_round_head(a, fin_v)) return;
+        if constexpr (NB > 0) { fin_v = reinterpret_cast<T*>(smem_raw); lds_load_issue<T, NB>(a.n, a.JJ, a.n, pre); }
+        else { __shared__ T fin_static[2 * kSolveMaxN]; fin_v = fin_static; }
+        if (!lm_round_head<T, NB>(a, fin_v, pre)) return;
     }
-    lm_solve_body<T, NB, BOUNDED>(a, (int)blockIdx.x, smem_raw);      // blockIdx.x: chain step
+    lm_solve_body<T, NB, BOUNDED>(a, (int)blockIdx.x, smem_raw, pre, a.fused != 0 && NB > 0);      // blockIdx.x: chain step
 }
 
 // n <= 16, f64: the same pass on ONE wave per ladder entry, every matrix a row per lane (solve_wave16.h): no LDS, no barrier,
@@ -965,8 +1054,9 @@ __global__ __launch_bounds__(kWave) void k_lm_solve_wave(LmSolveArgs<double> a)
 {
     const int n = a.n, kc = blockIdx.x, lane = threadIdx.x, r = lane & 15, g = lane >> 4;
     if (a.fused) {
-        __shared__ double fin_v[kW16];
-        if (!lm_round_head(a, fin_v)) return;
+        __shared__ double fin_v[2 * kW16];
+        LdsPreload<double, 1> none;
+        if (!lm_round_head<double, 0>(a, fin_v, none)) return;
     }
     const bool el = r < n;
     const int rc = el ? r : 0;

@@ -94,9 +94,9 @@ bool Solver<T>::setup()
     // speculatively (it needs the step and the two residual vectors, not the decision) and carries the trial's sum of squares,
     // ONE all-reduce serves LS:1115 and LS:1052 / 1065, and ONE kernel decides the trial, applies the pass's n x n side and
     // solves the next system: 3 launches and 1 collective per accepted Broyden pass instead of 7 and 2. Device callbacks, the
-    // read-only sweep (n <= kLrMaxN) and the one-workgroup solves (n <= kSolveMaxN) only; a trace or the solve's phase stamps
-    // keep the one-by-one rounds (MIR_LSQ_VARIANT_NO_PIPELINE selects them too): the same bits either way.
-    fused = device_cb && lowrank && !big_solve && !trace && !dbg_solve && !(variant & MIR_LSQ_VARIANT_NO_PIPELINE);
+    // read-only sweep (n <= kLrMaxN) and the one-workgroup solves (n <= kSolveMaxN) only; a trace keeps
+    // the one-by-one rounds (MIR_LSQ_VARIANT_NO_PIPELINE selects them too): the same bits either way.
+    fused = device_cb && lowrank && !big_solve && !trace && !(variant & MIR_LSQ_VARIANT_NO_PIPELINE);
     twh_h.resize(n);
     // x, lower, upper sit back to back in the workspace: one copy from the pinned block instead of three from pageable
     // memory (each of those is a staged blit kernel, ~18 us apart on the stream)
@@ -281,6 +281,28 @@ bool Solver<T>::read_state(const T* vec_dev)
     if (!ok(hipMemcpyAsync(st_h, B.st, sizeof(LmState<T>), hipMemcpyDeviceToHost, stream), "D2H state")) return false;
     if (vec_dev && !ok(hipMemcpyAsync(trial_h, vec_dev, n * sizeof(T), hipMemcpyDeviceToHost, stream), "D2H vec")) return false;
     return ok(hipStreamSynchronize(stream), "sync");
+}
+
+// MIR_LSQ_VARIANT_DEBUG_SOLVE: the phase stamps of the solve kernel that has just been enqueued (synchronises the stream)
+template <typename T>
+void Solver<T>::print_solve_dbg(bool fused_round)
+{
+    long long h[32];
+    if (hipMemcpy(h, B.sc[0].dbg, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return;
+    if (fused_round)
+        std::fprintf(stderr, "[solve dbg] fused round head (10ns ticks): decision + publication %lld (loads landed %lld, decided + point copied %lld, fence + sequence number %lld)  n x n side of the Broyden pass %lld\n", h[27] - h[26], h[29] - h[26], h[30] - h[29], h[31] - h[30], h[28] - h[27]);
+    std::fprintf(stderr, "[solve dbg] (10ns ticks) build %lld  copy/equil %lld  scale %lld  potrf %lld  potrs %lld  refine %lld  epilogue %lld  total %lld  shader MHz %.0f  [matvec1 %lld berr %lld]\n",
+                 h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[8] - h[7], h[8] - h[0], (double)(h[10] - h[9]) / (double)(h[8] - h[0]) * 100.0, h[11] - h[5], h[12] - h[11]);
+    if (n <= 128)
+        std::fprintf(stderr, "[solve dbg] load (10ns ticks): kernel entry -> loads landed %lld (of which inside posvx %lld)  reduction + LDS commit %lld  rest of the phase %lld\n",
+                     h[24] - h[0], h[24] - h[2], h[25] - h[24], h[3] - h[25]);
+    if (n <= 128)
+        std::fprintf(stderr, "[solve dbg] refinement (10ns ticks): residual 1 %lld  berr 1 %lld  potrs 2 %lld  residual 2 %lld  rest %lld  (correction applied: %lld)\n",
+                     h[11] - h[5], h[12] - h[11], h[13] - h[12], h[14] - h[13], h[6] - h[14], h[15]);
+    if (n <= 128)
+        std::fprintf(stderr, "[solve dbg] lds_potrf, wave 0 (shader cycles, summed over the panels): diagonal update + factor %lld  wait %lld  rows below %lld  wait %lld\n", h[20], h[21], h[22], h[23]);
+    if (n > 128)
+        std::fprintf(stderr, "[solve dbg] potrf_panel steps (10ns ticks, summed over the panels): earlier panels on MFMA %lld (of which publishing / waiting for the helpers' look-ahead jobs %lld)  diagonal rows %lld  other rows + store %lld\n", h[16], h[19], h[17], h[18]);
 }
 
 // the n x n part of a round (LS:1053-1110, 1141-1142) for ks ladder entries
@@ -547,23 +569,7 @@ typename Solver<T>::Result Solver<T>::run()
             }
         }
         if (!solve_enqueued && !enqueue_solve(ks, lam, newJacobian, lambda_from_state)) { fail = true; break; }
-        if (dbg_solve) {
-            long long h[32];
-            if (hipMemcpy(h, B.sc[0].dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
-                std::fprintf(stderr, "[solve dbg] (10ns ticks) build %lld  copy/equil %lld  scale %lld  potrf %lld  potrs %lld  refine %lld  epilogue %lld  total %lld  shader MHz %.0f  [matvec1 %lld berr %lld]\n",
-                             h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[8] - h[7], h[8] - h[0], (double)(h[10] - h[9]) / (double)(h[8] - h[0]) * 100.0, h[11] - h[5], h[12] - h[11]);
-                if (n <= 128)
-                    std::fprintf(stderr, "[solve dbg] load (10ns ticks): kernel entry -> loads landed %lld (of which inside posvx %lld)  reduction + LDS commit %lld  rest of the phase %lld\n",
-                                 h[24] - h[0], h[24] - h[2], h[25] - h[24], h[3] - h[25]);
-                if (n <= 128)
-                    std::fprintf(stderr, "[solve dbg] refinement (10ns ticks): residual 1 %lld  berr 1 %lld  potrs 2 %lld  residual 2 %lld  rest %lld  (correction applied: %lld)\n",
-                                 h[11] - h[5], h[12] - h[11], h[13] - h[12], h[14] - h[13], h[6] - h[14], h[15]);
-                if (n <= 128)
-                    std::fprintf(stderr, "[solve dbg] lds_potrf, wave 0 (shader cycles, summed over the panels): diagonal update + factor %lld  wait %lld  rows below %lld  wait %lld\n", h[20], h[21], h[22], h[23]);
-                if (n > 128)
-                    std::fprintf(stderr, "[solve dbg] potrf_panel steps (10ns ticks, summed over the panels): earlier panels on MFMA %lld (of which publishing / waiting for the helpers' look-ahead jobs %lld)  diagonal rows %lld  other rows + store %lld\n", h[16], h[19], h[17], h[18]);
-            }
-        }
+        if (dbg_solve && !solve_enqueued) print_solve_dbg(false);
 
         // null-step probe: one small read-back instead of ks residual evaluations, only while the tail is running
         if (device_cb && tail_null && last_rejected && !newJacobian && !no_null_skip) {
@@ -610,6 +616,7 @@ typename Solver<T>::Result Solver<T>::run()
         if (!wait_state(round_seq)) { fail = true; break; }
         if (fuse) {
             if (st_h->spec_ok) spec_live = true; else drop_spec_round();
+            if (dbg_solve && spec_live) print_solve_dbg(true);
         }
         if (ks == 1 && newJacobian) spec_predict = st_h->decision == kDecideAccept;
 
