@@ -204,8 +204,9 @@ enum {
                                                     the trial, applies the pass's n x n side and solves the next system): every
                                                     round kernel by kernel, decision first; bit-identical results either way */
     MIR_LSQ_VARIANT_DEBUG_HELPERS_ABSENT = 1u << 12, /* diagnostic: the helper workgroups of the any-n solve are NOT launched although
-                                                    its kernel expects them -- the first job times out (5 s) and the solve must end
-                                                    with numericError instead of hanging (tests) */
+                                                    its kernel expects them -- the first job times out (5 s), the rescue launch
+                                                    solves the pass on one workgroup, mir_lsq_stats.coop_timeouts counts it and the
+                                                    solve goes on without helpers: the one-workgroup result, no hang (tests) */
     MIR_LSQ_VARIANT_DEBUG_SOLVE = 1u << 7,       /* diagnostic: print phase stamps of the solve kernel (stderr) */
     MIR_LSQ_VARIANT_HOST_PROFILE = 1u << 8,      /* diagnostic: print host wall time per category of runtime call (stderr) */
     MIR_LSQ_VARIANT_LR_CAP_SHIFT = 16            /* bits 16..20 (a field, not a switch): fold the pending Broyden terms into J
@@ -265,6 +266,10 @@ typedef struct mir_lsq_stats {
                                         decision + n x n side + next solve); fused_passes: of those, the ones whose trial was
                                         accepted with a Broyden pass next -- the pass run ahead was the reference's next pass */
     uint64_t fused_passes;
+    uint64_t coop_timeouts;          /* n > 256: ladder entries whose helper workgroups did not answer within 5 s (a GPU shared with
+                                        other work) and that were solved again on one workgroup by the rescue launch -- the result
+                                        is the MIR_LSQ_VARIANT_SOLVE_ONE_WORKGROUP one (2e-8 from the helpers'), the status is not
+                                        touched; after the first one a solve stops asking for helpers */
 } mir_lsq_stats;
 /* Versioning of mir_lsq_stats: the library writes min(stats_size, sizeof(mir_lsq_stats)) bytes. A caller whose options
  * struct has no stats_size member (struct_size < 96), or leaves it 0, gets the layout of its era: 120 bytes (through

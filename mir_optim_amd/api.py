@@ -155,7 +155,7 @@ class Stats(C.Structure):
                 ("library_launches", C.c_uint64), ("round_launches", C.c_uint64 * 3), ("rounds", C.c_uint64 * 3),
                 ("fd_host_wall_ms", C.c_double), ("fd_host_f_ms", C.c_double), ("fd_host_columns", C.c_uint64),
                 ("host_f_ms", C.c_double), ("host_f_calls", C.c_uint64),
-                ("fused_rounds", C.c_uint64), ("fused_passes", C.c_uint64)]
+                ("fused_rounds", C.c_uint64), ("fused_passes", C.c_uint64), ("coop_timeouts", C.c_uint64)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if isinstance(getattr(self, k), C.Array) else getattr(self, k)) for k, _ in self._fields_}

@@ -193,6 +193,7 @@ struct Solver {
     bool spec_enqueue = false;     // set while the kernels of the pass run ahead are being enqueued (their events are tagged)
     size_t spec_events_from = 0;   // events of the pass run ahead start here
     bool big_solve = false;    // n > 256 (or MIR_LSQ_VARIANT_SOLVE_GENERIC): the any-n solve kernel
+    bool coop_disabled = false;   // helper workgroups timed out once in this solve: one workgroup per entry from now on
 
     LmState<T>* st_h;      // pinned mirror of the decision point being processed (one of st_slot[])
     LmState<T>* st_slot[2] = {nullptr, nullptr};     // the two mirrors, host and device addresses

@@ -273,6 +273,9 @@ __device__ inline int decide_chain_body(const DecideArgs<T>& a, const DecidePre<
                 && (s.lambda >= a.set.minLambda) && lr_spec_go(a.rec[0], a.set.absTolerance, a.set.relTolerance);
         }
         s.spec_ok = spec;
+        uint32_t rescued = 0;
+        for (int k = 0; k < a.ks; ++k) if (a.rec[k].flags & kFlagCoopRescued) ++rescued;
+        s.coop_rescued = rescued;
         s.decision = dec; s.accepted_k = acc; s.consumed = consumed; s.fcalls = fcalls;
         s.rejects = rejects; s.guards = guards; s.qp_active = qpact;
         s.null_tail = (dec == kDecideReject) ? null_tail : 0u;

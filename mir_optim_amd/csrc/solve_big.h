@@ -886,9 +886,10 @@ __device__ __forceinline__ void lm_solve_big_main(const LmSolveArgs<T>& a, int k
     if (tid == 0) {
         ChainRec<T> r{};
         r.lambda = lambda; r.new_dx_dot = ndd; r.predicted = pred; r.trial_xnorm = xn;
-        // a helper that did not answer within kCoopSpinSeconds: the pass is reported as failed (numericError upstream) even where
-        // this workgroup finished the piece on its own -- a stall of seconds is not a state to keep computing in
-        r.qp_status = (cc && cc->failed) ? 1 : qp; r.qp_iterations = qp_iters; r.flags = flags;
+        // a helper that did not answer within kCoopSpinSeconds: the entry is marked for the RESCUE launch that follows (it solves
+        // the entry again from its inputs on one workgroup, once every workgroup of this launch -- late helpers included -- has
+        // ended): a stall is a scheduling fact, the caller gets the one-workgroup answer and a count in its statistics
+        r.qp_status = (cc && cc->failed) ? kQpCoopTimeout : qp; r.qp_iterations = qp_iters; r.flags = flags;
         a.rec[kc] = r;
     }
 }
@@ -904,6 +905,15 @@ __global__ __launch_bounds__(kBigThreads) void k_lm_solve_big(LmSolveArgs<T> a)
     __shared__ unsigned long long s_cdesc[8];
     const int W = a.coop_w > 1 ? a.coop_w : 1;
     const int kc = (int)blockIdx.x / W, peer = (int)blockIdx.x % W;
+    if (a.coop_rescue) {                                         // (W == 1)
+        if (threadIdx.x == 0) s_cflag = a.rec[kc].qp_status == kQpCoopTimeout;
+        __syncthreads();
+        if (!s_cflag) return;
+        __syncthreads();
+        lm_solve_big_main<T>(a, kc, sm, nullptr);
+        if (threadIdx.x == 0) a.rec[kc].flags |= kFlagCoopRescued;
+        return;
+    }
     if (peer > 0) {
         coop_helper_loop<T>(a.sc[kc].coop, W, peer, a.coop_epoch, sm.span);
         return;

@@ -25,6 +25,8 @@ struct LmState {
     uint32_t rejects, guards, qp_active;
     uint32_t null_tail;        // the last consumed trial of the round was a null step (trial == x): the next ones probably are too
     uint32_t seq;              // host mirror only: number of the decision point this image belongs to (written last)
+    uint32_t coop_rescued;     // ladder entries of the round whose helper workgroups did not answer in time (solve_coop.h) and that
+                               // the rescue launch solved again on one workgroup: the host counts them and stops asking for helpers
     int32_t spec_ok;           // set by the decision at the head of a fused round: the Broyden pass the round's sweep prepared is the
                                // one the reference runs next (accepted step, no exit test fired) -- the kernel went on with it
 };
@@ -40,7 +42,11 @@ struct ChainRec {
 // callbacks are `pure` (LS:73-80): f(trial) is the residual vector the solver already holds, ||f(trial)||^2 == residual,
 // improvement == 0 and the pass is rejected (LS:1125) -- the evaluation can be elided without changing any result.
 enum : int32_t { kFlagDxNaN = 1, kFlagXNaN = 2, kFlagStepTooLong = 4, kFlagTrialNotFinite = 8, kFlagGradSmall = 16,
-                 kFlagNullStep = 32 };
+                 kFlagNullStep = 32,
+                 kFlagCoopRescued = 64 };   // the entry's helpers timed out; the rescue launch solved it again on one workgroup
+// ChainRec::qp_status beyond solveBoxQP's own 0 / 1 / 2 (QP:18-26): the entry's helper workgroups did not answer within
+// kCoopSpinSeconds -- a scheduling fact, not a numeric one; only ever seen between the any-n solve's launch and its rescue launch
+constexpr int32_t kQpCoopTimeout = 3;
 enum : int32_t {
     kDecideNone = 0, kDecideReject = 1, kDecideAccept = 2, kDecideAcceptNoPrediction = 3,
     kDecideNumericError = 4, kDecideGradSmall = 5
@@ -151,6 +157,8 @@ struct LmSolveArgs {
     int coop_w;            // k_lm_solve_big: workgroups per ladder entry (main + helpers, solve_coop.h); 0 / 1: none
     uint32_t coop_epoch;   // ... the number of this launch among the workspace's solve launches (> 0, increasing)
     int coop_absent;       // diagnostic (MIR_LSQ_VARIANT_DEBUG_HELPERS_ABSENT): launch the main workgroups only
+    int coop_rescue;       // k_lm_solve_big's RESCUE launch (one workgroup per entry, right behind the launch with helpers): an
+                           // entry whose record says kQpCoopTimeout is solved again from its inputs, alone; the others return
 };
 
 // standalone BOXCQP (mir_solve_box_qp_gpu_*)

@@ -318,7 +318,7 @@ LmSolveArgs<T> Solver<T>::solve_args(int ks, const T* lam, bool check_grad, bool
     a.lambda_from_state = lambda_from_state ? 1 : 0;
     if (!dbg_solve) a.sc[0].dbg = nullptr;
     // n > 256: every ladder entry's workgroup gets helpers (solve_coop.h)
-    a.coop_w = (big_solve && n > (uint32_t)kSolveMaxN && !(variant & MIR_LSQ_VARIANT_SOLVE_ONE_WORKGROUP)) ? coop_peers((int)n) : 1;
+    a.coop_w = (big_solve && n > (uint32_t)kSolveMaxN && !(variant & MIR_LSQ_VARIANT_SOLVE_ONE_WORKGROUP) && !coop_disabled) ? coop_peers((int)n) : 1;
     // an entry's workgroups hold a CU each (150 KB of LDS) and wait for one another: never more of them than half the device
     // (a partitioned or masked GPU), or a group could never be resident at once
     if (a.coop_w > ws->num_cu / 2) a.coop_w = ws->num_cu / 2 >= 2 ? ws->num_cu / 2 : 1;
@@ -621,6 +621,13 @@ typename Solver<T>::Result Solver<T>::run()
         if (ks == 1 && newJacobian) spec_predict = st_h->decision == kDecideAccept;
 
         if (trace && !trace_round(ks, ret.residual, ret.iterations)) { fail = true; break; }
+        if (st_h->coop_rescued) {
+            // helper workgroups of the any-n solve did not answer within kCoopSpinSeconds (a GPU shared with other work, a
+            // starved queue): the rescue launch has solved those entries on one workgroup; the rest of THIS solve does not ask
+            // for helpers again (one stall per solve at most) and the caller's statistics say so
+            if (stats) stats->coop_timeouts += st_h->coop_rescued;
+            coop_disabled = true;
+        }
         const int dec = st_h->decision;
         tail_null = st_h->null_tail != 0;
         ret.fCalls += st_h->fcalls;                                      // LS:1112

@@ -129,7 +129,7 @@ def test_gpu_options_trace_field_is_appended():
     assert api.GpuOptions.fbRowMajor.offset == 72 and api.GpuOptions.fbRowMajorDiff.offset == 80
     assert api.GpuOptions.stats_size.offset == 88 and api.GpuOptions().stats_size == C.sizeof(api.Stats)
     assert api.Stats.qp_active_set_passes.offset + 8 == 120 and api.Stats.jtj_fd_launches.offset + 8 == 144
-    assert api.Stats.trial_callback_points.offset + 8 == 264 and C.sizeof(api.Stats) == 264 + 14 * 8 and api.Stats.fused_rounds.offset == 264 + 12 * 8
+    assert api.Stats.trial_callback_points.offset + 8 == 264 and C.sizeof(api.Stats) == 264 + 15 * 8 and api.Stats.fused_rounds.offset == 264 + 12 * 8
     assert C.sizeof(api.TraceRecord) == 40
     assert C.sizeof(api.BatchedOptions) == 40 and api.BatchedOptions.basis.offset == 16 and api.BatchedOptions.timing.offset == 32
     t = api.Trace(8)
