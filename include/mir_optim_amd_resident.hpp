@@ -29,11 +29,23 @@
 // enqueued on options->stream and nothing is synchronised (except in the documented workspace fallback). Returns 0, or:
 // -1 bad arguments / settings that fail the reference's validation (the status is then in *status_out), -2 no device,
 // -3 the problem does not fit the chip's LDS (use the launch-chain path), -4 allocation failed, -5 the launch failed.
+//
+// SINGLE TENANT. Every workgroup of the launch must be resident at once (about 89 KB of LDS each at cfg 2: one per CU) and they
+// wait for one another with bounded spins (20 s). hipLaunchCooperativeKernel refuses a grid that cannot be resident IN THEORY;
+// it cannot know about other work on the device: two processes that each launch a resident solve (or a resident solve beside
+// long kernels of another tenant that hold CUs) can each end up half resident until the spins give up. That outcome is a
+// SCHEDULING fact, not a numeric one, and it is reported as such: the record's status is numericError (the only failure the
+// reference's enum has, LS:132) AND mir_lsq_resident_stats.abort_code != 0 (0 after every solve that ran to its own end,
+// including one that ended in a genuine numericError). A caller that may share the device passes `stats`, and on
+// abort_code != 0 runs the same problem through the launch chain (mir_optimize_least_squares_gpu_d, ordinary launches that
+// wait for nobody) in a fresh launch of the same process -- what mir_optim_amd.workloads.Resident(..., fallback=) does, keeping
+// abort_code in the statistics it returns. Same-process solves are safe: ROCm serialises cooperative launches.
 #pragma once
 
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstddef>
 
 #include "mir_optim_amd.h"
 #include "../mir_optim_amd/csrc/resident_kernel.h"
@@ -187,10 +199,12 @@ int launch_resident(const mir_least_squares_settings_d* S, size_t m, double* x, 
     a.sc.Pm = reinterpret_cast<double*>(ws + c.pm); a.sc.A = reinterpret_cast<double*>(ws + c.a);
     a.sc.Fg = reinterpret_cast<double*>(ws + c.fg); a.sc.vec = reinterpret_cast<double*>(ws + c.vec);
     a.sc.ivec = reinterpret_cast<int32_t*>(ws + c.ivec); a.sc.dbg = nullptr;
-    a.trace = opt ? opt->trace_records : nullptr;
-    a.trace_capacity = opt ? opt->trace_capacity : 0;
-    a.trace_count = opt ? opt->trace_count : nullptr;
-    a.stats = opt ? opt->stats : nullptr;
+    // mir_lsq_resident_options is versioned by struct_size: a member is read only when the caller's struct has it
+    auto has = [&](size_t offset, size_t size) { return opt && opt->struct_size >= offset + size; };
+    a.trace = has(offsetof(mir_lsq_resident_options, trace_records), sizeof(void*)) ? opt->trace_records : nullptr;
+    a.trace_capacity = has(offsetof(mir_lsq_resident_options, trace_capacity), sizeof(uint32_t)) ? opt->trace_capacity : 0;
+    a.trace_count = has(offsetof(mir_lsq_resident_options, trace_count), sizeof(void*)) ? opt->trace_count : nullptr;
+    a.stats = has(offsetof(mir_lsq_resident_options, stats), sizeof(void*)) ? opt->stats : nullptr;
 
     const bool unbounded = opt && (opt->variant & MIR_LSQ_RESIDENT_UNBOUNDED);
     const void* kern = unbounded ? reinterpret_cast<const void*>(k_lm_resident<Model, false>)

@@ -325,6 +325,14 @@ inline uint64_t splitmix64_mix(uint64_t z)
 
 }  // namespace
 
+__global__ __launch_bounds__(256) void k_busy(long long ticks)
+{
+    extern __shared__ unsigned char busy_smem[];
+    const long long t0 = wall_clock64();
+    if (threadIdx.x == 0) busy_smem[0] = 1;                  // (the LDS is really allocated)
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 extern "C" {
 
 // contexts: device data pointers + the stream the solver was given (mir_lsq_gpu_options.stream)
@@ -462,6 +470,13 @@ void wl_exp_decay_f_s(void* vctx, size_t m, size_t n, const float* x, float* y)
     auto* c = static_cast<wl_curve_ctx*>(vctx);
     hipLaunchKernelGGL(k_exp_decay<float>, dim3(blocks_for(m)), dim3(256), 0, (hipStream_t)c->stream,
                        (const float*)c->t, (const float*)c->data, x, y, m, c->kind);
+}
+
+// Test helper: `blocks` workgroups of 256 threads, each holding `lds_bytes` of LDS, that do nothing but stay on their CU for
+// `microseconds` (bounded: every wave leaves when the clock says so) -- the "other tenant" of the contention tests.
+void wl_busy(void* stream, unsigned blocks, unsigned lds_bytes, unsigned microseconds)
+{
+    hipLaunchKernelGGL(k_busy, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, (long long)microseconds * 100);
 }
 
 // host: out[k] = u(seed + offset + k)

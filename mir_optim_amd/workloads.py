@@ -173,7 +173,9 @@ class Resident:
         rowdata = np.ascontiguousarray(rowdata, dtype=np.float64)
         self.m = rowdata.shape[0]
         self.stream = stream or api.Stream()
-        self.fallback = fallback                       # a DeviceProblem with the same residual: used when the slices do not fit
+        # a DeviceProblem with the same residual (the launch chain): used when the slices do not fit the LDS, and when a launch
+        # gave up on a hand-off (abort_code != 0: a device shared with other work -- a scheduling fact, not a numeric one)
+        self.fallback = fallback
         self.max_workgroups = int(max_workgroups)
         WL = api.workloads_lib()
         out4 = (C.c_int * 4)()
@@ -252,6 +254,13 @@ class Resident:
         raw = api._Rd.from_buffer_copy(out[:32])
         x = self.d_x.download()[:n].copy()
         stats = ResidentStats.from_buffer_copy(out[64:64 + C.sizeof(ResidentStats)])
+        if stats.abort_code and self.fallback is not None:
+            # the launch gave up on a hand-off between its workgroups: the same problem through the launch chain (ordinary
+            # launches that wait for nobody), in a fresh launch of this process; the abort code stays in the statistics
+            res, xf = self.fallback.solve(x0, l, u, settings=settings, trace=trace, **fallback_kw)
+            d = stats.as_dict()
+            d["fallback"] = "launch chain"
+            return res, xf, d
         if trace is not None:
             cnt = int(np.frombuffer(out[32:36], dtype=np.uint32)[0])
             trace.header.count = cnt

@@ -298,6 +298,88 @@ def test_a_missing_workgroup_ends_in_numeric_error_not_in_a_hang():
     assert int(res2.status) >= 0 and st2["abort_code"] == 0 and np.allclose(x2, g["truth"], rtol=5e-3, atol=1e-3)
 
 
+def test_an_aborted_launch_degrades_to_the_launch_chain():
+    """A launch that gave up on a hand-off is a scheduling fact (a device shared with other work), not a numeric failure: with a
+    fallback problem the wrapper runs the same fit through the launch chain in a fresh launch of this process; the caller gets
+    that result, and the abort code stays in the statistics."""
+    g = P.gauss_sum(20000, K=3)
+    prob = W.Curve("gauss_sum", g["t"], g["data"])
+    r = W.Resident.gauss_sum(g["t"], g["data"], K=3, fallback=prob)
+    res, x, st = r.solve(g["x0"], g["lower"], g["upper"], variant=W.RESIDENT_DEBUG_DROP_WORKGROUP, batched=True)
+    assert st["abort_code"] != 0 and st["fallback"] == "launch chain"
+    ref, xr = prob.solve(g["x0"], g["lower"], g["upper"], batched=True)
+    assert int(res.status) >= 0 and (res.status, res.iterations, res.fCalls, res.residual) == (ref.status, ref.iterations, ref.fCalls, ref.residual)
+    assert x.tobytes() == xr.tobytes()
+    res2, x2, st2 = r.solve(g["x0"], g["lower"], g["upper"])           # the next launch is clean and stays on the resident path
+    assert int(res2.status) >= 0 and st2["abort_code"] == 0 and "fallback" not in st2
+
+
+def test_solves_beside_a_tenant_that_holds_every_cu_return_the_uncontended_bits():
+    """Contention (SURVEY 8b "Threading": re-entrant, every failure a status): while a third stream keeps EVERY CU busy with
+    50 ms filler kernels that also hold most of each CU's LDS (wl_busy), one host thread runs a wide-n solve (n = 300: helper
+    workgroups that wait for one another, solve_coop.h) and another a resident solve (a cooperative launch whose workgroups
+    wait for one another). Their workgroups start late and apart; nothing times out, and both return the bits of the same
+    solves on an idle device."""
+    import threading
+    from mir_optim_amd import api
+    WL = api.workloads_lib()
+    w = P.tanh_linear(1500, 300)
+    wide = W.TanhLinear(w["A"], w["b"])
+    g = P.gauss_sum(100000, K=5)
+    res_p = W.Resident.gauss_sum(g["t"], g["data"], K=5)
+    st0 = M.Stats()
+    ref_w = wide.solve(w["x0"], batched=True, stats=st0)
+    ref_r = res_p.solve(g["x0"], g["lower"], g["upper"])
+    assert int(ref_w[0].status) >= 0 and int(ref_r[0].status) >= 0 and st0.coop_timeouts == 0
+    filler = api.Stream()
+    stop = threading.Event()
+    out, err = {}, []
+
+    def tenant():
+        try:
+            while not stop.is_set():
+                for _ in range(4):                              # 4 x 50 ms queued, then wait: the device is never idle for long
+                    WL.wl_busy(C.c_void_p(filler.handle), C.c_uint(512), C.c_uint(72 * 1024), C.c_uint(50000))
+                filler.synchronize()
+        except BaseException as e:      # noqa: BLE001
+            err.append(e)
+
+    def wide_solves():
+        try:
+            got = []
+            for _ in range(2):
+                st = M.Stats()
+                r, x = wide.solve(w["x0"], batched=True, stats=st)
+                got.append((x.tobytes(), int(r.status), r.iterations, r.fCalls, r.residual, st.coop_timeouts))
+            out["wide"] = got
+        except BaseException as e:      # noqa: BLE001
+            err.append(e)
+
+    def resident_solves():
+        try:
+            got = []
+            for _ in range(3):
+                r, x, st = res_p.solve(g["x0"], g["lower"], g["upper"])
+                got.append((x.tobytes(), int(r.status), r.iterations, r.fCalls, r.residual, st["abort_code"]))
+            out["resident"] = got
+        except BaseException as e:      # noqa: BLE001
+            err.append(e)
+    tt = threading.Thread(target=tenant)
+    tt.start()
+    ts = [threading.Thread(target=wide_solves), threading.Thread(target=resident_solves)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(600)
+    stop.set()
+    tt.join(60)
+    assert not any(t.is_alive() for t in ts + [tt]) and not err, err
+    want_w = (ref_w[1].tobytes(), int(ref_w[0].status), ref_w[0].iterations, ref_w[0].fCalls, ref_w[0].residual, 0)
+    want_r = (ref_r[1].tobytes(), int(ref_r[0].status), ref_r[0].iterations, ref_r[0].fCalls, ref_r[0].residual, 0)
+    assert all(q == want_w for q in out["wide"]), [q[1:] for q in out["wide"]]
+    assert all(q == want_r for q in out["resident"]), [q[1:] for q in out["resident"]]
+
+
 def test_resident_does_not_fit_falls_back(oracle):
     """m x (n + nd + 3) doubles beyond the chip's LDS: launch_resident answers -3 and the caller takes the launch-chain path."""
     g = P.gauss_sum(1000000, K=5)
