@@ -10,10 +10,10 @@ part 1) is exactly the reference's `extern(C)` tier. So the direction of the ref
 here: D delegates -> C function pointers, then `mir_optimize_least_squares_d/_s`.
 
 Status: NOT COMPILED in the build image (no ldc2 / dmd / gdc / dub there). The struct layouts this file declares are
-pinned from the C side (static_asserts in csrc/lm_driver.hip, tests/test_abi.py, tests/test_c_harness.py):
+pinned from the C side (static_asserts in mir_optim_amd/csrc/abi.hip, tests/test_abi.py, tests/test_c_harness.py):
   LeastSquaresSettings!double 128 bytes (qpSettings at 104), !float 68; LeastSquaresResult!double 32, !float 24;
   Slice!(T*) = { size_t length; T* ptr }; LeastSquaresTask = 16-byte delegate { context, funcptr };
-  LeastSquaresStatus / BoxQPStatus 32-bit enums; lapackint = int (the `*-ilp` configurations are not supported).
+  LeastSquaresStatus / BoxQPStatus 32-bit enums; lapackint = int (the `*-ilp` configurations: dlang/README.md, "ILP64").
 BetterC: nothing here allocates with the GC or throws except `optimize` under version(D_Exceptions).
 
 Build: add this directory's `source` in front of mir-optim's own (or replace the two files) and link the library:
