@@ -74,10 +74,10 @@ template <typename T>
 __device__ __noinline__ int potrf_big(int n, const T* A_, int lda, T* F_, int ldf, BigLds<T>& sm, long long* dbg = nullptr,
                                       CoopCtx* cc = nullptr, T* cS_ = nullptr)
 {
-    // helpers (solve_coop.h, kCoopPotrfT): while this workgroup factors the four panels of a 64-column block, the helpers form the
-    // next block's update from the columns that are final (blocks <= B - 2 for block B): step 1 below then only covers the
-    // panels of blocks B - 1 and B (<= 7 of them). The factor travels through agent-scope stores; the helpers' part comes back
-    // through one of two n x 64 buffers at cS.
+    // helpers (solve_coop.h, kCoopPotrfT): while this workgroup factors the kCoopPanels (2) panels of a kCoopBlockCols (32)-column
+    // block, the helpers form the next block's update from the columns that are final (blocks <= B - 2 for block B): step 1 below
+    // then only covers the panels of blocks B - 1 and B (<= 2 kCoopPanels - 1 = 3 of them). The factor travels through agent-scope
+    // stores; the helpers' part comes back through one of two n x kCoopBlockCols buffers at cS.
     const bool coop = cc && cc->W > 1 && cS_ && !cc->failed;
     bool pending = false;                                       // a kCoopPotrfT job is out
     // address spaces spelled out: through the generic pointers of an out-of-line function every access is a FLAT instruction, which
@@ -587,8 +587,8 @@ __device__ __noinline__ int posvx_big(int n, T* A, int lda, T* F, int ldf, T* s,
     const T safe1 = T(n + 1) * safmin, safe2 = safe1 / eps;
     T lstres = 3;
     for (int count = 1;; ++count) {
-        if (n <= kBigRowsMaxN) residual_big<T>(n, A, lda, b, x, r, w, sm.xs, cc, cS ? cS + (size_t)n * 128 : nullptr);
-        else residual_big<T>(n, A, lda, b, x, r, w, sm.span, cc, cS ? cS + (size_t)n * 128 : nullptr);
+        if (n <= kBigRowsMaxN) residual_big<T>(n, A, lda, b, x, r, w, sm.xs, cc, cS ? cS + coop_part_offset(n) : nullptr);
+        else residual_big<T>(n, A, lda, b, x, r, w, sm.span, cc, cS ? cS + coop_part_offset(n) : nullptr);
         if (count == 1) MIRLSQ_STAMP(dbg, 11);
         T qv = 0;
         for (int i = tid; i < n; i += kBigThreads) {
@@ -843,7 +843,7 @@ __device__ __forceinline__ void lm_solve_big_main(const LmSolveArgs<T>& a, int k
         // lanes --, dx from LDS, 16 loads in flight (before: a wave per row and a wave reduction per row, 160 us at n = 512)
         __syncthreads();
         if (cc && !cc->failed) {
-            T* part = sc.cS + (size_t)n * 128;
+            T* part = sc.cS + coop_part_offset(n);
             const unsigned long long d[6] = {(unsigned long long)(uintptr_t)a.JJ, (unsigned long long)(uintptr_t)dx_out, (unsigned long long)(uintptr_t)part,
                                              (unsigned long long)(unsigned)n | ((unsigned long long)(unsigned)n << 32), 0ull, 0ull};
             coop_publish(*cc, kCoopSymv | kCoopFence, d);

@@ -29,8 +29,7 @@ constexpr int kCoopDescWord = kCoopLine * kCoopMaxPeers;
 constexpr int kCoopAbortWord = kCoopLine * (kCoopMaxPeers + 1);
 constexpr double kCoopSpinSeconds = 5.0;
 
-constexpr int kCoopPanels = 2;                                  // kCoopPotrfT: 16-column panels of a look-ahead block
-constexpr int kCoopBlockCols = 16 * kCoopPanels;
+// (kCoopPanels, kCoopBlockCols: solve_types.h -- the host sizes the scratch with them)
 enum : uint32_t { kCoopExit = 1, kCoopPotrfT = 2, kCoopSymv = 3, kCoopCopy2 = 4 };
 enum : uint32_t { kCoopFence = 0x100,                           // job flag: agent-scope fences around the job (see above)
                   kCoopRelease = 0x200 };                       // job flag: main writes its L2 back before publishing (its ordinary
@@ -164,7 +163,7 @@ __device__ inline void coop_done(CoopCtx& c, uint32_t type)
     if (threadIdx.x == 0) coop_st64(c.w + kCoopLine * c.p, ((unsigned long long)c.epoch << 32) | c.seq);
 }
 
-// ---- job kCoopPotrfT: ?potrf's update of a 64-column block AHEAD of the factorisation. potrf_big (left-looking, 16-column panels)
+// ---- job kCoopPotrfT: ?potrf's update of a look-ahead block (kCoopBlockCols = 32 columns) AHEAD of the factorisation. potrf_big (left-looking, 16-column panels)
 // spends 70 % of its time at n = 1024 on S = L[rows, :c0] L[panel, :c0]^T -- one CU's matrix cores. A job per panel would be a
 // dozen memory-level round trips per panel (measured: 52 us a panel against 57 on one workgroup); instead the helpers work one
 // BLOCK of kCoopPanels panels (w = 16 kCoopPanels columns) ahead: while main factors the panels of block B - 1 they form, for

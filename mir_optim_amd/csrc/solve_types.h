@@ -68,11 +68,12 @@ struct SolveScratch {    // global scratch, all L2 resident
     int32_t* ivec;  // 2 n: SI, flags
     long long* dbg; // optional phase stamps (diagnostic builds of the host pass a buffer; else nullptr)
     unsigned long long* coop;   // n > kSolveMaxN: the sync words of the entry's helper workgroups (solve_coop.h), zero at creation
-    T* cS;                      // ... and their scratch: two n x 64 look-ahead blocks of ?potrf + 2 x 16 n-vectors of partial products
+    T* cS;                      // ... and their scratch: two n x kCoopBlockCols look-ahead blocks of ?potrf + 2 x kCoopMaxPeers n-vectors of partial products
 };
 
 // helper workgroups of the any-n solve (solve_coop.h): sync words per ladder entry (64-bit; one 128-byte line per word that is
-// polled), peers per entry for a given n, and the entry's scratch behind cS (two n x 64 look-ahead blocks + 2 x kCoopMaxPeers n-vectors)
+// polled), peers per entry for a given n, and the entry's scratch behind cS (two n x kCoopBlockCols look-ahead blocks of
+// kCoopPanels 16-column panels each, then -- at coop_part_offset(n) -- 2 x kCoopMaxPeers n-vectors of partial products)
 constexpr int kCoopMaxPeers = 16;
 constexpr int kCoopLine = 16;
 constexpr int kCoopWords = kCoopLine * (kCoopMaxPeers + 3);
@@ -83,7 +84,10 @@ __host__ __device__ inline int coop_peers(int n)
     const int w = (nb + 3) / 4;                     // about four 16-row blocks a peer's eight waves at the start of ?potrf
     return w < 2 ? 2 : (w > kCoopMaxPeers ? kCoopMaxPeers : w);
 }
-__host__ __device__ inline size_t coop_scratch_elems(int n) { return n > kSolveMaxN ? (size_t)n * 128 + (size_t)2 * kCoopMaxPeers * n : 0; }
+constexpr int kCoopPanels = 2;                                  // kCoopPotrfT: 16-column panels of a look-ahead block
+constexpr int kCoopBlockCols = 16 * kCoopPanels;
+__host__ __device__ inline size_t coop_part_offset(int n) { return (size_t)2 * n * kCoopBlockCols; }
+__host__ __device__ inline size_t coop_scratch_elems(int n) { return n > kSolveMaxN ? coop_part_offset(n) + (size_t)2 * kCoopMaxPeers * n : 0; }
 
 constexpr int kLdsBlk = 272;     // solve_lds.h: 16 x 17 elements per LDS block
 __host__ __device__ constexpr int lds_solve_elems(int nb) { return nb * (nb + 1) * kLdsBlk + 48 * nb + 2; }

@@ -86,8 +86,10 @@ def test_collapsed_fd_interval_and_fixed_parameter(oracle):
     assert all(c[1] == 1.5 for c in calls)            # the collapsed column is never perturbed (LS:1033: no call when twh == 0)
     # fCalls: the fit ends in the reference's rejection tail (quirk Q3) at a residual that moves in its 16th digit; whether the
     # last candidate step is accepted (one more refresh + a second tail) is a rounding-level decision (scripts/dbg_collapsed.py
-    # prints both traces: identical events until that pass) -- the counters agree up to one such episode
-    assert abs(res.fCalls - ro.fCalls) <= 3 + 16
+    # prints both traces: identical events until that pass) -- the two known traces: the same counters, or exactly ONE such episode
+    # more on one side (a refresh: n = 3 calls, LS:1049, + a tail of at most 16 rejected trials)
+    d = abs(int(res.fCalls) - int(ro.fCalls))
+    assert d == 0 or 3 <= d <= 3 + 16, (res.fCalls, ro.fCalls)
 
 
 def test_degenerate_shapes(oracle):
