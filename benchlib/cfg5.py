@@ -5,14 +5,18 @@ import os
 import sys
 import time
 
-from .common import (F64_MFMA_PEAK_TF, HBM_PEAK_GBS, ROOT, _round_no, csrc_sha16, describe_comm, flush_c_stdio,  # noqa: F401
+from .common import (F64_MFMA_PEAK_TF, HBM_PEAK_GBS, ROOT, _round_no, csrc_sha16, describe_comm, flush_c_stdio,
+                     # noqa: F401
                      pmc_field, pmc_file, step_stats, traffic_source)
 
 
 def main_cfg5(args):
-    """BASELINE cfg 5: 4096 x (m = 512, n = 8) fp32, one wavefront per problem, the whole LM loop inside ONE kernel launch
-    (csrc/batched_kernel.h). A step = one launch = 4096 complete fits from their starting points; inputs resident in HBM.
-    value = accepted LM iterations (summed over the problems) per second. Independent problems: N > 1 would be replicas."""
+    """BASELINE cfg 5: 4096 x (m = 512, n = 8) fp32, one wavefront per problem, the whole LM loop inside ONE kernel
+    launch
+    (csrc/batched_kernel.h). A step = one launch = 4096 complete fits from their starting points; inputs resident in
+    HBM.
+    value = accepted LM iterations (summed over the problems) per second. Independent problems: N > 1 would be
+    replicas."""
     import numpy as np
     import torch
 
@@ -33,7 +37,8 @@ def main_cfg5(args):
     dup = api.DeviceBuffer(np.full(n, np.inf, dtype=np.float32))
     dres = api.DeviceBuffer(nbytes=count * 24, dtype=np.uint8, shape=(count * 24,))
     stream = api.Stream()
-    # the per-row basis table of the model (4096 x ... no: t is shared, 512 rows x 4 floats) is the caller's: no allocation per launch
+    # the per-row basis table of the model (4096 x ... no: t is shared, 512 rows x 4 floats) is the caller's: no
+    # allocation per launch
     basis = api.DeviceBuffer(nbytes=m * 4 * 4, dtype=np.uint8, shape=(m * 16,))
     bopt = api.BatchedOptions(stream=stream.handle, basis=basis.ptr, basis_bytes=m * 16)
 
@@ -41,7 +46,8 @@ def main_cfg5(args):
         # x is restored on the device (a D2D copy of 128 KB inside the timed region: part of "from the starting points")
         if L.mir_lsq_memcpy_d2d(dx.ptr, dx0.ptr, count * n * 4, stream.handle) != 0:
             raise SystemExit("d2d failed")
-        rc = L.mir_lsq_batched_kernel_s(C.byref(s), count, m, M.MODEL_EXP_DECAY_PAD8, dx.ptr, dlo.ptr, dup.ptr, dt_.ptr, 0,
+        rc = L.mir_lsq_batched_kernel_s(C.byref(s), count, m, M.MODEL_EXP_DECAY_PAD8, dx.ptr, dlo.ptr, dup.ptr,
+                                        dt_.ptr, 0,
                                         dd.ptr, dres.ptr, C.byref(bopt))
         if rc != 0:
             raise SystemExit(f"batched kernel launch failed: {rc}")
@@ -53,28 +59,39 @@ def main_cfg5(args):
         step()
     stream.synchronize()
     dt = time.perf_counter() - t0
-    raw = np.frombuffer(dres.download().tobytes(), dtype=np.dtype([("status", "<i4"), ("iterations", "<u4"), ("fCalls", "<u4"),
-                                                                   ("gCalls", "<u4"), ("residual", "<f4"), ("lambda", "<f4")]))
+    raw = np.frombuffer(dres.download().tobytes(), dtype=np.dtype([("status", "<i4"), ("iterations", "<u4"), ("fCalls",
+            "<u4"),
+                                                                   ("gCalls", "<u4"), ("residual", "<f4"), ("lambda",
+                                                                           "<f4")]))
     iters = int(raw["iterations"].sum())
     fcalls = int(raw["fCalls"].sum())
     ms = dt / args.steps * 1e3
-    # Work of one launch: every residual evaluation is m model evaluations (1 exp, ~20 flops; the four sin/cos values of a row do
-    # not depend on the parameters and come from the basis table k_batched_basis fills once per launch); a finite-difference
+    # Work of one launch: every residual evaluation is m model evaluations (1 exp, ~20 flops; the four sin/cos values of
+    # a row do
+    # not depend on the parameters and come from the basis table k_batched_basis fills once per launch); a
+    # finite-difference
     # Jacobian makes 2 n of them but fCalls counts n (quirk Q5), so 2 x fCalls x m bounds the evaluations from above
     evals = 2.0 * fcalls * m
     out = {
-        "metric": "LM iterations/sec", "value": iters / (ms * 1e-3), "unit": "iterations/s", "n_gpus": 1, "steps": args.steps,
+        "metric": "LM iterations/sec", "value": iters / (ms * 1e-3), "unit": "iterations/s", "n_gpus": 1,
+            "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"cfg5: {count} independent fits m={m} x n={n} fp32, exp-decay family padded to n=8, one wavefront per "
+        "config": {"workload": f"cfg5: {count} independent fits m={m} x n={n} fp32, exp-decay family padded to n=8, "
+                               f"one wavefront per "
                                "problem, whole LM loop in one kernel launch, FD Jacobian (jacobianEpsilon=2^-11)",
-                   "fits_per_s": count / (ms * 1e-3), "iterations_per_fit": iters / count, "fcalls_per_fit": fcalls / count,
-                   "status_counts": {str(int(k)): int(v) for k, v in zip(*np.unique(raw["status"], return_counts=True))},
-                   "mean_residual": float(raw["residual"].mean()), "parallelism": "replicas only (independent problems)"},
+                   "fits_per_s": count / (ms * 1e-3), "iterations_per_fit": iters / count,
+                       "fcalls_per_fit": fcalls / count,
+                   "status_counts": {str(int(k)): int(v) for k, v in zip(*np.unique(raw["status"],
+                           return_counts=True))},
+                   "mean_residual": float(raw["residual"].mean()),
+                       "parallelism": "replicas only (independent problems)"},
         "roofline": cfg5_roofline(ms, evals, args.steps, count, m, n),
     }
-    # ---- steady state (round-4 review): the 4096 fits differ 3 x in length and go to 2048 wave slots, so the launch ends with
-    # its stragglers. The same problems 16 times over (65 536 fits in one launch) amortise that tail: the kernel's rate where the
+    # ---- steady state (round-4 review): the 4096 fits differ 3 x in length and go to 2048 wave slots, so the launch
+    # ends with
+    # its stragglers. The same problems 16 times over (65 536 fits in one launch) amortise that tail: the kernel's rate
+    # where the
     # dispatcher always has a next problem for a finished wave.
     reps = max(1, args.cfg5_replicas)
     if reps > 1:
@@ -86,7 +103,8 @@ def main_cfg5(args):
         def step2():
             if L.mir_lsq_memcpy_d2d(dx2.ptr, dx02.ptr, big * n * 4, stream.handle) != 0:
                 raise SystemExit("d2d failed")
-            if L.mir_lsq_batched_kernel_s(C.byref(s), big, m, M.MODEL_EXP_DECAY_PAD8, dx2.ptr, dlo.ptr, dup.ptr, dt_.ptr, 0, dd2.ptr,
+            if L.mir_lsq_batched_kernel_s(C.byref(s), big, m, M.MODEL_EXP_DECAY_PAD8, dx2.ptr, dlo.ptr, dup.ptr,
+                                          dt_.ptr, 0, dd2.ptr,
                                           dres2.ptr, C.byref(bopt)) != 0:
                 raise SystemExit("batched kernel launch failed")
         step2()
@@ -99,13 +117,17 @@ def main_cfg5(args):
         ms2 = (time.perf_counter() - t0) / k2 * 1e3
         raw2 = np.frombuffer(dres2.download().tobytes(), dtype=raw.dtype)
         same = bool((raw2["iterations"].reshape(reps, count) == raw["iterations"][None, :]).all()
-                    and (raw2["residual"].view(np.uint32).reshape(reps, count) == raw["residual"].view(np.uint32)[None, :]).all())
+                    and (raw2["residual"].view(np.uint32).reshape(reps, count) == raw["residual"].view(np.uint32)[None,
+                            :]).all())
         rf = out["roofline"]
-        ss = {"fits_per_launch": big, "ms_per_launch": ms2, "fits_per_s": big / (ms2 * 1e-3), "iterations_per_s": iters * reps / (ms2 * 1e-3),
-              "speedup_over_4096_fit_launches": (big / ms2) / (count / ms), "replicas_bit_identical_with_the_4096_fit_launch": same}
+        ss = {"fits_per_launch": big, "ms_per_launch": ms2, "fits_per_s": big / (ms2 * 1e-3),
+              "iterations_per_s": iters * reps / (ms2 * 1e-3),
+              "speedup_over_4096_fit_launches": (big / ms2) / (count / ms),
+                  "replicas_bit_identical_with_the_4096_fit_launch": same}
         if rf.get("valu_instructions_per_launch"):
             ss["valu_frac"] = rf["valu_instructions_per_launch"] * reps / (ms2 * 1e-3) / 1e9 / rf["peak"]
-            ss["note"] = ("valu_frac = VALU instructions (the committed count of a 4096-fit launch x replicas: the same problems execute the same "
+            ss["note"] = ("valu_frac = VALU instructions (the committed count of a 4096-fit launch x replicas: the "
+                          "same problems execute the same "
                           "instructions) / launch time / the issue peak; where the straggler tail is amortised")
         out["config"]["steady_state"] = ss
     if not args.no_cpu_baseline:
@@ -123,16 +145,22 @@ def main_cfg5(args):
             ro, _ = O.optimize(f, m, x0[k], dtype=np.float32, fctx=C.addressof(ctx))
             it_cpu += ro.iterations
         dtc = time.perf_counter() - t1
-        out["cpu_baseline"] = {"value": it_cpu / dtc, "unit": "iterations/s", "cores": 1, "host_nproc": os.cpu_count(), "kind": "port",
-                               "sample": f"the first {sample} of the {count} problems, float oracle (plain loops; BLAS has nothing to do at "
-                                         f"n = 8), one thread, {dtc:.1f} s incl. ctypes call overhead", "fits_per_s": sample / dtc}
+        out["cpu_baseline"] = {"value": it_cpu / dtc, "unit": "iterations/s", "cores": 1, "host_nproc": os.cpu_count(),
+                               "kind": "port",
+                               "sample": f"the first {sample} of the {count} problems, float oracle (plain loops; BLAS "
+                                         f"has nothing to do at "
+                                         f"n = 8), one thread, {dtc:.1f} s incl. ctypes call overhead",
+                                             "fits_per_s": sample / dtc}
     print(json.dumps(out), flush=True)
 
 
 def cfg5_roofline(ms, evals, steps, count, m, n):
-    """k_lm_batched is neither HBM- nor MFMA-bound (8.4 MB of inputs per launch): its bound is the VALU issue rate -- one wave64
-    instruction per 4 cycles per SIMD, 1024 SIMDs at 2.4 GHz = 614.4 G wave-instructions/s. `achieved` = the VALU instructions
-    one launch executes (SQ_INSTS_VALU of the committed rocprofv3 pass, profiles/r03/cfg5_pmc.json: the instruction count of a
+    """k_lm_batched is neither HBM- nor MFMA-bound (8.4 MB of inputs per launch): its bound is the VALU issue rate --
+    one wave64
+    instruction per 4 cycles per SIMD, 1024 SIMDs at 2.4 GHz = 614.4 G wave-instructions/s. `achieved` = the VALU
+    instructions
+    one launch executes (SQ_INSTS_VALU of the committed rocprofv3 pass, profiles/r03/cfg5_pmc.json: the instruction
+    count of a
     launch does not depend on the box) over this run's launch time; `valu_busy_pmc` is the hardware's own figure
     (4 x SQ_ACTIVE_INST_VALU over GRBM_GUI_ACTIVE x 1024 SIMDs) from the same pass."""
     import glob
@@ -143,21 +171,29 @@ def cfg5_roofline(ms, evals, steps, count, m, n):
             doc = json.load(open(f))
             pm = next(v for k, v in doc["kernels"].items() if "k_lm_batched" in k)
             src = os.path.relpath(f, ROOT)
-            # the instruction count of a launch belongs to the kernel source (and the LM settings) it was counted on: the
+            # the instruction count of a launch belongs to the kernel source (and the LM settings) it was counted on:
+            # the
             # summary records the hash of batched_kernel.h; a different (or missing) hash leaves achieved / frac empty
             have, want = (doc.get("csrc_sha16") or {}).get("batched_kernel.h"), csrc_sha16("batched_kernel.h")
-            stale = None if have == want else f"{src} was counted on batched_kernel.h {have}, this tree has {want}: re-profile (scripts/profile_any.sh cfg5 ... VALU SQ1)"
+            stale = None if have == want else (
+                f"{src} was counted on batched_kernel.h {have}, this tree has {want}: re-profile "
+                "(scripts/profile_any.sh cfg5 ... VALU SQ1)")
         except (StopIteration, KeyError, ValueError):
             pass
-    out = {"kernel": "mirlsq::k_lm_batched<2> (one wavefront = one workgroup per problem: J, y in its 20 KB of LDS, FD + Broyden + "
-                     "J^T J + posvx (one matrix row per lane) + acceptance in registers; no barrier, no host round trip)",
+    out = {"kernel": "mirlsq::k_lm_batched<2> (one wavefront = one workgroup per problem: J, y in its 20 KB of LDS, FD "
+                     "+ Broyden + "
+                     "J^T J + posvx (one matrix row per lane) + acceptance in registers; no barrier, no host round "
+                     "trip)",
            "bound": "valu", "achieved": None, "peak": peak, "unit": "G wave64 VALU instructions/s", "frac": None,
            "avg_launch_ms": ms, "launches": steps, "traffic": None,
            "algorithmic_bytes_per_launch": float(count * (m * 4 + 2 * n * 4 + 24) + m * 4),
            "model_evaluations_per_s_upper_bound": evals / (ms * 1e-3),
-           "note": "neither HBM- nor MFMA-bound: 8.4 MB of inputs per launch (< 1 % of the launch time at HBM rate). LDS allows two "
-                   "waves per SIMD (20 KB a problem); while two are resident the VALU pipe is ~85 % busy, but the launch ends with "
-                   "its longest fits (29 iterations where the mean is 10; 4096 problems on 2048 slots): on average 1.1 waves are "
+           "note": "neither HBM- nor MFMA-bound: 8.4 MB of inputs per launch (< 1 % of the launch time at HBM rate). "
+                   "LDS allows two "
+                   "waves per SIMD (20 KB a problem); while two are resident the VALU pipe is ~85 % busy, but the "
+                   "launch ends with "
+                   "its longest fits (29 iterations where the mean is 10; 4096 problems on 2048 slots): on average 1.1 "
+                   "waves are "
                    "resident per SIMD (mean_resident_waves_per_simd), which is what holds the fraction near one half"}
     if stale:
         out["counters_stale"] = stale
@@ -167,7 +203,8 @@ def cfg5_roofline(ms, evals, steps, count, m, n):
         out["valu_instructions_per_launch"] = pm["SQ_INSTS_VALU"]
         out["transcendental_instructions_per_launch"] = pm.get("SQ_INSTS_VALU_TRANS_F32")
         out["valu_busy_pmc"] = pm.get("valu_util")
-        if pm.get("SQ_WAVE_CYCLES") and pm.get("GRBM_GUI_ACTIVE"):      # SQ_WAVE_CYCLES counts 4-cycle units, GUI_ACTIVE sums 8 XCDs
+        # SQ_WAVE_CYCLES counts 4-cycle units, GUI_ACTIVE sums 8 XCDs
+        if pm.get("SQ_WAVE_CYCLES") and pm.get("GRBM_GUI_ACTIVE"):
             out["mean_resident_waves_per_simd"] = 4.0 * pm["SQ_WAVE_CYCLES"] / (pm["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
         out["counters_source"] = src + " (committed rocprofv3 --pmc passes of this command; not measured in this run)"
     return out
