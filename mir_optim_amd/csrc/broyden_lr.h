@@ -326,57 +326,6 @@ __global__ __launch_bounds__(256) void k_lr_finish(const T* __restrict__ lr, T* 
     }
 }
 
-// The matrix side of k_lr_finish by ONE workgroup (any size), for the head of the fused round's kernel above n = 128 (k_lm_solve
-// with a.fused, 128 < n <= kSolveMaxN; up to 128 the kernel adds the term to the values of J^T J it holds in registers):
-// J^T J += v dx^T + dx v^T + uu dx dx^T, the same expression entry by entry -- the same bits. v, dxs: n elements each, in LDS.
-template <typename T>
-__device__ inline void lr_finish_matrix(T* __restrict__ JJ, int n, const T* v, const T* dxs, T uu)
-{
-    // J^T J += the rank-two term: 16 loads in flight per thread, then the 16 sums and stores (a plain read-modify-write loop
-    // serialises on may-alias load / store ordering: 15-20 us at n = 128 for one workgroup, this: ~3)
-    const int nn = n * n;
-    constexpr int UB = 16;
-    if (nn % 2 == 0) {
-        typedef T v2 __attribute__((ext_vector_type(2)));
-        v2* __restrict__ J2 = reinterpret_cast<v2*>(JJ);
-        const int np = nn / 2;
-        for (int base = threadIdx.x; base < np; base += UB * blockDim.x) {
-            v2 t[UB];
-#pragma unroll
-            for (int u = 0; u < UB; ++u) { const int idx = base + u * (int)blockDim.x; t[u] = J2[idx < np ? idx : np - 1]; }
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int idx = base + u * (int)blockDim.x;
-                if (idx < np) {
-                    const int e0 = 2 * idx, i0 = e0 / n, j0 = e0 - i0 * n;
-                    const int e1 = e0 + 1, i1 = e1 / n, j1 = e1 - i1 * n;
-                    const int r0 = i0 >= j0 ? i0 : j0, c0 = i0 >= j0 ? j0 : i0;
-                    const int r1 = i1 >= j1 ? i1 : j1, c1 = i1 >= j1 ? j1 : i1;
-                    v2 o = t[u];
-                    o.x += lr_jj_term(v[r0], v[c0], dxs[r0], dxs[c0], uu);
-                    o.y += lr_jj_term(v[r1], v[c1], dxs[r1], dxs[c1], uu);
-                    J2[idx] = o;
-                }
-            }
-        }
-    } else {
-        for (int base = threadIdx.x; base < nn; base += UB * blockDim.x) {
-            T t[UB];
-#pragma unroll
-            for (int u = 0; u < UB; ++u) { const int e = base + u * (int)blockDim.x; t[u] = JJ[e < nn ? e : nn - 1]; }
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int e = base + u * (int)blockDim.x;
-                if (e < nn) {
-                    const int i = e / n, j = e - i * n;
-                    const int r = i >= j ? i : j, c = i >= j ? j : i;
-                    JJ[e] = t[u] + lr_jj_term(v[r], v[c], dxs[r], dxs[c], uu);
-                }
-            }
-        }
-    }
-}
-
 // fold the k pending terms into J: J[i,:] += u_0[i] dx_0 + ... + u_{k-1}[i] dx_{k-1}, in update order
 template <typename T, int NCP, bool VEC>
 __global__ __launch_bounds__(256) void k_lr_flush(T* J, const T* __restrict__ U, const T* __restrict__ D,

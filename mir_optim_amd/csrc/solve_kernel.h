@@ -711,9 +711,13 @@ __device__ __forceinline__ int box_qp_device(int n, const T* Pm, const T* q, con
 // (resident_kernel.h), whose workgroup 0 runs the n x n part of every pass inside the one launch.
 // `pre` / preissued: the fused round's kernel has the values of J^T J in registers already (loaded at ITS entry, the Broyden pass's
 // rank-two term added on the way -- lm_round_head); otherwise the body issues the loads itself.
+// `fin` (NB = 0 only, the fused round above n = 128): the Broyden pass's rank-two term has NOT been applied to J^T J yet -- the
+// copy loop below reads the matrix anyway and adds it on the way (v, dx staged in LDS by lm_round_head), writing J^T J back.
+template <typename T> struct FinTerm { const T* v; const T* dxs; T uu; T* JJw; bool on; };
 template <typename T, int NB, bool BOUNDED = true>
 __device__ __forceinline__ void lm_solve_body(const LmSolveArgs<T>& a, const int kc, unsigned char* smem_raw,
-                                              LdsPreload<T, (NB > 0 ? NB : 1)>& pre, const bool preissued)
+                                              LdsPreload<T, (NB > 0 ? NB : 1)>& pre, const bool preissued,
+                                              const FinTerm<T> fin = FinTerm<T>{nullptr, nullptr, T(0), nullptr, false})
 {
     __shared__ T red[8];
     __shared__ int ired[12];
@@ -781,6 +785,7 @@ __device__ __forceinline__ void lm_solve_body(const LmSolveArgs<T>& a, const int
             const v2* __restrict__ s2 = reinterpret_cast<const v2*>(src);
             v2* __restrict__ p2 = reinterpret_cast<v2*>(dp);
             v2* __restrict__ a2 = reinterpret_cast<v2*>(da);
+            v2* __restrict__ w2 = reinterpret_cast<v2*>(fin.JJw);
             const int np = nn / 2;
             for (int base = tid; base < np; base += 16 * kSolveThreads) {
                 v2 v[16];
@@ -791,8 +796,17 @@ __device__ __forceinline__ void lm_solve_body(const LmSolveArgs<T>& a, const int
                     const int idx = base + u * kSolveThreads;
                     if (idx < np) {
                         v2 t = v[u];
-                        if ((2 * idx) % (n + 1) == 0) t.x += lambda;
-                        if ((2 * idx + 1) % (n + 1) == 0) t.y += lambda;
+                        const int i = (2 * idx) / n, j = 2 * idx - i * n;      // n even: both elements in row i
+                        if (fin.on) {
+                            const T vi = fin.v[i], di = fin.dxs[i];
+                            const T vj0 = fin.v[j], dj0 = fin.dxs[j], vj1 = fin.v[j + 1], dj1 = fin.dxs[j + 1];
+                            const bool l0 = i >= j, l1 = i >= j + 1;
+                            t.x += lr_jj_term(l0 ? vi : vj0, l0 ? vj0 : vi, l0 ? di : dj0, l0 ? dj0 : di, fin.uu);
+                            t.y += lr_jj_term(l1 ? vi : vj1, l1 ? vj1 : vi, l1 ? di : dj1, l1 ? dj1 : di, fin.uu);
+                            w2[idx] = t;
+                        }
+                        if (j == i) t.x += lambda;
+                        if (j + 1 == i) t.y += lambda;
                         if constexpr (kNeedPm) p2[idx] = t;
                         a2[idx] = t;
                     }
@@ -807,7 +821,14 @@ __device__ __forceinline__ void lm_solve_body(const LmSolveArgs<T>& a, const int
                 for (int u = 0; u < 16; ++u) {
                     const int idx = base + u * kSolveThreads;
                     if (idx < nn) {
-                        const T t = (idx % (n + 1) == 0) ? v[u] + lambda : v[u];
+                        T t = v[u];
+                        const int i = idx / n, j = idx - i * n;
+                        if (fin.on) {
+                            const bool lo = i >= j;
+                            t += lr_jj_term(fin.v[lo ? i : j], fin.v[lo ? j : i], fin.dxs[lo ? i : j], fin.dxs[lo ? j : i], fin.uu);
+                            fin.JJw[idx] = t;
+                        }
+                        if (i == j) t += lambda;
                         if constexpr (kNeedPm) dp[idx] = t;
                         da[idx] = t;
                     }
@@ -1018,13 +1039,12 @@ __device__ __forceinline__ bool lm_round_head(const LmSolveArgs<T>& a, T* fin_v,
                 }
             }
         if (el) pre.diag += lr_jj_term(v[tid], v[tid], dxs[tid], dxs[tid], uu);
-    } else {
-        lr_finish_matrix(a.fin_JJ, n, v, dxs, uu);
     }
-    // fin_v is free. The stores of J^T J, J^T y and D_k are NOT waited for: a thread reads back what it wrote itself (J^T y,
+    // (NB = 0: the body's copy of J^T J adds the term on its way -- FinTerm; v and the step stay in fin_v)
+    // fin_v is free (NB > 0). The stores of J^T J, J^T y and D_k are NOT waited for: a thread reads back what it wrote itself (J^T y,
     // program order), the matrix is read from memory again only behind the solve's own barriers (the prediction), D_k by later
     // kernels. (NB = 0: the body copies J^T J from memory at once -- a full barrier.)
-    if constexpr (NB > 0) lds_barrier(); else __syncthreads();
+    if constexpr (NB > 0) lds_barrier();
     MIRLSQ_STAMP(a.sc[0].dbg, 28);
     return true;
 }
@@ -1034,13 +1054,15 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     LdsPreload<T, (NB > 0 ? NB : 1)> pre;
+    FinTerm<T> fin{nullptr, nullptr, T(0), nullptr, false};
     if (a.fused) {
         T* fin_v;
         if constexpr (NB > 0) { fin_v = reinterpret_cast<T*>(smem_raw); lds_load_issue<T, NB>(a.n, a.JJ, a.n, pre); }
         else { __shared__ T fin_static[2 * kSolveMaxN]; fin_v = fin_static; }
         if (!lm_round_head<T, NB>(a, fin_v, pre)) return;
+        if constexpr (NB == 0) fin = FinTerm<T>{fin_v, fin_v + a.n, a.fin_lr[2 * a.n + 2 * kLrMax], a.fin_JJ, true};
     }
-    lm_solve_body<T, NB, BOUNDED>(a, (int)blockIdx.x, smem_raw, pre, a.fused != 0 && NB > 0);      // blockIdx.x: chain step
+    lm_solve_body<T, NB, BOUNDED>(a, (int)blockIdx.x, smem_raw, pre, a.fused != 0 && NB > 0, fin);  // blockIdx.x: chain step
 }
 
 // n <= 16, f64: the same pass on ONE wave per ladder entry, every matrix a row per lane (solve_wave16.h): no LDS, no barrier,
@@ -1053,8 +1075,8 @@ template <bool BOUNDED>
 __global__ __launch_bounds__(kWave) void k_lm_solve_wave(LmSolveArgs<double> a)
 {
     const int n = a.n, kc = blockIdx.x, lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+    __shared__ double fin_v[2 * kW16];
     if (a.fused) {
-        __shared__ double fin_v[2 * kW16];
         LdsPreload<double, 1> none;
         if (!lm_round_head<double, 0>(a, fin_v, none)) return;
     }
@@ -1063,7 +1085,26 @@ __global__ __launch_bounds__(kWave) void k_lm_solve_wave(LmSolveArgs<double> a)
     double JJrow[kW16];
 #pragma unroll
     for (int k = 0; k < kW16; ++k) { const double v = a.JJ[(size_t)rc * n + (k < n ? k : 0)]; JJrow[k] = (el && k < n) ? v : 0.0; }
-    const double djj_l = a.JJ[(size_t)rc * n + rc], jy_l = a.Jy[rc], x_l = a.x[rc], lo_l = a.lower[rc], up_l = a.upper[rc];
+    double djj_l = a.JJ[(size_t)rc * n + rc];
+    if (a.fused) {
+        // the Broyden pass's rank-two term (k_lr_finish's expression, entry by entry) on the row this lane holds; group 0 writes
+        // the updated J^T J back for the passes to come
+        const double uu = a.fin_lr[2 * n + 2 * kLrMax];
+        const double vr = fin_v[rc], dr = fin_v[n + rc];
+#pragma unroll
+        for (int k = 0; k < kW16; ++k) {
+            const int kk = k < n ? k : 0;
+            const double vk = fin_v[kk], dk = fin_v[n + kk];
+            const bool lower = rc >= kk;
+            const double t = lr_jj_term(lower ? vr : vk, lower ? vk : vr, lower ? dr : dk, lower ? dk : dr, uu);
+            if (el && k < n) {
+                JJrow[k] += t;
+                if (g == 0) a.fin_JJ[(size_t)rc * n + k] = JJrow[k];
+            }
+        }
+        djj_l += lr_jj_term(vr, vr, dr, dr, uu);
+    }
+    const double jy_l = a.Jy[rc], x_l = a.x[rc], lo_l = a.lower[rc], up_l = a.upper[rc];
     const double djj = el ? djj_l : 0.0, Jy_r = el ? jy_l : 0.0, x_r = el ? x_l : 0.0;
     const double lo_r = el ? lo_l : -Lim<double>::inf(), up_r = el ? up_l : Lim<double>::inf();
     const double lambda = (kc == 0 && (a.lambda_from_state || a.lambda_from_device)) ? a.st->lambda : a.lam[kc];
