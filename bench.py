@@ -101,6 +101,9 @@ def parse():
                          "global trajectory, the rank's own kernels uncontended, no xGMI hop. With --force-comm every "
                          "exchange "
                          "also passes through a one-rank ncclAllReduce")
+    ap.add_argument("--replay-latency-us", type=int, default=0,
+                    help="with --replay-ranks: a MODEL of the collectives' latency -- every replayed exchange first holds "
+                         "the stream this many microseconds (mir_lsq_comm_replay_set_delay); the line says so")
     ap.add_argument("--stall-bound", type=float, default=8.0,
                     help="RCCL only: upper bound (s, from communicator creation) of the warm-up loop that waits for "
                          "RCCL's "

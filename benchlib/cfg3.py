@@ -131,7 +131,10 @@ def main_cfg3(args):
         inner = comm
         inner_comm = inner
         comm = PAR.replay_comm(replay, 0, tape, inner)
+        if args.replay_latency_us and api.lib().mir_lsq_comm_replay_set_delay(comm, args.replay_latency_us) != 0:
+            raise SystemExit("mir_lsq_comm_replay_set_delay failed")
         replay_info = {"ranks": replay, "tape_doubles": int(tape.size), "grouped_solve_wall_ms": rwall * 1e3,
+                       "modelled_latency_us_per_exchange": args.replay_latency_us or None,
                        "grouped_solve": {"status": rres.status.name, "iterations": rres.iterations,
                                          "fcalls": rres.fCalls,
                                          "residual": rres.residual},

@@ -510,6 +510,10 @@ int mir_lsq_comm_record(mir_lsq_comm* comm, double* host_buf, size_t capacity);
 size_t mir_lsq_comm_recorded(const mir_lsq_comm* comm);
 mir_lsq_comm* mir_lsq_comm_create_replay(int nranks, int rank, const double* totals_host, size_t len, mir_lsq_comm* inner);
 int mir_lsq_comm_replay_rewind(mir_lsq_comm* comm);
+/* A MODEL of the collectives' latency for the replay tool: every replayed exchange first holds the stream for `microseconds`
+ * (one idle wave), so that a one-GPU replay of a rank charges each all-reduce what an N-rank RCCL call is ASSUMED to cost --
+ * bench.py --replay-ranks R --replay-latency-us L prints the solve time as a function of that assumption. 0 = off. */
+int mir_lsq_comm_replay_set_delay(mir_lsq_comm* comm, unsigned microseconds);
 /* ranks of the communicator as its transport reports them (RCCL: ncclCommCount); -1 on error */
 int mir_lsq_comm_ranks(const mir_lsq_comm* comm);
 /* One line about the transport, for logs: "rccl path=<shared object ncclAllReduce was bound from> version=<ncclGetVersion>

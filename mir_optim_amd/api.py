@@ -308,6 +308,8 @@ def lib():
         L.mir_lsq_comm_create_replay.argtypes = [C.c_int, C.c_int, C.c_void_p, sz, C.c_void_p]
         L.mir_lsq_comm_replay_rewind.restype = C.c_int
         L.mir_lsq_comm_replay_rewind.argtypes = [C.c_void_p]
+        L.mir_lsq_comm_replay_set_delay.restype = C.c_int
+        L.mir_lsq_comm_replay_set_delay.argtypes = [C.c_void_p, C.c_uint]
         L.mir_lsq_comm_ranks.restype = C.c_int
         L.mir_lsq_comm_ranks.argtypes = [C.c_void_p]
         for name in ("mir_lsq_comm_allreduce_d", "mir_lsq_comm_allreduce_s"):

@@ -75,6 +75,7 @@ struct mir_lsq_comm {
     double* replay_dev = nullptr;
     size_t replay_len = 0, replay_pos = 0;
     mir_lsq_comm* replay_inner = nullptr;
+    uint32_t replay_delay_us = 0;   // MODEL of a collective's latency: every replayed exchange first holds the stream this long
 };
 
 namespace mirlsq {
@@ -94,6 +95,9 @@ inline void* rccl_open(int* preloaded = nullptr)
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     return h;
 }
+
+// comm.hip: one wave that leaves after `us` microseconds (the replay communicator's latency model)
+void comm_replay_delay(uint32_t us, hipStream_t stream);
 
 // sum `count` elements of device buffer `buf` over all ranks, in place, ordered on `stream`
 template <typename T>
@@ -150,6 +154,7 @@ inline int comm_allreduce(mir_lsq_comm* c, T* buf, size_t count, hipStream_t str
                 std::fprintf(stderr, "[mir_optim_amd] replay communicator: the tape ends at %zu, exchange needs %zu more\n", c->replay_len, count);
                 return -1;
             }
+            if (c->replay_delay_us) comm_replay_delay(c->replay_delay_us, stream);
             if (hipMemcpyAsync(buf, c->replay_dev + c->replay_pos, count * sizeof(double), hipMemcpyDeviceToDevice, stream) != hipSuccess) return -1;
             c->replay_pos += count;
             return c->replay_inner ? comm_allreduce<T>(c->replay_inner, buf, count, stream) : 0;

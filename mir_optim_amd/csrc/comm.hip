@@ -5,6 +5,18 @@
 
 using namespace mirlsq;
 
+namespace mirlsq {
+__global__ void k_comm_replay_delay(long long ticks)          // 10 ns ticks; bounded: the wave leaves when the clock says so
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+void comm_replay_delay(uint32_t us, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_comm_replay_delay, dim3(1), dim3(64), 0, stream, (long long)us * 100);
+}
+}  // namespace mirlsq
+
 extern "C" {
 
 int mir_lsq_rccl_unique_id(void* out)
@@ -165,6 +177,12 @@ mir_lsq_comm* mir_lsq_comm_create_replay(int nranks, int rank, const double* tot
         return nullptr;
     }
     return comm;
+}
+int mir_lsq_comm_replay_set_delay(mir_lsq_comm* comm, unsigned microseconds)
+{
+    if (!comm || comm->kind != 4) return -1;
+    comm->replay_delay_us = microseconds;
+    return 0;
 }
 int mir_lsq_comm_replay_rewind(mir_lsq_comm* comm)
 {
