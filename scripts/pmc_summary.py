@@ -9,10 +9,25 @@ import collections, csv, glob, json, os, sys
 
 src, dst = sys.argv[1], sys.argv[2]
 out = {}
+
+
+def rows_of(path):
+    """The rows of a counter table. k_broyden_lr has two kinds of launches since the fused rounds (round 6): the sweep, and -- when
+    the record of the trial it runs behind rules a Broyden pass out -- a launch that only forms the trial's sum of squares
+    (8 MB instead of 1 GB). The per-launch figures are the SWEEP's: its launches are the ones that last at least half as long
+    as the kernel's longest (the table carries start / end timestamps per dispatch)."""
+    rows = list(csv.DictReader(open(path)))
+    longest = collections.defaultdict(float)
+    for r in rows:
+        if "k_broyden_lr" in r["Kernel_Name"]:
+            longest[r["Kernel_Name"]] = max(longest[r["Kernel_Name"]], float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    return [r for r in rows if "k_broyden_lr" not in r["Kernel_Name"]
+            or float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) >= 0.5 * longest[r["Kernel_Name"]]]
+
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     files = glob.glob(os.path.join(src, f"pmc_{c}", "**", "*counter_collection.csv"), recursive=True)
     agg = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(files[0])):
+    for r in rows_of(files[0]):
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
         agg[k][0] += 1
         agg[k][1] += float(r["Counter_Value"])
@@ -22,7 +37,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 mf = glob.glob(os.path.join(src, "pmc_MFMA", "**", "*counter_collection.csv"), recursive=True)
 if mf:
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
-    for r in csv.DictReader(open(mf[0])):
+    for r in rows_of(mf[0]):
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         agg[k]["_rows"] += 1
@@ -42,7 +57,7 @@ for sq in ("pmc_SQ1", "pmc_SQ2"):
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.defaultdict(lambda: collections.defaultdict(int))
-    for r in csv.DictReader(open(files[0])):
+    for r in rows_of(files[0]):
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[k][r["Counter_Name"]] += 1
