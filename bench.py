@@ -1,45 +1,41 @@
 #!/usr/bin/env python3
-"""bench.py -- LM iterations/sec on the BASELINE.json headline workload.
+"""bench.py -- LM iterations/sec on the BASELINE.json headline workload (the configurations live in benchlib/).
 
   python bench.py --gpus N --steps K --warmup W
-  N > 1 from a bare shell: this process starts the N rank processes itself (launch_ranks: children of this interpreter
-  with
-  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; the parent never imports torch or touches HIP) and relays rank 0's JSON
-  line.
-  Under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (WORLD_SIZE set) it is one rank.
+  N > 1 from a bare shell: this process starts the N rank processes itself (benchlib/launcher.py: children of this
+  interpreter with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; the parent never imports torch or touches HIP) and
+  relays rank 0's JSON line. Under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (WORLD_SIZE
+  set) it is one rank.
 
 Workload (cfg 3): tanh-linear synthetic NLS, r_i(x) = tanh(a_i . x) - b_i, m = 1e6 rows x n = 128
 parameters, fp64, finite-difference Jacobian through the user's batched residual callbacks, defaults except absTolerance
 (1e-5: every accept / reject decision of the solve has margin; the survey's 1e-9 is measured too and reported in
-config.survey_setting -- there the last acceptance compares rounding noise, DESIGN.md section 5).
+config.survey_setting -- there the last acceptance compares rounding noise, DESIGN.md section 6).
 
 Scaling (BASELINE.json: "m=1e6 x n=128 ... 1/2/4/8 MI355X"):
   --scaling strong (default)  the SAME 1e6-row problem, rows split over the N ranks (rank r owns rows
                               row_shard(1e6, N, r)); `value` = LM iterations of that one global solve per second.
   --scaling weak              1e6 rows PER GPU (cfg 4's partition; the global problem grows with N); `value` is still
-  the
-                              global solve's iterations per second -- it does NOT multiply by N.
-Per pass the ranks exchange one sum all-reduce of the packed [J^T J | J^T y] (full refresh) or of the 2n + 34 sweep
-vector
-(Broyden pass) and one of the trial residual sums, on the solver's own RCCL communicator.
+                              the global solve's iterations per second -- it does NOT multiply by N.
+Per solve the ranks exchange one sum all-reduce of the packed [J^T J | J^T y] per full refresh, ONE of the
+[sweep vector | trial sum of squares] (2n + 35 doubles) per trial of a fused round, and one scalar for the entry
+residual, on the solver's own RCCL communicator (cfg 3: 9 collectives per solve).
 
 A "step" is one complete LM solve (mir_optimize_least_squares_gpu_d from x0 to termination): residual + FD Jacobian
 callbacks, Broyden updates, J^T J / J^T y, damped BOXCQP solves, step acceptance -- nothing is skipped or cached between
 solves. Inputs are resident in HBM before the timed region.
 
 The JSON line also carries
-  roofline       the kernel with the most time in the timed region -- caller-side kernels included (at cfg 3 it is the
-  caller's
-                 finite-difference GEMM) --, HIP-event timed on the solver's stream; `object` names the entry it copies
-  jtj_kernel, broyden_kernel    the two hot LIBRARY kernels (fused FD / plain J^T J; the Broyden sweep)
-  residual_gemm, trial_residual the CALLER-side device callbacks (the synthetic workload's kernels, csrc/workloads.hip +
-  workloads_gemm.hip),
-                                event-timed on the same stream: they are most of a solve and get their own roofline
-                                objects
-  solve_kernel   the one-workgroup n x n kernel (latency-bound; time only)
-  cpu_baseline   the oracle (CPU port of the reference algorithm, OpenBLAS for syrk/gemv/ger/posvx) on a bounded sample
-  of
-                 the same workload at min(nproc, 64) threads, plus cpu_baseline_1thread; rank 0, N = 1 only.
+  roofline        the kernel with the most time in the timed region -- caller-side kernels included (at cfg 3 it is the
+                  caller's finite-difference GEMM) --, HIP-event timed on the solver's stream; `object` names the entry
+                  it copies
+  jtj_kernel, broyden_kernel     the two hot LIBRARY kernels (fused FD / plain J^T J; the Broyden sweep)
+  residual_gemm, trial_residual  the CALLER-side device callbacks (the synthetic workload's kernels, csrc/workloads.hip
+                  + workloads_gemm.hip), event-timed on the same stream: they are most of a solve and get their own
+                  roofline objects
+  solve_kernel    the one-workgroup n x n kernel (latency-bound; time only)
+  cpu_baseline    the oracle (CPU port of the reference algorithm, OpenBLAS for syrk/gemv/ger/posvx) on a bounded sample
+                  of the same workload at min(nproc, 64) threads, plus cpu_baseline_1thread; rank 0, N = 1 only.
 """
 import argparse
 import os
@@ -102,8 +98,8 @@ def parse():
                          "exchange "
                          "also passes through a one-rank ncclAllReduce")
     ap.add_argument("--replay-latency-us", type=int, default=0,
-                    help="with --replay-ranks: a MODEL of the collectives' latency -- every replayed exchange first holds "
-                         "the stream this many microseconds (mir_lsq_comm_replay_set_delay); the line says so")
+                    help="with --replay-ranks: a MODEL of the collectives' latency -- every replayed exchange first "
+                         "holds the stream this many microseconds (mir_lsq_comm_replay_set_delay); the line says so")
     ap.add_argument("--stall-bound", type=float, default=8.0,
                     help="RCCL only: upper bound (s, from communicator creation) of the warm-up loop that waits for "
                          "RCCL's "

@@ -13,11 +13,9 @@ from .common import (F64_MFMA_PEAK_TF, HBM_PEAK_GBS, ROOT, _round_no, csrc_sha16
 
 def main_cfg2(args):
     """BASELINE cfg 2: Gaussian-sum curve fit, m = 1e5 residuals x n = 16 parameters, fp64, width bounds, FD Jacobian
-    through
-    the device callbacks (--fd batched: one launch for the 2n points of a refresh; --fd serial: one per point) (SURVEY
-    8d). J is 12.8 MB: every kernel of a pass is a few microseconds, so the solve is
-    bound by launch latency and host round trips, not by HBM or MFMA -- the line reports the time per pass and per
-    launch."""
+    through the device callbacks (--fd batched: one launch for the 2n points of a refresh; --fd serial: one per point)
+    (SURVEY 8d). J is 12.8 MB: every kernel of a pass is a few microseconds, so the solve is bound by launch latency and
+    host round trips, not by HBM or MFMA -- the line reports the time per pass and per launch."""
     import numpy as np
     import torch
 
@@ -36,8 +34,7 @@ def main_cfg2(args):
     for _ in range(max(1, args.warmup)):
         res, x = prob.solve(g["x0"], g["lower"], g["upper"], workspace=ws, variant=args.variant, batched=fdb)
     # the timed region carries NO kernel events: at ~6 event pairs per round and 41 rounds per solve they cost 0.9 ms of
-    # a
-    # 3 ms solve (scripts/ab_bench.sh); the per-kernel split comes from a second, instrumented pass of the same solves
+    # a 3 ms solve (scripts/ab_bench.sh); the per-kernel split comes from a second, instrumented pass of the same solves
     iters = 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -84,8 +81,7 @@ def main_cfg2(args):
                              "round runs for microseconds; the figure of merit is us_per_round"},
     }
     # ---- the resident-J path (include/mir_optim_amd_resident.hpp): the whole loop in ONE cooperative launch, J in the
-    # CUs' LDS.
-    # It is the product path for a problem of this size; the launch chain timed above stays on the line as
+    # CUs' LDS. It is the product path for a problem of this size; the launch chain timed above stays on the line as
     # `launch_chain`.
     chain = {k: out[k] for k in ("value", "ms_per_step")}
     chain.update({k: out["config"][k] for k in ("iterations_per_solve", "passes_per_solve", "rounds_per_solve",
@@ -115,9 +111,8 @@ def main_cfg2(args):
         tick = 1e-2                                               # stats are in 10 ns ticks -> us
         rounds_r, passes_r = rst["rounds"], rst["passes"]
         # `value` is the resident path's (the product path for a problem of this size; it needs a compile-time residual
-        # model);
-        # the launch chain's -- the one reachable through the reference's callback ABI -- stands beside it under its own
-        # key
+        # model); the launch chain's -- the one reachable through the reference's callback ABI -- stands beside it under
+        # its own key
         out.update({"value": riters / rdt, "ms_per_step": rdt / K * 1e3, "value_path": "resident",
                     "value_resident": riters / rdt, "value_launch_chain": chain["value"],
                     "ms_per_step_resident": rdt / K * 1e3, "ms_per_step_launch_chain": chain["ms_per_step"]})

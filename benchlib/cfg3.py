@@ -31,8 +31,7 @@ def main_cfg3(args):
     if not torch.cuda.is_available() or M.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: mir_optim_amd has no CPU path")
     # rehearsals: ranks share the GPUs there are (asked for, or forced: fewer visible devices than ranks -- RCCL then
-    # refuses
-    # the communicator and the run takes the labelled callback fallback below instead of dying in set_device)
+    # refuses the communicator and the run takes the labelled callback fallback below instead of dying in set_device)
     ndev = torch.cuda.device_count()
     share = args.comm == "gloo-callback" or os.environ.get("BENCH_SHARE_GPU") == "1" or ndev < world
     if ndev < world and rank == 0:
@@ -52,8 +51,8 @@ def main_cfg3(args):
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         # Control plane (unique-id exchange, the barriers around the timed region, the max over ranks):
-        # torch.distributed.
-        # Data plane (every collective of the solve): the solver's OWN RCCL communicator over xGMI, created below.
+        # torch.distributed. Data plane (every collective of the solve): the solver's OWN RCCL communicator over xGMI,
+        # created below.
         if args.control_plane == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             ctl_dev = "cuda"
@@ -67,10 +66,9 @@ def main_cfg3(args):
         comm_fallback = None
         if args.comm == "rccl":
             # the solver's own RCCL communicator (xGMI), id via torch.distributed; checked with one all-reduce of a
-            # known
-            # payload before anything is timed. If ANY rank fails to create or verify it, every rank falls back to the
-            # callback
-            # communicator over the control plane -- slower, labelled in config, but a measured line instead of a crash.
+            # known payload before anything is timed. If ANY rank fails to create or verify it, every rank falls back to
+            # the callback communicator over the control plane -- slower, labelled in config, but a measured line
+            # instead of a crash.
             err = None
             try:
                 comm = PAR.rccl_comm(world, rank, bcast)
@@ -159,16 +157,12 @@ def main_cfg3(args):
                           batched=fdb)
 
     # RCCL finishes part of its initialisation asynchronously: a few seconds after ncclCommInitRank every HIP launch of
-    # the
-    # process stalls once or twice for 60-150 ms (measured on a one-GPU box with --force-comm: 160-310 it/s when that
-    # lands
-    # in the timed region, 740-760 when not; RCCL / NCCL knobs and warm collectives do not move it). Instead of sleeping
-    # a
-    # fixed time, run untimed solves and WATCH for it: a solve that takes more than 4x the fastest one seen is the
-    # stall;
-    # the loop ends once a stall has been seen and 20 solves in a row are back to normal, or at --stall-bound seconds
-    # after
-    # communicator creation. All ranks take the same decision (the flag is max-reduced over the control plane).
+    # the process stalls once or twice for 60-150 ms (measured on a one-GPU box with --force-comm: 160-310 it/s when
+    # that lands in the timed region, 740-760 when not; RCCL / NCCL knobs and warm collectives do not move it). Instead
+    # of sleeping a fixed time, run untimed solves and WATCH for it: a solve that takes more than 4x the fastest one
+    # seen is the stall; the loop ends once a stall has been seen and 20 solves in a row are back to normal, or at
+    # --stall-bound seconds after communicator creation. All ranks take the same decision (the flag is max-reduced over
+    # the control plane).
     stall = {"observed": 0, "max_ms": 0.0, "waited_s": 0.0, "solves": 0}
     if t_comm is not None and args.stall_bound > 0:
         best, calm = None, 0
@@ -196,8 +190,7 @@ def main_cfg3(args):
 
     def timed(count, s):
         # two statistics records: `st` for the steps whose kernels are bracketed with HIP events (its per-launch figures
-        # --
-        # milliseconds, pending columns, points per call -- all refer to the same launches), `st_all` for every step
+        # -- milliseconds, pending columns, points per call -- all refer to the same launches), `st_all` for every step
         # (counters)
         st, st_plain = M.Stats(), M.Stats()
         iters = 0
@@ -259,8 +252,7 @@ def main_cfg3(args):
         kern_ms = st["jtj_broyden_ms"] / nb
         survey_bytes = 8.0 * (2.0 * m * n + 3.0 * m)         # T (2 m n + 3 m), Broyden pass with J rewritten
         # broyden_lr.h: J is read once and never written; the sweep also reads the k pending columns of U, y_new, y_old
-        # and
-        # writes one column: T (m n + (k + 3) m), k averaged over the timed launches
+        # and writes one column: T (m n + (k + 3) m), k averaged over the timed launches
         kbar = st["broyden_lr_columns"] / nb
         alg_bytes = 8.0 * (m * n + (kbar + 3.0) * m)
         ncp = 1 if n <= 32 else 2 if n <= 64 else 4 if n <= 128 else 8
@@ -291,9 +283,8 @@ def main_cfg3(args):
             fd_rate = fd_bytes / (fd_ms * 1e-3) / 1e9
             fd_tf = (jtj_flops + 2.0 * m * n) / (fd_ms * 1e-3) / 1e12
             # which roofline bounds it: n (n + 1) flop against 16 (or 24) bytes per row element -- at n = 128 the HBM
-            # time at
-            # 8 TB/s (0.26 ms) exceeds the MFMA time at 78.6 TF (0.21 ms), at n = 256 it is the other way round (0.51 vs
-            # 0.84 ms)
+            # time at 8 TB/s (0.26 ms) exceeds the MFMA time at 78.6 TF (0.21 ms), at n = 256 it is the other way round
+            # (0.51 vs 0.84 ms)
             mfma_bound = (jtj_flops / (F64_MFMA_PEAK_TF * 1e12)) > (fd_bytes / (HBM_PEAK_GBS * 1e9))
             fresh = {
                 "kernel": fd_name + (" (finite-difference rows from the m x n DIFFERENCE panel" if diff_panel else
@@ -445,10 +436,9 @@ def main_cfg3(args):
                     "total_wall": sta["total_ms"] / K},
             },
             # `roofline` = the kernel with the most time in the TIMED REGION, caller-side kernels included (round-4
-            # review: the
-            # caller's GEMM is 46 % of the GPU time at cfg 3, the library's busiest kernel 13 %); the two hot library
-            # kernels always
-            # have their own objects (jtj_kernel, broyden_kernel), the caller's theirs (residual_gemm, trial_residual)
+            # review: the caller's GEMM is 46 % of the GPU time at cfg 3, the library's busiest kernel 13 %); the two
+            # hot library kernels always have their own objects (jtj_kernel, broyden_kernel), the caller's theirs
+            # (residual_gemm, trial_residual)
             "roofline": None,
             "jtj_kernel": fresh,
             "broyden_kernel": sweep,

@@ -12,10 +12,8 @@ from .common import (F64_MFMA_PEAK_TF, HBM_PEAK_GBS, ROOT, _round_no, csrc_sha16
 
 def main_cfg5(args):
     """BASELINE cfg 5: 4096 x (m = 512, n = 8) fp32, one wavefront per problem, the whole LM loop inside ONE kernel
-    launch
-    (csrc/batched_kernel.h). A step = one launch = 4096 complete fits from their starting points; inputs resident in
-    HBM.
-    value = accepted LM iterations (summed over the problems) per second. Independent problems: N > 1 would be
+    launch (csrc/batched_kernel.h). A step = one launch = 4096 complete fits from their starting points; inputs resident
+    in HBM. value = accepted LM iterations (summed over the problems) per second. Independent problems: N > 1 would be
     replicas."""
     import numpy as np
     import torch
@@ -59,18 +57,16 @@ def main_cfg5(args):
         step()
     stream.synchronize()
     dt = time.perf_counter() - t0
-    raw = np.frombuffer(dres.download().tobytes(), dtype=np.dtype([("status", "<i4"), ("iterations", "<u4"), ("fCalls",
-            "<u4"),
-                                                                   ("gCalls", "<u4"), ("residual", "<f4"), ("lambda",
-                                                                           "<f4")]))
+    rec_dtype = np.dtype([("status", "<i4"), ("iterations", "<u4"), ("fCalls", "<u4"), ("gCalls", "<u4"),
+                          ("residual", "<f4"), ("lambda", "<f4")])
+    raw = np.frombuffer(dres.download().tobytes(), dtype=rec_dtype)
     iters = int(raw["iterations"].sum())
     fcalls = int(raw["fCalls"].sum())
     ms = dt / args.steps * 1e3
     # Work of one launch: every residual evaluation is m model evaluations (1 exp, ~20 flops; the four sin/cos values of
-    # a row do
-    # not depend on the parameters and come from the basis table k_batched_basis fills once per launch); a
-    # finite-difference
-    # Jacobian makes 2 n of them but fCalls counts n (quirk Q5), so 2 x fCalls x m bounds the evaluations from above
+    # a row do not depend on the parameters and come from the basis table k_batched_basis fills once per launch); a
+    # finite-difference Jacobian makes 2 n of them but fCalls counts n (quirk Q5), so 2 x fCalls x m bounds the
+    # evaluations from above
     evals = 2.0 * fcalls * m
     out = {
         "metric": "LM iterations/sec", "value": iters / (ms * 1e-3), "unit": "iterations/s", "n_gpus": 1,
@@ -89,10 +85,8 @@ def main_cfg5(args):
         "roofline": cfg5_roofline(ms, evals, args.steps, count, m, n),
     }
     # ---- steady state (round-4 review): the 4096 fits differ 3 x in length and go to 2048 wave slots, so the launch
-    # ends with
-    # its stragglers. The same problems 16 times over (65 536 fits in one launch) amortise that tail: the kernel's rate
-    # where the
-    # dispatcher always has a next problem for a finished wave.
+    # ends with its stragglers. The same problems 16 times over (65 536 fits in one launch) amortise that tail: the
+    # kernel's rate where the dispatcher always has a next problem for a finished wave.
     reps = max(1, args.cfg5_replicas)
     if reps > 1:
         big = count * reps
@@ -156,13 +150,10 @@ def main_cfg5(args):
 
 def cfg5_roofline(ms, evals, steps, count, m, n):
     """k_lm_batched is neither HBM- nor MFMA-bound (8.4 MB of inputs per launch): its bound is the VALU issue rate --
-    one wave64
-    instruction per 4 cycles per SIMD, 1024 SIMDs at 2.4 GHz = 614.4 G wave-instructions/s. `achieved` = the VALU
-    instructions
-    one launch executes (SQ_INSTS_VALU of the committed rocprofv3 pass, profiles/r03/cfg5_pmc.json: the instruction
-    count of a
-    launch does not depend on the box) over this run's launch time; `valu_busy_pmc` is the hardware's own figure
-    (4 x SQ_ACTIVE_INST_VALU over GRBM_GUI_ACTIVE x 1024 SIMDs) from the same pass."""
+    one wave64 instruction per 4 cycles per SIMD, 1024 SIMDs at 2.4 GHz = 614.4 G wave-instructions/s. `achieved` = the
+    VALU instructions one launch executes (SQ_INSTS_VALU of the committed rocprofv3 pass, profiles/r03/cfg5_pmc.json:
+    the instruction count of a launch does not depend on the box) over this run's launch time; `valu_busy_pmc` is the
+    hardware's own figure (4 x SQ_ACTIVE_INST_VALU over GRBM_GUI_ACTIVE x 1024 SIMDs) from the same pass."""
     import glob
     peak = 1024 * 2.4e9 / 4.0 / 1e9
     pm, stale = None, None
@@ -172,8 +163,8 @@ def cfg5_roofline(ms, evals, steps, count, m, n):
             pm = next(v for k, v in doc["kernels"].items() if "k_lm_batched" in k)
             src = os.path.relpath(f, ROOT)
             # the instruction count of a launch belongs to the kernel source (and the LM settings) it was counted on:
-            # the
-            # summary records the hash of batched_kernel.h; a different (or missing) hash leaves achieved / frac empty
+            # the summary records the hash of batched_kernel.h; a different (or missing) hash leaves achieved / frac
+            # empty
             have, want = (doc.get("csrc_sha16") or {}).get("batched_kernel.h"), csrc_sha16("batched_kernel.h")
             stale = None if have == want else (
                 f"{src} was counted on batched_kernel.h {have}, this tree has {want}: re-profile "

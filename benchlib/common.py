@@ -21,8 +21,7 @@ def _round_no(path):
 
 def pmc_file(m=1_000_000, n=128):
     """The newest (by round NUMBER) committed PMC summary for the per-GPU shape: profiles/rNN/pmc_traffic.json was taken
-    at
-    m = 1e6 x n = 128 (cfg 3), profiles/rNN/n256_pmc.json at m = 1e6 x n = 256 (cfg 4's per-GPU shape)."""
+    at m = 1e6 x n = 128 (cfg 3), profiles/rNN/n256_pmc.json at m = 1e6 x n = 256 (cfg 4's per-GPU shape)."""
     import glob
     name = {(1_000_000, 128): "pmc_traffic.json", (1_000_000, 256): "n256_pmc.json"}.get((m, n))
     if name is None:
@@ -42,10 +41,8 @@ def csrc_sha16(name):
 def pmc_field(kernel, m, n, field):
     """HBM bytes per launch (or MFMA pipe utilisation) of `kernel` from the COMMITTED rocprofv3 PMC summary (made by
     scripts/pmc_summary.py / pmc_summary2.py from separate --pmc passes of this same command): PMC counters cannot be
-    read
-    from inside the timed run, so this is a stored measurement -- `traffic_source` in the JSON line says so. None if
-    absent
-    or if the per-GPU shape is not one of the profiled ones (m = 1e6 with n = 128 or 256)."""
+    read from inside the timed run, so this is a stored measurement -- `traffic_source` in the JSON line says so. None
+    if absent or if the per-GPU shape is not one of the profiled ones (m = 1e6 with n = 128 or 256)."""
     f = pmc_file(m, n)
     if f is None:
         return None

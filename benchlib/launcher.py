@@ -1,6 +1,5 @@
 """bench.py --gpus N from a bare shell: this process starts the N rank processes itself and relays rank 0's JSON line
-(the
-parent never imports torch or touches HIP)."""
+(the parent never imports torch or touches HIP)."""
 import ctypes as C
 import json
 import os
@@ -33,11 +32,9 @@ def launch_ranks(args):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_SELF_LAUNCHED="1")
         # The image exports HSA_ENABLE_IPC_MODE_LEGACY=0 (its host driver only supports dmabuf IPC: without it RCCL's
-        # P2P set-up
-        # fails with `hipIpcGetMemHandle: invalid argument`). Whatever the box has set is INHERITED, never overridden;
-        # the default
-        # is only supplied when the variable is missing altogether (a shell that lost the image's profile). DESIGN.md
-        # section 6.
+        # P2P set-up fails with `hipIpcGetMemHandle: invalid argument`). Whatever the box has set is INHERITED, never
+        # overridden; the default is only supplied when the variable is missing altogether (a shell that lost the
+        # image's profile). DESIGN.md section 6.
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", str(max(1, min(os.cpu_count() or 1, 64) // n)))
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, cwd=os.getcwd()))
