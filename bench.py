@@ -4,8 +4,8 @@
   python bench.py --gpus N --steps K --warmup W
   N > 1 from a bare shell: this process starts the N rank processes itself (benchlib/launcher.py: children of this
   interpreter with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; the parent never imports torch or touches HIP) and
-  relays rank 0's JSON line. Under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (WORLD_SIZE
-  set) it is one rank.
+  relays rank 0's JSON line. Under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+  (WORLD_SIZE set) it is one rank.
 
 Workload (cfg 3): tanh-linear synthetic NLS, r_i(x) = tanh(a_i . x) - b_i, m = 1e6 rows x n = 128
 parameters, fp64, finite-difference Jacobian through the user's batched residual callbacks, defaults except absTolerance
