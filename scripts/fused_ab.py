@@ -1,3 +1,5 @@
+"""Fused rounds against the one-by-one rounds (MIR_LSQ_VARIANT_NO_PIPELINE) on tanh-linear problems of several n: results (must be
+the same bits), fused rounds / passes, launches per round kind. usage: python scripts/fused_ab.py"""
 import os, sys; sys.path[:0] = [os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'), os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests')]
 import numpy as np
 import mir_optim_amd as M
