@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void k_lr_finish(const T* __restrict__ lr, T* 
     if (i < n) {
         for (int j = threadIdx.x; j < n; j += blockDim.x) {
             T s = lr[j];
-            for (int l = 0; l < k; ++l) s += D[(size_t)l * n + j] * w[l];
+            for (int l = 0; l < k; ++l) s = dfma(D[(size_t)l * n + j], w[l], s);     // (explicit: the fused round's kernel forms the same sums)
             v[j] = s;
         }
         __syncthreads();
@@ -309,8 +309,8 @@ __global__ __launch_bounds__(256) void k_lr_finish(const T* __restrict__ lr, T* 
     T mx = 0;
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
         T s = lr[n + j];
-        for (int l = 0; l < k; ++l) s += D[(size_t)l * n + j] * h[l];
-        s += dx[j] * uy;
+        for (int l = 0; l < k; ++l) s = dfma(D[(size_t)l * n + j], h[l], s);
+        s = dfma(dx[j], uy, s);
         Jy[j] = s;
         const T av = dabs(s);
         if (av > mx) mx = av;

@@ -28,6 +28,9 @@ constexpr int kWave = 64;  // CDNA wavefront
 inline thread_local uint64_t tl_launches = 0;
 #define MIRLSQ_LAUNCH(...) do { ++::mirlsq::tl_launches; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
+// one rounding, whatever the compiler's contraction setting: sums that two kernels must form bit for bit alike
+__device__ inline double dfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ inline float dfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 // ---- pending rank-one Broyden terms (broyden_lr.h): sizes shared by the sweep, its reduction and the n x n finish
 constexpr int kLrMax = 16;
 // [ v0 (n) | g0 (n) | w (kLrMax) | h (kLrMax) | uu | uy | yy ]   yy = ||y_new||^2: the trial's sum of squares (LS:1115) rides on
@@ -37,8 +40,15 @@ __host__ __device__ constexpr int lr_yy(int n) { return 2 * n + 2 * kLrMax + 2; 
 constexpr int kLrMaxN = 512;     // widest problem of the read-only Broyden sweep (16 column-pair chunks of 32 a lane); above, J is rewritten
 constexpr int kReduceRanges = 32;
 // one entry of the symmetric rank-two update J_k^T J_k = J_{k-1}^T J_{k-1} + v dx^T + dx v^T + uu dx dx^T, r >= c (k_lr_finish)
+// Written out in fused multiply-adds: the SAME roundings wherever the term is formed (k_lr_finish; the fused round's kernel adds
+// it to the registers that hold J^T J) -- left to the compiler's contraction, two call sites of `(vr dc + dr vc) + uu dr dc` may
+// round different products (seen: one entry of J^T J an ulp apart between the two, tests/test_gpu_fused_rounds.py).
 template <typename T>
-__device__ __forceinline__ T lr_jj_term(T vr, T vc, T dr, T dc, T uu) { return (vr * dc + dr * vc) + uu * dr * dc; }
+__device__ __forceinline__ T lr_jj_term(T vr, T vc, T dr, T dc, T uu)
+{
+#pragma clang fp contract(off)
+    return dfma(uu * dr, dc, dfma(vr, dc, dr * vc));
+}
 
 template <typename T> struct Lim;
 template <> struct Lim<double> {
@@ -270,9 +280,6 @@ __device__ inline void rsqrt_sqrt(float a, float& rinv, float& d)
     rinv = 1.0f / d;
 }
 
-// one rounding, whatever the compiler's contraction setting: sums that two kernels must form bit for bit alike
-__device__ inline double dfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-__device__ inline float dfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ inline double dsqrt(double v) { return sqrt(v); }
 __device__ inline float dsqrt(float v) { return sqrtf(v); }
 __device__ inline double dabs(double v) { return fabs(v); }

@@ -967,7 +967,7 @@ __device__ __forceinline__ void lm_solve_body(const LmSolveArgs<T>& a, const int
 // decision; the pass's rank-two term is added IN THESE REGISTERS (entry by entry k_lr_finish's expression: the same bits), the
 // updated matrix goes back to memory (both triangles) for the passes to come, and the body commits the registers to LDS --
 // one trip through memory where a separate finish costs a read-modify-write AND the body's read (7.5 us at n = 128 -> 1.5).
-template <typename T, int NB>
+template <typename T, int NB, bool BOUNDED>
 __device__ __forceinline__ bool lm_round_head(const LmSolveArgs<T>& a, T* fin_v, LdsPreload<T, (NB > 0 ? NB : 1)>& pre)
 {
     MIRLSQ_STAMP(a.sc[0].dbg, 26);
@@ -998,10 +998,10 @@ __device__ __forceinline__ bool lm_round_head(const LmSolveArgs<T>& a, T* fin_v,
     {
         T s = lv, g = lg;
 #pragma unroll
-        for (int l = 0; l < kLrMax; ++l) if (l < k) s += dl[l] * wl[l];
+        for (int l = 0; l < kLrMax; ++l) if (l < k) s = dfma(dl[l], wl[l], s);
 #pragma unroll
-        for (int l = 0; l < kLrMax; ++l) if (l < k) g += dl[l] * hl[l];
-        g += dp.dv * uy;
+        for (int l = 0; l < kLrMax; ++l) if (l < k) g = dfma(dl[l], hl[l], g);
+        g = dfma(dp.dv, uy, g);
         if (el) {
             fin_v[tid] = s;
             fin_v[n + tid] = dp.dv;
@@ -1041,10 +1041,13 @@ __device__ __forceinline__ bool lm_round_head(const LmSolveArgs<T>& a, T* fin_v,
         if (el) pre.diag += lr_jj_term(v[tid], v[tid], dxs[tid], dxs[tid], uu);
     }
     // (NB = 0: the body's copy of J^T J adds the term on its way -- FinTerm; v and the step stay in fin_v)
-    // fin_v is free (NB > 0). The stores of J^T J, J^T y and D_k are NOT waited for: a thread reads back what it wrote itself (J^T y,
-    // program order), the matrix is read from memory again only behind the solve's own barriers (the prediction), D_k by later
-    // kernels. (NB = 0: the body copies J^T J from memory at once -- a full barrier.)
-    if constexpr (NB > 0) lds_barrier();
+    // fin_v is free (NB > 0). UNBOUNDED problems do not wait for the stores of J^T J, J^T y and D_k: a thread reads back what it wrote
+    // itself (J^T y, program order), the matrix is read from memory again only behind the solve's own barriers (the
+    // prediction), D_k by later kernels. A BOUNDED problem's body copies J^T J from memory into the matrices of the BOXCQP
+    // loop at once -- other threads' entries: the stores must have landed (a full barrier; without it the copy raced with
+    // them, tests/test_gpu_fused_rounds.py).
+    if constexpr (NB > 0 && BOUNDED) __syncthreads();
+    else if constexpr (NB > 0) lds_barrier();
     MIRLSQ_STAMP(a.sc[0].dbg, 28);
     return true;
 }
@@ -1059,7 +1062,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_lm_solve(LmSolveArgs<T> a)
         T* fin_v;
         if constexpr (NB > 0) { fin_v = reinterpret_cast<T*>(smem_raw); lds_load_issue<T, NB>(a.n, a.JJ, a.n, pre); }
         else { __shared__ T fin_static[2 * kSolveMaxN]; fin_v = fin_static; }
-        if (!lm_round_head<T, NB>(a, fin_v, pre)) return;
+        if (!lm_round_head<T, NB, BOUNDED>(a, fin_v, pre)) return;
         if constexpr (NB == 0) fin = FinTerm<T>{fin_v, fin_v + a.n, a.fin_lr[2 * a.n + 2 * kLrMax], a.fin_JJ, true};
     }
     lm_solve_body<T, NB, BOUNDED>(a, (int)blockIdx.x, smem_raw, pre, a.fused != 0 && NB > 0, fin);  // blockIdx.x: chain step
@@ -1078,7 +1081,7 @@ __global__ __launch_bounds__(kWave) void k_lm_solve_wave(LmSolveArgs<double> a)
     __shared__ double fin_v[2 * kW16];
     if (a.fused) {
         LdsPreload<double, 1> none;
-        if (!lm_round_head<double, 0>(a, fin_v, none)) return;
+        if (!lm_round_head<double, 0, BOUNDED>(a, fin_v, none)) return;
     }
     const bool el = r < n;
     const int rc = el ? r : 0;
