@@ -108,3 +108,47 @@ def test_pending_terms_cap_and_flush_inside_a_fused_chain():
             assert stats[1].fused_passes < stats[1].jacobian_broyden             # the passes behind a flush were not run ahead
             flushed += 1
     assert flushed >= 1
+
+
+@pytest.mark.parametrize("m_total,n,world,bounded", [(60000, 64, 3, True), (64000, 128, 4, False), (30001, 128, 2, True), (40000, 16, 5, True)])
+def test_fused_rounds_on_row_shards_give_the_bits_of_the_one_by_one_rounds(m_total, n, world, bounded):
+    """Row shards over an in-process group (one host thread per shard): a fused round exchanges [sweep | trial sum] ONCE where the
+    one-by-one rounds exchange the trial's sum and the sweep apart (LS:1115; LS:1052, 1065) -- every rank must end on the same
+    bits in both, and on the same bits as every other rank."""
+    import threading
+    from mir_optim_amd import parallel as PAR
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
+    full = P.tanh_linear(m_total, n)
+    lo = up = None
+    x0 = full["x0"]
+    if bounded:
+        lo = np.where(np.arange(n) % 3 == 0, full["xstar"] + 0.02, -np.inf)
+        up = np.full(n, np.inf)
+        x0 = np.maximum(x0, np.where(np.isfinite(lo), lo, -np.inf))
+    probs = []
+    for r in range(world):
+        off, ml = PAR.row_shard(m_total, world, r)
+        w = P.tanh_linear(ml, n, row_offset=off, m_total=m_total)
+        probs.append(W.TanhLinear(w["A"], w["b"]))
+    per_flow = []
+    for variant in (M.VARIANT_NO_PIPELINE, 0):
+        comms, close = PAR.local_group(world)
+        res, err, sts = [None] * world, [None] * world, [M.Stats() for _ in range(world)]
+
+        def one(r):
+            try:
+                rr, xx = probs[r].solve(x0, l=lo, u=up, settings=s, comm=comms[r], stats=sts[r], batched=True, variant=variant)
+                res[r] = outcome(rr, xx, sts[r])
+            except BaseException as e:   # noqa: BLE001
+                err[r] = e
+        ts = [threading.Thread(target=one, args=(r,)) for r in range(world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(600)
+        close()
+        assert not any(t.is_alive() for t in ts) and not any(err), err
+        assert len(set(res)) == 1                                    # every rank: the same bits
+        per_flow.append((res[0], sum(sts[0].allreduce_calls), sts[0].fused_rounds))
+    assert per_flow[0][0] == per_flow[1][0]                           # and the same in both flows
+    assert per_flow[1][2] >= 1 and per_flow[1][1] < per_flow[0][1]    # with fewer exchanges
