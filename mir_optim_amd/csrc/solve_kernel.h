@@ -745,6 +745,16 @@ __device__ __forceinline__ void lm_solve_body(const LmSolveArgs<T>& a, const int
     // gradient test, LS:1053: stop before touching lambda when ||Jy||_inf <= gradTolerance
     if (a.check_grad && !(jy_inf > a.set.gradTolerance)) {
         if (tid == 0) { ChainRec<T> r{}; r.flags = kFlagGradSmall; a.rec[kc] = r; }
+        // (fin.on: the copy loop below, which adds the Broyden pass's rank-two term to J^T J on its way, is not reached -- but the
+        // pass HAS happened, and after a failed gradient test with an aged Jacobian the next pass solves with this J^T J again
+        // (LS:1053-1062, quirk Q4): the term goes into memory here, entry by entry k_lr_finish's expression)
+        if (fin.on) {
+            for (int idx = tid; idx < n * n; idx += kSolveThreads) {
+                const int i = idx / n, j = idx - i * n;
+                const bool lo = i >= j;
+                fin.JJw[idx] += lr_jj_term(fin.v[lo ? i : j], fin.v[lo ? j : i], fin.dxs[lo ? i : j], fin.dxs[lo ? j : i], fin.uu);
+            }
+        }
         return;
     }
 

@@ -152,3 +152,41 @@ def test_fused_rounds_on_row_shards_give_the_bits_of_the_one_by_one_rounds(m_tot
         per_flow.append((res[0], sum(sts[0].allreduce_calls), sts[0].fused_rounds))
     assert per_flow[0][0] == per_flow[1][0]                           # and the same in both flows
     assert per_flow[1][2] >= 1 and per_flow[1][1] < per_flow[0][1]    # with fewer exchanges
+
+
+@pytest.mark.parametrize("m,n", [(900, 129), (1500, 144), (700, 200), (4000, 64), (3000, 16)])
+def test_gradient_test_exit_of_a_pass_run_ahead_keeps_its_rank_two_term(m, n):
+    """A failed gradient test with an aged Jacobian (LS:1053-1062, quirk Q4) ends the pass before its solve -- but the Broyden update
+    has happened and the NEXT pass solves with that J^T J again. The fused round's kernel runs the pass ahead; above n = 128 the
+    rank-two term rides on the solve's own copy of J^T J, which the early exit never reaches: the term must go into memory
+    there (it was lost: found by scripts/fuzz_fused.py, seeds 71, 307, 492, 575 at n = 129)."""
+    w = P.tanh_linear(m, n)
+    prob = W.TanhLinear(w["A"], w["b"])
+    hit = 0
+    for gtol in (1e-3, 1e-2, 3e-2):
+        s = M.LeastSquaresSettings(); s.gradTolerance = gtol; s.absTolerance = 1e-9
+        outs, stats = both(prob, w["x0"], settings=s, batched=False)
+        assert outs[0] == outs[1], (gtol, outs[0][1:], outs[1][1:])
+        hit += int(outs[0][1] == int(M.LeastSquaresStatus.gConverged) and stats[1].fused_rounds >= 1)
+    assert hit >= 1
+
+
+@pytest.mark.parametrize("seed,dtype", [(71, np.float32), (492, np.float32), (575, np.float64)])
+def test_the_cases_the_differential_fuzzer_found(seed, dtype):
+    """scripts/fuzz_fused.py, seeds 71 / 492 / 575 (n = 129, gradTolerance 1e-3): the fused rounds lost the rank-two term of a pass
+    whose gradient test failed -- kept here as they were drawn."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    from fuzz_parity import case
+    c = case(seed)
+    s = M.LeastSquaresSettings(dtype)
+    for key, v in c["s"].items():
+        setattr(s, key, v)
+    if dtype == np.float32:
+        s.absTolerance = max(s.absTolerance, 1e-6); s.gradTolerance = max(s.gradTolerance, 1e-7)
+    lo = c["lo"].astype(dtype) if c["bounded"] else None
+    up = c["up"].astype(dtype) if c["bounded"] else None
+    prob = W.TanhLinear(c["A"], c["b"], dtype=dtype)
+    outs, stats = both(prob, c["x0"].astype(dtype), lo, up, s, batched=False)
+    assert c["n"] == 129 and outs[0] == outs[1] and stats[1].fused_rounds >= 1
