@@ -1,7 +1,9 @@
 """Randomised differential sweep of the FUSED rounds against the one-by-one rounds (MIR_LSQ_VARIANT_NO_PIPELINE): the problems of
 fuzz_parity.py (random shape, bounds incl. binding / pinned / tight boxes, starting point, settings), every callback flavour,
 analytic Jacobian now and then, f64 and f32 -- both flows must return THE SAME BITS (x, status, counters, residual, lambda,
-pass / rejection / QP statistics). Prints only the cases that differ.   python scripts/fuzz_fused.py [cases=600] [seed0=0]"""
+pass / rejection / QP statistics). Prints only the cases that differ.   python scripts/fuzz_fused.py [cases=600] [seed0=0] [shards]
+`shards`: the same comparison on 2 ... 8 in-process row shards (one host thread each): a fused round exchanges [sweep | trial sum]
+once where the one-by-one rounds exchange them apart -- every rank of both flows must hold the same bits."""
 import os
 import sys
 
@@ -43,11 +45,63 @@ def mid_case(seed):
     return dict(A=A, b=b, x0=x0, lo=lo, up=up, m=m, n=n, s=s, bounded=bounded)
 
 
+def run_shards(c, sg, world, variant, lo, up):
+    import threading
+    from mir_optim_amd import parallel as PAR
+    comms, close = PAR.local_group(world)
+    probs = []
+    for r in range(world):
+        off, ml = PAR.row_shard(c["m"], world, r)
+        probs.append(W.TanhLinear(c["A"][off:off + ml], c["b"][off:off + ml]))
+    out, err, sts = [None] * world, [None] * world, [M.Stats() for _ in range(world)]
+
+    def one(r):
+        try:
+            rr, xx = probs[r].solve(c["x0"], lo, up, settings=sg, comm=comms[r], stats=sts[r], batched=True, variant=variant)
+            out[r] = outcome(rr, xx, sts[r])
+        except BaseException as e:      # noqa: BLE001
+            err[r] = e
+    ts = [threading.Thread(target=one, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    hung = any(t.is_alive() for t in ts)
+    close()
+    for pb in probs:
+        pb.dA.free(); pb.db.free()
+    if hung or any(err):
+        raise RuntimeError(f"sharded solve failed: hung={hung} {err}")
+    return out, sts[0].fused_rounds
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 600
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    shards = len(sys.argv) > 3 and sys.argv[3] == "shards"
     tally = {"same": 0, "DIFFER": 0, "never fused": 0}
-    for k in range(cases):
+    for k in range(cases if shards else 0):
+        c = mid_case(seed0 + k) if k % 4 == 3 else case(seed0 + k)
+        rng = np.random.default_rng(seed0 + k + 4242)
+        world = int(rng.choice([2, 3, 4, 8]))
+        if c["m"] < 2 * world:
+            continue
+        sg = M.LeastSquaresSettings()
+        for key, v in c["s"].items():
+            setattr(sg, key, v)
+        lo = c["lo"] if c["bounded"] else None
+        up = c["up"] if c["bounded"] else None
+        a, _ = run_shards(c, sg, world, M.VARIANT_NO_PIPELINE, lo, up)
+        b, fused = run_shards(c, sg, world, 0, lo, up)
+        if len(set(a)) == 1 and len(set(b)) == 1 and a[0] == b[0]:
+            tally["same" if fused else "never fused"] += 1
+        else:
+            tally["DIFFER"] += 1
+            print(f"DIFFER seed {seed0 + k} shards {world} m {c['m']} n {c['n']} bounded {c['bounded']} {c['s']}: ranks agree {len(set(a)) == 1} / {len(set(b)) == 1}\n"
+                  f"   one-by-one {a[0][1:]}\n   fused      {b[0][1:]}", flush=True)
+        if k % 25 == 0:
+            print(f"... case {k}: {world} shards m {c['m']} n {c['n']} {tally}", flush=True)
+    for k in range(0 if shards else cases):
         c = mid_case(seed0 + k) if (k % 4 == 3 or os.environ.get("FUZZ_MID") == "1") else case(seed0 + k)
         rng = np.random.default_rng(seed0 + k + 999)
         dtype = np.float32 if rng.random() < 0.25 else np.float64
