@@ -119,7 +119,7 @@ def main():
             print(f"{cat:10s} seed {seed0 + k} {c['model']} m {c['m']} grid {st['grid']} bounded {c['bounded']} {c['s']}  gpu ({int(res.status)}, {res.iterations}, "
                   f"{res.fCalls}, {res.residual:.17g})  oracle ({ro.status}, {ro.iterations}, {ro.fCalls}, {ro.residual:.17g})  xerr {xerr:.2e} rerr {rerr:.2e}",
                   flush=True)
-        elif k % 50 == 0:
+        elif k % 10 == 0:
             print(f"... case {k}: {cat} ({c['model']} m {c['m']} grid {st['grid']})", flush=True)
         for b in (r.d_rows, r.d_ws, r.d_x, r.d_out):
             b.free()
