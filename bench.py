@@ -43,6 +43,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The image exports HSA_ENABLE_IPC_MODE_LEGACY=0 (the host driver only supports dmabuf IPC; without it RCCL's peer setup
+# fails with hipIpcGetMemHandle: invalid argument). A launcher that builds its own environment may drop it: keep it, before
+# anything loads the HIP runtime.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def parse():
