@@ -239,3 +239,45 @@ def test_record_and_replay_of_a_small_sharded_solve(oracle):
     # a tape that is too small reports (size_t)-1
     with pytest.raises(RuntimeError, match="overflow"):
         PAR.record_rank_tape(shard, world, w["x0"], capacity=16, settings=s, batched=True)
+
+
+def test_replay_latency_model_delays_every_exchange_and_changes_no_bit():
+    """mir_lsq_comm_replay_set_delay (the measurement tool behind `bench.py --replay-ranks R --replay-latency-us L`, DESIGN.md
+    section 7): every replayed exchange first holds the stream L microseconds -- a MODEL of what an N-rank all-reduce costs.
+    The solve's bits must not depend on it, its wall time must grow by at least L per exchange, and only a replay
+    communicator accepts it."""
+    import time
+    import torch
+    m_total, n, world = 40000, 32, 4
+    w = P.tanh_linear(m_total, n)
+
+    def shard(r):
+        o, ml = PAR.row_shard(m_total, world, r)
+        d = P.tanh_linear(ml, n, row_offset=o, m_total=m_total)
+        return W.TanhLinear(d["A"], d["b"])
+    s = M.LeastSquaresSettings(); s.absTolerance = 1e-9
+    L = M.api.lib()
+    tape, rres, rx, _ = PAR.record_rank_tape(shard, world, w["x0"], settings=s, batched=True)
+    prob = shard(0)
+    comm = PAR.replay_comm(world, 0, tape)
+    walls, outs, exchanges = [], [], 0
+    for delay_us in (0, 2000):
+        assert L.mir_lsq_comm_replay_set_delay(C.c_void_p(comm), delay_us) == 0
+        best = None
+        for rep in range(3):
+            assert L.mir_lsq_comm_replay_rewind(C.c_void_p(comm)) == 0
+            st = M.Stats()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r1, x1 = prob.solve(w["x0"], settings=s, comm=comm, batched=True, stats=st)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+            outs.append((x1.tobytes(), int(r1.status), r1.iterations, r1.fCalls, r1.residual, r1.lambda_))
+            exchanges = sum(st.allreduce_calls)
+        walls.append(best)
+    assert len(set(outs)) == 1 and outs[0][0] == rx.tobytes() and exchanges >= 3
+    assert walls[1] - walls[0] >= 0.9 * exchanges * 2000e-6, (walls, exchanges)      # every exchange was charged
+    L.mir_lsq_comm_destroy(C.c_void_p(comm))
+    comms, close = PAR.local_group(1)
+    assert L.mir_lsq_comm_replay_set_delay(C.c_void_p(comms[0]), 10) == -1           # not a replay communicator
+    close()
