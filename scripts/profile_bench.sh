@@ -9,7 +9,10 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 args="--steps 4 --warmup 1 --no-cpu-baseline --no-host-callback --survey-steps 0 $*"
-rocprofv3 --output-format csv --kernel-trace --stats -d "$out/stats" -o stats -- python3 "$root/bench.py" $args > "$out/stats.log" 2>&1 || exit 1
+# the stats pass runs 33 solves: with 5 the kernel averages carry the clock ramp of a fresh process (the caller GEMM 1.39 ms
+# instead of 1.33 by the run's own HIP events); the counter passes stay short
+sargs="--steps 30 --warmup 3 --no-cpu-baseline --no-host-callback --survey-steps 0 $*"
+rocprofv3 --output-format csv --kernel-trace --stats -d "$out/stats" -o stats -- python3 "$root/bench.py" $sargs > "$out/stats.log" 2>&1 || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --output-format csv --pmc $c --kernel-trace -d "$out/pmc_$c" -o pmc -- python3 "$root/bench.py" $args > "$out/pmc_$c.log" 2>&1 || exit 1
 done
